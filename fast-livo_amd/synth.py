@@ -1,0 +1,310 @@
+"""Seeded synthetic frames for the ESKF hot path.
+
+Scene: a 20 x 20 x 5 m room plus three slanted planes.  A *map* is sampled on the planes
+(spacing ~ filter_size_map, 1 cm normal noise); a *scan* of N points on the same planes is expressed
+in the LiDAR frame at a true pose T*; the prior is T* perturbed by U(-0.5,0.5) deg / U(-2,2) cm
+(magnitudes taken from /root/reference/Log/mat_out.txt).  Neighbours come
+from scipy's cKDTree, the stand-in for the host ikd-Tree (KD_TREE::Nearest_Search,
+/root/reference/include/ikd-Tree/ikd_Tree.cpp:350-380): 5 nearest map points, ascending distance,
+float32, valid iff 5 were found and the 5th squared distance is <= 5
+(/root/reference/src/laserMapping.cpp:1549,1567).
+
+The VIO part renders a smooth 640 x 512 u8 texture, places M map points in front of the camera and
+builds their 3-level 8x8 reference patches by sampling the image at the true pose with the same
+anchor/bilinear formula the update uses (/root/reference/src/lidar_selection.cpp:807-837), plus noise.
+"""
+from __future__ import annotations
+
+import dataclasses
+import numpy as np
+
+SEED = 20241108
+
+# /root/reference/config/avia.yaml:32-35,42-45 ; config/camera_pinhole.yaml
+AVIA_T_LI = np.array([0.04165, 0.02326, -0.0284])
+AVIA_R_LI = np.eye(3)
+AVIA_RCL = np.array([[0.00162756, -0.999991, 0.00390957],
+                     [-0.0126748, -0.00392989, -0.999912],
+                     [0.999918, 0.00157786, -0.012681]])
+AVIA_PCL = np.array([0.0409257, 0.0318424, -0.0927219])
+PINHOLE = dict(width=640, height=512, fx=431.795259219, fy=431.550090267,
+               cx=310.833037316, cy=266.985989326,
+               d=(-0.0944205499243979, 0.0946727677776504, -0.00807970960613932,
+                  8.07461209775283e-05, 0.0))
+# /root/reference/config/NTU_VIRAL.yaml:32-35,43-46 ; config/camera_NTU_VIRAL.yaml
+NTU_T_LI = np.zeros(3)
+NTU_RCL = np.array([[0.0218308, 0.99976, -0.00201407],
+                    [-0.0131205, 0.00230088, 0.999911],
+                    [0.999676, -0.0218025, 0.0131676]])
+NTU_PCL = np.array([0.122993, 0.0398643, -0.0577101])
+NTU_CAM = dict(width=752, height=480, fx=4.250258563372763e+02, fy=4.267976260903337e+02,
+               cx=3.860151866550880e+02, cy=2.419130336743440e+02,
+               d=(-0.288105327549552, 0.074578284234601, 7.784489598138802e-04,
+                  -2.277853975035461e-04, 0.0))
+
+LASER_POINT_COV = 0.001   # avia.yaml:16
+IMG_POINT_COV = 100.0     # avia.yaml:15
+INIT_COV = 0.001          # common_lib.h:38
+
+
+def exp_so3(v):
+    """Rodrigues, same thresholding as so3_math.h:54-72."""
+    v = np.asarray(v, dtype=np.float64)
+    n = np.linalg.norm(v)
+    if n <= 1e-5:
+        return np.eye(3)
+    k = v / n
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(n) * K + (1 - np.cos(n)) * K @ K
+
+
+def quat_from_R(R):
+    """Rotation matrix -> quaternion (x, y, z, w), w >= 0."""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = np.zeros(4)
+        q[i] = 0.25 * s
+        q[j] = (R[j, i] + R[i, j]) / s
+        q[k] = (R[k, i] + R[i, k]) / s
+        q[3] = (R[k, j] - R[j, k]) / s
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+@dataclasses.dataclass
+class Scene:
+    planes: list          # (origin, e1, e2) rectangles; points = origin + a*e1 + b*e2, a,b in [0,1]
+    areas: np.ndarray
+    map_xyz: np.ndarray   # float32 (K,3)
+    tree: object
+
+
+def _room_planes():
+    L, H = 20.0, 5.0
+    h = L / 2
+    P = []
+    P.append((np.array([-h, -h, 0.0]), np.array([L, 0, 0.0]), np.array([0, L, 0.0])))      # floor
+    P.append((np.array([-h, -h, H]), np.array([L, 0, 0.0]), np.array([0, L, 0.0])))        # ceiling
+    P.append((np.array([-h, -h, 0.0]), np.array([L, 0, 0.0]), np.array([0, 0, H])))        # wall y=-h
+    P.append((np.array([-h, h, 0.0]), np.array([L, 0, 0.0]), np.array([0, 0, H])))         # wall y=+h
+    P.append((np.array([-h, -h, 0.0]), np.array([0, L, 0.0]), np.array([0, 0, H])))        # wall x=-h
+    P.append((np.array([h, -h, 0.0]), np.array([0, L, 0.0]), np.array([0, 0, H])))         # wall x=+h
+    # three slanted panels
+    P.append((np.array([3.0, -6.0, 0.0]), np.array([4.0, 2.0, 0.0]), np.array([-1.0, 0.5, 3.5])))
+    P.append((np.array([-7.0, 2.0, 0.5]), np.array([1.0, 5.0, 0.5]), np.array([1.5, 0.0, 3.0])))
+    P.append((np.array([4.0, 4.0, 0.0]), np.array([3.0, -1.0, 1.0]), np.array([0.5, 2.0, 3.0])))
+    return P
+
+
+def _sample_planes(rng, planes, areas, count, noise):
+    which = rng.choice(len(planes), size=count, p=areas / areas.sum())
+    a = rng.random(count)
+    b = rng.random(count)
+    O = np.stack([planes[w][0] for w in range(len(planes))])
+    E1 = np.stack([planes[w][1] for w in range(len(planes))])
+    E2 = np.stack([planes[w][2] for w in range(len(planes))])
+    pts = O[which] + a[:, None] * E1[which] + b[:, None] * E2[which]
+    nrm = np.cross(E1, E2)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    pts = pts + nrm[which] * rng.normal(0.0, noise, size=(count, 1))
+    return pts
+
+
+def make_scene(seed=SEED, map_spacing=0.15, noise=0.01):
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(seed)
+    planes = _room_planes()
+    areas = np.array([np.linalg.norm(np.cross(e1, e2)) for (_, e1, e2) in planes])
+    k = int(areas.sum() / (map_spacing * map_spacing))
+    map_xyz = _sample_planes(rng, planes, areas, k, noise).astype(np.float32)
+    return Scene(planes=planes, areas=areas, map_xyz=map_xyz, tree=cKDTree(map_xyz))
+
+
+def knn5(scene: Scene, world_xyz: np.ndarray):
+    """5-NN like KD_TREE::Nearest_Search: (n,5,3) float32 ascending + valid (n,) uint8."""
+    d, idx = scene.tree.query(np.asarray(world_xyz, dtype=np.float32), k=5)
+    nbr = scene.map_xyz[idx].astype(np.float32)
+    sq = (d[:, 4].astype(np.float32)) ** 2
+    valid = (np.isfinite(d[:, 4]) & (sq <= 5.0)).astype(np.uint8)
+    return np.ascontiguousarray(nbr), valid
+
+
+@dataclasses.dataclass
+class LioFrame:
+    n: int
+    body_xyz: np.ndarray        # float32 (n,3) LiDAR-frame points
+    R_LI: np.ndarray
+    t_LI: np.ndarray
+    R_true: np.ndarray
+    p_true: np.ndarray
+    R_prior: np.ndarray
+    p_prior: np.ndarray
+    vel: np.ndarray
+    bg: np.ndarray
+    ba: np.ndarray
+    grav: np.ndarray
+    cov18: np.ndarray           # 18x18 prior covariance (Mode-18 ordering rot,pos,vel,bg,ba,grav)
+    cov23: np.ndarray           # 23x23 prior covariance (IKFoM ordering)
+    scene: Scene
+    laser_point_cov: float = LASER_POINT_COV
+
+    def world_at(self, R, p):
+        pi = self.body_xyz.astype(np.float64) @ self.R_LI.T + self.t_LI
+        return (pi @ R.T + p).astype(np.float32)
+
+
+def _spd(rng, n, base, pert):
+    A = rng.normal(size=(n, n))
+    return base * np.eye(n) + pert * (A @ A.T) / n
+
+
+def make_lio_frame(n, seed=SEED, scene=None, t_LI=AVIA_T_LI, R_LI=AVIA_R_LI, scan_noise=0.01,
+                   rot_pert_deg=0.5, pos_pert=0.02):
+    rng = np.random.default_rng(seed + 1)
+    scene = scene or make_scene(seed)
+    R_true = exp_so3(np.array([0.03, -0.02, 0.4]))
+    p_true = np.array([0.8, -0.5, 1.6])
+    pts = np.zeros((0, 3))
+    while len(pts) < n:
+        cand = _sample_planes(rng, scene.planes, scene.areas, int((n - len(pts)) * 1.3) + 16, scan_noise)
+        rng_ = np.linalg.norm(cand - p_true, axis=1)
+        cand = cand[(rng_ > 1.0) & (rng_ < 30.0)]
+        pts = np.concatenate([pts, cand])[:n]
+    p_imu = (pts - p_true) @ R_true                      # R^T (p_w - p)
+    body = (p_imu - t_LI) @ R_LI                         # R_LI^T (p_i - t_LI)
+    body = body.astype(np.float32)
+    drot = np.deg2rad(rng.uniform(-rot_pert_deg, rot_pert_deg, 3))
+    dpos = rng.uniform(-pos_pert, pos_pert, 3)
+    R_prior = R_true @ exp_so3(drot)
+    p_prior = p_true + dpos
+    cov18 = _spd(rng, 18, INIT_COV, 1e-5)
+    cov23 = _spd(rng, 23, INIT_COV, 1e-5)
+    return LioFrame(n=n, body_xyz=np.ascontiguousarray(body), R_LI=np.array(R_LI, dtype=np.float64),
+                    t_LI=np.array(t_LI, dtype=np.float64), R_true=R_true, p_true=p_true,
+                    R_prior=R_prior, p_prior=p_prior,
+                    vel=rng.normal(0, 0.1, 3), bg=rng.normal(0, 1e-3, 3), ba=rng.normal(0, 1e-2, 3),
+                    grav=np.array([-0.27, -0.40, -9.80]), cov18=cov18, cov23=cov23, scene=scene)
+
+
+# ------------------------------------------------------------------------------------------ VIO
+@dataclasses.dataclass
+class VioFrame:
+    m: int
+    img: np.ndarray             # uint8 (H,W)
+    ref_patch: np.ndarray       # float32 (m,3,64): [level][8*x + y]
+    pos: np.ndarray             # float64 (m,3) world positions
+    search_level: np.ndarray    # int32 (m,)
+    cam: dict
+    Rcl: np.ndarray
+    Pcl: np.ndarray
+    R_LI: np.ndarray
+    t_LI: np.ndarray
+    img_point_cov: float = IMG_POINT_COV
+    max_iterations: int = 10
+    patch_size: int = 8
+
+
+def make_image(width, height, seed=SEED):
+    rng = np.random.default_rng(seed + 2)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    img = np.zeros((height, width))
+    for _ in range(64):
+        fx, fy = rng.uniform(-0.12, 0.12, 2)
+        ph = rng.uniform(0, 2 * np.pi)
+        img += rng.uniform(0.3, 1.0) * np.sin(fx * xx + fy * yy + ph)
+    noise = rng.normal(size=(height, width))
+    k = np.array([1, 4, 6, 4, 1], dtype=np.float64) / 16
+    for _ in range(2):
+        noise = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, noise)
+        noise = np.apply_along_axis(lambda c: np.convolve(c, k, mode="same"), 0, noise)
+    img = img / np.abs(img).max() * 100.0 + 128.0 + 6.0 * noise / noise.std()
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def world2cam(cam, xyz_c):
+    """vk::PinholeCamera::world2cam as restated in oracle/orc_vio.c (from memory of rpg_vikit)."""
+    u = xyz_c[..., 0] / xyz_c[..., 2]
+    v = xyz_c[..., 1] / xyz_c[..., 2]
+    d = cam["d"]
+    if not abs(d[0]) > 1e-7:
+        return np.stack([cam["fx"] * u + cam["cx"], cam["fy"] * v + cam["cy"]], -1)
+    r2 = u * u + v * v
+    r4 = r2 * r2
+    r6 = r4 * r2
+    a1, a2, a3 = 2 * u * v, r2 + 2 * u * u, r2 + 2 * v * v
+    cd = 1 + d[0] * r2 + d[1] * r4 + d[4] * r6
+    xd = u * cd + d[2] * a1 + d[3] * a2
+    yd = v * cd + d[3] * a1 + d[2] * a3
+    return np.stack([xd * cam["fx"] + cam["cx"], yd * cam["fy"] + cam["cy"]], -1)
+
+
+def cam_pose(Rcl, Pcl, R_LI, t_LI, R_wi, p_wi):
+    """Rcw, Pcw of lidar_selection.cpp:35-52,780-783."""
+    Rli = R_LI.T
+    Pli = -R_LI.T @ t_LI
+    Rci = Rcl @ Rli
+    Pci = Rcl @ Pli + Pcl
+    Rcw = Rci @ R_wi.T
+    Pcw = -Rci @ R_wi.T @ p_wi + Pci
+    return Rcw, Pcw
+
+
+def sample_patches(img, pc, scale, patch=8):
+    """Bilinear 8x8 samples around pixel pc (m,2) at pyramid scale, lidar_selection.cpp:807-837."""
+    H, W = img.shape
+    m = pc.shape[0]
+    pcf = pc.astype(np.float32)
+    ui = (np.floor((pc[:, 0] / scale).astype(np.float32)) * scale).astype(np.int64)
+    vi = (np.floor((pc[:, 1] / scale).astype(np.float32)) * scale).astype(np.int64)
+    su = ((pcf[:, 0] - ui.astype(np.float32)) / np.float32(scale)).astype(np.float32)
+    sv = ((pcf[:, 1] - vi.astype(np.float32)) / np.float32(scale)).astype(np.float32)
+    wtl = ((1.0 - su.astype(np.float64)) * (1.0 - sv.astype(np.float64))).astype(np.float32)
+    wtr = (su.astype(np.float64) * (1.0 - sv.astype(np.float64))).astype(np.float32)
+    wbl = ((1.0 - su.astype(np.float64)) * sv.astype(np.float64)).astype(np.float32)
+    wbr = su * sv
+    half = patch // 2
+    xs = np.arange(patch)
+    rows = vi[:, None] + (xs[None, :] - half) * scale          # (m,8)
+    cols = ui[:, None] + (xs[None, :] - half) * scale
+    r = rows[:, :, None]
+    c = cols[:, None, :]
+    f = img.astype(np.float32)
+    out = (wtl[:, None, None] * f[r, c] + wtr[:, None, None] * f[r, c + scale]
+           + wbl[:, None, None] * f[r + scale, c] + wbr[:, None, None] * f[r + scale, c + scale])
+    return out.reshape(m, patch * patch).astype(np.float32)
+
+
+def make_vio_frame(m, lio: LioFrame, seed=SEED, cam=None, Rcl=AVIA_RCL, Pcl=AVIA_PCL, distortion=False,
+                   ref_noise=2.0, img_point_cov=IMG_POINT_COV, max_iterations=10):
+    rng = np.random.default_rng(seed + 3)
+    cam = dict(cam or PINHOLE)
+    if not distortion:
+        cam["d"] = (0.0, 0.0, 0.0, 0.0, 0.0)
+    img = make_image(cam["width"], cam["height"], seed)
+    Rcw, Pcw = cam_pose(Rcl, Pcl, lio.R_LI, lio.t_LI, lio.R_true, lio.p_true)
+    border = (8 // 2 + 1) * 8 + 8   # lidar_selection.cpp:445 margin (+8 so the perturbed prior stays inside)
+    pos = np.zeros((0, 3))
+    while len(pos) < m:
+        k = (m - len(pos)) * 2 + 16
+        px = np.stack([rng.uniform(border, cam["width"] - border, k), rng.uniform(border, cam["height"] - border, k)], -1)
+        depth = rng.uniform(2.0, 20.0, k)
+        xyc = np.stack([(px[:, 0] - cam["cx"]) / cam["fx"], (px[:, 1] - cam["cy"]) / cam["fy"], np.ones(k)], -1) * depth[:, None]
+        pc = world2cam(cam, xyc)
+        ok = (pc[:, 0] > border) & (pc[:, 0] < cam["width"] - border) & (pc[:, 1] > border) & (pc[:, 1] < cam["height"] - border)
+        pw = (xyc[ok] - Pcw) @ Rcw                        # Rcw^T (pf - Pcw)
+        pos = np.concatenate([pos, pw])[:m]
+    pf = pos @ Rcw.T + Pcw
+    pc = world2cam(cam, pf)
+    ref = np.zeros((m, 3, 64), dtype=np.float32)
+    for level in range(3):
+        ref[:, level, :] = sample_patches(img, pc, 1 << level) + rng.normal(0, ref_noise, (m, 64)).astype(np.float32)
+    return VioFrame(m=m, img=img, ref_patch=np.ascontiguousarray(ref), pos=np.ascontiguousarray(pos),
+                    search_level=np.zeros(m, dtype=np.int32), cam=cam, Rcl=np.array(Rcl), Pcl=np.array(Pcl),
+                    R_LI=lio.R_LI, t_LI=lio.t_LI, img_point_cov=img_point_cov, max_iterations=max_iterations)

@@ -1,0 +1,156 @@
+/*
+ * oracle/fastlivo_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * C interface of the CPU oracle: a dependency-free restatement of the FAST-LIVO ESKF hot path
+ * (reference snapshot 2024-11-08). Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product (fast-livo_amd/) never does.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path and
+ * cannot be compiled in this environment (no Eigen/PCL/ROS/OpenCV/vikit), so the
+ * oracle's authority is "faithful restatement of the cited lines", cross-checked by an
+ * independent numpy restatement (oracle/np_oracle.py) and analytic properties (tests/).
+ */
+#ifndef FASTLIVO_ORACLE_H
+#define FASTLIVO_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_DIM18 18
+
+/* StatesGroup, /root/reference/include/common_lib.h:296-381. Matrices are row-major. */
+typedef struct orc_state18 {
+    double rot[9];
+    double pos[3];
+    double vel[3];
+    double bg[3];
+    double ba[3];
+    double grav[3];
+    double cov[ORC_DIM18 * ORC_DIM18];
+} orc_state18;
+
+typedef struct orc_lio18_iter_out {
+    double HTH[36];       /* Hsub^T Hsub                        laserMapping.cpp:1666 */
+    double HTz[6];        /* Hsub^T meas_vec                    laserMapping.cpp:1665 */
+    double solution[18];  /* delta applied to the state         laserMapping.cpp:1672 */
+    double total_residual;/* sum |pd2| over effective points    laserMapping.cpp:1597 */
+    int32_t effct_feat_num;
+    int32_t converged;    /* flg_EKF_converged                  laserMapping.cpp:1688-1691 */
+    int32_t status;       /* 0 ok, 1 singular, 2 non-finite */
+    int32_t pad;
+} orc_lio18_iter_out;
+
+/* One pass of the body of the Mode-18 loop, laserMapping.cpp:1506-1695 ([A]-[D] of SURVEY 3.2),
+ * with the kNN already done: nbr = 5 neighbours per point (ascending distance), and on entry
+ * sel[i] = point_selected_surf[i] (on a search pass: the kNN validity sq[4]<=5 && count==5).
+ * sel, normvec, res_last persist between calls exactly like the reference's globals.
+ * G (18x18) is the reference's persistent G matrix (columns 0..5 rewritten). */
+int orc_lio18_iterate(orc_state18 *x, const orc_state18 *x_prop, const float *body_xyz,
+                      const float *nbr_xyz, uint8_t *sel, int n, const double *R_LI,
+                      const double *t_LI, double laser_point_cov, int nthreads, float *world_xyz,
+                      float *normvec, double *res_last, double *G, orc_lio18_iter_out *out);
+
+/* kNN provider: fills nbr (n x 5 x 3 floats, ascending) and valid (n) for the given world points. */
+typedef void (*orc_knn_fn)(void *ctx, const float *world_xyz, int n, float *nbr_xyz, uint8_t *valid);
+
+typedef struct orc_lio_frame_out {
+    int32_t iterations;   /* passes of the loop body executed */
+    int32_t searches;     /* passes with nearest_search_en */
+    int32_t effct_feat_num;
+    int32_t converged_last;
+    double total_residual;
+} orc_lio_frame_out;
+
+/* Whole per-frame loop incl. rematch/stop logic and covariance update, laserMapping.cpp:1472-1732.
+ * sel_out (n) / normvec_out (n x 4) receive the last pass's selection (publish_effect_world input). */
+int orc_lio18_frame(orc_state18 *x, const float *body_xyz, int n, const double *R_LI,
+                    const double *t_LI, double laser_point_cov, int max_iterations, orc_knn_fn knn,
+                    void *knn_ctx, int nthreads, uint8_t *sel_out, float *normvec_out,
+                    orc_lio_frame_out *out);
+
+/* ---------------------------------------------------------------- VIO (lidar_selection.cpp) */
+typedef struct orc_vio_config {
+    double Rcl[9], Pcl[3];    /* camera <- lidar extrinsic (avia.yaml:42-45)            */
+    double R_LI[9], t_LI[3];  /* imu <- lidar extrinsic (set_extrinsic, :35-39)         */
+    double fx, fy, cx, cy;    /* pinhole intrinsics                                      */
+    double d[5];              /* radtan distortion k1,k2,p1,p2,k3 (vikit; 0 => off)      */
+    int32_t width, height;
+    int32_t max_iterations;   /* NUM_MAX_ITERATIONS                                      */
+    int32_t patch_size;       /* 8 */
+    double img_point_cov;
+} orc_vio_config;
+
+typedef struct orc_vio_level_out {
+    double HTH[36];
+    double HTz[6];
+    double solution[18];
+    float error;        /* returned last_error */
+    int32_t iterations; /* iterations executed at this level */
+    int32_t n_meas;
+    int32_t accepted;   /* accepted solves */
+} orc_vio_level_out;
+
+/* LidarSelector::UpdateState(img, total_residual, level), lidar_selection.cpp:743-902.
+ * ref_patch: m x 3 x 64 floats (index 64*level + 8*x + y); pos: m x 3 doubles (world);
+ * search_level: m ints; errors: m floats out. G persists (18x18). */
+float orc_vio_update_state(const orc_vio_config *cfg, orc_state18 *x, const orc_state18 *x_prop,
+                           const uint8_t *img, const float *ref_patch, const double *pos,
+                           const int32_t *search_level, int m, float total_residual, int level,
+                           float *errors, double *G, orc_vio_level_out *out);
+
+/* LidarSelector::ComputeJ, lidar_selection.cpp:967-983: levels 2,1,0 then cov -= G*cov. */
+int orc_vio_compute_j(const orc_vio_config *cfg, orc_state18 *x, const orc_state18 *x_prop,
+                      const uint8_t *img, const float *ref_patch, const double *pos,
+                      const int32_t *search_level, int m, float *errors,
+                      orc_vio_level_out *out3 /* [3], index = level */);
+
+/* vk::PinholeCamera::world2cam (rpg_vikit, unpinned master; restated from memory). */
+void orc_world2cam(const orc_vio_config *cfg, const double *xyz_c, double *px);
+
+/* ------------------------------------------------------------- Mode-23 (IKFoM, dormant path) */
+typedef struct orc_state23 {
+    double pos[3];
+    double rot[4];          /* Eigen quaternion coeffs order x,y,z,w */
+    double offset_R_L_I[4]; /* x,y,z,w */
+    double offset_T_L_I[3];
+    double vel[3];
+    double bg[3];
+    double ba[3];
+    double grav[3];         /* S2, |grav| = 9.809 */
+} orc_state23;
+
+typedef struct orc_ikfom_out {
+    double HTH[144];      /* last h_x^T h_x */
+    double HTh[12];       /* last h_x^T h */
+    double dx[23];        /* last dx_ */
+    int32_t iterations;   /* calls of h_share_model */
+    int32_t searches;     /* calls with converge == true */
+    int32_t effct_feat_num;
+    int32_t status;
+} orc_ikfom_out;
+
+/* h_share_model, laserMapping.cpp:961-1093: fills h_x (n_eff x 12) and h (n_eff); returns n_eff.
+ * converge != 0 => caller has refreshed nbr/sel from a kNN pass at the current state. */
+int orc_h_share_model(const orc_state23 *s, const float *body_xyz, const float *nbr_xyz,
+                      uint8_t *sel, int n, int nthreads, float *world_xyz, float *normvec,
+                      double *res_last, double *h_x /* n x 12 */, double *h /* n */,
+                      double *total_residual);
+
+/* esekf::update_iterated_dyn_share_modified(R, solve_time), esekfom.hpp:1619-1928, driving
+ * orc_h_share_model + the kNN provider. P is 23x23 row-major, in/out. */
+int orc_ikfom_update_iterated(orc_state23 *x, double *P, const float *body_xyz, int n, double R,
+                              int maximum_iter, const double *limit /*23*/, orc_knn_fn knn,
+                              void *knn_ctx, int nthreads, uint8_t *sel_out, float *normvec_out,
+                              orc_ikfom_out *out);
+
+/* state_ikfom boxplus / boxminus (build_manifold.hpp:192-200) exposed for unit tests. */
+void orc_state23_boxplus(orc_state23 *x, const double *dx /*23*/);
+void orc_state23_boxminus(const orc_state23 *x, const orc_state23 *other, double *dx /*23*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,254 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+PARITY UNPINNED: see oracle/fastlivo_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "liboracle.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(_DIR, f) for f in os.listdir(_DIR) if f.endswith((".c", ".h")) or f == "Makefile"]
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return LIB_PATH
+    subprocess.check_call(["make", "-C", _DIR, "-s", "liboracle.so"])
+    return LIB_PATH
+
+
+class State18(C.Structure):
+    _fields_ = [("rot", C.c_double * 9), ("pos", C.c_double * 3), ("vel", C.c_double * 3),
+                ("bg", C.c_double * 3), ("ba", C.c_double * 3), ("grav", C.c_double * 3),
+                ("cov", C.c_double * 324)]
+
+    @staticmethod
+    def make(R, p, vel, bg, ba, grav, cov):
+        s = State18()
+        s.rot[:] = np.asarray(R, dtype=np.float64).reshape(9)
+        s.pos[:] = p
+        s.vel[:] = vel
+        s.bg[:] = bg
+        s.ba[:] = ba
+        s.grav[:] = grav
+        s.cov[:] = np.asarray(cov, dtype=np.float64).reshape(324)
+        return s
+
+    def copy(self):
+        o = State18()
+        C.memmove(C.byref(o), C.byref(self), C.sizeof(State18))
+        return o
+
+    def vec(self):
+        """rot(9), pos, vel, bg, ba, grav as one flat array (24)."""
+        return np.concatenate([np.array(self.rot), np.array(self.pos), np.array(self.vel),
+                               np.array(self.bg), np.array(self.ba), np.array(self.grav)])
+
+    def cov_np(self):
+        return np.array(self.cov).reshape(18, 18)
+
+
+class LioIterOut(C.Structure):
+    _fields_ = [("HTH", C.c_double * 36), ("HTz", C.c_double * 6), ("solution", C.c_double * 18),
+                ("total_residual", C.c_double), ("effct_feat_num", C.c_int32), ("converged", C.c_int32),
+                ("status", C.c_int32), ("pad", C.c_int32)]
+
+
+class LioFrameOut(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("searches", C.c_int32), ("effct_feat_num", C.c_int32),
+                ("converged_last", C.c_int32), ("total_residual", C.c_double)]
+
+
+class VioConfig(C.Structure):
+    _fields_ = [("Rcl", C.c_double * 9), ("Pcl", C.c_double * 3), ("R_LI", C.c_double * 9),
+                ("t_LI", C.c_double * 3), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double),
+                ("cy", C.c_double), ("d", C.c_double * 5), ("width", C.c_int32), ("height", C.c_int32),
+                ("max_iterations", C.c_int32), ("patch_size", C.c_int32), ("img_point_cov", C.c_double)]
+
+
+class VioLevelOut(C.Structure):
+    _fields_ = [("HTH", C.c_double * 36), ("HTz", C.c_double * 6), ("solution", C.c_double * 18),
+                ("error", C.c_float), ("iterations", C.c_int32), ("n_meas", C.c_int32),
+                ("accepted", C.c_int32)]
+
+
+class State23(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("rot", C.c_double * 4), ("offset_R_L_I", C.c_double * 4),
+                ("offset_T_L_I", C.c_double * 3), ("vel", C.c_double * 3), ("bg", C.c_double * 3),
+                ("ba", C.c_double * 3), ("grav", C.c_double * 3)]
+
+    def copy(self):
+        o = State23()
+        C.memmove(C.byref(o), C.byref(self), C.sizeof(State23))
+        return o
+
+    def vec(self):
+        return np.concatenate([np.array(getattr(self, f)) for f, _ in self._fields_])
+
+
+class IkfomOut(C.Structure):
+    _fields_ = [("HTH", C.c_double * 144), ("HTh", C.c_double * 12), ("dx", C.c_double * 23),
+                ("iterations", C.c_int32), ("searches", C.c_int32), ("effct_feat_num", C.c_int32),
+                ("status", C.c_int32)]
+
+
+KNN_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float),
+                     C.POINTER(C.c_uint8))
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        dp, fp, u8p, i32p = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+        L.orc_lio18_iterate.restype = C.c_int
+        L.orc_lio18_iterate.argtypes = [C.POINTER(State18), C.POINTER(State18), fp, fp, u8p, C.c_int, dp, dp,
+                                        C.c_double, C.c_int, fp, fp, dp, dp, C.POINTER(LioIterOut)]
+        L.orc_lio18_frame.restype = C.c_int
+        L.orc_lio18_frame.argtypes = [C.POINTER(State18), fp, C.c_int, dp, dp, C.c_double, C.c_int, KNN_FN,
+                                      C.c_void_p, C.c_int, u8p, fp, C.POINTER(LioFrameOut)]
+        L.orc_vio_update_state.restype = C.c_float
+        L.orc_vio_update_state.argtypes = [C.POINTER(VioConfig), C.POINTER(State18), C.POINTER(State18), u8p, fp,
+                                           dp, i32p, C.c_int, C.c_float, C.c_int, fp, dp, C.POINTER(VioLevelOut)]
+        L.orc_vio_compute_j.restype = C.c_int
+        L.orc_vio_compute_j.argtypes = [C.POINTER(VioConfig), C.POINTER(State18), C.POINTER(State18), u8p, fp, dp,
+                                        i32p, C.c_int, fp, C.POINTER(VioLevelOut)]
+        L.orc_world2cam.restype = None
+        L.orc_world2cam.argtypes = [C.POINTER(VioConfig), dp, dp]
+        L.orc_h_share_model.restype = C.c_int
+        L.orc_h_share_model.argtypes = [C.POINTER(State23), fp, fp, u8p, C.c_int, C.c_int, fp, fp, dp, dp, dp, dp]
+        L.orc_ikfom_update_iterated.restype = C.c_int
+        L.orc_ikfom_update_iterated.argtypes = [C.POINTER(State23), dp, fp, C.c_int, C.c_double, C.c_int, dp,
+                                                KNN_FN, C.c_void_p, C.c_int, u8p, fp, C.POINTER(IkfomOut)]
+        L.orc_state23_boxplus.restype = None
+        L.orc_state23_boxplus.argtypes = [C.POINTER(State23), dp]
+        L.orc_state23_boxminus.restype = None
+        L.orc_state23_boxminus.argtypes = [C.POINTER(State23), C.POINTER(State23), dp]
+        _lib = L
+    return _lib
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+def knn_callback(scene_knn):
+    """Wrap `scene_knn(world (n,3) float32) -> (nbr (n,5,3) f32, valid (n,) u8)` as an orc_knn_fn."""
+    def cb(ctx, world, n, nbr, valid):
+        w = np.ctypeslib.as_array(world, shape=(n, 3))
+        nb, va = scene_knn(w)
+        np.ctypeslib.as_array(nbr, shape=(n, 5, 3))[:] = nb
+        np.ctypeslib.as_array(valid, shape=(n,))[:] = va
+    return KNN_FN(cb)
+
+
+def state18_from_frame(fr, R=None, p=None):
+    return State18.make(fr.R_prior if R is None else R, fr.p_prior if p is None else p,
+                        fr.vel, fr.bg, fr.ba, fr.grav, fr.cov18)
+
+
+def state23_from_frame(fr, quat_from_R):
+    s = State23()
+    s.pos[:] = fr.p_prior
+    s.rot[:] = quat_from_R(fr.R_prior)
+    s.offset_R_L_I[:] = quat_from_R(fr.R_LI)
+    s.offset_T_L_I[:] = fr.t_LI
+    s.vel[:] = fr.vel
+    s.bg[:] = fr.bg
+    s.ba[:] = fr.ba
+    g = np.asarray(fr.grav, dtype=np.float64)
+    s.grav[:] = g / np.linalg.norm(g) * 9.809
+    return s
+
+
+def lio18_iterate(x, x_prop, body, nbr, sel, R_LI, t_LI, cov, nthreads=4, G=None,
+                  normvec=None, res_last=None, want_world=False):
+    """One Mode-18 iteration.  Mutates x, sel (and G / normvec / res_last when given)."""
+    n = body.shape[0]
+    out = LioIterOut()
+    G = np.zeros((18, 18)) if G is None else G
+    normvec = np.zeros((n, 4), dtype=np.float32) if normvec is None else normvec
+    res_last = np.zeros(n) if res_last is None else res_last
+    world = np.zeros((n, 3), dtype=np.float32) if want_world else None
+    R_LI = np.ascontiguousarray(R_LI, dtype=np.float64)
+    t_LI = np.ascontiguousarray(t_LI, dtype=np.float64)
+    st = lib().orc_lio18_iterate(C.byref(x), C.byref(x_prop), _p(body, C.c_float), _p(nbr, C.c_float),
+                                 _p(sel, C.c_uint8), n, _p(R_LI, C.c_double), _p(t_LI, C.c_double), cov,
+                                 nthreads, _p(world, C.c_float) if want_world else None,
+                                 _p(normvec, C.c_float), _p(res_last, C.c_double), _p(G, C.c_double),
+                                 C.byref(out))
+    return dict(status=st, out=out, G=G, normvec=normvec, res_last=res_last, world=world)
+
+
+def lio18_frame(x, body, R_LI, t_LI, cov, max_iter, scene_knn, nthreads=4):
+    n = body.shape[0]
+    out = LioFrameOut()
+    sel = np.zeros(n, dtype=np.uint8)
+    normvec = np.zeros((n, 4), dtype=np.float32)
+    cb = knn_callback(scene_knn)
+    R_LI = np.ascontiguousarray(R_LI, dtype=np.float64)
+    t_LI = np.ascontiguousarray(t_LI, dtype=np.float64)
+    st = lib().orc_lio18_frame(C.byref(x), _p(body, C.c_float), n, _p(R_LI, C.c_double), _p(t_LI, C.c_double),
+                               cov, max_iter, cb, None, nthreads, _p(sel, C.c_uint8), _p(normvec, C.c_float),
+                               C.byref(out))
+    return dict(status=st, out=out, sel=sel, normvec=normvec)
+
+
+def vio_config(vf):
+    c = VioConfig()
+    c.Rcl[:] = np.asarray(vf.Rcl).reshape(9)
+    c.Pcl[:] = vf.Pcl
+    c.R_LI[:] = np.asarray(vf.R_LI).reshape(9)
+    c.t_LI[:] = vf.t_LI
+    c.fx, c.fy, c.cx, c.cy = vf.cam["fx"], vf.cam["fy"], vf.cam["cx"], vf.cam["cy"]
+    c.d[:] = vf.cam["d"]
+    c.width, c.height = vf.cam["width"], vf.cam["height"]
+    c.max_iterations = vf.max_iterations
+    c.patch_size = vf.patch_size
+    c.img_point_cov = vf.img_point_cov
+    return c
+
+
+def vio_update_state(vf, x, x_prop, total_residual, level, G=None):
+    cfg = vio_config(vf)
+    G = np.zeros((18, 18)) if G is None else G
+    errors = np.zeros(vf.m, dtype=np.float32)
+    out = VioLevelOut()
+    err = lib().orc_vio_update_state(C.byref(cfg), C.byref(x), C.byref(x_prop), _p(vf.img, C.c_uint8),
+                                     _p(vf.ref_patch, C.c_float), _p(vf.pos, C.c_double),
+                                     _p(vf.search_level, C.c_int32), vf.m, total_residual, level,
+                                     _p(errors, C.c_float), _p(G, C.c_double), C.byref(out))
+    return dict(error=err, out=out, errors=errors, G=G)
+
+
+def vio_compute_j(vf, x, x_prop):
+    cfg = vio_config(vf)
+    errors = np.zeros(vf.m, dtype=np.float32)
+    outs = (VioLevelOut * 3)()
+    st = lib().orc_vio_compute_j(C.byref(cfg), C.byref(x), C.byref(x_prop), _p(vf.img, C.c_uint8),
+                                 _p(vf.ref_patch, C.c_float), _p(vf.pos, C.c_double),
+                                 _p(vf.search_level, C.c_int32), vf.m, _p(errors, C.c_float), outs)
+    return dict(status=st, outs=outs, errors=errors)
+
+
+def ikfom_update(x, P, body, R, max_iter, scene_knn, limit=None, nthreads=4):
+    n = body.shape[0]
+    out = IkfomOut()
+    sel = np.zeros(n, dtype=np.uint8)
+    normvec = np.zeros((n, 4), dtype=np.float32)
+    limit = np.full(23, 0.001) if limit is None else np.ascontiguousarray(limit, dtype=np.float64)
+    cb = knn_callback(scene_knn)
+    st = lib().orc_ikfom_update_iterated(C.byref(x), _p(P, C.c_double), _p(body, C.c_float), n, R, max_iter,
+                                         _p(limit, C.c_double), cb, None, nthreads, _p(sel, C.c_uint8),
+                                         _p(normvec, C.c_float), C.byref(out))
+    return dict(status=st, out=out, sel=sel, normvec=normvec)
