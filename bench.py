@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""bench.py -- ESKF iterations/s of the FAST-LIVO hot path on MI355X (BASELINE.json metric).
+
+One *step* = one LIVO ESKF iteration over one synthetic frame already resident in HBM:
+  * one LIO pass  : 50 000 down-sampled LiDAR points -> point-to-plane residuals + gates + 1x6 rows
+                    -> H^T H / H^T z reduction -> 18-state gain solve -> state (+)= delta
+  * one VIO pass  : 2 000 8x8 photometric patches (pyramid level 0) -> same reduction/solve
+(BASELINE config 3, "LIVO: 50k pts + 2k 8x8 patches"; kNN excluded on both sides, neighbours
+pre-staged -- SURVEY.md section 8d).  With --gpus N (launched by torch.distributed.run, one rank
+per GPU) every rank holds its own 50k-point / 2k-patch shard of an N-times larger frame (weak
+scaling), reduces its partial normal equations on the device, all-reduces the 32-double record
+over RCCL and runs the gain solve redundantly.  `value` = shard-iterations/s summed over ranks
+(= N x frame-iterations/s); `frame_iterations_per_s` is reported next to it.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_POINTS = 50000
+N_PATCHES = 2000
+VIO_LEVEL = 0
+# algorithmic HBM bytes per unit and launch
+LIO_BYTES_PER_POINT = 12 + 16 + 1      # body xyz + cached plane (n,d) + selection flag
+VIO_BYTES_PER_PATCH = 405 + 4          # 256 ref + 121 image footprint + 24 pos + 4 level, + 4 written
+HBM_PEAK_GBS = 8000.0                  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--points", type=int, default=N_POINTS)
+    ap.add_argument("--patches", type=int, default=N_PATCHES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle sample")
+    ap.add_argument("--sweep", action="store_true", help="also print a kernel-only size sweep to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(fr, vf, nbr, valid, budget_s):
+    """The CPU oracle (a port of the reference loop bodies; the reference itself cannot be built
+    here) timed on this box's host cores: LIO pass with the reference's OpenMP width (4 threads,
+    CMakeLists.txt:23-26), VIO pass single-threaded as in the reference."""
+    from oracle import oracle as orc
+    threads = min(4, os.cpu_count() or 1)
+    x0 = orc.state18_from_frame(fr)
+    vf1 = vf
+    old_max = vf1.max_iterations
+    vf1.max_iterations = 1
+    times = []
+    t_end = time.perf_counter() + budget_s
+    reps = 0
+    while reps < 3 or (time.perf_counter() < t_end and reps < 200):
+        x = x0.copy()
+        sel = valid.copy()
+        t0 = time.perf_counter()
+        orc.lio18_iterate(x, x0, fr.body_xyz, nbr, sel, fr.R_LI, fr.t_LI, fr.laser_point_cov, nthreads=threads)
+        xv = x0.copy()
+        orc.vio_update_state(vf1, xv, x0, 1e10, VIO_LEVEL)
+        times.append(time.perf_counter() - t0)
+        reps += 1
+    vf1.max_iterations = old_max
+    t = np.array(times[1:]) if len(times) > 1 else np.array(times)
+    med = float(np.median(t))
+    return {"value": 1.0 / med, "unit": "iterations/s", "cores": threads, "kind": "port",
+            "host_cores_available": os.cpu_count(),
+            "sample": f"{len(t)} LIVO iterations ({fr.n} pts LIO pass with {threads} OpenMP threads + {vf.m} patches VIO pass "
+                      f"single-thread, level {VIO_LEVEL}); median {med * 1e3:.2f} ms, p10 {np.percentile(t, 10) * 1e3:.2f}, "
+                      f"p90 {np.percentile(t, 90) * 1e3:.2f}"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ESKF hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import fastlivo  # noqa: F401
+    from fast_livo_amd import capi, synth
+
+    # ---- synthetic frame: this rank's shard of an (world x points)-point scan
+    scene = synth.make_scene()
+    fr = synth.make_lio_frame(args.points, scene=scene, point_seed=synth.SEED + 101 + 17 * rank)
+    vf = synth.make_vio_frame(args.patches, fr, patch_seed=synth.SEED + 103 + 17 * rank)
+    world_pts = fr.world_at(fr.R_prior, fr.p_prior)
+    nbr, valid = synth.knn5(scene, world_pts)
+
+    cfg = capi.config_from_frames(fr, vf, max_iterations=10, device=local_rank)
+    hl = capi.Handle(cfg)   # LIO filter
+    hv = capi.Handle(cfg)   # VIO filter
+    side = torch.cuda.Stream()            # everything (kernels, RCCL ordering, events) on one non-default stream
+    torch.cuda.set_stream(side)
+    stream = torch.cuda.current_stream().cuda_stream
+    hl.set_stream(stream)
+    hv.set_stream(stream)
+    x0 = capi.state18_from_frame(fr)
+    hl.lio_set_points(fr.body_xyz)
+    hl.lio_begin18(x0, x0)
+    hl.lio_set_neighbours(nbr, valid)
+    hv.vio_set_frame(vf.img)
+    hv.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+    hv.vio_begin(x0, x0)
+    F = capi.FL_ITER_FORCE
+    sums_l = torch.zeros(capi.FL_SUMS18, dtype=torch.float64, device="cuda")
+    sums_v = torch.zeros(capi.FL_SUMS18, dtype=torch.float64, device="cuda")
+
+    def step():
+        if not distributed:
+            hl.lio_iterate18(1, F, want_info=False)
+            hv.vio_iterate(VIO_LEVEL, 1, F, want_info=False)
+        else:
+            hl.lio_accumulate18(sums_l.data_ptr(), F)
+            dist.all_reduce(sums_l)
+            hl.lio_solve18(sums_l.data_ptr(), F)
+            hv.vio_accumulate(VIO_LEVEL, sums_v.data_ptr())
+            dist.all_reduce(sums_v)
+            hv.vio_solve(sums_v.data_ptr(), F)
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the filters must have produced finite states
+    xs = hl.lio_get_state18().vec()
+    xv = hv.vio_get_state18().vec()
+    finite = bool(np.isfinite(xs).all() and np.isfinite(xv).all())
+
+    # ---- roofline of the dominant kernel (LIO pass), HIP events on the launch stream
+    roof = None
+    if rank == 0:
+        K = max(200, min(args.steps, 2000))
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tmp = torch.zeros(capi.FL_SUMS18, dtype=torch.float64, device="cuda")
+        for _ in range(50):
+            hl.lio_iterate18(1, F, want_info=False)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(K):
+            hl.lio_iterate18(1, F, want_info=False)
+        ev1.record()
+        torch.cuda.synchronize()
+        lio_us = ev0.elapsed_time(ev1) * 1e3 / K
+        ev0.record()
+        for _ in range(K):
+            hv.vio_iterate(VIO_LEVEL, 1, F, want_info=False)
+        ev1.record()
+        torch.cuda.synchronize()
+        vio_us = ev0.elapsed_time(ev1) * 1e3 / K
+        del tmp
+        lio_bytes = LIO_BYTES_PER_POINT * args.points
+        vio_bytes = VIO_BYTES_PER_PATCH * args.patches
+        dom = "lio18_iterate_kernel" if lio_us >= vio_us else "vio_iterate_kernel"
+        dom_bytes, dom_us = (lio_bytes, lio_us) if lio_us >= vio_us else (vio_bytes, vio_us)
+        ach = dom_bytes / (dom_us * 1e-6) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us,
+                "method": f"HIP events around {K} back-to-back launches on the launch stream (includes the "
+                          "inter-kernel boundary)",
+                "lio_pass_us": lio_us, "vio_pass_us": vio_us,
+                "note": "latency-bound at BASELINE sizes: 1.45 MB/launch is 0.18 us at 8 TB/s, below one kernel boundary "
+                        "(SURVEY.md fact 5); see DESIGN.md size sweep"}
+        if args.sweep:
+            sweep(capi, synth, scene, cfg, x0, sys.stderr)
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and not distributed:
+        cpu = cpu_baseline(fr, vf, nbr, valid, args.cpu_seconds)
+
+    hl.close()
+    hv.close()
+    if rank == 0:
+        frame_it_s = args.steps / elapsed
+        out = {
+            "metric": "ESKF iterations/sec (50k LiDAR pts + 2k 8x8 patches)",
+            "value": frame_it_s * world,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 point/pixel math + f64 Jacobian rows, reduction and solve",
+            "data": "synthetic",
+            "config": {"workload": f"LIVO (BASELINE config 3): {args.points} pts point-to-plane LIO pass + {args.patches} "
+                                   f"8x8 patches VIO pass (level {VIO_LEVEL}) per GPU, 18-state (StatesGroup) ESKF, "
+                                   "neighbours/planes/image resident in HBM",
+                       "points_per_gpu": args.points, "patches_per_gpu": args.patches,
+                       "iteration_definition": "one LIO pass + one VIO pass, each = residuals + Jacobian rows + "
+                                               "normal equations + gain solve + state update",
+                       "parallelism": f"point/patch-range shards x{world}, all-reduce of the 32-double normal-equation "
+                                      "record per pass" if world > 1 else "single GPU, fused pass kernels"},
+            "frame_iterations_per_s": frame_it_s,
+            "state_finite": finite,
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        if cpu:
+            out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+def sweep(capi, synth, scene, cfg, x0, fh):
+    """Kernel-only effective bandwidth of the LIO pass over a size sweep."""
+    import torch
+    for n in (50000, 200000, 1000000, 4000000, 8000000):
+        fr = synth.make_lio_frame(min(n, 200000), scene=scene)
+        reps = (n + fr.n - 1) // fr.n
+        body = np.tile(fr.body_xyz, (reps, 1))[:n]
+        w = fr.world_at(fr.R_prior, fr.p_prior)
+        nbr, valid = synth.knn5(scene, w)
+        nbr = np.tile(nbr, (reps, 1, 1))[:n]
+        valid = np.tile(valid, reps)[:n]
+        h = capi.Handle(cfg)
+        h.set_stream(torch.cuda.current_stream().cuda_stream)
+        h.lio_set_points(body)
+        h.lio_begin18(x0, x0)
+        h.lio_set_neighbours(nbr, valid)
+        K = 100 if n <= 1000000 else 20
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            h.lio_iterate18(1, capi.FL_ITER_FORCE, want_info=False)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(K):
+            h.lio_iterate18(1, capi.FL_ITER_FORCE, want_info=False)
+        ev1.record()
+        torch.cuda.synchronize()
+        us = ev0.elapsed_time(ev1) * 1e3 / K
+        gbs = LIO_BYTES_PER_POINT * n / (us * 1e-6) / 1e9
+        print(json.dumps({"sweep_points": n, "lio_pass_us": us, "effective_GBps": gbs, "frac_of_8TBps": gbs / HBM_PEAK_GBS}),
+              file=fh)
+        h.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,361 @@
+"""ctypes binding of libfastlivo_hip.so (include/fastlivo_hip.h).
+
+This is the host-side mirror used by tests and bench.py.  It raises if the HIP extension is missing
+or no GPU is visible -- there is no CPU fallback anywhere in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import LIB_PATH, PKG_DIR
+
+FL_ITER_FORCE = 1
+FL_ITER_KEEP_NORMVEC = 2
+FL_SUMS18 = 32
+FL_SUMS23 = 96
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("max_iterations", C.c_int32), ("img_width", C.c_int32),
+                ("img_height", C.c_int32), ("patch_size", C.c_int32), ("reserved0", C.c_int32),
+                ("R_LI", C.c_double * 9), ("t_LI", C.c_double * 3), ("Rcl", C.c_double * 9),
+                ("Pcl", C.c_double * 3), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double),
+                ("cy", C.c_double), ("d", C.c_double * 5), ("laser_point_cov", C.c_double),
+                ("img_point_cov", C.c_double)]
+
+
+class State18(C.Structure):
+    _fields_ = [("rot", C.c_double * 9), ("pos", C.c_double * 3), ("vel", C.c_double * 3),
+                ("bg", C.c_double * 3), ("ba", C.c_double * 3), ("grav", C.c_double * 3),
+                ("cov", C.c_double * 324)]
+
+    @staticmethod
+    def make(R, p, vel, bg, ba, grav, cov):
+        s = State18()
+        s.rot[:] = np.asarray(R, dtype=np.float64).reshape(9)
+        s.pos[:] = p
+        s.vel[:] = vel
+        s.bg[:] = bg
+        s.ba[:] = ba
+        s.grav[:] = grav
+        s.cov[:] = np.asarray(cov, dtype=np.float64).reshape(324)
+        return s
+
+    def copy(self):
+        o = State18()
+        C.memmove(C.byref(o), C.byref(self), C.sizeof(State18))
+        return o
+
+    def vec(self):
+        return np.concatenate([np.array(self.rot), np.array(self.pos), np.array(self.vel),
+                               np.array(self.bg), np.array(self.ba), np.array(self.grav)])
+
+    def cov_np(self):
+        return np.array(self.cov).reshape(18, 18)
+
+
+class State23(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("rot", C.c_double * 4), ("offset_R_L_I", C.c_double * 4),
+                ("offset_T_L_I", C.c_double * 3), ("vel", C.c_double * 3), ("bg", C.c_double * 3),
+                ("ba", C.c_double * 3), ("grav", C.c_double * 3)]
+
+    def copy(self):
+        o = State23()
+        C.memmove(C.byref(o), C.byref(self), C.sizeof(State23))
+        return o
+
+    def vec(self):
+        return np.concatenate([np.array(getattr(self, f)) for f, _ in self._fields_])
+
+
+class IterInfo(C.Structure):
+    _fields_ = [("solution", C.c_double * 23), ("total_residual", C.c_double), ("effct_feat_num", C.c_int32),
+                ("converged", C.c_int32), ("status", C.c_int32), ("iterations", C.c_int32),
+                ("need_search", C.c_int32), ("stop", C.c_int32), ("accepted", C.c_int32), ("reserved", C.c_int32)]
+
+
+KNN_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_uint8))
+
+_dp, _fp, _u8p, _i32p = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+_H = C.c_void_p
+
+# name -> (restype, argtypes): every symbol include/fastlivo_hip.h declares
+SYMBOLS = {
+    "fl_create": (C.c_int32, [C.POINTER(Config), C.POINTER(_H)]),
+    "fl_destroy": (C.c_int32, [_H]),
+    "fl_last_error_string": (C.c_char_p, [_H]),
+    "fl_set_stream": (C.c_int32, [_H, C.c_void_p]),
+    "fl_sync": (C.c_int32, [_H]),
+    "fl_set_timing": (C.c_int32, [_H, C.c_int32]),
+    "fl_get_last_kernel_ms": (C.c_int32, [_H, _fp]),
+    "fl_lio_set_points": (C.c_int32, [_H, _fp, C.c_int32]),
+    "fl_lio_set_neighbours": (C.c_int32, [_H, _fp, _u8p, C.c_int32]),
+    "fl_lio_get_selection": (C.c_int32, [_H, _u8p, _fp]),
+    "fl_lio_get_world_points": (C.c_int32, [_H, _fp]),
+    "fl_lio_begin18": (C.c_int32, [_H, C.POINTER(State18), C.POINTER(State18)]),
+    "fl_lio_iterate18": (C.c_int32, [_H, C.c_int32, C.c_int32, C.POINTER(IterInfo)]),
+    "fl_lio_finish18": (C.c_int32, [_H, C.POINTER(State18)]),
+    "fl_lio_get_state18": (C.c_int32, [_H, C.POINTER(State18)]),
+    "fl_lio_frame18": (C.c_int32, [_H, C.POINTER(State18), _fp, C.c_int32, KNN_FN, C.c_void_p, C.POINTER(IterInfo)]),
+    "fl_lio_accumulate18": (C.c_int32, [_H, C.c_void_p, C.c_int32]),
+    "fl_lio_solve18": (C.c_int32, [_H, C.c_void_p, C.c_int32, C.POINTER(IterInfo)]),
+    "fl_vio_set_frame": (C.c_int32, [_H, _u8p, C.c_int32, C.c_int32, C.c_int32]),
+    "fl_vio_set_patches": (C.c_int32, [_H, _fp, _dp, _i32p, C.c_int32]),
+    "fl_vio_begin": (C.c_int32, [_H, C.POINTER(State18), C.POINTER(State18)]),
+    "fl_vio_update_state": (C.c_int32, [_H, C.c_float, C.c_int32, _fp, C.POINTER(IterInfo)]),
+    "fl_vio_compute_j": (C.c_int32, [_H, C.POINTER(State18), C.POINTER(State18), C.POINTER(IterInfo)]),
+    "fl_vio_get_errors": (C.c_int32, [_H, _fp]),
+    "fl_vio_iterate": (C.c_int32, [_H, C.c_int32, C.c_int32, C.c_int32, C.POINTER(IterInfo)]),
+    "fl_vio_accumulate": (C.c_int32, [_H, C.c_int32, C.c_void_p]),
+    "fl_vio_solve": (C.c_int32, [_H, C.c_void_p, C.c_int32, C.POINTER(IterInfo)]),
+    "fl_vio_get_state18": (C.c_int32, [_H, C.POINTER(State18)]),
+    "fl_ikfom_begin": (C.c_int32, [_H, C.POINTER(State23), _dp, _dp]),
+    "fl_h_share_model_sums": (C.c_int32, [_H, C.POINTER(State23), _dp, _dp, _i32p, _dp]),
+    "fl_h_share_model_rows": (C.c_int32, [_H, C.POINTER(State23), _dp, _dp, _i32p]),
+    "fl_ikfom_iterate": (C.c_int32, [_H, C.c_int32, C.c_int32, C.POINTER(IterInfo)]),
+    "fl_ikfom_get": (C.c_int32, [_H, C.POINTER(State23), _dp]),
+    "fl_ikfom_update_iterated": (C.c_int32, [_H, C.POINTER(State23), _dp, _fp, C.c_int32, C.c_double, _dp, KNN_FN,
+                                             C.c_void_p, C.POINTER(IterInfo)]),
+    "fl_ikfom_accumulate": (C.c_int32, [_H, C.c_void_p, C.c_int32]),
+    "fl_ikfom_solve": (C.c_int32, [_H, C.c_void_p, C.c_int32, C.POINTER(IterInfo)]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libfastlivo_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(PKG_DIR, "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)]
+    srcs.append(os.path.join(os.path.dirname(PKG_DIR), "include", "fastlivo_hip.h"))
+    srcs.append(os.path.join(PKG_DIR, "build.sh"))
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return LIB_PATH
+    subprocess.check_call(["bash", os.path.join(PKG_DIR, "build.sh")])
+    return LIB_PATH
+
+
+def lib():
+    """Load the HIP library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                               "there is no CPU fallback for the ESKF hot path")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)      # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class FlError(RuntimeError):
+    pass
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+def make_config(R_LI, t_LI, Rcl, Pcl, cam, max_iterations=10, laser_point_cov=0.001, img_point_cov=100.0, device=0):
+    c = Config()
+    c.device = device
+    c.max_iterations = max_iterations
+    c.img_width, c.img_height = cam["width"], cam["height"]
+    c.patch_size = 8
+    c.R_LI[:] = np.asarray(R_LI, dtype=np.float64).reshape(9)
+    c.t_LI[:] = np.asarray(t_LI, dtype=np.float64)
+    c.Rcl[:] = np.asarray(Rcl, dtype=np.float64).reshape(9)
+    c.Pcl[:] = np.asarray(Pcl, dtype=np.float64)
+    c.fx, c.fy, c.cx, c.cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+    c.d[:] = cam["d"]
+    c.laser_point_cov = laser_point_cov
+    c.img_point_cov = img_point_cov
+    return c
+
+
+class Handle:
+    """RAII wrapper of fl_handle with numpy-friendly methods (names follow the C ABI)."""
+
+    def __init__(self, cfg: Config):
+        self.L = lib()
+        self.h = _H()
+        self.cfg = cfg
+        st = self.L.fl_create(C.byref(cfg), C.byref(self.h))
+        if st != 0:
+            msg = self.L.fl_last_error_string(None)
+            raise FlError(f"fl_create failed ({st}): {msg.decode() if msg else ''}")
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.L.fl_destroy(self.h)
+            self.h = _H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st, what):
+        if st < 0:
+            msg = self.L.fl_last_error_string(self.h)
+            raise FlError(f"{what} failed ({st}): {msg.decode() if msg else ''}")
+        return st
+
+    # ---- common
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.fl_set_stream(self.h, C.c_void_p(stream_ptr)), "fl_set_stream")
+
+    def sync(self):
+        self._chk(self.L.fl_sync(self.h), "fl_sync")
+
+    def set_timing(self, on):
+        self._chk(self.L.fl_set_timing(self.h, 1 if on else 0), "fl_set_timing")
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._chk(self.L.fl_get_last_kernel_ms(self.h, C.byref(ms)), "fl_get_last_kernel_ms")
+        return ms.value
+
+    # ---- LIO
+    def lio_set_points(self, body):
+        body = np.ascontiguousarray(body, dtype=np.float32)
+        self._chk(self.L.fl_lio_set_points(self.h, _p(body, C.c_float), body.shape[0]), "fl_lio_set_points")
+
+    def lio_set_neighbours(self, nbr, valid):
+        nbr = np.ascontiguousarray(nbr, dtype=np.float32)
+        valid = np.ascontiguousarray(valid, dtype=np.uint8)
+        self._chk(self.L.fl_lio_set_neighbours(self.h, _p(nbr, C.c_float), _p(valid, C.c_uint8), valid.shape[0]),
+                  "fl_lio_set_neighbours")
+
+    def lio_get_selection(self, n):
+        mask = np.zeros(n, dtype=np.uint8)
+        nv = np.zeros((n, 4), dtype=np.float32)
+        self._chk(self.L.fl_lio_get_selection(self.h, _p(mask, C.c_uint8), _p(nv, C.c_float)), "fl_lio_get_selection")
+        return mask, nv
+
+    def lio_get_world_points(self, n):
+        w = np.zeros((n, 3), dtype=np.float32)
+        self._chk(self.L.fl_lio_get_world_points(self.h, _p(w, C.c_float)), "fl_lio_get_world_points")
+        return w
+
+    def lio_begin18(self, state, prop):
+        self._chk(self.L.fl_lio_begin18(self.h, C.byref(state), C.byref(prop)), "fl_lio_begin18")
+
+    def lio_iterate18(self, count=1, flags=0, want_info=True):
+        info = IterInfo()
+        st = self.L.fl_lio_iterate18(self.h, count, flags, C.byref(info) if want_info else None)
+        self._chk(st, "fl_lio_iterate18")
+        return info
+
+    def lio_finish18(self):
+        out = State18()
+        self._chk(self.L.fl_lio_finish18(self.h, C.byref(out)), "fl_lio_finish18")
+        return out
+
+    def lio_get_state18(self):
+        out = State18()
+        self._chk(self.L.fl_lio_get_state18(self.h, C.byref(out)), "fl_lio_get_state18")
+        return out
+
+    def lio_frame18(self, state, body, scene_knn):
+        body = np.ascontiguousarray(body, dtype=np.float32)
+        n = body.shape[0]
+
+        def cb(ctx, world, nn, nbr, valid):
+            w = np.ctypeslib.as_array(world, shape=(nn, 3))
+            nb, va = scene_knn(w)
+            np.ctypeslib.as_array(nbr, shape=(nn, 5, 3))[:] = nb
+            np.ctypeslib.as_array(valid, shape=(nn,))[:] = va
+        cbf = KNN_FN(cb)
+        info = IterInfo()
+        self._chk(self.L.fl_lio_frame18(self.h, C.byref(state), _p(body, C.c_float), n, cbf, None, C.byref(info)),
+                  "fl_lio_frame18")
+        return info
+
+    def lio_accumulate18(self, d_sums_ptr, flags=0):
+        self._chk(self.L.fl_lio_accumulate18(self.h, C.c_void_p(d_sums_ptr), flags), "fl_lio_accumulate18")
+
+    def lio_solve18(self, d_sums_ptr, flags=0, want_info=False):
+        info = IterInfo()
+        self._chk(self.L.fl_lio_solve18(self.h, C.c_void_p(d_sums_ptr), flags, C.byref(info) if want_info else None),
+                  "fl_lio_solve18")
+        return info
+
+    # ---- VIO
+    def vio_set_frame(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        self._chk(self.L.fl_vio_set_frame(self.h, _p(img, C.c_uint8), img.shape[1], img.shape[0], img.shape[1]),
+                  "fl_vio_set_frame")
+
+    def vio_set_patches(self, ref, pos, slevel):
+        ref = np.ascontiguousarray(ref, dtype=np.float32)
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        slevel = np.ascontiguousarray(slevel, dtype=np.int32)
+        self._chk(self.L.fl_vio_set_patches(self.h, _p(ref, C.c_float), _p(pos, C.c_double), _p(slevel, C.c_int32),
+                                            slevel.shape[0]), "fl_vio_set_patches")
+
+    def vio_begin(self, state, prop):
+        self._chk(self.L.fl_vio_begin(self.h, C.byref(state), C.byref(prop)), "fl_vio_begin")
+
+    def vio_update_state(self, total_residual, level):
+        err = C.c_float()
+        info = IterInfo()
+        self._chk(self.L.fl_vio_update_state(self.h, total_residual, level, C.byref(err), C.byref(info)),
+                  "fl_vio_update_state")
+        return err.value, info
+
+    def vio_compute_j(self, state, prop):
+        infos = (IterInfo * 3)()
+        self._chk(self.L.fl_vio_compute_j(self.h, C.byref(state), C.byref(prop), infos), "fl_vio_compute_j")
+        return infos
+
+    def vio_get_errors(self, m):
+        e = np.zeros(m, dtype=np.float32)
+        self._chk(self.L.fl_vio_get_errors(self.h, _p(e, C.c_float)), "fl_vio_get_errors")
+        return e
+
+    def vio_iterate(self, level, count=1, flags=0, want_info=True):
+        info = IterInfo()
+        self._chk(self.L.fl_vio_iterate(self.h, level, count, flags, C.byref(info) if want_info else None),
+                  "fl_vio_iterate")
+        return info
+
+    def vio_accumulate(self, level, d_sums_ptr):
+        self._chk(self.L.fl_vio_accumulate(self.h, level, C.c_void_p(d_sums_ptr)), "fl_vio_accumulate")
+
+    def vio_solve(self, d_sums_ptr, flags=0, want_info=False):
+        info = IterInfo()
+        self._chk(self.L.fl_vio_solve(self.h, C.c_void_p(d_sums_ptr), flags, C.byref(info) if want_info else None),
+                  "fl_vio_solve")
+        return info
+
+    def vio_get_state18(self):
+        out = State18()
+        self._chk(self.L.fl_vio_get_state18(self.h, C.byref(out)), "fl_vio_get_state18")
+        return out
+
+
+def config_from_frames(lio, vio=None, max_iterations=10, device=0):
+    """fl_config for a synthetic frame pair (fast_livo_amd.synth)."""
+    from . import synth
+    cam = vio.cam if vio is not None else dict(synth.PINHOLE, d=(0.0,) * 5)
+    Rcl = vio.Rcl if vio is not None else synth.AVIA_RCL
+    Pcl = vio.Pcl if vio is not None else synth.AVIA_PCL
+    ipc = vio.img_point_cov if vio is not None else synth.IMG_POINT_COV
+    return make_config(lio.R_LI, lio.t_LI, Rcl, Pcl, cam, max_iterations=max_iterations,
+                       laser_point_cov=lio.laser_point_cov, img_point_cov=ipc, device=device)
+
+
+def state18_from_frame(fr, R=None, p=None):
+    return State18.make(fr.R_prior if R is None else R, fr.p_prior if p is None else p,
+                        fr.vel, fr.bg, fr.ba, fr.grav, fr.cov18)

@@ -1,0 +1,459 @@
+// fastlivo_hip.hip -- C ABI (include/fastlivo_hip.h) over the gfx950 ESKF kernels.
+// Built by hipcc --offload-arch=gfx950 -ffp-contract=off into fast-livo_amd/libfastlivo_hip.so.
+// No CPU fallback: every entry point needs a live HIP device and fails loudly otherwise.
+#include "../../include/fastlivo_hip.h"
+
+#include "fl_device.h"
+#include "fl_math.h"
+#include "lio_kernels.h"
+#include "vio_kernels.h"
+#include "ikfom_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#define FL_MAX_BLOCKS 1024
+
+struct fl_context {
+    fl_config cfg;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // LIO
+    float *d_body = nullptr, *d_nbr = nullptr, *d_world = nullptr;
+    uint8_t *d_valid = nullptr, *d_sel = nullptr;
+    float4 *d_plane = nullptr, *d_normvec = nullptr;
+    int cap_points = 0, n = 0;
+    bool have_nbr = false;
+    // 18-state block, reduction scratch
+    FlDev18 *d_dev = nullptr;
+    FlDev18 *h_dev = nullptr;      // pinned mirror
+    double *d_partials = nullptr;
+    unsigned *d_ticket = nullptr;
+    double *d_sums_tmp = nullptr;
+    // VIO
+    FlVioConst *d_vc = nullptr;
+    FlVioConst h_vc;
+    uint8_t *d_img = nullptr;
+    size_t cap_img = 0;
+    float *d_ref = nullptr, *d_errors = nullptr;
+    double *d_pos = nullptr;
+    int32_t *d_slevel = nullptr;
+    int cap_patches = 0, m = 0;
+    bool have_img = false;
+    // Mode-23
+    FlDev23 *d_dev23 = nullptr;
+    FlDev23 *h_dev23 = nullptr;
+    // misc
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = false;
+    float last_ms = 0.f;
+    int last_launches = 0;
+    std::string err;
+};
+
+static thread_local std::string g_err;
+
+#define HIPCHK(h, call)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            char b_[512];                                                                          \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            if (h) (h)->err = b_; else g_err = b_;                                                 \
+            return FL_ERR_HIP;                                                                     \
+        }                                                                                          \
+    } while (0)
+
+static int32_t fail_arg(fl_handle h, const char *msg)
+{
+    if (h) h->err = msg; else g_err = msg;
+    return FL_ERR_ARG;
+}
+
+// lidar_selection.cpp:35-59 (set_extrinsic + init): constants of the photometric Jacobian chain.
+static void build_vio_const(const fl_config &c, FlVioConst &v)
+{
+    auto mul = [](const double *A, const double *B, double *C) {
+        double T[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) T[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+        memcpy(C, T, sizeof T);
+    };
+    auto mv = [](const double *A, const double *x, double *o) {
+        double t[3];
+        for (int i = 0; i < 3; i++) t[i] = A[i * 3] * x[0] + A[i * 3 + 1] * x[1] + A[i * 3 + 2] * x[2];
+        memcpy(o, t, sizeof t);
+    };
+    double Rli[9], Pli[3], t[3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Rli[i * 3 + j] = c.R_LI[j * 3 + i];
+    mv(Rli, c.t_LI, t);
+    for (int i = 0; i < 3; i++) Pli[i] = -t[i];
+    mul(c.Rcl, Rli, v.Rci);
+    mv(c.Rcl, Pli, v.Pci);
+    for (int i = 0; i < 3; i++) v.Pci[i] += c.Pcl[i];
+    memcpy(v.Jdphi_dR, v.Rci, sizeof v.Rci);
+    double nRt[9], Pic[3], K[9], nR[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) nRt[i * 3 + j] = -v.Rci[j * 3 + i];
+    mv(nRt, v.Pci, Pic);
+    K[0] = 0; K[1] = -Pic[2]; K[2] = Pic[1]; K[3] = Pic[2]; K[4] = 0; K[5] = -Pic[0]; K[6] = -Pic[1]; K[7] = Pic[0]; K[8] = 0;
+    for (int i = 0; i < 9; i++) nR[i] = -v.Rci[i];
+    mul(nR, K, v.Jdp_dR);
+    v.fx_abs = fabs(c.fx);
+    v.fy_abs = fabs(4.0 * c.fx * c.fy) / (4. * v.fx_abs);
+    v.fx = c.fx; v.fy = c.fy; v.cx = c.cx; v.cy = c.cy;
+    for (int i = 0; i < 5; i++) v.d[i] = c.d[i];
+    v.width = c.img_width; v.height = c.img_height; v.stride = c.img_width;
+    v.distort = (fabs(c.d[0]) > 0.0000001) ? 1 : 0;
+}
+
+extern "C" {
+
+int32_t fl_create(const fl_config *cfg, fl_handle *out)
+{
+    if (!cfg || !out) return fail_arg(nullptr, "fl_create: null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_err = "fl_create: no HIP device visible (this library has no CPU path)";
+        return FL_ERR_NODEVICE;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) return fail_arg(nullptr, "fl_create: bad device ordinal");
+    if (cfg->patch_size != 8) return fail_arg(nullptr, "fl_create: patch_size must be 8");
+    fl_context *h = new fl_context();
+    h->cfg = *cfg;
+    HIPCHK(h, hipSetDevice(cfg->device));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    HIPCHK(h, hipMalloc(&h->d_dev, sizeof(FlDev18)));
+    HIPCHK(h, hipHostMalloc(&h->h_dev, sizeof(FlDev18)));
+    HIPCHK(h, hipMalloc(&h->d_dev23, sizeof(FlDev23)));
+    HIPCHK(h, hipHostMalloc(&h->h_dev23, sizeof(FlDev23)));
+    HIPCHK(h, hipMalloc(&h->d_partials, sizeof(double) * FL_MAX_BLOCKS * FL_SUMS23));
+    HIPCHK(h, hipMalloc(&h->d_ticket, 64));
+    HIPCHK(h, hipMalloc(&h->d_sums_tmp, sizeof(double) * FL_SUMS23));
+    HIPCHK(h, hipMalloc(&h->d_vc, sizeof(FlVioConst)));
+    HIPCHK(h, hipMemset(h->d_ticket, 0, 64));
+    HIPCHK(h, hipMemset(h->d_dev, 0, sizeof(FlDev18)));
+    HIPCHK(h, hipMemset(h->d_dev23, 0, sizeof(FlDev23)));
+    build_vio_const(h->cfg, h->h_vc);
+    HIPCHK(h, hipMemcpy(h->d_vc, &h->h_vc, sizeof(FlVioConst), hipMemcpyHostToDevice));
+    HIPCHK(h, hipEventCreate(&h->ev0));
+    HIPCHK(h, hipEventCreate(&h->ev1));
+    *out = h;
+    return FL_OK;
+}
+
+int32_t fl_destroy(fl_handle h)
+{
+    if (!h) return FL_OK;
+    hipSetDevice(h->cfg.device);
+    hipStreamSynchronize(h->stream);
+    hipFree(h->d_body); hipFree(h->d_nbr); hipFree(h->d_world); hipFree(h->d_valid); hipFree(h->d_sel);
+    hipFree(h->d_plane); hipFree(h->d_normvec); hipFree(h->d_dev); hipFree(h->d_dev23); hipFree(h->d_partials);
+    hipFree(h->d_ticket); hipFree(h->d_sums_tmp); hipFree(h->d_vc); hipFree(h->d_img); hipFree(h->d_ref);
+    hipFree(h->d_errors); hipFree(h->d_pos); hipFree(h->d_slevel);
+    if (h->h_dev) hipHostFree(h->h_dev);
+    if (h->h_dev23) hipHostFree(h->h_dev23);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    delete h;
+    return FL_OK;
+}
+
+const char *fl_last_error_string(fl_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int32_t fl_set_stream(fl_handle h, void *s)
+{
+    if (!h) return fail_arg(nullptr, "null handle");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->stream = (hipStream_t)s;   // exactly the caller's stream; NULL is HIP's default (null) stream
+    return FL_OK;
+}
+
+int32_t fl_sync(fl_handle h)
+{
+    if (!h) return fail_arg(nullptr, "null handle");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return FL_OK;
+}
+
+int32_t fl_set_timing(fl_handle h, int32_t enable)
+{
+    if (!h) return fail_arg(nullptr, "null handle");
+    h->timing = enable != 0;
+    return FL_OK;
+}
+
+int32_t fl_get_last_kernel_ms(fl_handle h, float *ms)
+{
+    if (!h || !ms) return fail_arg(h, "null argument");
+    HIPCHK(h, hipEventSynchronize(h->ev1));
+    HIPCHK(h, hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    *ms = h->last_ms;
+    return FL_OK;
+}
+
+// ------------------------------------------------------------------------------------------ LIO
+static int32_t ensure_points(fl_handle h, int n)
+{
+    if (n <= h->cap_points) return FL_OK;
+    int cap = h->cap_points ? h->cap_points : 4096;
+    while (cap < n) cap *= 2;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    hipFree(h->d_body); hipFree(h->d_nbr); hipFree(h->d_world); hipFree(h->d_valid); hipFree(h->d_sel);
+    hipFree(h->d_plane); hipFree(h->d_normvec);
+    h->d_body = h->d_nbr = h->d_world = nullptr; h->d_valid = h->d_sel = nullptr; h->d_plane = h->d_normvec = nullptr;
+    h->cap_points = 0;
+    HIPCHK(h, hipMalloc(&h->d_body, sizeof(float) * 3 * (size_t)cap));
+    HIPCHK(h, hipMalloc(&h->d_nbr, sizeof(float) * 15 * (size_t)cap));
+    HIPCHK(h, hipMalloc(&h->d_world, sizeof(float) * 3 * (size_t)cap));
+    HIPCHK(h, hipMalloc(&h->d_valid, (size_t)cap));
+    HIPCHK(h, hipMalloc(&h->d_sel, (size_t)cap));
+    HIPCHK(h, hipMalloc(&h->d_plane, sizeof(float4) * (size_t)cap));
+    HIPCHK(h, hipMalloc(&h->d_normvec, sizeof(float4) * (size_t)cap));
+    h->cap_points = cap;
+    return FL_OK;
+}
+
+static inline int lio_grid(int n)
+{
+    int b = (n + FL_BLOCK - 1) / FL_BLOCK;
+    if (b < 1) b = 1;
+    return b > FL_MAX_BLOCKS ? FL_MAX_BLOCKS : b;
+}
+
+int32_t fl_lio_set_points(fl_handle h, const float *body_xyz, int32_t n)
+{
+    if (!h || !body_xyz || n <= 0) return fail_arg(h, "fl_lio_set_points: bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int32_t st = ensure_points(h, n);
+    if (st) return st;
+    h->n = n;
+    h->have_nbr = false;
+    HIPCHK(h, hipMemcpyAsync(h->d_body, body_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_sel, 0, (size_t)n, h->stream));
+    return FL_OK;
+}
+
+int32_t fl_lio_set_neighbours(fl_handle h, const float *nbr_xyz, const uint8_t *valid, int32_t n)
+{
+    if (!h || !nbr_xyz || !valid) return fail_arg(h, "fl_lio_set_neighbours: null argument");
+    if (n != h->n || n <= 0) return fail_arg(h, "fl_lio_set_neighbours: n differs from fl_lio_set_points");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(h->d_nbr, nbr_xyz, sizeof(float) * 15 * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_valid, valid, (size_t)n, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(lio_fit_planes_kernel, dim3((n + FL_BLOCK - 1) / FL_BLOCK), dim3(FL_BLOCK), 0, h->stream,
+                       h->d_nbr, h->d_valid, h->d_plane, h->d_sel, n);
+    HIPCHK(h, hipGetLastError());
+    // the search pass is done: nearest_search_en = false for the passes that follow
+    HIPCHK(h, hipMemsetAsync((char *)h->d_dev + offsetof(FlDev18, need_search), 0, sizeof(int32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync((char *)h->d_dev23 + offsetof(FlDev23, need_search), 0, sizeof(int32_t), h->stream));
+    h->have_nbr = true;
+    return FL_OK;
+}
+
+int32_t fl_lio_get_selection(fl_handle h, uint8_t *mask, float *normvec)
+{
+    if (!h || h->n <= 0) return fail_arg(h, "fl_lio_get_selection: no points");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int n = h->n;
+    std::vector<float> nv((size_t)n * 4);
+    std::vector<uint8_t> sel((size_t)n);
+    HIPCHK(h, hipMemcpyAsync(nv.data(), h->d_normvec, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(sel.data(), h->d_sel, (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; i++) {
+        // effective = point_selected_surf && res_last <= 2.0 (laserMapping.cpp:1593)
+        if (mask) mask[i] = (uint8_t)(sel[i] && ((double)fabsf(nv[(size_t)i * 4 + 3]) <= 2.0));
+        if (normvec) {
+            if (sel[i]) memcpy(normvec + (size_t)i * 4, nv.data() + (size_t)i * 4, sizeof(float) * 4);
+            else memset(normvec + (size_t)i * 4, 0, sizeof(float) * 4);
+        }
+    }
+    return FL_OK;
+}
+
+int32_t fl_lio_get_world_points(fl_handle h, float *world_xyz)
+{
+    if (!h || !world_xyz || h->n <= 0) return fail_arg(h, "fl_lio_get_world_points: bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(lio_world_points_kernel, dim3((h->n + FL_BLOCK - 1) / FL_BLOCK), dim3(FL_BLOCK), 0, h->stream,
+                       h->d_body, h->d_world, h->n, h->d_dev);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(world_xyz, h->d_world, sizeof(float) * 3 * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return FL_OK;
+}
+
+static void pack_state18(const fl_state18 *s, double *x24)
+{
+    memcpy(x24, s->rot, sizeof(double) * 9);
+    memcpy(x24 + 9, s->pos, sizeof(double) * 3);
+    memcpy(x24 + 12, s->vel, sizeof(double) * 3);
+    memcpy(x24 + 15, s->bg, sizeof(double) * 3);
+    memcpy(x24 + 18, s->ba, sizeof(double) * 3);
+    memcpy(x24 + 21, s->grav, sizeof(double) * 3);
+}
+static void unpack_state18(const double *x24, const double *P, fl_state18 *s)
+{
+    memcpy(s->rot, x24, sizeof(double) * 9);
+    memcpy(s->pos, x24 + 9, sizeof(double) * 3);
+    memcpy(s->vel, x24 + 12, sizeof(double) * 3);
+    memcpy(s->bg, x24 + 15, sizeof(double) * 3);
+    memcpy(s->ba, x24 + 18, sizeof(double) * 3);
+    memcpy(s->grav, x24 + 21, sizeof(double) * 3);
+    memcpy(s->cov, P, sizeof(double) * 324);
+}
+
+static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_state18 *prop, double meas_cov)
+{
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // h_dev is reused
+    FlDev18 *D = h->h_dev;
+    memset(D, 0, sizeof(FlDev18));
+    pack_state18(state, D->x);
+    pack_state18(prop, D->xprop);
+    memcpy(D->xold, D->x, sizeof D->x);
+    memcpy(D->P, state->cov, sizeof(double) * 324);
+    memcpy(D->R_LI, h->cfg.R_LI, sizeof(double) * 9);
+    memcpy(D->t_LI, h->cfg.t_LI, sizeof(double) * 3);
+    D->meas_cov = meas_cov;
+    D->iterCount = -1;
+    D->rematch_num = 0;
+    D->need_search = 1;
+    D->stop = 0;
+    D->max_iter = h->cfg.max_iterations;
+    D->last_error = 1e10f;
+    HIPCHK(h, hipMemcpyAsync(h->d_dev, D, sizeof(FlDev18), hipMemcpyHostToDevice, h->stream));
+    return FL_OK;
+}
+
+int32_t fl_lio_begin18(fl_handle h, const fl_state18 *state, const fl_state18 *prop)
+{
+    if (!h || !state || !prop) return fail_arg(h, "fl_lio_begin18: null argument");
+    int32_t st = begin18_common(h, state, prop, h->cfg.laser_point_cov);
+    if (st) return st;
+    if (h->have_nbr)  // neighbours staged before begin (benchmark order): the search pass is done
+        HIPCHK(h, hipMemsetAsync((char *)h->d_dev + offsetof(FlDev18, need_search), 0, sizeof(int32_t), h->stream));
+    return FL_OK;
+}
+
+static int32_t read_info18(fl_handle h, fl_iter_info *info)
+{
+    HIPCHK(h, hipMemcpyAsync(h->h_dev, h->d_dev, sizeof(FlDev18), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!info) return FL_OK;
+    const FlDev18 *D = h->h_dev;
+    memset(info, 0, sizeof *info);
+    memcpy(info->solution, D->solution, sizeof(double) * 18);
+    info->total_residual = D->total_residual;
+    info->effct_feat_num = D->neff;
+    info->converged = D->converged;
+    info->status = D->status;
+    info->iterations = D->iters_run;
+    info->need_search = D->need_search;
+    info->stop = D->stop;
+    info->accepted = D->accepted;
+    return FL_OK;
+}
+
+int32_t fl_lio_iterate18(fl_handle h, int32_t count, int32_t flags, fl_iter_info *info)
+{
+    if (!h || count < 0) return fail_arg(h, "fl_lio_iterate18: bad argument");
+    if (h->n <= 0 || !h->have_nbr) return fail_arg(h, "fl_lio_iterate18: points/neighbours not staged");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int grid = lio_grid(h->n);
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < count; i++)
+        hipLaunchKernelGGL(lio18_iterate_kernel<0>, dim3(grid), dim3(FL_BLOCK), 0, h->stream, h->d_body, h->d_plane, h->d_sel,
+                           h->d_normvec, h->n, h->d_dev, h->d_partials, h->d_ticket, (double *)nullptr, (int)flags);
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipGetLastError());
+    h->last_launches = count;
+    if (info) return read_info18(h, info);
+    return FL_OK;
+}
+
+int32_t fl_lio_get_state18(fl_handle h, fl_state18 *out)
+{
+    if (!h || !out) return fail_arg(h, "fl_lio_get_state18: null argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int32_t st = read_info18(h, nullptr);
+    if (st) return st;
+    unpack_state18(h->h_dev->x, h->h_dev->P, out);
+    return FL_OK;
+}
+
+int32_t fl_lio_finish18(fl_handle h, fl_state18 *out)
+{
+    if (!h) return fail_arg(h, "fl_lio_finish18: null handle");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(eskf18_cov_update_kernel, dim3(1), dim3(384), 0, h->stream, h->d_dev);
+    HIPCHK(h, hipGetLastError());
+    if (out) return fl_lio_get_state18(h, out);
+    return FL_OK;
+}
+
+int32_t fl_lio_frame18(fl_handle h, fl_state18 *state_io, const float *body_xyz, int32_t n, fl_knn_fn knn, void *knn_ctx,
+                       fl_iter_info *info)
+{
+    if (!h || !state_io || !body_xyz || !knn || n <= 0) return fail_arg(h, "fl_lio_frame18: bad argument");
+    int32_t st;
+    if ((st = fl_lio_set_points(h, body_xyz, n))) return st;
+    if ((st = fl_lio_begin18(h, state_io, state_io))) return st;   // state_propagat = state (:1292)
+    std::vector<float> world((size_t)n * 3), nbr((size_t)n * 15);
+    std::vector<uint8_t> valid((size_t)n);
+    fl_iter_info li;
+    memset(&li, 0, sizeof li);
+    const int total = h->cfg.max_iterations + 1;       // iterCount = -1 .. max-1
+    int acc_status = 0;
+    while (li.iterations < total) {
+        // nearest_search_en: transform at the current state, search on the host, restage (:1527-1549)
+        if ((st = fl_lio_get_world_points(h, world.data()))) return st;
+        knn(knn_ctx, world.data(), n, nbr.data(), valid.data());
+        if ((st = fl_lio_set_neighbours(h, nbr.data(), valid.data(), n))) return st;
+        if ((st = fl_lio_iterate18(h, total - li.iterations, FL_ITER_KEEP_NORMVEC, &li))) return st;
+        acc_status |= li.status;
+        if (li.stop || !li.need_search) break;
+    }
+    if ((st = fl_lio_finish18(h, state_io))) return st;
+    if (info) { *info = li; info->status = acc_status; }
+    return FL_OK;
+}
+
+int32_t fl_lio_accumulate18(fl_handle h, double *d_sums, int32_t flags)
+{
+    if (!h || !d_sums) return fail_arg(h, "fl_lio_accumulate18: null argument");
+    if (h->n <= 0 || !h->have_nbr) return fail_arg(h, "fl_lio_accumulate18: points/neighbours not staged");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(lio18_iterate_kernel<1>, dim3(lio_grid(h->n)), dim3(FL_BLOCK), 0, h->stream, h->d_body, h->d_plane,
+                       h->d_sel, h->d_normvec, h->n, h->d_dev, h->d_partials, h->d_ticket, d_sums, (int)flags);
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipGetLastError());
+    return FL_OK;
+}
+
+int32_t fl_lio_solve18(fl_handle h, const double *d_sums, int32_t flags, fl_iter_info *info)
+{
+    if (!h || !d_sums) return fail_arg(h, "fl_lio_solve18: null argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(eskf18_solve_kernel, dim3(1), dim3(64), 0, h->stream, h->d_dev, d_sums, 1.0, 0, (int)flags);
+    HIPCHK(h, hipGetLastError());
+    if (info) return read_info18(h, info);
+    return FL_OK;
+}
+
+#include "api_vio.inc"
+#include "api_ikfom.inc"
+
+}  // extern "C"

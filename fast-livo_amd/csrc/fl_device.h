@@ -1,0 +1,232 @@
+// fl_device.h -- device-side data layout and small math for the gfx950 ESKF kernels.
+//
+// All code in csrc/ is compiled with -ffp-contract=off: the float part of the measurement model
+// (world point, plane fit, pd2, gates) must round exactly like the reference's x86-64 build, which
+// has no FMA (CMakeLists.txt:8 has no -march), because the selection gates are discontinuous.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FL_WAVE 64
+#define FL_BLOCK 256
+#define FL_SUMS18 32
+#define FL_SUMS23 96
+
+// Reduction record layout (Mode-18 and VIO), FL_SUMS18 doubles:
+//   [0..20]  upper triangle of the 6x6 H^T H, row-major (i<=j)
+//   [21..26] H^T z
+//   [27]     number of effective measurements
+//   [28]     LIO: sum |pd2|            VIO: sum res^2
+//   [29]     LIO: sum pd2^2            VIO: unused
+//   [30..31] zero
+#define FL_S_HTZ 21
+#define FL_S_NEFF 27
+#define FL_S_RES 28
+#define FL_S_RES2 29
+
+// Device-resident block for the 18-state filter (one per handle, in HBM, ~6 KB).
+struct FlDev18 {
+    double x[24];       // rot(9, row-major) pos vel bg ba grav : current state
+    double xprop[24];   // state_propagat
+    double xold[24];    // VIO old_state (lidar_selection.cpp:747,863)
+    double P[324];      // state.cov (constant during the iterations of a frame)
+    double G6[108];     // G.block<18,6>(0,0), 18x6 row-major
+    double R_LI[9];
+    double t_LI[3];
+    double solution[24];
+    double sums[FL_SUMS18];
+    double total_residual;
+    double meas_cov;    // LASER_POINT_COV or IMG_POINT_COV
+    float last_error;   // VIO
+    float error;        // VIO
+    int32_t iterCount;  // LIO loop counter (starts at -1)
+    int32_t rematch_num;
+    int32_t need_search;
+    int32_t stop;
+    int32_t converged;
+    int32_t neff;
+    int32_t status;
+    int32_t iters_run;
+    int32_t accepted;
+    int32_t max_iter;
+    int32_t level;      // VIO pyramid level of the current UpdateState
+    int32_t pad;
+};
+
+// VIO constants (lidar_selection.cpp:35-59 + camera), computed on the host once per handle.
+struct FlVioConst {
+    double Rci[9], Pci[3], Jdphi_dR[9], Jdp_dR[9];
+    double fx_abs, fy_abs;          // errorMultiplier2(), errorMultiplier()/(4 fx)
+    double fx, fy, cx, cy, d[5];    // projection (world2cam)
+    int32_t width, height, stride, distort;
+};
+
+// ---- 3x3 helpers (row-major, double) --------------------------------------------------------
+__device__ __forceinline__ void m3_vec(const double *A, const double *v, double *o)
+{
+    double t0 = A[0] * v[0] + A[1] * v[1] + A[2] * v[2];
+    double t1 = A[3] * v[0] + A[4] * v[1] + A[5] * v[2];
+    double t2 = A[6] * v[0] + A[7] * v[1] + A[8] * v[2];
+    o[0] = t0; o[1] = t1; o[2] = t2;
+}
+__device__ __forceinline__ void m3t_vec(const double *A, const double *v, double *o)
+{
+    double t0 = A[0] * v[0] + A[3] * v[1] + A[6] * v[2];
+    double t1 = A[1] * v[0] + A[4] * v[1] + A[7] * v[2];
+    double t2 = A[2] * v[0] + A[5] * v[1] + A[8] * v[2];
+    o[0] = t0; o[1] = t1; o[2] = t2;
+}
+__device__ __forceinline__ void m3_mul(const double *A, const double *B, double *C)
+{
+    double T[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            T[i * 3 + j] = A[i * 3 + 0] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; i++) C[i] = T[i];
+}
+__device__ __forceinline__ void m3_tr(const double *A, double *T)
+{
+    double t[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) t[j * 3 + i] = A[i * 3 + j];
+#pragma unroll
+    for (int i = 0; i < 9; i++) T[i] = t[i];
+}
+__device__ __forceinline__ void skew3(const double *v, double *K)
+{
+    K[0] = 0.0;   K[1] = -v[2]; K[2] = v[1];
+    K[3] = v[2];  K[4] = 0.0;   K[5] = -v[0];
+    K[6] = -v[1]; K[7] = v[0];  K[8] = 0.0;
+}
+// Exp(v1,v2,v3), so3_math.h:54-72
+__device__ __forceinline__ void so3_Exp(double v1, double v2, double v3, double *R)
+{
+    double nrm = sqrt(v1 * v1 + v2 * v2 + v3 * v3);
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    if (nrm > 0.00001) {
+        double r[3] = {v1 / nrm, v2 / nrm, v3 / nrm};
+        double K[9], KK[9];
+        skew3(r, K);
+        m3_mul(K, K, KK);
+        double s = sin(nrm), c = 1.0 - cos(nrm);
+#pragma unroll
+        for (int i = 0; i < 9; i++) R[i] = R[i] + s * K[i] + c * KK[i];
+    }
+}
+// Log(R), so3_math.h:75-81
+__device__ __forceinline__ void so3_Log(const double *R, double *out)
+{
+    double tr = R[0] + R[4] + R[8];
+    double theta = (tr > 3.0 - 1e-6) ? 0.0 : acos(0.5 * (tr - 1));
+    double K0 = R[7] - R[5], K1 = R[2] - R[6], K2 = R[3] - R[1];
+    double f = (fabs(theta) < 0.001) ? 0.5 : (0.5 * theta / sin(theta));
+    out[0] = f * K0; out[1] = f * K1; out[2] = f * K2;
+}
+
+// ---- wavefront reduction --------------------------------------------------------------------
+// Transposing butterfly: every lane enters with V partial sums; on exit lane L holds in v[0] the
+// wave-wide total of value (L >> 1) (both lanes of a pair hold the same total). V must be 32.
+// 32 exchanges instead of the 32 x 6 of an independent butterfly per value.
+template <int HALF, int MASK>
+__device__ __forceinline__ void wave_transpose_step(double (&v)[32], int lane)
+{
+    const bool upper = (lane & MASK) != 0;
+#pragma unroll
+    for (int i = 0; i < HALF; i++) {
+        const double send = upper ? v[i] : v[i + HALF];
+        const double keep = upper ? v[i + HALF] : v[i];
+        v[i] = keep + __shfl_xor(send, MASK, FL_WAVE);
+    }
+}
+__device__ __forceinline__ void wave_transpose_reduce32(double (&v)[32], int lane)
+{
+    wave_transpose_step<16, 32>(v, lane);
+    wave_transpose_step<8, 16>(v, lane);
+    wave_transpose_step<4, 8>(v, lane);
+    wave_transpose_step<2, 4>(v, lane);
+    wave_transpose_step<1, 2>(v, lane);
+    v[0] = v[0] + __shfl_xor(v[0], 1, FL_WAVE);
+}
+
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, FL_WAVE);
+    return x;
+}
+
+// Write-through (sc1) 8-byte store / L1-bypassing load: the cross-workgroup hand-off form of
+// cdna_hip_programming.md Guideline 16 (R1) -- no release/acquire fence needed.
+__device__ __forceinline__ void store_wt(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_wt(const double *p)
+{
+    unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+    return __longlong_as_double((long long)u);
+}
+
+// Block-level reduction of per-thread partial sums and publication of this workgroup's record.
+// Returns true in EVERY thread of the last-arriving workgroup, which then owns the final reduce.
+// `partials` holds gridDim.x records of NV doubles; the order of the final sum is by block index,
+// so results do not depend on arrival order.
+template <int NV>
+__device__ __forceinline__ bool block_publish(double (&v)[NV], double *partials, unsigned *ticket, double *lds /* >= 4*NV */)
+{
+    static_assert(NV % 32 == 0, "NV multiple of 32");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int g = 0; g < NV / 32; g++) {
+        double w[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++) w[i] = v[g * 32 + i];
+        wave_transpose_reduce32(w, lane);
+        if ((lane & 1) == 0) lds[wave * NV + g * 32 + (lane >> 1)] = w[0];
+    }
+    __syncthreads();
+    if (tid < NV) {
+        double s = lds[tid];
+#pragma unroll
+        for (int w = 1; w < FL_BLOCK / 64; w++) s += lds[w * NV + tid];
+        store_wt(&partials[(size_t)blockIdx.x * NV + tid], s);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ unsigned s_ticket;
+    if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    return s_ticket == gridDim.x - 1;
+}
+
+// Final reduce by the last workgroup: sums[k] = sum over blocks (ascending) of partials[b][k].
+template <int NV>
+__device__ __forceinline__ void final_reduce(const double *partials, int nblocks, double *lds /* >= FL_BLOCK */, double *out_lds /* NV */)
+{
+    const int tid = threadIdx.x;
+    constexpr int GROUPS = FL_BLOCK / 32;       // 8 block-groups x 32 values per pass
+#pragma unroll
+    for (int g = 0; g < NV / 32; g++) {
+        const int k = g * 32 + (tid & 31), grp = tid >> 5;
+        double s = 0.0;
+        for (int b = grp; b < nblocks; b += GROUPS) s += load_wt(&partials[(size_t)b * NV + k]);
+        lds[tid] = s;
+        __syncthreads();
+        if (tid < 32) {
+            double t = lds[tid];
+#pragma unroll
+            for (int j = 1; j < GROUPS; j++) t += lds[j * 32 + tid];
+            out_lds[g * 32 + tid] = t;
+        }
+        __syncthreads();
+    }
+}

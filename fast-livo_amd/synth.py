@@ -166,8 +166,9 @@ def _spd(rng, n, base, pert):
 
 
 def make_lio_frame(n, seed=SEED, scene=None, t_LI=AVIA_T_LI, R_LI=AVIA_R_LI, scan_noise=0.01,
-                   rot_pert_deg=0.5, pos_pert=0.02):
-    rng = np.random.default_rng(seed + 1)
+                   rot_pert_deg=0.5, pos_pert=0.02, point_seed=None):
+    """point_seed varies only the scan points (shards of one frame share pose, prior and covariance)."""
+    rng = np.random.default_rng(seed + 1 if point_seed is None else point_seed)
     scene = scene or make_scene(seed)
     R_true = exp_so3(np.array([0.03, -0.02, 0.4]))
     p_true = np.array([0.8, -0.5, 1.6])
@@ -180,6 +181,7 @@ def make_lio_frame(n, seed=SEED, scene=None, t_LI=AVIA_T_LI, R_LI=AVIA_R_LI, sca
     p_imu = (pts - p_true) @ R_true                      # R^T (p_w - p)
     body = (p_imu - t_LI) @ R_LI                         # R_LI^T (p_i - t_LI)
     body = body.astype(np.float32)
+    rng = np.random.default_rng(seed + 1000)      # state / prior stream, independent of the points
     drot = np.deg2rad(rng.uniform(-rot_pert_deg, rot_pert_deg, 3))
     dpos = rng.uniform(-pos_pert, pos_pert, 3)
     R_prior = R_true @ exp_so3(drot)
@@ -282,8 +284,9 @@ def sample_patches(img, pc, scale, patch=8):
 
 
 def make_vio_frame(m, lio: LioFrame, seed=SEED, cam=None, Rcl=AVIA_RCL, Pcl=AVIA_PCL, distortion=False,
-                   ref_noise=2.0, img_point_cov=IMG_POINT_COV, max_iterations=10):
-    rng = np.random.default_rng(seed + 3)
+                   ref_noise=2.0, img_point_cov=IMG_POINT_COV, max_iterations=10, patch_seed=None):
+    """patch_seed varies only the patch set (the image and camera are shared by all shards)."""
+    rng = np.random.default_rng(seed + 3 if patch_seed is None else patch_seed)
     cam = dict(cam or PINHOLE)
     if not distortion:
         cam["d"] = (0.0, 0.0, 0.0, 0.0, 0.0)

@@ -1,0 +1,216 @@
+/*
+ * include/fastlivo_hip.h -- C ABI of libfastlivo_hip.so, the MI355X (gfx950) implementation of
+ * FAST-LIVO's per-frame residual/Jacobian assembly + iterated error-state Kalman update.
+ *
+ * Drop-in boundary.  Every entry point names the reference code whose body
+ * it replaces (paths relative to the reference tree, snapshot 2024-11-08).  The reference-side
+ * bindings (what a maintainer pastes into laserMapping.cpp / lidar_selection.cpp) are shown in
+ * INTEGRATION.md and compiled against mock Eigen-free types in fast-livo_amd/host/.
+ *
+ * Conventions: plain C types only; all matrices row-major doubles; caller owns every host
+ * pointer and the library retains none past the call; the library owns all device memory; a
+ * handle is NOT thread-safe (one per caller thread, like the reference's single main thread,
+ * src/laserMapping.cpp:1260-1264); every call returns an int32 status (0 ok, <0 HIP/usage
+ * error, >0 numerical) and never throws.  There is no CPU fallback: without a HIP device
+ * fl_create fails.
+ */
+#ifndef FASTLIVO_HIP_H
+#define FASTLIVO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FL_OK 0
+#define FL_ERR_HIP (-1)       /* a HIP runtime call failed (see fl_last_error_string) */
+#define FL_ERR_ARG (-2)       /* bad argument / call order */
+#define FL_ERR_NODEVICE (-3)  /* no usable gfx950 device */
+#define FL_NUM_SINGULAR 1     /* gain solve met a zero pivot */
+#define FL_NUM_NONFINITE 2    /* NaN/Inf in the state delta */
+#define FL_NUM_FEWPOINTS 4    /* no effective measurement */
+
+#define FL_DIM18 18           /* DIM_STATE, include/common_lib.h:34 */
+#define FL_DIM23 23           /* state_ikfom::DOF, include/use-ikfom.hpp:12-21 */
+#define FL_NUM_MATCH_POINTS 5 /* include/common_lib.h:39 */
+#define FL_SUMS18 32          /* doubles in a Mode-18 / VIO reduction record */
+#define FL_SUMS23 96          /* doubles in a Mode-23 reduction record */
+
+typedef struct fl_context *fl_handle;
+
+/* Run-time parameters the path reads (src/laserMapping.cpp:1096-1137 readParameters,
+ * src/lidar_selection.cpp:35-59 init/set_extrinsic, config/ yaml files). */
+typedef struct fl_config {
+    int32_t device;           /* HIP device ordinal */
+    int32_t max_iterations;   /* NUM_MAX_ITERATIONS ("max_iteration") */
+    int32_t img_width, img_height;
+    int32_t patch_size;       /* must be 8 ("patch_size") */
+    int32_t reserved0;
+    double R_LI[9], t_LI[3];  /* Lidar_rot_to_IMU / Lidar_offset_to_IMU ("mapping/extrinsic_R,T") */
+    double Rcl[9], Pcl[3];    /* "camera/Rcl", "camera/Pcl" */
+    double fx, fy, cx, cy;    /* cam_fx .. cam_cy */
+    double d[5];              /* cam_d0..d3 (+k3): radtan distortion of vk::PinholeCamera; 0 = off */
+    double laser_point_cov;   /* LASER_POINT_COV */
+    double img_point_cov;     /* IMG_POINT_COV */
+} fl_config;
+
+/* StatesGroup (include/common_lib.h:296-381). */
+typedef struct fl_state18 {
+    double rot[9];  /* rot_end, row-major */
+    double pos[3];  /* pos_end */
+    double vel[3];  /* vel_end */
+    double bg[3];   /* bias_g */
+    double ba[3];   /* bias_a */
+    double grav[3]; /* gravity */
+    double cov[FL_DIM18 * FL_DIM18];
+} fl_state18;
+
+/* state_ikfom (include/use-ikfom.hpp:12-21); quaternions in Eigen coeffs order x,y,z,w. */
+typedef struct fl_state23 {
+    double pos[3];
+    double rot[4];
+    double offset_R_L_I[4];
+    double offset_T_L_I[3];
+    double vel[3];
+    double bg[3];
+    double ba[3];
+    double grav[3];           /* S2 of length 9.809 */
+} fl_state23;
+
+/* What one ESKF iteration reports back (the reference keeps these in globals:
+ * effct_feat_num, total_residual, flg_EKF_converged, solution; laserMapping.cpp:1588-1695). */
+typedef struct fl_iter_info {
+    double solution[FL_DIM23];  /* state delta applied (18 used in Mode-18 / VIO) */
+    double total_residual;      /* LIO: sum |pd2| ; VIO: mean squared photometric error */
+    int32_t effct_feat_num;     /* LIO: effective points ; VIO: n_meas_ */
+    int32_t converged;          /* LIO: flg_EKF_converged ; VIO: EKF_end */
+    int32_t status;             /* FL_OK or FL_NUM_* bits */
+    int32_t iterations;         /* iterations executed so far in this frame / level */
+    int32_t need_search;        /* LIO: nearest_search_en for the next pass */
+    int32_t stop;               /* LIO: EKF_stop_flg */
+    int32_t accepted;           /* VIO: accepted (error <= last_error) solves at this level */
+    int32_t reserved;
+} fl_iter_info;
+
+/* ------------------------------------------------------------------------------------------------
+ * Common
+ * ---------------------------------------------------------------------------------------------- */
+int32_t fl_create(const fl_config *cfg, fl_handle *out);
+int32_t fl_destroy(fl_handle h);
+const char *fl_last_error_string(fl_handle h);
+/* Run all work of this handle on an existing hipStream_t (e.g. torch's current stream, so that an
+ * RCCL all-reduce enqueued by the caller is ordered with the kernels). NULL selects HIP's default
+ * (null) stream. Without this call a handle runs on a private non-blocking stream. */
+int32_t fl_set_stream(fl_handle h, void *hip_stream);
+int32_t fl_sync(fl_handle h);
+/* Times the last fl_lio_iterate18 / fl_vio_iterate batch with HIP events on the handle's stream. */
+int32_t fl_set_timing(fl_handle h, int32_t enable);
+int32_t fl_get_last_kernel_ms(fl_handle h, float *ms);
+
+/* ------------------------------------------------------------------------------------------------
+ * LIO staging (both modes)
+ * ---------------------------------------------------------------------------------------------- */
+/* feats_down_body after downSizeFilterSurf (src/laserMapping.cpp:1398-1399): n x (x,y,z) float. */
+int32_t fl_lio_set_points(fl_handle h, const float *body_xyz, int32_t n);
+/* Output of the host ikd-Tree search pass, KD_TREE::Nearest_Search
+ * (include/ikd-Tree/ikd_Tree.cpp:350-380, call site src/laserMapping.cpp:1543): nbr_xyz = n x 5 x 3
+ * floats ascending by distance; valid[i] = (5 neighbours returned && sqdist[4] <= 5), i.e.
+ * point_selected_surf[i] of src/laserMapping.cpp:1549,1567.  Fits the n planes (esti_plane,
+ * include/common_lib.h:448-493) once on the device and re-arms the per-point selection flags. */
+int32_t fl_lio_set_neighbours(fl_handle h, const float *nbr_xyz, const uint8_t *valid, int32_t n);
+/* point_selected_surf && res_last<=2 mask and normvec (n x 4: nx,ny,nz,pd2) of the last iteration:
+ * the inputs of publish_effect_world (src/laserMapping.cpp:871-885). Either pointer may be NULL. */
+int32_t fl_lio_get_selection(fl_handle h, uint8_t *mask, float *normvec);
+/* feats_down_world at the current device state (pointBodyToWorld, src/laserMapping.cpp:272-286):
+ * what the host kNN needs on a rematch pass. */
+int32_t fl_lio_get_world_points(fl_handle h, float *world_xyz);
+
+/* ------------------------------------------------------------------------------------------------
+ * LIO Mode-18: the inline ESKF loop of main(), src/laserMapping.cpp:1504-1733
+ * ---------------------------------------------------------------------------------------------- */
+/* Start a frame: state and state_propagat (= state, src/laserMapping.cpp:1292); zeroes G and the
+ * loop counters (iterCount=-1, rematch_num=0, nearest_search_en=true; :1472-1473,1506). */
+int32_t fl_lio_begin18(fl_handle h, const fl_state18 *state, const fl_state18 *state_propagat);
+/* Enqueue `count` passes of the loop body (:1506-1731: residuals, Hsub^T Hsub, gain solve, state
+ * += solution, rematch/stop judgement) without host round trips. Passes issued after the device
+ * raised need_search or stop are no-ops, exactly where the reference would search or break.
+ * info (nullable) is filled after a stream sync with the last executed pass.
+ * flags: FL_ITER_FORCE ignores need_search/stop (benchmark: identical work every pass). */
+#define FL_ITER_FORCE 1
+#define FL_ITER_KEEP_NORMVEC 2  /* also store per-point normvec for fl_lio_get_selection */
+int32_t fl_lio_iterate18(fl_handle h, int32_t count, int32_t flags, fl_iter_info *info);
+/* state.cov = (I - G) * state.cov (src/laserMapping.cpp:1715) then read the state back. */
+int32_t fl_lio_finish18(fl_handle h, fl_state18 *state_out);
+int32_t fl_lio_get_state18(fl_handle h, fl_state18 *state_out);
+
+/* Host kNN provider for the whole-frame driver (stands in for ikdtree.Nearest_Search). */
+typedef void (*fl_knn_fn)(void *ctx, const float *world_xyz, int32_t n, float *nbr_xyz, uint8_t *valid);
+/* The whole `if(lidar_en){ for(iterCount=-1; ...) }` block, src/laserMapping.cpp:1504-1733. */
+int32_t fl_lio_frame18(fl_handle h, fl_state18 *state_io, const float *body_xyz, int32_t n,
+                       fl_knn_fn knn, void *knn_ctx, fl_iter_info *info);
+
+/* Sharded form: this rank's points only. accumulate writes FL_SUMS18 doubles
+ * [HTH upper 21 | HTz 6 | n_eff | sum|res| | sum res^2 | 0 0] to a DEVICE buffer the caller then
+ * all-reduces (sum); solve consumes the reduced record and runs the gain solve + state update
+ * redundantly on every rank. */
+int32_t fl_lio_accumulate18(fl_handle h, double *d_sums, int32_t flags);
+int32_t fl_lio_solve18(fl_handle h, const double *d_sums, int32_t flags, fl_iter_info *info);
+
+/* ------------------------------------------------------------------------------------------------
+ * VIO: LidarSelector::ComputeJ / UpdateState, src/lidar_selection.cpp:743-983
+ * ---------------------------------------------------------------------------------------------- */
+/* cv::Mat img (CV_8UC1) as read at src/lidar_selection.cpp:821. stride in bytes. */
+int32_t fl_vio_set_frame(fl_handle h, const uint8_t *gray, int32_t width, int32_t height, int32_t stride);
+/* sub_sparse_map (include/common_lib.h:263-292): patch[i] = 3 x 64 floats indexed
+ * 64*level + 8*x + y (src/lidar_selection.cpp:837), voxel_points[i]->pos_, search_levels[i]. */
+int32_t fl_vio_set_patches(fl_handle h, const float *ref_patch, const double *pos,
+                           const int32_t *search_level, int32_t m);
+int32_t fl_vio_begin(fl_handle h, const fl_state18 *state, const fl_state18 *state_propagat);
+/* UpdateState(img, total_residual, level): up to max_iterations accept/revert iterations at one
+ * pyramid level, fully on the device; returns last_error through *error_out. */
+int32_t fl_vio_update_state(fl_handle h, float total_residual, int32_t level, float *error_out,
+                            fl_iter_info *info);
+/* ComputeJ(img): levels 2,1,0, then cov -= G*cov (src/lidar_selection.cpp:967-983). */
+int32_t fl_vio_compute_j(fl_handle h, fl_state18 *state_io, const fl_state18 *state_propagat,
+                         fl_iter_info *info3 /* [3] by level, nullable */);
+/* sub_sparse_map->errors (src/lidar_selection.cpp:851). */
+int32_t fl_vio_get_errors(fl_handle h, float *errors);
+/* Benchmark/sharded form: one iteration's sums at `level` for this rank's patches, and the solve. */
+int32_t fl_vio_iterate(fl_handle h, int32_t level, int32_t count, int32_t flags, fl_iter_info *info);
+int32_t fl_vio_accumulate(fl_handle h, int32_t level, double *d_sums);
+int32_t fl_vio_solve(fl_handle h, const double *d_sums, int32_t flags, fl_iter_info *info);
+int32_t fl_vio_get_state18(fl_handle h, fl_state18 *state_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * LIO Mode-23 (IKFoM): h_share_model, src/laserMapping.cpp:961-1093, and
+ * esekf::update_iterated_dyn_share_modified, include/IKFoM_toolkit/esekfom/esekfom.hpp:1619-1928
+ * ---------------------------------------------------------------------------------------------- */
+/* kf.change_x / change_P + the x_propagated/P_propagated copies made at esekfom.hpp:1625-1626. */
+int32_t fl_ikfom_begin(fl_handle h, const fl_state23 *x, const double *P /* 23x23 */,
+                       const double *limit /* 23, init_dyn_share's limit[] */);
+/* "sum-compat" body of h_share_model: residuals + 12-wide rows reduced on the device to
+ * h_x^T h_x (12x12 row-major), h_x^T h (12) and effct_feat_num at state s. The caller shim turns
+ * them into the surrogate h_x/h described in INTEGRATION.md so esekfom.hpp runs unmodified. */
+int32_t fl_h_share_model_sums(fl_handle h, const fl_state23 *s, double *HTH12, double *HTh12,
+                              int32_t *effct_feat_num, double *total_residual);
+/* "row-compat" body (parity/debug): fills h_x (n_eff x 12, row-major) and h (n_eff) in the
+ * reference's order (ascending point index). h_x/h must hold n rows. */
+int32_t fl_h_share_model_rows(fl_handle h, const fl_state23 *s, double *h_x, double *hvec,
+                              int32_t *effct_feat_num);
+/* `count` passes of the body of update_iterated_dyn_share_modified's loop on the device. */
+int32_t fl_ikfom_iterate(fl_handle h, int32_t count, int32_t flags, fl_iter_info *info);
+/* The final covariance block (esekfom.hpp:1831-1924) runs inside the pass that finishes; this
+ * reads x_ and P_ back. */
+int32_t fl_ikfom_get(fl_handle h, fl_state23 *x_out, double *P_out);
+/* The whole update_iterated_dyn_share_modified(R, solve_time) with a host kNN provider. */
+int32_t fl_ikfom_update_iterated(fl_handle h, fl_state23 *x_io, double *P_io, const float *body_xyz,
+                                 int32_t n, double R, const double *limit, fl_knn_fn knn,
+                                 void *knn_ctx, fl_iter_info *info);
+int32_t fl_ikfom_accumulate(fl_handle h, double *d_sums, int32_t flags);
+int32_t fl_ikfom_solve(fl_handle h, const double *d_sums, int32_t flags, fl_iter_info *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTLIVO_HIP_H */

@@ -1,0 +1,55 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import fastlivo  # noqa: E402,F401  registers the package fast_livo_amd
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    return os.path.exists("/dev/kfd")
+
+
+@pytest.fixture(scope="session")
+def scene():
+    from fast_livo_amd import synth
+    return synth.make_scene()
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    from oracle import oracle as orc
+    orc.build()
+    return orc
+
+
+@pytest.fixture(scope="session")
+def emul_lib():
+    """Host build of the product's per-measurement arithmetic (tests/host_emul) -- test-only."""
+    import ctypes
+    d = os.path.join(ROOT, "tests", "host_emul")
+    so = os.path.join(d, "libemul.so")
+    src = os.path.join(d, "emul.cpp")
+    hdr = os.path.join(ROOT, "fast-livo_amd", "csrc", "fl_math.h")
+    hdrs = [hdr, os.path.join(ROOT, "fast-livo_amd", "csrc", "fl_ikfom_math.h")]
+    hdrs = [h for h in hdrs if os.path.exists(h)]
+    if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in [src] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src, "-lm"])
+    return ctypes.CDLL(so)
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    if not _has_gpu():
+        pytest.skip("no GPU in this container")
+    from fast_livo_amd import capi
+    return capi

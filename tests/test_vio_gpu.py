@@ -1,0 +1,142 @@
+"""GPU parity: photometric 8x8 patch ESKF (fl_vio_*) against the CPU oracle.
+
+Per-pixel float arithmetic mirrors the reference order, so residuals match bitwise; the float
+accumulators `patch_error`/`error` are reduced in fp64 on the device (SURVEY A.5 allows this:
+compare to 1e-5 relative) and the state delta to 1e-9 absolute.
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_delta_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(synth, scene, m, n=2000, distortion=False, cam=None, **kw):
+    fr = synth.make_lio_frame(n, scene=scene)
+    vf = synth.make_vio_frame(m, fr, distortion=distortion, cam=cam, **kw)
+    return fr, vf
+
+
+def _handle(capi, fr, vf):
+    h = capi.Handle(capi.config_from_frames(fr, vf, max_iterations=vf.max_iterations))
+    h.vio_set_frame(vf.img)
+    h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+    return h
+
+
+@pytest.mark.parametrize("m,level", [(1, 0), (5, 2), (300, 1), (2000, 0), (2000, 2)])
+def test_single_iteration_matches_oracle(gpu_lib, oracle_lib, scene, m, level):
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    fr, vf = _frames(synth, scene, m)
+    vf.max_iterations = 1
+    xo = orc.state18_from_frame(fr)
+    ro = orc.vio_update_state(vf, xo, xo.copy(), 1e10, level)
+    h = _handle(capi, fr, vf)
+    xg = capi.state18_from_frame(fr)
+    h.vio_begin(xg, xg)
+    err, info = h.vio_update_state(1e10, level)
+    assert info.iterations == 1 and info.accepted == 1
+    assert info.effct_feat_num == ro["out"].n_meas == 64 * m
+    assert abs(err - ro["error"]) <= 1e-5 * ro["error"]
+    e = h.vio_get_errors(m)
+    assert np.abs(e - ro["errors"]).max() <= 1e-5 * np.abs(ro["errors"]).max()
+    assert_delta_close(np.array(info.solution)[:18], np.array(ro["out"].solution))
+    xs = h.vio_get_state18()
+    assert np.abs(xs.vec() - xo.vec()).max() <= 1e-9
+    h.close()
+
+
+@pytest.mark.parametrize("distortion", [False, True])
+def test_compute_j_matches_oracle(gpu_lib, oracle_lib, scene, distortion):
+    """Full ComputeJ: levels 2,1,0 with accept/revert and the covariance update."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    fr, vf = _frames(synth, scene, 500, distortion=distortion)
+    xo = orc.state18_from_frame(fr)
+    ro = orc.vio_compute_j(vf, xo, xo.copy())
+    h = _handle(capi, fr, vf)
+    xg = capi.state18_from_frame(fr)
+    infos = h.vio_compute_j(xg, xg.copy())
+    for lv in (2, 1, 0):
+        assert infos[lv].iterations == ro["outs"][lv].iterations, lv
+        assert infos[lv].accepted == ro["outs"][lv].accepted, lv
+        assert abs(infos[lv].total_residual - ro["outs"][lv].error) <= 1e-5 * ro["outs"][lv].error
+    assert np.abs(xg.vec() - xo.vec()).max() <= 1e-9
+    assert np.abs(xg.cov_np() - xo.cov_np()).max() <= 1e-12
+    e = h.vio_get_errors(vf.m)
+    assert np.abs(e - ro["errors"]).max() <= 1e-5 * np.abs(ro["errors"]).max()
+    h.close()
+
+
+def test_ntu_viral_camera_and_search_levels(gpu_lib, oracle_lib, scene):
+    """NTU_VIRAL intrinsics/extrinsics (config 5) and non-zero search levels."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    fr = synth.make_lio_frame(2000, scene=scene, t_LI=synth.NTU_T_LI)
+    vf = synth.make_vio_frame(400, fr, cam=synth.NTU_CAM, Rcl=synth.NTU_RCL, Pcl=synth.NTU_PCL, distortion=True,
+                              img_point_cov=1000.0)
+    vf.search_level[::3] = 1
+    xo = orc.state18_from_frame(fr)
+    ro = orc.vio_update_state(vf, xo, xo.copy(), 1e10, 1)
+    h = _handle(capi, fr, vf)
+    xg = capi.state18_from_frame(fr)
+    h.vio_begin(xg, xg)
+    err, info = h.vio_update_state(1e10, 1)
+    assert info.iterations == ro["out"].iterations
+    assert abs(err - ro["error"]) <= 1e-5 * ro["error"]
+    xs = h.vio_get_state18()
+    assert np.abs(xs.vec() - xo.vec()).max() <= 1e-9
+    h.close()
+
+
+def test_revert_on_error_increase(gpu_lib, oracle_lib, scene):
+    """total_residual below the achievable error => first iteration is rejected, state restored."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    fr, vf = _frames(synth, scene, 200)
+    xo = orc.state18_from_frame(fr)
+    x0 = xo.vec().copy()
+    ro = orc.vio_update_state(vf, xo, xo.copy(), 0.5, 0)
+    assert ro["out"].accepted == 0
+    h = _handle(capi, fr, vf)
+    xg = capi.state18_from_frame(fr)
+    h.vio_begin(xg, xg)
+    err, info = h.vio_update_state(0.5, 0)
+    assert info.accepted == 0 and info.iterations == 1
+    assert err == pytest.approx(0.5)
+    assert np.array_equal(h.vio_get_state18().vec(), x0)
+    h.close()
+
+
+def test_sharded_accumulate_then_solve_equals_fused(gpu_lib, scene):
+    capi = gpu_lib
+    import torch
+    from fast_livo_amd import synth
+    fr, vf = _frames(synth, scene, 1000)
+    h = _handle(capi, fr, vf)
+    xg = capi.state18_from_frame(fr)
+    h.vio_begin(xg, xg)
+    info_f = h.vio_iterate(1, 1, capi.FL_ITER_FORCE)
+    x_f = h.vio_get_state18()
+    total = torch.zeros(capi.FL_SUMS18, dtype=torch.float64, device="cuda")
+    hs = []
+    for lo, hi in ((0, 400), (400, 1000)):
+        hh = capi.Handle(capi.config_from_frames(fr, vf))
+        hh.vio_set_frame(vf.img)
+        hh.vio_set_patches(vf.ref_patch[lo:hi], vf.pos[lo:hi], vf.search_level[lo:hi])
+        hh.vio_begin(xg, xg)
+        t = torch.zeros(capi.FL_SUMS18, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        hh.vio_accumulate(1, t.data_ptr())
+        hh.sync()
+        total += t
+        hs.append(hh)
+    torch.cuda.synchronize()
+    info_s = hs[0].vio_solve(total.data_ptr(), capi.FL_ITER_FORCE, want_info=True)
+    assert_delta_close(np.array(info_s.solution)[:18], np.array(info_f.solution)[:18], tol=1e-11)
+    assert np.abs(hs[0].vio_get_state18().vec() - x_f.vec()).max() <= 1e-11
+    for hh in hs:
+        hh.close()
+    h.close()
