@@ -147,6 +147,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
                                "there is no CPU fallback for the ESKF hot path")
+        # One process must not mix two HIP/HSA runtimes: PyTorch bundles its own libamdhip64.so.7 and
+        # refuses to see the GPU if the system copy (our RUNPATH) was loaded first.  Importing torch
+        # first makes both share torch's copy (same soname); torch is only plumbing here.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)      # AttributeError if the library does not export a declared symbol
