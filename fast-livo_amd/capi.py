@@ -15,6 +15,7 @@ from . import LIB_PATH, PKG_DIR
 
 FL_ITER_FORCE = 1
 FL_ITER_KEEP_NORMVEC = 2
+FL_ITER_STAMP = 4
 FL_SUMS18 = 32
 FL_SUMS23 = 96
 
@@ -92,6 +93,7 @@ SYMBOLS = {
     "fl_sync": (C.c_int32, [_H]),
     "fl_set_timing": (C.c_int32, [_H, C.c_int32]),
     "fl_get_last_kernel_ms": (C.c_int32, [_H, _fp]),
+    "fl_debug_get_stamps": (C.c_int32, [_H, C.POINTER(C.c_longlong)]),
     "fl_lio_set_points": (C.c_int32, [_H, _fp, C.c_int32]),
     "fl_lio_set_neighbours": (C.c_int32, [_H, _fp, _u8p, C.c_int32]),
     "fl_lio_get_selection": (C.c_int32, [_H, _u8p, _fp]),
@@ -232,6 +234,11 @@ class Handle:
         ms = C.c_float()
         self._chk(self.L.fl_get_last_kernel_ms(self.h, C.byref(ms)), "fl_get_last_kernel_ms")
         return ms.value
+
+    def debug_stamps(self):
+        a = (C.c_longlong * 64)()
+        self._chk(self.L.fl_debug_get_stamps(self.h, a), "fl_debug_get_stamps")
+        return np.array(a[:], dtype=np.int64)
 
     # ---- LIO
     def lio_set_points(self, body):

@@ -334,6 +334,8 @@ static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_sta
     D->max_iter = h->cfg.max_iterations;
     D->last_error = 1e10f;
     HIPCHK(h, hipMemcpyAsync(h->d_dev, D, sizeof(FlDev18), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(eskf18_prepare_kernel, dim3(1), dim3(64), 0, h->stream, h->d_dev);
+    HIPCHK(h, hipGetLastError());
     return FL_OK;
 }
 
@@ -447,9 +449,19 @@ int32_t fl_lio_solve18(fl_handle h, const double *d_sums, int32_t flags, fl_iter
 {
     if (!h || !d_sums) return fail_arg(h, "fl_lio_solve18: null argument");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(eskf18_solve_kernel, dim3(1), dim3(64), 0, h->stream, h->d_dev, d_sums, 1.0, 0, (int)flags);
+    hipLaunchKernelGGL(eskf18_solve_kernel, dim3(1), dim3(FL_BLOCK), 0, h->stream, h->d_dev, d_sums, 1.0, 0, (int)flags);
     HIPCHK(h, hipGetLastError());
     if (info) return read_info18(h, info);
+    return FL_OK;
+}
+
+// Debug: phase timestamps (shader clock) of the last pass launched with FL_ITER_STAMP (tools/kstamps.py).
+int32_t fl_debug_get_stamps(fl_handle h, long long *out64)
+{
+    if (!h || !out64) return fail_arg(h, "fl_debug_get_stamps: null argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_fl_stamps), sizeof(long long) * 64));
     return FL_OK;
 }
 

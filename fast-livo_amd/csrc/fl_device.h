@@ -31,7 +31,10 @@ struct FlDev18 {
     double xprop[24];   // state_propagat
     double xold[24];    // VIO old_state (lidar_selection.cpp:747,863)
     double P[324];      // state.cov (constant during the iterations of a frame)
-    double G6[108];     // G.block<18,6>(0,0), 18x6 row-major
+    double G6[108];     // G.block<18,6>(0,0), 18x6 row-major (formed by the finish kernels)
+    double Q[36];       // (P66/meas_cov)^-1, per-frame prepare (fl_math.h fl_prepare18)
+    double T[108];      // (P[:,0:6]/meas_cov) Q, 18x6 row-major
+    double sums_acc[FL_SUMS18]; // record of the last executed (LIO) / accepted (VIO) pass: source of G
     double R_LI[9];
     double t_LI[3];
     double solution[24];
@@ -130,29 +133,79 @@ __device__ __forceinline__ void so3_Log(const double *R, double *out)
     out[0] = f * K0; out[1] = f * K1; out[2] = f * K2;
 }
 
+__device__ long long g_fl_stamps[64];
+
 // ---- wavefront reduction --------------------------------------------------------------------
 // Transposing butterfly: every lane enters with V partial sums; on exit lane L holds in v[0] the
 // wave-wide total of value (L >> 1) (both lanes of a pair hold the same total). V must be 32.
 // 32 exchanges instead of the 32 x 6 of an independent butterfly per value.
-template <int HALF, int MASK>
-__device__ __forceinline__ void wave_transpose_step(double (&v)[32], int lane)
+// 64-bit helpers over the 32-bit cross-lane instructions.
+__device__ __forceinline__ unsigned f64_lo(double x) { return (unsigned)__double2loint(x); }
+__device__ __forceinline__ unsigned f64_hi(double x) { return (unsigned)__double2hiint(x); }
+__device__ __forceinline__ double f64_make(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
+
+// v_permlane32_swap: lanes 32..63 of a <-> lanes 0..31 of b (gfx950). After the swap a+b holds, in the
+// lower half-wave, a's total over the lane pair (l, l+32) and, in the upper half-wave, b's total.
+__device__ __forceinline__ void swap32_f64(double &a, double &b)
 {
-    const bool upper = (lane & MASK) != 0;
-#pragma unroll
-    for (int i = 0; i < HALF; i++) {
-        const double send = upper ? v[i] : v[i + HALF];
-        const double keep = upper ? v[i + HALF] : v[i];
-        v[i] = keep + __shfl_xor(send, MASK, FL_WAVE);
-    }
+    auto lo = __builtin_amdgcn_permlane32_swap(f64_lo(a), f64_lo(b), false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap(f64_hi(a), f64_hi(b), false, false);
+    a = f64_make(lo[0], hi[0]);
+    b = f64_make(lo[1], hi[1]);
 }
+// v_permlane16_swap: odd 16-lane rows of a <-> even rows of b (gfx950).
+__device__ __forceinline__ void swap16_f64(double &a, double &b)
+{
+    auto lo = __builtin_amdgcn_permlane16_swap(f64_lo(a), f64_lo(b), false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap(f64_hi(a), f64_hi(b), false, false);
+    a = f64_make(lo[0], hi[0]);
+    b = f64_make(lo[1], hi[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x)
+{
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, f64_lo(x), CTRL, 0xf, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, f64_hi(x), CTRL, 0xf, 0xf, false);
+    return f64_make(lo, hi);
+}
+#define FL_DPP_ROW_ROR8 0x128       // lane ^ 8 inside a 16-lane row
+#define FL_DPP_QUAD_XOR2 0x4E       // quad_perm [2,3,0,1]
+#define FL_DPP_QUAD_XOR1 0xB1       // quad_perm [1,0,3,2]
+
+// Transposing butterfly: every lane enters with 32 partial sums; on exit lane L holds in v[0] the
+// wave-wide total of value (L >> 1) (both lanes of a pair hold the same total).
+// Exchanges: 16 + 8 lane-swaps (no selects), then 4+2+1+1 DPP/bpermute steps, instead of 32 x 6.
 __device__ __forceinline__ void wave_transpose_reduce32(double (&v)[32], int lane)
 {
-    wave_transpose_step<16, 32>(v, lane);
-    wave_transpose_step<8, 16>(v, lane);
-    wave_transpose_step<4, 8>(v, lane);
-    wave_transpose_step<2, 4>(v, lane);
-    wave_transpose_step<1, 2>(v, lane);
-    v[0] = v[0] + __shfl_xor(v[0], 1, FL_WAVE);
+#pragma unroll
+    for (int i = 0; i < 16; i++) { swap32_f64(v[i], v[i + 16]); v[i] = v[i] + v[i + 16]; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { swap16_f64(v[i], v[i + 8]); v[i] = v[i] + v[i + 8]; }
+    {
+        const bool upper = (lane & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const double send = upper ? v[i] : v[i + 4];
+            const double keep = upper ? v[i + 4] : v[i];
+            v[i] = keep + dpp_f64<FL_DPP_ROW_ROR8>(send);
+        }
+    }
+    {
+        const bool upper = (lane & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const double send = upper ? v[i] : v[i + 2];
+            const double keep = upper ? v[i + 2] : v[i];
+            v[i] = keep + __shfl_xor(send, 4, FL_WAVE);
+        }
+    }
+    {
+        const bool upper = (lane & 2) != 0;
+        const double send = upper ? v[0] : v[1];
+        const double keep = upper ? v[1] : v[0];
+        v[0] = keep + dpp_f64<FL_DPP_QUAD_XOR2>(send);
+    }
+    v[0] = v[0] + dpp_f64<FL_DPP_QUAD_XOR1>(v[0]);
 }
 
 __device__ __forceinline__ double wave_sum(double x)
@@ -193,6 +246,7 @@ __device__ __forceinline__ bool block_publish(double (&v)[NV], double *partials,
         wave_transpose_reduce32(w, lane);
         if ((lane & 1) == 0) lds[wave * NV + g * 32 + (lane >> 1)] = w[0];
     }
+    if (blockIdx.x == 0 && tid == 0) g_fl_stamps[30] = (long long)__builtin_readcyclecounter();
     __syncthreads();
     if (tid < NV) {
         double s = lds[tid];
@@ -201,25 +255,48 @@ __device__ __forceinline__ bool block_publish(double (&v)[NV], double *partials,
         store_wt(&partials[(size_t)blockIdx.x * NV + tid], s);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (blockIdx.x == 0 && tid == 0) g_fl_stamps[31] = (long long)__builtin_readcyclecounter();
     __syncthreads();
     __shared__ unsigned s_ticket;
     if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
+    if (blockIdx.x == 0 && tid == 0) g_fl_stamps[32] = (long long)__builtin_readcyclecounter();
     __syncthreads();
     return s_ticket == gridDim.x - 1;
 }
 
-// Final reduce by the last workgroup: sums[k] = sum over blocks (ascending) of partials[b][k].
+// Final reduce by the last workgroup: sums[k] = sum over blocks of partials[b][k], in an order fixed
+// by the block indices. Records were published write-through (sc1); they are read back with 16-byte
+// sc1 buffer loads (L1-bypassing, counted by the compiler's s_waitcnt, out-of-range records read as
+// zero through the descriptor's bounds check, so there is no branch per load). All loads of a batch
+// are in flight together: the hand-off costs about one memory round trip.
+typedef unsigned int fl_u4 __attribute__((ext_vector_type(4)));
+#define FL_FIN_LDS (2 * FL_BLOCK)
 template <int NV>
-__device__ __forceinline__ void final_reduce(const double *partials, int nblocks, double *lds /* >= FL_BLOCK */, double *out_lds /* NV */)
+__device__ __forceinline__ void final_reduce(const double *partials, int nblocks, double *lds /* >= FL_FIN_LDS */, double *out_lds /* NV */)
 {
     const int tid = threadIdx.x;
-    constexpr int GROUPS = FL_BLOCK / 32;       // 8 block-groups x 32 values per pass
+    constexpr int GROUPS = FL_BLOCK / 16;       // 16 block-groups x 16 value-pairs per pass
+    constexpr int BATCH = 16;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)partials, 0, nblocks * NV * 8, 0x00020000);
 #pragma unroll
     for (int g = 0; g < NV / 32; g++) {
-        const int k = g * 32 + (tid & 31), grp = tid >> 5;
-        double s = 0.0;
-        for (int b = grp; b < nblocks; b += GROUPS) s += load_wt(&partials[(size_t)b * NV + k]);
-        lds[tid] = s;
+        const int kp = tid & 15, grp = tid >> 4;
+        double s0 = 0.0, s1 = 0.0;
+        for (int b0 = grp; b0 < nblocks; b0 += GROUPS * BATCH) {
+            fl_u4 t[BATCH];
+#pragma unroll
+            for (int j = 0; j < BATCH; j++) {
+                const int b = b0 + j * GROUPS;
+                t[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (b * NV + g * 32 + kp * 2) * 8, 0, 16 /* sc1 */);
+            }
+#pragma unroll
+            for (int j = 0; j < BATCH; j++) {
+                s0 += f64_make(t[j].x, t[j].y);
+                s1 += f64_make(t[j].z, t[j].w);
+            }
+        }
+        lds[tid * 2] = s0;
+        lds[tid * 2 + 1] = s1;
         __syncthreads();
         if (tid < 32) {
             double t = lds[tid];
@@ -229,4 +306,12 @@ __device__ __forceinline__ void final_reduce(const double *partials, int nblocks
         }
         __syncthreads();
     }
+}
+
+// Optional phase timestamps (s_memtime) for tools/kstamps.py: slot i of workgroup 0 and of the last
+// workgroup. Enabled by the FL_ITER_STAMP flag; costs nothing when the flag is clear.
+#define FL_ITER_STAMP 4
+__device__ __forceinline__ void fl_stamp(int flags, int slot)
+{
+    if ((flags & FL_ITER_STAMP) && threadIdx.x == 0) g_fl_stamps[slot] = (long long)__builtin_readcyclecounter();
 }

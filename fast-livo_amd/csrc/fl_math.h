@@ -407,3 +407,168 @@ FL_HD int fl_solve18_serial(double *x, const double *xprop, const double *P, dou
         if (!(fabs(delta[r]) <= DBL_MAX)) st |= 2;
     return st;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Fast per-iteration form of the same gain solve.  P (hence A = P/R) is constant while a frame
+// iterates (the reference only rewrites state.cov after the loop, laserMapping.cpp:1715;
+// lidar_selection.cpp:980), so the part that depends on P alone is hoisted to a per-frame prepare:
+//     Q = A66^-1 (6x6, SPD)            T = A[:,0:6] Q   (18x6; its top block is I)
+// and with (I + S A66)^-1 = Q^-1 ... : W = (I + S A66)^-1 = A66^-1 (A66^-1 + S)^-1 = Q (Q+S)^-1, i.e.
+//     A[:,0:6] W = T' with  K_1[:,0:6] = A[:,0:6] Q (Q+S)^-1 = T (Q+S)^-1.
+// Per iteration only the SPD 6x6 system (Q + S) z = sign*HTz - S vec6 is factorised (LDL^T, no
+// pivoting needed for SPD) and  delta = T z + vec.   G[:,0:6] = T (Q+S)^-1 S is needed only for the
+// covariance update after the last pass and is formed there (fl_gain18).
+// ------------------------------------------------------------------------------------------------
+FL_HD int fl_prepare18(const double *P, double meas_cov, double *Q /*36*/, double *T /*108*/)
+{
+    double M[6][6], B[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            M[i][j] = 0.5 * (P[i * 18 + j] + P[j * 18 + i]) / meas_cov;   // symmetrised A66
+            B[i][j] = (i == j) ? 1.0 : 0.0;
+        }
+    const int st = fl_gauss_solve<6, 6>(M, B);
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) Q[i * 6 + j] = 0.5 * (B[i][j] + B[j][i]);
+    for (int r = 0; r < 18; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) s += (P[r * 18 + k] / meas_cov) * Q[k * 6 + c];
+            T[r * 6 + c] = s;
+        }
+    return st;
+}
+
+// LDL^T factorisation of the SPD 6x6 C (full storage, lower part used). Returns 1 if a pivot <= 0.
+struct FlLdl6 {
+    double L[6][6];
+    double dinv[6];
+};
+#if defined(__HIPCC__)
+#define FL_FP_CONTRACT _Pragma("clang fp contract(fast)")
+#else
+#define FL_FP_CONTRACT
+#endif
+FL_HD int fl_ldl6(const double (&C)[6][6], FlLdl6 &f)
+{
+    FL_FP_CONTRACT   // the solve is compared to the oracle by tolerance, never bitwise
+    int bad = 0;
+    double d[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double dj = C[j][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) dj -= f.L[j][k] * f.L[j][k] * d[k];
+        d[j] = dj;
+        if (!(dj > 0.0)) bad = 1;
+        f.dinv[j] = 1.0 / dj;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            double v = C[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) v -= f.L[i][k] * f.L[j][k] * d[k];
+            f.L[i][j] = v * f.dinv[j];
+        }
+    }
+    return bad;
+}
+FL_HD void fl_ldl6_solve(const FlLdl6 &f, double *b /*6, in: rhs, out: solution*/)
+{
+    FL_FP_CONTRACT
+#pragma unroll
+    for (int i = 1; i < 6; i++)
+#pragma unroll
+        for (int k = 0; k < i; k++) b[i] -= f.L[i][k] * b[k];
+#pragma unroll
+    for (int i = 0; i < 6; i++) b[i] *= f.dinv[i];
+#pragma unroll
+    for (int i = 4; i >= 0; i--)
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) b[i] -= f.L[k][i] * b[k];
+}
+
+FL_HD void fl_unpack_S(const double *sums, double (&S)[6][6])
+{
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++) { S[i][j] = sums[k]; S[j][i] = sums[k]; k++; }
+}
+
+// z = (Q+S)^-1 (sign*HTz - S vec6). Returns status bits (1 = not positive definite).
+FL_HD int fl_solve18_z(const double *Q, const double *sums, const double *vec /*18*/, double sign, double *z /*6*/)
+{
+    double S[6][6], C[6][6];
+    fl_unpack_S(sums, S);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) C[i][j] = Q[i * 6 + j] + S[i][j];
+        double b = sign * sums[21 + i];
+#pragma unroll
+        for (int k = 0; k < 6; k++) b -= S[i][k] * vec[k];
+        z[i] = b;
+    }
+    FlLdl6 f;
+    const int bad = fl_ldl6(C, f);
+    fl_ldl6_solve(f, z);
+    return bad;
+}
+
+// Whole fast solve on one thread: delta = T z + vec ; x (+)= delta.
+FL_HD int fl_solve18_fast(double *x, const double *xprop, const double *Q, const double *T, const double *sums, double sign,
+                          double *delta)
+{
+    double vec[18], z[6];
+    fl_state18_minus(xprop, x, vec);
+    int st = fl_solve18_z(Q, sums, vec, sign, z);
+    for (int r = 0; r < 18; r++) {
+        double dl = vec[r];
+#pragma unroll
+        for (int c = 0; c < 6; c++) dl += T[r * 6 + c] * z[c];
+        delta[r] = dl;
+    }
+    fl_state18_plus(x, delta);
+    for (int r = 0; r < 18; r++)
+        if (!(fabs(delta[r]) <= DBL_MAX)) st |= 2;
+    return st;
+}
+
+// G[:,0:6] = T (Q+S)^-1 S  (18x6), from the record of the last executed/accepted pass.
+FL_HD int fl_gain18(const double *Q, const double *T, const double *sums, double *G6)
+{
+    double S[6][6], C[6][6];
+    fl_unpack_S(sums, S);
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) C[i][j] = Q[i * 6 + j] + S[i][j];
+    FlLdl6 f;
+    const int bad = fl_ldl6(C, f);
+    double X[6][6];   // X = (Q+S)^-1 S, column by column
+    for (int c = 0; c < 6; c++) {
+        double b[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) b[i] = S[i][c];
+        fl_ldl6_solve(f, b);
+#pragma unroll
+        for (int i = 0; i < 6; i++) X[i][c] = b[i];
+    }
+    for (int r = 0; r < 18; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) s += T[r * 6 + k] * X[k][c];
+            G6[r * 6 + c] = s;
+        }
+    return bad;
+}

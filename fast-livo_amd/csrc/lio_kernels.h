@@ -16,6 +16,7 @@
 
 #include "fl_device.h"
 #include "fl_math.h"
+#include "solve18.h"
 
 #define FL_ITER_FORCE 1
 #define FL_ITER_KEEP_NORMVEC 2
@@ -64,19 +65,30 @@ __device__ __forceinline__ void lio18_judge(FlDev18 *D, const double *delta, con
     D->status = st | ((sums[FL_S_NEFF] < 1.0) ? 4 : 0);
 }
 
-// Gain solve + state update executed by one thread of the final workgroup (serial form).
+// Per-frame prepare: Q and T of fl_math.h (depends on P and the measurement covariance only).
+__global__ void eskf18_prepare_kernel(FlDev18 *__restrict__ D)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double Q[36], T[108];
+    const int st = fl_prepare18(D->P, D->meas_cov, Q, T);
+    for (int i = 0; i < 36; i++) D->Q[i] = Q[i];
+    for (int i = 0; i < 108; i++) D->T[i] = T[i];
+    D->status = st;
+}
+
+// Gain solve + state update executed by one thread of the final workgroup.
 __device__ __forceinline__ void eskf18_solve_serial(FlDev18 *D, const double *sums, double sign)
 {
     double x[24], xp[24], delta[18];
 #pragma unroll
     for (int i = 0; i < 24; i++) { x[i] = D->x[i]; xp[i] = D->xprop[i]; }
-    const int st = fl_solve18_serial(x, xp, D->P, D->meas_cov, sums, sign, D->G6, delta);
+    const int st = fl_solve18_fast(x, xp, D->Q, D->T, sums, sign, delta);
 #pragma unroll
     for (int i = 0; i < 24; i++) D->x[i] = x[i];
 #pragma unroll
     for (int i = 0; i < 18; i++) D->solution[i] = delta[i];
 #pragma unroll
-    for (int i = 0; i < FL_SUMS18; i++) D->sums[i] = sums[i];
+    for (int i = 0; i < FL_SUMS18; i++) { D->sums[i] = sums[i]; D->sums_acc[i] = sums[i]; }
     lio18_judge(D, delta, sums, st);
 }
 
@@ -90,8 +102,9 @@ __global__ __launch_bounds__(FL_BLOCK) void lio18_iterate_kernel(const float *__
 {
     if (!(flags & FL_ITER_FORCE) && (D->stop || D->need_search)) return;
     __shared__ double s_red[4 * FL_SUMS18];
-    __shared__ double s_fin[FL_BLOCK];
+    __shared__ double s_fin[FL_FIN_LDS];
     __shared__ double s_sums[FL_SUMS18];
+    __shared__ FlSolveLds s_solve;
 
     double R[9], p[3], RLI[9], tLI[3];
 #pragma unroll
@@ -102,6 +115,7 @@ __global__ __launch_bounds__(FL_BLOCK) void lio18_iterate_kernel(const float *__
     double v[FL_SUMS18];
 #pragma unroll
     for (int k = 0; k < FL_SUMS18; k++) v[k] = 0.0;
+    if (blockIdx.x == 0) fl_stamp(flags, 0);
 
     for (int i = blockIdx.x * FL_BLOCK + threadIdx.x; i < n; i += gridDim.x * FL_BLOCK) {
         if (!sel[i]) continue;
@@ -124,17 +138,19 @@ __global__ __launch_bounds__(FL_BLOCK) void lio18_iterate_kernel(const float *__
         }
     }
 
+    if (blockIdx.x == 0) fl_stamp(flags, 1);
     const bool last = block_publish<FL_SUMS18>(v, partials, ticket, s_red);
+    if (blockIdx.x == 0) fl_stamp(flags, 2);
     if (!last) return;
+    fl_stamp(flags, 8);
     final_reduce<FL_SUMS18>(partials, gridDim.x, s_fin, s_sums);
-    if (threadIdx.x == 0) {
-        *ticket = 0u;
-        if (MODE == 0) {
-            eskf18_solve_serial(D, s_sums, 1.0);
-        } else {
-#pragma unroll
-            for (int k = 0; k < FL_SUMS18; k++) sums_out[k] = s_sums[k];
-        }
+    fl_stamp(flags, 9);
+    if (threadIdx.x == 0) *ticket = 0u;
+    if (MODE == 0) {
+        eskf18_epilogue_block<FL_EPI_LIO>(D, s_sums, s_solve);
+        fl_stamp(flags, 10);
+    } else {
+        if (threadIdx.x < FL_SUMS18) sums_out[threadIdx.x] = s_sums[threadIdx.x];
     }
 }
 
@@ -149,7 +165,11 @@ __global__ __launch_bounds__(384) void eskf18_cov_update_kernel(FlDev18 *__restr
     __shared__ double sG[108];
     const int t = threadIdx.x;
     if (t < 324) sP[t] = D->P[t];
-    if (t < 108) sG[t] = D->G6[t];
+    if (t == 0) {   // G[:,0:6] of the last executed pass
+        double G6[108];
+        fl_gain18(D->Q, D->T, D->sums_acc, G6);
+        for (int i = 0; i < 108; i++) { sG[i] = G6[i]; D->G6[i] = G6[i]; }
+    }
     __syncthreads();
     if (t < 324) {
         const int r = t / 18, c = t % 18;

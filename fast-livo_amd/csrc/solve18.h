@@ -1,0 +1,216 @@
+// solve18.h -- workgroup-cooperative epilogue of one 18-state ESKF pass (runs in the last-arriving
+// workgroup of the pass kernel, or alone in eskf18_solve_kernel for the sharded path).
+//
+// Math: fl_math.h (fast form):  C = Q + S (SPD 6x6),  z = C^-1 (sign*HTz - S vec6),
+//       delta = T z + vec,  x (+)= delta, then the rematch/stop (LIO, laserMapping.cpp:1688-1728)
+//       or accept/revert bookkeeping (VIO, lidar_selection.cpp:857-899).
+// Latency is what matters here (one workgroup, ~600 dependent fp64 operations if done by one
+// thread), so the independent chains run on different wavefronts of the workgroup:
+//   wave 0   : LDL^T factorisation of C in registers  ||  wave 2: Log(R^T R_prop)  ||  wave 1: vector diffs
+//   sync
+//   wave 0   : rhs, triangular solves (all lanes redundantly), lanes 0..17: delta_r = vec_r + T_r . z
+//   sync
+//   wave 0 lanes 0..8: one element each of R*Exp(delta_rot) || wave 1: additive states || wave 2: judgement
+#pragma once
+
+#include "fl_device.h"
+#include "fl_math.h"
+
+struct FlSolveLds {
+    double vec[18];
+    double delta[18];
+    int accept;
+    int st;
+};
+
+enum { FL_EPI_LIO = 0, FL_EPI_VIO = 1 };
+
+// FMA contraction is allowed in the solve (it is compared to the oracle by tolerance, never bitwise).
+template <int KIND>
+__device__ __forceinline__ void eskf18_epilogue_block(FlDev18 *__restrict__ D, const double *s_sums, FlSolveLds &L)
+{
+#pragma clang fp contract(fast)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const double sign = (KIND == FL_EPI_VIO) ? -1.0 : 1.0;
+
+    if (KIND == FL_EPI_VIO) {
+        // error = sum(res^2) / n_meas ; accept iff error <= last_error (lidar_selection.cpp:857-861)
+        if (tid == 0) {
+            const float n_meas = (float)s_sums[FL_S_NEFF];
+            const float error = (float)s_sums[FL_S_RES] / n_meas;
+            const int acc = (error <= D->last_error) ? 1 : 0;
+            L.accept = acc;
+            D->error = error;
+            if (acc) D->last_error = error;
+        }
+        __syncthreads();
+        if (!L.accept) {   // revert: state = old_state ; EKF_end (:888-892)
+            if (tid < 24) D->x[tid] = D->xold[tid];
+            if (tid == 64) {
+                const int it = D->iters_run + 1;
+                D->iters_run = it;
+                D->stop = 1;
+                D->converged = 1;
+                D->neff = (int)s_sums[FL_S_NEFF];
+                D->total_residual = (double)D->last_error;
+                D->status = 0;
+            }
+            if (wave == 3 && lane < FL_SUMS18) D->sums[lane] = s_sums[lane];
+            return;
+        }
+    }
+
+    // ---------------- stage A: independent chains on different waves
+    FlLdl6 f;
+    double S[6][6];
+    double Trow[6];
+    double Rrow[3] = {0.0, 0.0, 0.0};
+    double xadd = 0.0;
+    int bad = 0;
+    if (wave == 0) {
+        if (lane < 18) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) Trow[c] = D->T[lane * 6 + c];
+        }
+        if (lane < 9) {
+            const int i = lane / 3;
+#pragma unroll
+            for (int k = 0; k < 3; k++) Rrow[k] = D->x[i * 3 + k];   // row of the old rotation for stage C
+        }
+        double C[6][6];
+        fl_unpack_S(s_sums, S);
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j < 6; j++) C[i][j] = D->Q[i * 6 + j] + S[i][j];
+        bad = fl_ldl6(C, f);
+    } else if (wave == 1) {
+        if (lane < 15) {
+            xadd = D->x[9 + lane];
+            L.vec[3 + lane] = D->xprop[9 + lane] - xadd;
+            if (KIND == FL_EPI_VIO) D->xold[9 + lane] = xadd;        // old_state = *state (:863)
+        }
+    } else if (wave == 2) {
+        if (lane == 0) {
+            double xr[9], xp[9], rd[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) { xr[i] = D->x[i]; xp[i] = D->xprop[i]; }
+            if (KIND == FL_EPI_VIO) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) D->xold[i] = xr[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) rd[i * 3 + j] = xr[0 * 3 + i] * xp[0 * 3 + j] + xr[1 * 3 + i] * xp[1 * 3 + j] + xr[2 * 3 + i] * xp[2 * 3 + j];
+            const double tr = rd[0] + rd[4] + rd[8];
+            const double theta = (tr > 3.0 - 1e-6) ? 0.0 : acos(0.5 * (tr - 1));
+            const double fk = (fabs(theta) < 0.001) ? 0.5 : (0.5 * theta / sin(theta));
+            L.vec[0] = fk * (rd[7] - rd[5]);
+            L.vec[1] = fk * (rd[2] - rd[6]);
+            L.vec[2] = fk * (rd[3] - rd[1]);
+        }
+    } else {
+        if (lane < FL_SUMS18) {
+            const double sv = s_sums[lane];
+            D->sums[lane] = sv;
+            D->sums_acc[lane] = sv;   // LIO: last executed pass ; VIO: last accepted pass (we are on the accept path)
+        }
+    }
+    if (tid == 0) g_fl_stamps[20] = (long long)__builtin_readcyclecounter();
+    __syncthreads();
+    if (tid == 0) g_fl_stamps[21] = (long long)__builtin_readcyclecounter();
+
+    // ---------------- stage B: wave 0 -- rhs, substitution, delta
+    if (wave == 0) {
+        double z[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double b = sign * s_sums[FL_S_HTZ + i];
+#pragma unroll
+            for (int k = 0; k < 6; k++) b -= S[i][k] * L.vec[k];
+            z[i] = b;
+        }
+        fl_ldl6_solve(f, z);
+        if (lane < 18) {
+            double dl = L.vec[lane];
+#pragma unroll
+            for (int c = 0; c < 6; c++) dl += Trow[c] * z[c];
+            L.delta[lane] = dl;
+            D->solution[lane] = dl;
+        }
+        if (lane == 0) L.st = bad;
+    }
+    if (tid == 0) g_fl_stamps[22] = (long long)__builtin_readcyclecounter();
+    __syncthreads();
+    if (tid == 0) g_fl_stamps[23] = (long long)__builtin_readcyclecounter();
+
+    // ---------------- stage C: state update and judgement on separate waves
+    if (wave == 0) {
+        if (lane < 9) {
+            // R <- R * Exp(d0,d1,d2): lane (i,j) forms its element (so3_math.h:54-72, common_lib.h:345)
+            const int i = lane / 3, j = lane % 3;
+            const double d0 = L.delta[0], d1 = L.delta[1], d2 = L.delta[2];
+            const double nrm = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+            if (nrm > 0.00001) {
+                const double r0 = d0 / nrm, r1 = d1 / nrm, r2 = d2 / nrm;
+                const double K[9] = {0.0, -r2, r1, r2, 0.0, -r0, -r1, r0, 0.0};
+                const double s = sin(nrm), c = 1.0 - cos(nrm);
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    double e[3];   // row k of E = I + s K + c K K
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        const double kk = K[k * 3 + 0] * K[0 * 3 + q] + K[k * 3 + 1] * K[1 * 3 + q] + K[k * 3 + 2] * K[2 * 3 + q];
+                        e[q] = ((k == q) ? 1.0 : 0.0) + s * K[k * 3 + q] + c * kk;
+                    }
+                    const double ekj = (j == 0) ? e[0] : ((j == 1) ? e[1] : e[2]);
+                    acc += Rrow[k] * ekj;
+                }
+                D->x[lane] = acc;
+            }
+        }
+    } else if (wave == 1) {
+        if (lane < 15) D->x[9 + lane] = xadd + L.delta[3 + lane];
+    } else if (wave == 2) {
+        if (lane == 0) {
+            const double rn = sqrt(L.delta[0] * L.delta[0] + L.delta[1] * L.delta[1] + L.delta[2] * L.delta[2]);
+            const double tn = sqrt(L.delta[3] * L.delta[3] + L.delta[4] * L.delta[4] + L.delta[5] * L.delta[5]);
+            int st = L.st;
+#pragma unroll
+            for (int r = 0; r < 18; r++)
+                if (!(fabs(L.delta[r]) <= DBL_MAX)) st |= 2;
+            if (KIND == FL_EPI_LIO) {
+                // laserMapping.cpp:1688-1728
+                const int converged = (rn * 57.3 < 0.01) && (tn * 100 < 0.015);
+                int rematch = D->rematch_num, need_search = 0, stop = 0;
+                const int it = D->iterCount;
+                if (converged || ((rematch == 0) && (it == (D->max_iter - 2)))) { need_search = 1; rematch++; }
+                if (rematch >= 2 || (it == D->max_iter - 1)) stop = 1;
+                D->converged = converged;
+                D->rematch_num = rematch;
+                D->need_search = need_search;
+                D->stop = stop;
+                D->iterCount = it + 1;
+                D->iters_run = D->iters_run + 1;
+                D->neff = (int)s_sums[FL_S_NEFF];
+                D->total_residual = s_sums[FL_S_RES];
+                D->status = st | ((s_sums[FL_S_NEFF] < 1.0) ? 4 : 0);
+            } else {
+                // lidar_selection.cpp:883-899
+                int stop = ((rn * 57.3f < 0.001f) && (tn * 100.0f < 0.001f)) ? 1 : 0;
+                D->converged = stop;
+                D->accepted = D->accepted + 1;
+                const int it = D->iters_run + 1;
+                D->iters_run = it;
+                if (it >= D->max_iter) stop = 1;
+                D->stop = stop;
+                D->neff = (int)s_sums[FL_S_NEFF];
+                D->total_residual = (double)D->last_error;
+                D->status = st;
+            }
+        }
+    }
+}

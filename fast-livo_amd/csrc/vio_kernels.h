@@ -109,7 +109,9 @@ __device__ __forceinline__ void vio_epilogue_serial(FlDev18 *D, const double *su
 #pragma unroll
         for (int i = 0; i < 24; i++) { x[i] = D->x[i]; xp[i] = D->xprop[i]; D->xold[i] = x[i]; }
         D->last_error = error;
-        st = fl_solve18_serial(x, xp, D->P, D->meas_cov, sums, -1.0, D->G6, delta);
+        st = fl_solve18_fast(x, xp, D->Q, D->T, sums, -1.0, delta);
+#pragma unroll
+        for (int i = 0; i < FL_SUMS18; i++) D->sums_acc[i] = sums[i];
 #pragma unroll
         for (int i = 0; i < 24; i++) D->x[i] = x[i];
         D->accepted = D->accepted + 1;
@@ -147,8 +149,9 @@ __global__ __launch_bounds__(FL_BLOCK) void vio_iterate_kernel(const uint8_t *__
 {
     if (!(flags & FL_ITER_FORCE) && D->stop) return;
     __shared__ double s_red[4 * FL_SUMS18];
-    __shared__ double s_fin[FL_BLOCK];
+    __shared__ double s_fin[FL_FIN_LDS];
     __shared__ double s_sums[FL_SUMS18];
+    __shared__ FlSolveLds s_solve;
     const int level = (level_arg >= 0) ? level_arg : D->level;
 
     // wave-uniform camera pose: Rcw = Rci Rwi^T, Pcw = -Rci Rwi^T Pwi + Pci  (:780-784)
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(FL_BLOCK) void vio_iterate_kernel(const uint8_t *__
 #pragma unroll
     for (int k = 0; k < FL_SUMS18; k++) v[k] = 0.0;
 
+    if (blockIdx.x == 0) fl_stamp(flags, 0);
     for (int i = blockIdx.x * (FL_BLOCK / 64) + wave; i < m; i += gridDim.x * (FL_BLOCK / 64)) {
         const int scale = 1 << (level + slevel[i]);
         const double ps[3] = {pos[i * 3 + 0], pos[i * 3 + 1], pos[i * 3 + 2]};
@@ -210,30 +214,33 @@ __global__ __launch_bounds__(FL_BLOCK) void vio_iterate_kernel(const uint8_t *__
         if (lane == 0) errors[i] = (float)pe;
     }
 
+    if (blockIdx.x == 0) fl_stamp(flags, 1);
     const bool last = block_publish<FL_SUMS18>(v, partials, ticket, s_red);
+    if (blockIdx.x == 0) fl_stamp(flags, 2);
     if (!last) return;
+    fl_stamp(flags, 8);
     final_reduce<FL_SUMS18>(partials, gridDim.x, s_fin, s_sums);
-    if (threadIdx.x == 0) {
-        *ticket = 0u;
-        if (MODE == 0) {
-            vio_epilogue_serial(D, s_sums);
-        } else {
-#pragma unroll
-            for (int k = 0; k < FL_SUMS18; k++) sums_out[k] = s_sums[k];
-        }
+    fl_stamp(flags, 9);
+    if (threadIdx.x == 0) *ticket = 0u;
+    if (MODE == 0) {
+        eskf18_epilogue_block<FL_EPI_VIO>(D, s_sums, s_solve);
+        fl_stamp(flags, 10);
+    } else {
+        if (threadIdx.x < FL_SUMS18) sums_out[threadIdx.x] = s_sums[threadIdx.x];
     }
 }
 
 // Solve from an externally reduced record (sharded form). vio != 0 selects the VIO epilogue.
-__global__ void eskf18_solve_kernel(FlDev18 *__restrict__ D, const double *__restrict__ sums_in, double sign, int vio, int flags)
+__global__ __launch_bounds__(FL_BLOCK) void eskf18_solve_kernel(FlDev18 *__restrict__ D, const double *__restrict__ sums_in,
+                                                               double sign, int vio, int flags)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (!(flags & FL_ITER_FORCE) && (D->stop || (!vio && D->need_search))) return;
-    double s[FL_SUMS18];
-#pragma unroll
-    for (int k = 0; k < FL_SUMS18; k++) s[k] = sums_in[k];
-    if (vio) vio_epilogue_serial(D, s);
-    else eskf18_solve_serial(D, s, sign);
+    __shared__ double s_sums[FL_SUMS18];
+    __shared__ FlSolveLds s_solve;
+    if (threadIdx.x < FL_SUMS18) s_sums[threadIdx.x] = sums_in[threadIdx.x];
+    __syncthreads();
+    if (vio) eskf18_epilogue_block<FL_EPI_VIO>(D, s_sums, s_solve);
+    else eskf18_epilogue_block<FL_EPI_LIO>(D, s_sums, s_solve);
 }
 
 // UpdateState prologue: old_state = *state, last_error = total_residual (:747,756); per-level counters.
@@ -275,7 +282,11 @@ __global__ __launch_bounds__(384) void vio_cov_update_kernel(FlDev18 *__restrict
     const int t = threadIdx.x;
     const bool apply = D->last_error < 1e10f;
     if (t < 324) sP[t] = D->P[t];
-    if (t < 108) sG[t] = D->G6[t];
+    if (t == 0) {   // G[:,0:6] of the last ACCEPTED iteration (G is only rewritten on acceptance, :877)
+        double G6[108];
+        fl_gain18(D->Q, D->T, D->sums_acc, G6);
+        for (int i = 0; i < 108; i++) { sG[i] = G6[i]; D->G6[i] = G6[i]; }
+    }
     __syncthreads();
     if (apply && t < 324) {
         const int r = t / 18, c = t % 18;

@@ -107,6 +107,9 @@ int32_t fl_sync(fl_handle h);
 /* Times the last fl_lio_iterate18 / fl_vio_iterate batch with HIP events on the handle's stream. */
 int32_t fl_set_timing(fl_handle h, int32_t enable);
 int32_t fl_get_last_kernel_ms(fl_handle h, float *ms);
+/* Debug: shader-clock phase stamps of the last pass launched with flag FL_ITER_STAMP (64 slots). */
+#define FL_ITER_STAMP 4
+int32_t fl_debug_get_stamps(fl_handle h, long long *out64);
 
 /* ------------------------------------------------------------------------------------------------
  * LIO staging (both modes)

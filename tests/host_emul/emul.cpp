@@ -40,4 +40,15 @@ int emul_solve18(double *x, const double *xprop, const double *P, double meas_co
 {
     return fl_solve18_serial(x, xprop, P, meas_cov, sums, sign, G6, delta);
 }
+
+// per-frame prepare + fast per-iteration solve + gain (the forms the device kernels run)
+int emul_solve18_fast(double *x, const double *xprop, const double *P, double meas_cov, const double *sums, double sign,
+                      double *G6, double *delta)
+{
+    double Q[36], T[108];
+    int st = fl_prepare18(P, meas_cov, Q, T);
+    st |= fl_solve18_fast(x, xprop, Q, T, sums, sign, delta);
+    st |= fl_gain18(Q, T, sums, G6);
+    return st;
+}
 }

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Phase breakdown of one fused pass from in-kernel shader-clock stamps (FL_ITER_STAMP).
+slots: 0 block0 start-of-loop, 1 block0 end-of-loop, 2 block0 after publish+ticket,
+       8 last block after ticket, 9 after final reduce, 10 after solve."""
+import os, sys, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import fastlivo  # noqa
+from fast_livo_amd import capi, synth
+scene = synth.make_scene()
+fr = synth.make_lio_frame(50000, scene=scene)
+vf = synth.make_vio_frame(2000, fr)
+nbr, valid = synth.knn5(scene, fr.world_at(fr.R_prior, fr.p_prior))
+cfg = capi.config_from_frames(fr, vf)
+hl = capi.Handle(cfg); hv = capi.Handle(cfg)
+x0 = capi.state18_from_frame(fr)
+hl.lio_set_points(fr.body_xyz); hl.lio_begin18(x0, x0); hl.lio_set_neighbours(nbr, valid)
+hv.vio_set_frame(vf.img); hv.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level); hv.vio_begin(x0, x0)
+F = capi.FL_ITER_FORCE | capi.FL_ITER_STAMP
+def show(name, st):
+    t0 = st[0]
+    d = {k: int(st[k] - t0) for k in (1, 2, 8, 9, 10)}
+    print(name, json.dumps({"loop_end": d[1], "blk0_published": d[2], "last_ticket": d[8], "final_reduced": d[9], "solved": d[10],
+                            "reduce_cycles": d[9]-d[8], "solve_cycles": d[10]-d[9],
+                            "pub_wavereduce": int(st[30]-st[1]), "pub_store_wait": int(st[31]-st[30]), "pub_atomic": int(st[32]-st[31]),
+                            "epi_stageA": int(st[20]-st[9]), "epi_sync1": int(st[21]-st[20]), "epi_stageB": int(st[22]-st[21]),
+                            "epi_sync2": int(st[23]-st[22]), "epi_stageC": int(st[10]-st[23])}))
+for rep in range(3):
+    for _ in range(5): hl.lio_iterate18(1, capi.FL_ITER_FORCE, want_info=False)
+    hl.lio_iterate18(1, F, want_info=False); show("lio", hl.debug_stamps())
+    for _ in range(5): hv.vio_iterate(0, 1, capi.FL_ITER_FORCE, want_info=False)
+    hv.vio_iterate(0, 1, F, want_info=False); show("vio", hv.debug_stamps())
