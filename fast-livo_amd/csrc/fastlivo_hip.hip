@@ -33,8 +33,8 @@ struct fl_context {
     // 18-state block, reduction scratch
     FlDev18 *d_dev = nullptr;
     FlDev18 *h_dev = nullptr;      // pinned mirror
-    double *d_partials = nullptr;
-    unsigned *d_ticket = nullptr;
+    void *d_records = nullptr;      // tagged per-workgroup records (handoff.h)
+    unsigned *d_epoch = nullptr;    // launch epoch of the records, advanced on the device
     double *d_sums_tmp = nullptr;
     // VIO
     FlVioConst *d_vc = nullptr;
@@ -136,11 +136,16 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
     HIPCHK(h, hipHostMalloc(&h->h_dev, sizeof(FlDev18)));
     HIPCHK(h, hipMalloc(&h->d_dev23, sizeof(FlDev23)));
     HIPCHK(h, hipHostMalloc(&h->h_dev23, sizeof(FlDev23)));
-    HIPCHK(h, hipMalloc(&h->d_partials, sizeof(double) * FL_MAX_BLOCKS * FL_SUMS23));
-    HIPCHK(h, hipMalloc(&h->d_ticket, 64));
+    HIPCHK(h, hipMalloc(&h->d_records, (size_t)16 * FL_MAX_BLOCKS * FL_SUMS23));
+    HIPCHK(h, hipMalloc(&h->d_epoch, 64));
     HIPCHK(h, hipMalloc(&h->d_sums_tmp, sizeof(double) * FL_SUMS23));
     HIPCHK(h, hipMalloc(&h->d_vc, sizeof(FlVioConst)));
-    HIPCHK(h, hipMemset(h->d_ticket, 0, 64));
+    HIPCHK(h, hipMemset(h->d_records, 0, (size_t)16 * FL_MAX_BLOCKS * FL_SUMS23));
+    {
+        const unsigned one = 1u;   // epoch 0 is the "never written" tag
+        HIPCHK(h, hipMemset(h->d_epoch, 0, 64));
+        HIPCHK(h, hipMemcpy(h->d_epoch, &one, sizeof one, hipMemcpyHostToDevice));
+    }
     HIPCHK(h, hipMemset(h->d_dev, 0, sizeof(FlDev18)));
     HIPCHK(h, hipMemset(h->d_dev23, 0, sizeof(FlDev23)));
     build_vio_const(h->cfg, h->h_vc);
@@ -157,8 +162,8 @@ int32_t fl_destroy(fl_handle h)
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
     hipFree(h->d_body); hipFree(h->d_nbr); hipFree(h->d_world); hipFree(h->d_valid); hipFree(h->d_sel);
-    hipFree(h->d_plane); hipFree(h->d_normvec); hipFree(h->d_dev); hipFree(h->d_dev23); hipFree(h->d_partials);
-    hipFree(h->d_ticket); hipFree(h->d_sums_tmp); hipFree(h->d_vc); hipFree(h->d_img); hipFree(h->d_ref);
+    hipFree(h->d_plane); hipFree(h->d_normvec); hipFree(h->d_dev); hipFree(h->d_dev23); hipFree(h->d_records);
+    hipFree(h->d_epoch); hipFree(h->d_sums_tmp); hipFree(h->d_vc); hipFree(h->d_img); hipFree(h->d_ref);
     hipFree(h->d_errors); hipFree(h->d_pos); hipFree(h->d_slevel);
     if (h->h_dev) hipHostFree(h->h_dev);
     if (h->h_dev23) hipHostFree(h->h_dev23);
@@ -224,11 +229,13 @@ static int32_t ensure_points(fl_handle h, int n)
     return FL_OK;
 }
 
+// producers + 1 solver workgroup (handoff.h)
 static inline int lio_grid(int n)
 {
-    int b = (n + FL_BLOCK - 1) / FL_BLOCK;
+    int b = (n + FL_LIO_NT - 1) / FL_LIO_NT;
     if (b < 1) b = 1;
-    return b > FL_MAX_BLOCKS ? FL_MAX_BLOCKS : b;
+    if (b > FL_MAX_BLOCKS - 1) b = FL_MAX_BLOCKS - 1;
+    return b + 1;
 }
 
 int32_t fl_lio_set_points(fl_handle h, const float *body_xyz, int32_t n)
@@ -376,8 +383,8 @@ int32_t fl_lio_iterate18(fl_handle h, int32_t count, int32_t flags, fl_iter_info
     const int grid = lio_grid(h->n);
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     for (int i = 0; i < count; i++)
-        hipLaunchKernelGGL(lio18_iterate_kernel<0>, dim3(grid), dim3(FL_BLOCK), 0, h->stream, h->d_body, h->d_plane, h->d_sel,
-                           h->d_normvec, h->n, h->d_dev, h->d_partials, h->d_ticket, (double *)nullptr, (int)flags);
+        hipLaunchKernelGGL(lio18_pass_kernel<0>, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_body, h->d_plane, h->d_sel,
+                           h->d_normvec, h->n, h->d_dev, h->d_records, h->d_epoch, (double *)nullptr, (int)flags);
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipGetLastError());
     h->last_launches = count;
@@ -438,8 +445,8 @@ int32_t fl_lio_accumulate18(fl_handle h, double *d_sums, int32_t flags)
     if (h->n <= 0 || !h->have_nbr) return fail_arg(h, "fl_lio_accumulate18: points/neighbours not staged");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(lio18_iterate_kernel<1>, dim3(lio_grid(h->n)), dim3(FL_BLOCK), 0, h->stream, h->d_body, h->d_plane,
-                       h->d_sel, h->d_normvec, h->n, h->d_dev, h->d_partials, h->d_ticket, d_sums, (int)flags);
+    hipLaunchKernelGGL(lio18_pass_kernel<1>, dim3(lio_grid(h->n)), dim3(FL_LIO_NT), 0, h->stream, h->d_body, h->d_plane,
+                       h->d_sel, h->d_normvec, h->n, h->d_dev, h->d_records, h->d_epoch, d_sums, (int)flags);
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipGetLastError());
     return FL_OK;
@@ -449,7 +456,7 @@ int32_t fl_lio_solve18(fl_handle h, const double *d_sums, int32_t flags, fl_iter
 {
     if (!h || !d_sums) return fail_arg(h, "fl_lio_solve18: null argument");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(eskf18_solve_kernel, dim3(1), dim3(FL_BLOCK), 0, h->stream, h->d_dev, d_sums, 1.0, 0, (int)flags);
+    hipLaunchKernelGGL(eskf18_solve_kernel, dim3(1), dim3(FL_BLOCK), 0, h->stream, h->d_dev, d_sums, 0, (int)flags);
     HIPCHK(h, hipGetLastError());
     if (info) return read_info18(h, info);
     return FL_OK;
@@ -462,6 +469,15 @@ int32_t fl_debug_get_stamps(fl_handle h, long long *out64)
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_fl_stamps), sizeof(long long) * 64));
+    return FL_OK;
+}
+
+int32_t fl_debug_get_wall(fl_handle h, long long *out2048)
+{
+    if (!h || !out2048) return fail_arg(h, "fl_debug_get_wall: null argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyFromSymbol(out2048, HIP_SYMBOL(g_fl_wall), sizeof(long long) * 2048));
     return FL_OK;
 }
 

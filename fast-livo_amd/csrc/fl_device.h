@@ -134,6 +134,7 @@ __device__ __forceinline__ void so3_Log(const double *R, double *out)
 }
 
 __device__ long long g_fl_stamps[64];
+__device__ long long g_fl_wall[2048];   // debug: per-workgroup start/end wall clock (100 MHz)
 
 // ---- wavefront reduction --------------------------------------------------------------------
 // Transposing butterfly: every lane enters with V partial sums; on exit lane L holds in v[0] the
@@ -229,89 +230,12 @@ __device__ __forceinline__ double load_wt(const double *p)
     return __longlong_as_double((long long)u);
 }
 
-// Block-level reduction of per-thread partial sums and publication of this workgroup's record.
-// Returns true in EVERY thread of the last-arriving workgroup, which then owns the final reduce.
-// `partials` holds gridDim.x records of NV doubles; the order of the final sum is by block index,
-// so results do not depend on arrival order.
-template <int NV>
-__device__ __forceinline__ bool block_publish(double (&v)[NV], double *partials, unsigned *ticket, double *lds /* >= 4*NV */)
-{
-    static_assert(NV % 32 == 0, "NV multiple of 32");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int g = 0; g < NV / 32; g++) {
-        double w[32];
-#pragma unroll
-        for (int i = 0; i < 32; i++) w[i] = v[g * 32 + i];
-        wave_transpose_reduce32(w, lane);
-        if ((lane & 1) == 0) lds[wave * NV + g * 32 + (lane >> 1)] = w[0];
-    }
-    if (blockIdx.x == 0 && tid == 0) g_fl_stamps[30] = (long long)__builtin_readcyclecounter();
-    __syncthreads();
-    if (tid < NV) {
-        double s = lds[tid];
-#pragma unroll
-        for (int w = 1; w < FL_BLOCK / 64; w++) s += lds[w * NV + tid];
-        store_wt(&partials[(size_t)blockIdx.x * NV + tid], s);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (blockIdx.x == 0 && tid == 0) g_fl_stamps[31] = (long long)__builtin_readcyclecounter();
-    __syncthreads();
-    __shared__ unsigned s_ticket;
-    if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
-    if (blockIdx.x == 0 && tid == 0) g_fl_stamps[32] = (long long)__builtin_readcyclecounter();
-    __syncthreads();
-    return s_ticket == gridDim.x - 1;
-}
-
-// Final reduce by the last workgroup: sums[k] = sum over blocks of partials[b][k], in an order fixed
-// by the block indices. Records were published write-through (sc1); they are read back with 16-byte
-// sc1 buffer loads (L1-bypassing, counted by the compiler's s_waitcnt, out-of-range records read as
-// zero through the descriptor's bounds check, so there is no branch per load). All loads of a batch
-// are in flight together: the hand-off costs about one memory round trip.
 typedef unsigned int fl_u4 __attribute__((ext_vector_type(4)));
-#define FL_FIN_LDS (2 * FL_BLOCK)
-template <int NV>
-__device__ __forceinline__ void final_reduce(const double *partials, int nblocks, double *lds /* >= FL_FIN_LDS */, double *out_lds /* NV */)
-{
-    const int tid = threadIdx.x;
-    constexpr int GROUPS = FL_BLOCK / 16;       // 16 block-groups x 16 value-pairs per pass
-    constexpr int BATCH = 16;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)partials, 0, nblocks * NV * 8, 0x00020000);
-#pragma unroll
-    for (int g = 0; g < NV / 32; g++) {
-        const int kp = tid & 15, grp = tid >> 4;
-        double s0 = 0.0, s1 = 0.0;
-        for (int b0 = grp; b0 < nblocks; b0 += GROUPS * BATCH) {
-            fl_u4 t[BATCH];
-#pragma unroll
-            for (int j = 0; j < BATCH; j++) {
-                const int b = b0 + j * GROUPS;
-                t[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (b * NV + g * 32 + kp * 2) * 8, 0, 16 /* sc1 */);
-            }
-#pragma unroll
-            for (int j = 0; j < BATCH; j++) {
-                s0 += f64_make(t[j].x, t[j].y);
-                s1 += f64_make(t[j].z, t[j].w);
-            }
-        }
-        lds[tid * 2] = s0;
-        lds[tid * 2 + 1] = s1;
-        __syncthreads();
-        if (tid < 32) {
-            double t = lds[tid];
-#pragma unroll
-            for (int j = 1; j < GROUPS; j++) t += lds[j * 32 + tid];
-            out_lds[g * 32 + tid] = t;
-        }
-        __syncthreads();
-    }
-}
 
 // Optional phase timestamps (s_memtime) for tools/kstamps.py: slot i of workgroup 0 and of the last
 // workgroup. Enabled by the FL_ITER_STAMP flag; costs nothing when the flag is clear.
 #define FL_ITER_STAMP 4
 __device__ __forceinline__ void fl_stamp(int flags, int slot)
 {
-    if ((flags & FL_ITER_STAMP) && threadIdx.x == 0) g_fl_stamps[slot] = (long long)__builtin_readcyclecounter();
+    if ((flags & FL_ITER_STAMP) && threadIdx.x == 0) g_fl_stamps[slot] = (long long)wall_clock64();
 }

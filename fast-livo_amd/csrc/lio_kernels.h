@@ -4,22 +4,27 @@
 //                              The plane depends only on the neighbours, not on the state, so the
 //                              reference's per-iteration esti_plane (laserMapping.cpp:1571) is
 //                              hoisted out of the iteration loop with bit-identical results.
-//  K1  lio18_iterate_kernel    one ESKF pass: per-point residual + gates + 1x6 row, fp64 wave /
-//                              block reduction of the 32-double record, write-through hand-off of
-//                              per-block partials, and -- in the last-arriving workgroup -- the
-//                              fixed-order final reduce, the gain solve, the state update and the
-//                              rematch/stop judgement. One launch per pass, no host round trip.
-//  K1a lio18_accumulate_kernel sharded form: same but stops after the final reduce (sums out).
+//  K1  lio18_pass_kernel       one ESKF pass in ONE launch: producer workgroups do the per-point
+//                              residual + gates + 1x6 row and reduce to one 32-double record each
+//                              (fp64, transposing wave butterfly -> LDS -> tagged write-through
+//                              record); the last workgroup of the grid is the solver (handoff.h,
+//                              solve18.h): gathers the records in block order, runs the gain solve,
+//                              updates the state in HBM and makes the rematch/stop judgement.
+//                              MODE 1 (sharded form) stops after the gather: sums -> sums_out.
 //  K3  eskf18_solve_kernel     sharded form: gain solve from an (all-reduced) record.
-//  K4  lio18_finish_kernel     P <- (I - G) P   (laserMapping.cpp:1715)
+//  K4  eskf18_cov_update_kernel  P <- (I - G) P   (laserMapping.cpp:1715)
 #pragma once
 
 #include "fl_device.h"
 #include "fl_math.h"
+#include "handoff.h"
 #include "solve18.h"
 
 #define FL_ITER_FORCE 1
 #define FL_ITER_KEEP_NORMVEC 2
+#ifndef FL_LIO_NT
+#define FL_LIO_NT 256
+#endif
 
 // -------------------------------------------------------------------------------------------- K0
 __global__ __launch_bounds__(FL_BLOCK) void lio_fit_planes_kernel(const float *__restrict__ nbr, const uint8_t *__restrict__ valid,
@@ -43,28 +48,6 @@ __global__ __launch_bounds__(FL_BLOCK) void lio_fit_planes_kernel(const float *_
     sel[i] = (uint8_t)((valid[i] != 0) && ok);
 }
 
-// ------------------------------------------------------------------------------------ epilogues
-// Rematch / stop judgement of the Mode-18 loop, laserMapping.cpp:1688-1728 (one thread).
-__device__ __forceinline__ void lio18_judge(FlDev18 *D, const double *delta, const double *sums, int st)
-{
-    const double rn = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
-    const double tn = sqrt(delta[3] * delta[3] + delta[4] * delta[4] + delta[5] * delta[5]);
-    const int converged = (rn * 57.3 < 0.01) && (tn * 100 < 0.015);
-    int rematch = D->rematch_num, need_search = 0, stop = 0;
-    const int it = D->iterCount;
-    if (converged || ((rematch == 0) && (it == (D->max_iter - 2)))) { need_search = 1; rematch++; }
-    if (rematch >= 2 || (it == D->max_iter - 1)) stop = 1;
-    D->converged = converged;
-    D->rematch_num = rematch;
-    D->need_search = need_search;
-    D->stop = stop;
-    D->iterCount = it + 1;
-    D->iters_run = D->iters_run + 1;
-    D->neff = (int)sums[FL_S_NEFF];
-    D->total_residual = sums[FL_S_RES];
-    D->status = st | ((sums[FL_S_NEFF] < 1.0) ? 4 : 0);
-}
-
 // Per-frame prepare: Q and T of fl_math.h (depends on P and the measurement covariance only).
 __global__ void eskf18_prepare_kernel(FlDev18 *__restrict__ D)
 {
@@ -76,36 +59,43 @@ __global__ void eskf18_prepare_kernel(FlDev18 *__restrict__ D)
     D->status = st;
 }
 
-// Gain solve + state update executed by one thread of the final workgroup.
-__device__ __forceinline__ void eskf18_solve_serial(FlDev18 *D, const double *sums, double sign)
-{
-    double x[24], xp[24], delta[18];
-#pragma unroll
-    for (int i = 0; i < 24; i++) { x[i] = D->x[i]; xp[i] = D->xprop[i]; }
-    const int st = fl_solve18_fast(x, xp, D->Q, D->T, sums, sign, delta);
-#pragma unroll
-    for (int i = 0; i < 24; i++) D->x[i] = x[i];
-#pragma unroll
-    for (int i = 0; i < 18; i++) D->solution[i] = delta[i];
-#pragma unroll
-    for (int i = 0; i < FL_SUMS18; i++) { D->sums[i] = sums[i]; D->sums_acc[i] = sums[i]; }
-    lio18_judge(D, delta, sums, st);
-}
-
 // -------------------------------------------------------------------------------------------- K1
-// mode 0: fused (accumulate + final reduce + solve).  mode 1: accumulate only, sums -> sums_out.
+// grid = producers + 1 ; MODE 0: fused pass ; MODE 1: accumulate only (sums -> sums_out)
 template <int MODE>
-__global__ __launch_bounds__(FL_BLOCK) void lio18_iterate_kernel(const float *__restrict__ body, const float4 *__restrict__ plane,
-                                                                uint8_t *__restrict__ sel, float4 *__restrict__ normvec, int n,
-                                                                FlDev18 *__restrict__ D, double *__restrict__ partials,
-                                                                unsigned *__restrict__ ticket, double *__restrict__ sums_out, int flags)
+__global__ __launch_bounds__(FL_LIO_NT) void lio18_pass_kernel(const float *__restrict__ body, const float4 *__restrict__ plane,
+                                                              uint8_t *__restrict__ sel, float4 *__restrict__ normvec, int n,
+                                                              FlDev18 *__restrict__ D, void *__restrict__ records,
+                                                              unsigned *__restrict__ epoch_ptr, double *__restrict__ sums_out,
+                                                              int flags)
 {
+    constexpr int NT = FL_LIO_NT;
+    if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();
     if (!(flags & FL_ITER_FORCE) && (D->stop || D->need_search)) return;
-    __shared__ double s_red[4 * FL_SUMS18];
-    __shared__ double s_fin[FL_FIN_LDS];
-    __shared__ double s_sums[FL_SUMS18];
-    __shared__ FlSolveLds s_solve;
+    const unsigned epoch = *epoch_ptr;
+    const int nprod = gridDim.x - 1;
 
+    if (blockIdx.x == nprod) {
+        // ------------------------------------------------------------------ solver workgroup
+        __shared__ double s_fin[2 * NT];
+        __shared__ double s_sums[FL_SUMS18];
+        __shared__ FlSolveLds s_solve;
+        fl_stamp(flags, 8);
+        if (MODE == 0) eskf18_prefetch(D, s_solve);
+        fl_stamp(flags, 9);
+        const int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
+        fl_stamp(flags, 10);
+        if (threadIdx.x == 0) *epoch_ptr = epoch + 1u;
+        if (MODE == 0) {
+            eskf18_solve_block<FL_EPI_LIO>(D, s_sums, s_solve, gst);
+        } else {
+            if (threadIdx.x < FL_SUMS18) sums_out[threadIdx.x] = s_sums[threadIdx.x];
+        }
+        fl_stamp(flags, 11);
+        return;
+    }
+
+    // -------------------------------------------------------------------- producer workgroups
+    __shared__ double s_red[(NT / 64) * FL_SUMS18];
     double R[9], p[3], RLI[9], tLI[3];
 #pragma unroll
     for (int i = 0; i < 9; i++) { R[i] = D->x[i]; RLI[i] = D->R_LI[i]; }
@@ -117,7 +107,7 @@ __global__ __launch_bounds__(FL_BLOCK) void lio18_iterate_kernel(const float *__
     for (int k = 0; k < FL_SUMS18; k++) v[k] = 0.0;
     if (blockIdx.x == 0) fl_stamp(flags, 0);
 
-    for (int i = blockIdx.x * FL_BLOCK + threadIdx.x; i < n; i += gridDim.x * FL_BLOCK) {
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += nprod * NT) {
         if (!sel[i]) continue;
         const float pb[3] = {body[i * 3 + 0], body[i * 3 + 1], body[i * 3 + 2]};
         const float4 plq = plane[i];
@@ -137,35 +127,37 @@ __global__ __launch_bounds__(FL_BLOCK) void lio18_iterate_kernel(const float *__
             v[FL_S_RES2] += (double)pd2 * (double)pd2;
         }
     }
-
     if (blockIdx.x == 0) fl_stamp(flags, 1);
-    const bool last = block_publish<FL_SUMS18>(v, partials, ticket, s_red);
+    const double mine = block_reduce_record<NT, FL_SUMS18>(v, s_red);
+    publish_record<FL_SUMS18>(mine, epoch, records, nprod);
     if (blockIdx.x == 0) fl_stamp(flags, 2);
-    if (!last) return;
-    fl_stamp(flags, 8);
-    final_reduce<FL_SUMS18>(partials, gridDim.x, s_fin, s_sums);
-    fl_stamp(flags, 9);
-    if (threadIdx.x == 0) *ticket = 0u;
-    if (MODE == 0) {
-        eskf18_epilogue_block<FL_EPI_LIO>(D, s_sums, s_solve);
-        fl_stamp(flags, 10);
-    } else {
-        if (threadIdx.x < FL_SUMS18) sums_out[threadIdx.x] = s_sums[threadIdx.x];
-    }
+    if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();
 }
 
 // -------------------------------------------------------------------------------------------- K3
-__global__ void eskf18_solve_kernel(FlDev18 *__restrict__ D, const double *__restrict__ sums_in, double sign, int vio, int flags);
+// Solve from an externally reduced record (sharded form). vio != 0 selects the VIO epilogue.
+__global__ __launch_bounds__(FL_BLOCK) void eskf18_solve_kernel(FlDev18 *__restrict__ D, const double *__restrict__ sums_in,
+                                                               int vio, int flags)
+{
+    if (!(flags & FL_ITER_FORCE) && (D->stop || (!vio && D->need_search))) return;
+    __shared__ double s_sums[FL_SUMS18];
+    __shared__ FlSolveLds s_solve;
+    if (threadIdx.x < FL_SUMS18) s_sums[threadIdx.x] = sums_in[threadIdx.x];
+    eskf18_prefetch(D, s_solve);
+    __syncthreads();
+    if (vio) eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, 0);
+    else eskf18_solve_block<FL_EPI_LIO>(D, s_sums, s_solve, 0);
+}
 
 // -------------------------------------------------------------------------------------------- K4
-// P <- P - G6 * P[0:6,:]  (== (I - G) P with G's columns 6..17 zero)
+// P <- P - G6 * P[0:6,:]  (== (I - G) P with G's columns 6..17 zero); G from the last executed pass.
 __global__ __launch_bounds__(384) void eskf18_cov_update_kernel(FlDev18 *__restrict__ D)
 {
     __shared__ double sP[324];
     __shared__ double sG[108];
     const int t = threadIdx.x;
     if (t < 324) sP[t] = D->P[t];
-    if (t == 0) {   // G[:,0:6] of the last executed pass
+    if (t == 0) {
         double G6[108];
         fl_gain18(D->Q, D->T, D->sums_acc, G6);
         for (int i = 0; i < 108; i++) { sG[i] = G6[i]; D->G6[i] = G6[i]; }

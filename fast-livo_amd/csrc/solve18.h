@@ -1,33 +1,72 @@
-// solve18.h -- workgroup-cooperative epilogue of one 18-state ESKF pass (runs in the last-arriving
-// workgroup of the pass kernel, or alone in eskf18_solve_kernel for the sharded path).
+// solve18.h -- the dedicated solver workgroup of an 18-state ESKF pass (see handoff.h), also used
+// alone by eskf18_solve_kernel for the sharded (multi-GPU) path.
 //
-// Math: fl_math.h (fast form):  C = Q + S (SPD 6x6),  z = C^-1 (sign*HTz - S vec6),
-//       delta = T z + vec,  x (+)= delta, then the rematch/stop (LIO, laserMapping.cpp:1688-1728)
-//       or accept/revert bookkeeping (VIO, lidar_selection.cpp:857-899).
-// Latency is what matters here (one workgroup, ~600 dependent fp64 operations if done by one
-// thread), so the independent chains run on different wavefronts of the workgroup:
-//   wave 0   : LDL^T factorisation of C in registers  ||  wave 2: Log(R^T R_prop)  ||  wave 1: vector diffs
-//   sync
-//   wave 0   : rhs, triangular solves (all lanes redundantly), lanes 0..17: delta_r = vec_r + T_r . z
-//   sync
-//   wave 0 lanes 0..8: one element each of R*Exp(delta_rot) || wave 1: additive states || wave 2: judgement
+// Math (fl_math.h, fast form):  C = Q + S (SPD 6x6),  z = C^-1 (sign*HTz - S vec6),
+//       delta = T z + vec,  x (+)= delta, then the rematch/stop judgement (LIO,
+//       laserMapping.cpp:1688-1728) or the accept/revert bookkeeping (VIO, lidar_selection.cpp:857-899).
+// Latency is what matters (one workgroup on the critical path of every pass), so
+//   * everything that depends only on the incoming state is done BEFORE the records arrive, while
+//     the producers are still working: Q, T, x, x_prop staged in LDS, vec = x_prop (-) x including
+//     the SO(3) Log;
+//   * after the gather the independent chains run on different wavefronts:
+//       wave 0: LDL^T of C in registers, rhs, triangular solves; lanes 0..17: delta_r = vec_r + T_r.z
+//       then wave 0 lanes 0..8: one element each of R*Exp(delta_rot) || wave 1: additive states ||
+//       wave 2: judgement.
 #pragma once
 
 #include "fl_device.h"
 #include "fl_math.h"
+#include "handoff.h"
 
 struct FlSolveLds {
+    double Q[36];
+    double T[108];
+    double x[24];
+    double xp[24];
     double vec[18];
     double delta[18];
+    float last_error;
     int accept;
     int st;
+    int pad;
 };
 
 enum { FL_EPI_LIO = 0, FL_EPI_VIO = 1 };
 
-// FMA contraction is allowed in the solve (it is compared to the oracle by tolerance, never bitwise).
+// Stage 0 (before the gather): stage the solve inputs in LDS and form vec = x_prop (-) x.
+__device__ __forceinline__ void eskf18_prefetch(const FlDev18 *__restrict__ D, FlSolveLds &L)
+{
+    const int tid = threadIdx.x;
+    if (tid < 36) L.Q[tid] = D->Q[tid];
+    else if (tid < 144) L.T[tid - 36] = D->T[tid - 36];
+    else if (tid < 168) L.x[tid - 144] = D->x[tid - 144];
+    else if (tid < 192) L.xp[tid - 168] = D->xprop[tid - 168];
+    else if (tid == 192) L.last_error = D->last_error;
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    if (wave == 1) {
+        if (lane < 15) L.vec[3 + lane] = L.xp[9 + lane] - L.x[9 + lane];
+    } else if (wave == 2 && lane == 0) {
+        // Log(R^T R_prop), common_lib.h:354-358, so3_math.h:75-81
+        double rd[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) rd[i * 3 + j] = L.x[0 * 3 + i] * L.xp[0 * 3 + j] + L.x[1 * 3 + i] * L.xp[1 * 3 + j] + L.x[2 * 3 + i] * L.xp[2 * 3 + j];
+        const double tr = rd[0] + rd[4] + rd[8];
+        const double theta = (tr > 3.0 - 1e-6) ? 0.0 : acos(0.5 * (tr - 1));
+        const double fk = (fabs(theta) < 0.001) ? 0.5 : (0.5 * theta / sin(theta));
+        L.vec[0] = fk * (rd[7] - rd[5]);
+        L.vec[1] = fk * (rd[2] - rd[6]);
+        L.vec[2] = fk * (rd[3] - rd[1]);
+    }
+    // visibility of L.vec to wave 0 is ensured by the __syncthreads inside the gather / before the solve
+}
+
+// Solve + state update + judgement. All threads of the workgroup call it (NT >= 256); s_sums in LDS.
+// FMA contraction is allowed here (compared to the oracle by tolerance, never bitwise).
 template <int KIND>
-__device__ __forceinline__ void eskf18_epilogue_block(FlDev18 *__restrict__ D, const double *s_sums, FlSolveLds &L)
+__device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, const double *s_sums, FlSolveLds &L, int gather_status)
 {
 #pragma clang fp contract(fast)
     const int tid = threadIdx.x;
@@ -39,92 +78,37 @@ __device__ __forceinline__ void eskf18_epilogue_block(FlDev18 *__restrict__ D, c
         if (tid == 0) {
             const float n_meas = (float)s_sums[FL_S_NEFF];
             const float error = (float)s_sums[FL_S_RES] / n_meas;
-            const int acc = (error <= D->last_error) ? 1 : 0;
+            const int acc = (error <= L.last_error) ? 1 : 0;
             L.accept = acc;
             D->error = error;
-            if (acc) D->last_error = error;
+            if (acc) { D->last_error = error; L.last_error = error; }
         }
         __syncthreads();
         if (!L.accept) {   // revert: state = old_state ; EKF_end (:888-892)
             if (tid < 24) D->x[tid] = D->xold[tid];
             if (tid == 64) {
-                const int it = D->iters_run + 1;
-                D->iters_run = it;
+                D->iters_run = D->iters_run + 1;
                 D->stop = 1;
                 D->converged = 1;
                 D->neff = (int)s_sums[FL_S_NEFF];
-                D->total_residual = (double)D->last_error;
-                D->status = 0;
+                D->total_residual = (double)L.last_error;
+                D->status = gather_status;
             }
             if (wave == 3 && lane < FL_SUMS18) D->sums[lane] = s_sums[lane];
             return;
         }
     }
 
-    // ---------------- stage A: independent chains on different waves
-    FlLdl6 f;
-    double S[6][6];
-    double Trow[6];
-    double Rrow[3] = {0.0, 0.0, 0.0};
-    double xadd = 0.0;
-    int bad = 0;
+    // ---- wave 0: factorise, solve, delta.  Other waves: side outputs.
     if (wave == 0) {
-        if (lane < 18) {
-#pragma unroll
-            for (int c = 0; c < 6; c++) Trow[c] = D->T[lane * 6 + c];
-        }
-        if (lane < 9) {
-            const int i = lane / 3;
-#pragma unroll
-            for (int k = 0; k < 3; k++) Rrow[k] = D->x[i * 3 + k];   // row of the old rotation for stage C
-        }
-        double C[6][6];
+        FlLdl6 f;
+        double S[6][6], C[6][6], z[6];
         fl_unpack_S(s_sums, S);
 #pragma unroll
         for (int i = 0; i < 6; i++)
 #pragma unroll
-            for (int j = 0; j < 6; j++) C[i][j] = D->Q[i * 6 + j] + S[i][j];
-        bad = fl_ldl6(C, f);
-    } else if (wave == 1) {
-        if (lane < 15) {
-            xadd = D->x[9 + lane];
-            L.vec[3 + lane] = D->xprop[9 + lane] - xadd;
-            if (KIND == FL_EPI_VIO) D->xold[9 + lane] = xadd;        // old_state = *state (:863)
-        }
-    } else if (wave == 2) {
-        if (lane == 0) {
-            double xr[9], xp[9], rd[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) { xr[i] = D->x[i]; xp[i] = D->xprop[i]; }
-            if (KIND == FL_EPI_VIO) {
-#pragma unroll
-                for (int i = 0; i < 9; i++) D->xold[i] = xr[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++) rd[i * 3 + j] = xr[0 * 3 + i] * xp[0 * 3 + j] + xr[1 * 3 + i] * xp[1 * 3 + j] + xr[2 * 3 + i] * xp[2 * 3 + j];
-            const double tr = rd[0] + rd[4] + rd[8];
-            const double theta = (tr > 3.0 - 1e-6) ? 0.0 : acos(0.5 * (tr - 1));
-            const double fk = (fabs(theta) < 0.001) ? 0.5 : (0.5 * theta / sin(theta));
-            L.vec[0] = fk * (rd[7] - rd[5]);
-            L.vec[1] = fk * (rd[2] - rd[6]);
-            L.vec[2] = fk * (rd[3] - rd[1]);
-        }
-    } else {
-        if (lane < FL_SUMS18) {
-            const double sv = s_sums[lane];
-            D->sums[lane] = sv;
-            D->sums_acc[lane] = sv;   // LIO: last executed pass ; VIO: last accepted pass (we are on the accept path)
-        }
-    }
-    if (tid == 0) g_fl_stamps[20] = (long long)__builtin_readcyclecounter();
-    __syncthreads();
-    if (tid == 0) g_fl_stamps[21] = (long long)__builtin_readcyclecounter();
-
-    // ---------------- stage B: wave 0 -- rhs, substitution, delta
-    if (wave == 0) {
-        double z[6];
+            for (int j = 0; j < 6; j++) C[i][j] = L.Q[i * 6 + j] + S[i][j];
+        const int bad = fl_ldl6(C, f);
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             double b = sign * s_sums[FL_S_HTZ + i];
@@ -136,17 +120,23 @@ __device__ __forceinline__ void eskf18_epilogue_block(FlDev18 *__restrict__ D, c
         if (lane < 18) {
             double dl = L.vec[lane];
 #pragma unroll
-            for (int c = 0; c < 6; c++) dl += Trow[c] * z[c];
+            for (int c = 0; c < 6; c++) dl += L.T[lane * 6 + c] * z[c];
             L.delta[lane] = dl;
             D->solution[lane] = dl;
         }
-        if (lane == 0) L.st = bad;
+        if (lane == 0) L.st = bad | gather_status;
+    } else if (wave == 3) {
+        if (lane < FL_SUMS18) {
+            const double sv = s_sums[lane];
+            D->sums[lane] = sv;
+            D->sums_acc[lane] = sv;   // LIO: last executed pass ; VIO: last accepted pass (accept path)
+        }
+    } else if (KIND == FL_EPI_VIO && wave == 1) {
+        if (lane < 24) D->xold[lane] = L.x[lane];   // old_state = *state (:863)
     }
-    if (tid == 0) g_fl_stamps[22] = (long long)__builtin_readcyclecounter();
     __syncthreads();
-    if (tid == 0) g_fl_stamps[23] = (long long)__builtin_readcyclecounter();
 
-    // ---------------- stage C: state update and judgement on separate waves
+    // ---- state update and judgement on separate waves
     if (wave == 0) {
         if (lane < 9) {
             // R <- R * Exp(d0,d1,d2): lane (i,j) forms its element (so3_math.h:54-72, common_lib.h:345)
@@ -167,13 +157,13 @@ __device__ __forceinline__ void eskf18_epilogue_block(FlDev18 *__restrict__ D, c
                         e[q] = ((k == q) ? 1.0 : 0.0) + s * K[k * 3 + q] + c * kk;
                     }
                     const double ekj = (j == 0) ? e[0] : ((j == 1) ? e[1] : e[2]);
-                    acc += Rrow[k] * ekj;
+                    acc += L.x[i * 3 + k] * ekj;
                 }
                 D->x[lane] = acc;
             }
         }
     } else if (wave == 1) {
-        if (lane < 15) D->x[9 + lane] = xadd + L.delta[3 + lane];
+        if (lane < 15) D->x[9 + lane] = L.x[9 + lane] + L.delta[3 + lane];
     } else if (wave == 2) {
         if (lane == 0) {
             const double rn = sqrt(L.delta[0] * L.delta[0] + L.delta[1] * L.delta[1] + L.delta[2] * L.delta[2]);
@@ -208,7 +198,7 @@ __device__ __forceinline__ void eskf18_epilogue_block(FlDev18 *__restrict__ D, c
                 if (it >= D->max_iter) stop = 1;
                 D->stop = stop;
                 D->neff = (int)s_sums[FL_S_NEFF];
-                D->total_residual = (double)D->last_error;
+                D->total_residual = (double)L.last_error;
                 D->status = st;
             }
         }

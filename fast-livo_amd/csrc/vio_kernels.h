@@ -95,63 +95,47 @@ FL_HD void fl_pixel_row(const FlPatchGeom &g, const float t[4][4], float ref, co
     *res_out = (double)(wtl * t[1][1] + wtr * t[1][2] + wbl * t[2][1] + wbr * t[2][2] - ref);
 }
 
-// Accept/revert + solve of one UpdateState iteration (lidar_selection.cpp:857-899), one thread.
-__device__ __forceinline__ void vio_epilogue_serial(FlDev18 *D, const double *sums)
-{
-    const float n_meas = (float)sums[FL_S_NEFF];
-    const float error = (float)sums[FL_S_RES] / n_meas;
-    int stop = 0, st = 0;
-    double delta[18];
-#pragma unroll
-    for (int i = 0; i < 18; i++) delta[i] = 0.0;
-    if (error <= D->last_error) {
-        double x[24], xp[24];
-#pragma unroll
-        for (int i = 0; i < 24; i++) { x[i] = D->x[i]; xp[i] = D->xprop[i]; D->xold[i] = x[i]; }
-        D->last_error = error;
-        st = fl_solve18_fast(x, xp, D->Q, D->T, sums, -1.0, delta);
-#pragma unroll
-        for (int i = 0; i < FL_SUMS18; i++) D->sums_acc[i] = sums[i];
-#pragma unroll
-        for (int i = 0; i < 24; i++) D->x[i] = x[i];
-        D->accepted = D->accepted + 1;
-        const double rn = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
-        const double tn = sqrt(delta[3] * delta[3] + delta[4] * delta[4] + delta[5] * delta[5]);
-        if ((rn * 57.3f < 0.001f) && (tn * 100.0f < 0.001f)) stop = 1;
-        D->converged = stop;
-#pragma unroll
-        for (int i = 0; i < 18; i++) D->solution[i] = delta[i];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 24; i++) D->x[i] = D->xold[i];
-        stop = 1;
-        D->converged = 1;
-    }
-    D->error = error;
-    D->iters_run = D->iters_run + 1;
-    if (D->iters_run >= D->max_iter) stop = 1;
-    D->stop = stop;
-    D->neff = (int)sums[FL_S_NEFF];
-    D->total_residual = (double)D->last_error;
-    D->status = st;
-#pragma unroll
-    for (int i = 0; i < FL_SUMS18; i++) D->sums[i] = sums[i];
-}
+#define FL_VIO_NT 512
 
-// MODE 0: fused; MODE 1: accumulate only (sums -> sums_out)
+// grid = producers + 1 ; MODE 0: fused pass ; MODE 1: accumulate only (sums -> sums_out).
+// 512-thread workgroups (8 patches in flight per workgroup): 2000 patches -> 250 records, which the
+// solver workgroup gathers in a single sweep.
 template <int MODE>
-__global__ __launch_bounds__(FL_BLOCK) void vio_iterate_kernel(const uint8_t *__restrict__ img, const float *__restrict__ ref,
-                                                              const double *__restrict__ pos, const int32_t *__restrict__ slevel,
-                                                              float *__restrict__ errors, int m, int level_arg,
-                                                              const FlVioConst *__restrict__ VC, FlDev18 *__restrict__ D,
-                                                              double *__restrict__ partials, unsigned *__restrict__ ticket,
-                                                              double *__restrict__ sums_out, int flags)
+__global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__restrict__ img, const float *__restrict__ ref,
+                                                            const double *__restrict__ pos, const int32_t *__restrict__ slevel,
+                                                            float *__restrict__ errors, int m, int level_arg,
+                                                            const FlVioConst *__restrict__ VC, FlDev18 *__restrict__ D,
+                                                            void *__restrict__ records, unsigned *__restrict__ epoch_ptr,
+                                                            double *__restrict__ sums_out, int flags)
 {
+    constexpr int NT = FL_VIO_NT;
+    constexpr int WPB = NT / 64;
     if (!(flags & FL_ITER_FORCE) && D->stop) return;
-    __shared__ double s_red[4 * FL_SUMS18];
-    __shared__ double s_fin[FL_FIN_LDS];
-    __shared__ double s_sums[FL_SUMS18];
-    __shared__ FlSolveLds s_solve;
+    const unsigned epoch = *epoch_ptr;
+    const int nprod = gridDim.x - 1;
+
+    if (blockIdx.x == nprod) {
+        // ------------------------------------------------------------------ solver workgroup
+        __shared__ double s_fin[2 * NT];
+        __shared__ double s_sums[FL_SUMS18];
+        __shared__ FlSolveLds s_solve;
+        fl_stamp(flags, 8);
+        if (MODE == 0) eskf18_prefetch(D, s_solve);
+        fl_stamp(flags, 9);
+        const int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
+        fl_stamp(flags, 10);
+        if (threadIdx.x == 0) *epoch_ptr = epoch + 1u;
+        if (MODE == 0) {
+            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, gst);
+        } else {
+            if (threadIdx.x < FL_SUMS18) sums_out[threadIdx.x] = s_sums[threadIdx.x];
+        }
+        fl_stamp(flags, 11);
+        return;
+    }
+
+    // -------------------------------------------------------------------- producer workgroups
+    __shared__ double s_red[WPB * FL_SUMS18];
     const int level = (level_arg >= 0) ? level_arg : D->level;
 
     // wave-uniform camera pose: Rcw = Rci Rwi^T, Pcw = -Rci Rwi^T Pwi + Pci  (:780-784)
@@ -179,7 +163,7 @@ __global__ __launch_bounds__(FL_BLOCK) void vio_iterate_kernel(const uint8_t *__
     for (int k = 0; k < FL_SUMS18; k++) v[k] = 0.0;
 
     if (blockIdx.x == 0) fl_stamp(flags, 0);
-    for (int i = blockIdx.x * (FL_BLOCK / 64) + wave; i < m; i += gridDim.x * (FL_BLOCK / 64)) {
+    for (int i = blockIdx.x * WPB + wave; i < m; i += nprod * WPB) {
         const int scale = 1 << (level + slevel[i]);
         const double ps[3] = {pos[i * 3 + 0], pos[i * 3 + 1], pos[i * 3 + 2]};
         FlPatchGeom g;
@@ -213,34 +197,10 @@ __global__ __launch_bounds__(FL_BLOCK) void vio_iterate_kernel(const uint8_t *__
         const double pe = wave_sum(r2);
         if (lane == 0) errors[i] = (float)pe;
     }
-
     if (blockIdx.x == 0) fl_stamp(flags, 1);
-    const bool last = block_publish<FL_SUMS18>(v, partials, ticket, s_red);
+    const double mine = block_reduce_record<NT, FL_SUMS18>(v, s_red);
+    publish_record<FL_SUMS18>(mine, epoch, records, nprod);
     if (blockIdx.x == 0) fl_stamp(flags, 2);
-    if (!last) return;
-    fl_stamp(flags, 8);
-    final_reduce<FL_SUMS18>(partials, gridDim.x, s_fin, s_sums);
-    fl_stamp(flags, 9);
-    if (threadIdx.x == 0) *ticket = 0u;
-    if (MODE == 0) {
-        eskf18_epilogue_block<FL_EPI_VIO>(D, s_sums, s_solve);
-        fl_stamp(flags, 10);
-    } else {
-        if (threadIdx.x < FL_SUMS18) sums_out[threadIdx.x] = s_sums[threadIdx.x];
-    }
-}
-
-// Solve from an externally reduced record (sharded form). vio != 0 selects the VIO epilogue.
-__global__ __launch_bounds__(FL_BLOCK) void eskf18_solve_kernel(FlDev18 *__restrict__ D, const double *__restrict__ sums_in,
-                                                               double sign, int vio, int flags)
-{
-    if (!(flags & FL_ITER_FORCE) && (D->stop || (!vio && D->need_search))) return;
-    __shared__ double s_sums[FL_SUMS18];
-    __shared__ FlSolveLds s_solve;
-    if (threadIdx.x < FL_SUMS18) s_sums[threadIdx.x] = sums_in[threadIdx.x];
-    __syncthreads();
-    if (vio) eskf18_epilogue_block<FL_EPI_VIO>(D, s_sums, s_solve);
-    else eskf18_epilogue_block<FL_EPI_LIO>(D, s_sums, s_solve);
 }
 
 // UpdateState prologue: old_state = *state, last_error = total_residual (:747,756); per-level counters.

@@ -20,13 +20,10 @@ hl.lio_set_points(fr.body_xyz); hl.lio_begin18(x0, x0); hl.lio_set_neighbours(nb
 hv.vio_set_frame(vf.img); hv.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level); hv.vio_begin(x0, x0)
 F = capi.FL_ITER_FORCE | capi.FL_ITER_STAMP
 def show(name, st):
-    t0 = st[0]
-    d = {k: int(st[k] - t0) for k in (1, 2, 8, 9, 10)}
-    print(name, json.dumps({"loop_end": d[1], "blk0_published": d[2], "last_ticket": d[8], "final_reduced": d[9], "solved": d[10],
-                            "reduce_cycles": d[9]-d[8], "solve_cycles": d[10]-d[9],
-                            "pub_wavereduce": int(st[30]-st[1]), "pub_store_wait": int(st[31]-st[30]), "pub_atomic": int(st[32]-st[31]),
-                            "epi_stageA": int(st[20]-st[9]), "epi_sync1": int(st[21]-st[20]), "epi_stageB": int(st[22]-st[21]),
-                            "epi_sync2": int(st[23]-st[22]), "epi_stageC": int(st[10]-st[23])}))
+    print(name, json.dumps({"producer0_loop": int(st[1]-st[0]), "producer0_reduce_publish": int(st[2]-st[1]),
+                            "solver_prefetch": int(st[9]-st[8]), "solver_gather_wait": int(st[10]-st[9]), "solver_solve": int(st[11]-st[10]),
+                            "solver_total": int(st[11]-st[8]), "spins": int(st[39]),
+                            "sweep_ends_rel_prefetch_end": [int(st[40+i]-st[9]) for i in range(min(int(st[39])+1, 8))]}))
 for rep in range(3):
     for _ in range(5): hl.lio_iterate18(1, capi.FL_ITER_FORCE, want_info=False)
     hl.lio_iterate18(1, F, want_info=False); show("lio", hl.debug_stamps())
