@@ -186,7 +186,7 @@ def main():
         del tmp
         lio_bytes = LIO_BYTES_PER_POINT * args.points
         vio_bytes = VIO_BYTES_PER_PATCH * args.patches
-        dom = "lio18_iterate_kernel" if lio_us >= vio_us else "vio_iterate_kernel"
+        dom = "lio18_pass_kernel" if lio_us >= vio_us else "vio_pass_kernel"
         dom_bytes, dom_us = (lio_bytes, lio_us) if lio_us >= vio_us else (vio_bytes, vio_us)
         ach = dom_bytes / (dom_us * 1e-6) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -373,3 +373,86 @@ def config_from_frames(lio, vio=None, max_iterations=10, device=0):
 def state18_from_frame(fr, R=None, p=None):
     return State18.make(fr.R_prior if R is None else R, fr.p_prior if p is None else p,
                         fr.vel, fr.bg, fr.ba, fr.grav, fr.cov18)
+
+
+# ---------------------------------------------------------------------------------------- Mode-23
+def _ikfom_methods():
+    def ikfom_begin(self, x23, P, limit=None):
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        limit = np.full(23, 0.001) if limit is None else np.ascontiguousarray(limit, dtype=np.float64)
+        self._chk(self.L.fl_ikfom_begin(self.h, C.byref(x23), _p(P, C.c_double), _p(limit, C.c_double)), "fl_ikfom_begin")
+
+    def ikfom_iterate(self, count=1, flags=0, want_info=True):
+        info = IterInfo()
+        self._chk(self.L.fl_ikfom_iterate(self.h, count, flags, C.byref(info) if want_info else None), "fl_ikfom_iterate")
+        return info
+
+    def ikfom_get(self):
+        x = State23()
+        P = np.zeros((23, 23))
+        self._chk(self.L.fl_ikfom_get(self.h, C.byref(x), _p(P, C.c_double)), "fl_ikfom_get")
+        return x, P
+
+    def h_share_model_sums(self, s23):
+        HTH = np.zeros((12, 12))
+        HTh = np.zeros(12)
+        neff = C.c_int32()
+        res = C.c_double()
+        self._chk(self.L.fl_h_share_model_sums(self.h, C.byref(s23), _p(HTH, C.c_double), _p(HTh, C.c_double), C.byref(neff),
+                                               C.byref(res)), "fl_h_share_model_sums")
+        return HTH, HTh, neff.value, res.value
+
+    def h_share_model_rows(self, s23, n):
+        h_x = np.zeros((n, 12))
+        hv = np.zeros(n)
+        neff = C.c_int32()
+        self._chk(self.L.fl_h_share_model_rows(self.h, C.byref(s23), _p(h_x, C.c_double), _p(hv, C.c_double), C.byref(neff)),
+                  "fl_h_share_model_rows")
+        return h_x[:neff.value], hv[:neff.value]
+
+    def ikfom_update_iterated(self, x23, P, body, R, scene_knn, limit=None):
+        body = np.ascontiguousarray(body, dtype=np.float32)
+        n = body.shape[0]
+        limit = np.full(23, 0.001) if limit is None else np.ascontiguousarray(limit, dtype=np.float64)
+
+        def cb(ctx, world, nn, nbr, valid):
+            w = np.ctypeslib.as_array(world, shape=(nn, 3))
+            nb, va = scene_knn(w)
+            np.ctypeslib.as_array(nbr, shape=(nn, 5, 3))[:] = nb
+            np.ctypeslib.as_array(valid, shape=(nn,))[:] = va
+        cbf = KNN_FN(cb)
+        info = IterInfo()
+        self._chk(self.L.fl_ikfom_update_iterated(self.h, C.byref(x23), _p(P, C.c_double), _p(body, C.c_float), n, R,
+                                                  _p(limit, C.c_double), cbf, None, C.byref(info)), "fl_ikfom_update_iterated")
+        return info
+
+    def ikfom_accumulate(self, d_sums_ptr, flags=0):
+        self._chk(self.L.fl_ikfom_accumulate(self.h, C.c_void_p(d_sums_ptr), flags), "fl_ikfom_accumulate")
+
+    def ikfom_solve(self, d_sums_ptr, flags=0, want_info=False):
+        info = IterInfo()
+        self._chk(self.L.fl_ikfom_solve(self.h, C.c_void_p(d_sums_ptr), flags, C.byref(info) if want_info else None),
+                  "fl_ikfom_solve")
+        return info
+
+    for f in (ikfom_begin, ikfom_iterate, ikfom_get, h_share_model_sums, h_share_model_rows, ikfom_update_iterated,
+              ikfom_accumulate, ikfom_solve):
+        setattr(Handle, f.__name__, f)
+
+
+_ikfom_methods()
+
+
+def state23_from_frame(fr):
+    from . import synth
+    s = State23()
+    s.pos[:] = fr.p_prior
+    s.rot[:] = synth.quat_from_R(fr.R_prior)
+    s.offset_R_L_I[:] = synth.quat_from_R(fr.R_LI)
+    s.offset_T_L_I[:] = fr.t_LI
+    s.vel[:] = fr.vel
+    s.bg[:] = fr.bg
+    s.ba[:] = fr.ba
+    g = np.asarray(fr.grav, dtype=np.float64)
+    s.grav[:] = g / np.linalg.norm(g) * 9.809
+    return s

@@ -1,22 +1,35 @@
-// ikfom_kernels.h -- Mode-23 (IKFoM) device block and kernels. (filled in below)
+// ikfom_kernels.h -- Mode-23 (IKFoM) device block and kernels: the dormant USE_IKFOM path of the
+// reference (h_share_model, src/laserMapping.cpp:961-1093, driven by
+// esekf::update_iterated_dyn_share_modified, include/IKFoM_toolkit/esekfom/esekfom.hpp:1619-1928).
+//
+//  ikfom_pass_kernel   one pass of the iterated update in ONE launch, same producer / solver
+//                      structure as the Mode-18 pass (handoff.h): producers form the 1x12 rows
+//                      [n, A, B, C] and reduce the 96-double record (78 unique h_x^T h_x + 12 h_x^T h
+//                      + 3 scalars); the solver workgroup gathers it and runs the manifold update
+//                      (fl_ikfom_math.h) with the 23x23 covariance staged in LDS.
+//                      MODE 1: accumulate only (the "sum-compat" body of h_share_model and the sharded form).
+//  ikfom_rows_kernel   the "row-compat" body of h_share_model: per-point rows + mask for the host to compact.
 #pragma once
+
 #include "fl_device.h"
 #include "fl_math.h"
+#include "fl_ikfom_math.h"
+#include "handoff.h"
 
 struct FlDev23 {
-    double x[27];        // pos(3) rot(4 xyzw) offset_R_L_I(4) offset_T_L_I(3) vel bg ba grav(3)
-    double xprop[27];
-    double P[529];       // P_ (working / result)
-    double Pprop[529];   // P_propagated
+    double x[FL_X23_LEN];     // state_ikfom, see fl_ikfom_math.h
+    double xprop[FL_X23_LEN]; // x_propagated
+    double P[529];            // P_ (projected while iterating; final P_ after the finishing pass)
+    double Pprop[529];        // P_propagated
     double limit[23];
-    double solution[23];
+    double solution[23];      // last dx_
     double sums[FL_SUMS23];
     double total_residual;
-    double meas_cov;
-    int32_t iter_i;      // loop index i of esekfom.hpp:1633 (starts at -1)
-    int32_t t_count;     // t
-    int32_t need_search; // dyn_share.converge
-    int32_t stop;
+    double meas_cov;          // R
+    int32_t iter_i;           // loop index i of esekfom.hpp:1633 (starts at -1)
+    int32_t t_count;          // t
+    int32_t need_search;      // dyn_share.converge: the next h_share_model call re-runs the kNN
+    int32_t stop;             // the final covariance block has run (or max iterations reached)
     int32_t converged;
     int32_t neff;
     int32_t status;
@@ -24,3 +37,146 @@ struct FlDev23 {
     int32_t max_iter;
     int32_t pad;
 };
+
+#define FL_IK_NT 256
+
+__device__ __forceinline__ void ikfom_solver_serial(FlDev23 *__restrict__ D, const double *s_sums, double *s_P, double *s_work, int gst)
+{
+    // one thread; big arrays live in LDS (s_P, s_work), Pprop is read from HBM
+    double x[FL_X23_LEN], xp[FL_X23_LEN], dx[23];
+    for (int i = 0; i < FL_X23_LEN; i++) { x[i] = D->x[i]; xp[i] = D->xprop[i]; }
+    FlIkfomCtl c;
+    c.iter_i = D->iter_i; c.t_count = D->t_count; c.converge = 0; c.finished = 0; c.max_iter = D->max_iter; c.status = gst;
+    fl_ikfom_iterate(x, xp, D->Pprop, s_P, D->limit, D->meas_cov, s_sums, &c, dx, s_work);
+    for (int i = 0; i < FL_X23_LEN; i++) D->x[i] = x[i];
+    for (int i = 0; i < 23; i++) D->solution[i] = dx[i];
+    for (int i = 0; i < 529; i++) D->P[i] = s_P[i];
+    for (int i = 0; i < FL_SUMS23; i++) D->sums[i] = s_sums[i];
+    D->iter_i = c.iter_i;
+    D->t_count = c.t_count;
+    D->need_search = c.converge;
+    D->converged = c.converge;
+    D->stop = (c.finished || c.iter_i >= c.max_iter) ? 1 : 0;
+    D->neff = (int)s_sums[FL_S23_NEFF];
+    D->total_residual = s_sums[FL_S23_RES];
+    D->status = c.status;
+    D->iters_run = D->iters_run + 1;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float *__restrict__ body, const float4 *__restrict__ plane,
+                                                             uint8_t *__restrict__ sel, float4 *__restrict__ normvec, int n,
+                                                             FlDev23 *__restrict__ D, void *__restrict__ records,
+                                                             unsigned *__restrict__ epoch_ptr, double *__restrict__ sums_out,
+                                                             int flags)
+{
+    constexpr int NT = FL_IK_NT;
+    if (!(flags & FL_ITER_FORCE) && (D->stop || D->need_search)) return;
+    const unsigned epoch = *epoch_ptr;
+    const int nprod = gridDim.x - 1;
+
+    if (blockIdx.x == nprod) {
+        __shared__ double s_fin[NT];
+        __shared__ double s_sums[FL_SUMS23];
+        __shared__ double s_P[529];
+        __shared__ double s_work[FL_IKFOM_WORK];
+        const int gst = gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums);
+        if (threadIdx.x == 0) {
+            *epoch_ptr = epoch + 1u;
+            if (MODE == 0) {
+                ikfom_solver_serial(D, s_sums, s_P, s_work, gst);
+            } else {
+                for (int k = 0; k < FL_SUMS23; k++) sums_out[k] = s_sums[k];
+            }
+        }
+        return;
+    }
+
+    __shared__ double s_red[(NT / 64) * FL_SUMS23];
+    double x[FL_X23_LEN];
+#pragma unroll
+    for (int i = 0; i < FL_X23_LEN; i++) x[i] = D->x[i];
+    double v[FL_SUMS23];
+#pragma unroll
+    for (int k = 0; k < FL_SUMS23; k++) v[k] = 0.0;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += nprod * NT) {
+        if (!sel[i]) continue;
+        const float pb[3] = {body[i * 3 + 0], body[i * 3 + 1], body[i * 3 + 2]};
+        const float4 plq = plane[i];
+        const float pl[4] = {plq.x, plq.y, plq.z, plq.w};
+        double p_i[3];
+        float pw[3], pd2;
+        int eff;
+        fl_world_point23(x, pb, p_i, pw);
+        const int s = fl_gates_from_pw(pb, pl, pw, &pd2, &eff);
+        if (!s) sel[i] = 0;
+        if ((flags & FL_ITER_KEEP_NORMVEC) && s) normvec[i] = make_float4(pl[0], pl[1], pl[2], pd2);
+        if (eff) {
+            double row[12], z;
+            fl_row23(x, pb, p_i, pl, pd2, row, &z);
+            fl_accum12(v, row, z);
+            v[FL_S23_NEFF] += 1.0;
+            v[FL_S23_RES] += (double)fabsf(pd2);
+            v[FL_S23_RES2] += (double)pd2 * (double)pd2;
+        }
+    }
+    const double mine = block_reduce_record<NT, FL_SUMS23>(v, s_red);
+    publish_record<FL_SUMS23>(mine, epoch, records, nprod);
+}
+
+// Solve from an externally reduced record (sharded form).
+__global__ __launch_bounds__(FL_IK_NT) void ikfom_solve_kernel(FlDev23 *__restrict__ D, const double *__restrict__ sums_in, int flags)
+{
+    if (!(flags & FL_ITER_FORCE) && (D->stop || D->need_search)) return;
+    __shared__ double s_sums[FL_SUMS23];
+    __shared__ double s_P[529];
+    __shared__ double s_work[FL_IKFOM_WORK];
+    if (threadIdx.x < FL_SUMS23) s_sums[threadIdx.x] = sums_in[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) ikfom_solver_serial(D, s_sums, s_P, s_work, 0);
+}
+
+// world points at the current state_ikfom (laserMapping.cpp:980-984) for the host kNN
+__global__ __launch_bounds__(FL_BLOCK) void ikfom_world_points_kernel(const float *__restrict__ body, float *__restrict__ world, int n,
+                                                                     const FlDev23 *__restrict__ D)
+{
+    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double x[FL_X23_LEN], p_i[3];
+#pragma unroll
+    for (int k = 0; k < FL_X23_LEN; k++) x[k] = D->x[k];
+    float pw[3];
+    const float pb[3] = {body[i * 3], body[i * 3 + 1], body[i * 3 + 2]};
+    fl_world_point23(x, pb, p_i, pw);
+    world[i * 3] = pw[0]; world[i * 3 + 1] = pw[1]; world[i * 3 + 2] = pw[2];
+}
+
+// "row-compat" h_share_model: every point writes its 12-wide row, h and an effective flag; the host
+// compacts them in ascending point order exactly like laserMapping.cpp:1041-1052.
+__global__ __launch_bounds__(FL_BLOCK) void ikfom_rows_kernel(const float *__restrict__ body, const float4 *__restrict__ plane,
+                                                             uint8_t *__restrict__ sel, int n, const FlDev23 *__restrict__ D,
+                                                             double *__restrict__ rows /* n x 13 */, uint8_t *__restrict__ eff_out)
+{
+    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    eff_out[i] = 0;
+    if (!sel[i]) return;
+    double x[FL_X23_LEN], p_i[3];
+#pragma unroll
+    for (int k = 0; k < FL_X23_LEN; k++) x[k] = D->x[k];
+    const float pb[3] = {body[i * 3], body[i * 3 + 1], body[i * 3 + 2]};
+    const float4 plq = plane[i];
+    const float pl[4] = {plq.x, plq.y, plq.z, plq.w};
+    float pw[3], pd2;
+    int eff;
+    fl_world_point23(x, pb, p_i, pw);
+    const int s = fl_gates_from_pw(pb, pl, pw, &pd2, &eff);
+    if (!s) sel[i] = 0;
+    if (eff) {
+        double row[12], z;
+        fl_row23(x, pb, p_i, pl, pd2, row, &z);
+        for (int k = 0; k < 12; k++) rows[(size_t)i * 13 + k] = row[k];
+        rows[(size_t)i * 13 + 12] = z;
+        eff_out[i] = 1;
+    }
+}
