@@ -123,20 +123,17 @@ def main():
     hv.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
     hv.vio_begin(x0, x0)
     F = capi.FL_ITER_FORCE
-    sums_l = torch.zeros(capi.FL_SUMS18, dtype=torch.float64, device="cuda")
-    sums_v = torch.zeros(capi.FL_SUMS18, dtype=torch.float64, device="cuda")
+    from fast_livo_amd.sharded import GpuLioBackend, GpuVioBackend, ShardedPass
+    lio_pass = ShardedPass(GpuLioBackend(hl, F), dist)      # accumulate -> all_reduce(32 doubles) -> solve
+    vio_pass = ShardedPass(GpuVioBackend(hv, VIO_LEVEL, F), dist)
 
     def step():
         if not distributed:
-            hl.lio_iterate18(1, F, want_info=False)
+            hl.lio_iterate18(1, F, want_info=False)          # fused pass kernel (reduce + solve in-launch)
             hv.vio_iterate(VIO_LEVEL, 1, F, want_info=False)
         else:
-            hl.lio_accumulate18(sums_l.data_ptr(), F)
-            dist.all_reduce(sums_l)
-            hl.lio_solve18(sums_l.data_ptr(), F)
-            hv.vio_accumulate(VIO_LEVEL, sums_v.data_ptr())
-            dist.all_reduce(sums_v)
-            hv.vio_solve(sums_v.data_ptr(), F)
+            lio_pass.step()
+            vio_pass.step()
 
     def fence():
         torch.cuda.synchronize()
@@ -167,7 +164,6 @@ def main():
     if rank == 0:
         K = max(200, min(args.steps, 2000))
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        tmp = torch.zeros(capi.FL_SUMS18, dtype=torch.float64, device="cuda")
         for _ in range(50):
             hl.lio_iterate18(1, F, want_info=False)
         torch.cuda.synchronize()
@@ -183,7 +179,6 @@ def main():
         ev1.record()
         torch.cuda.synchronize()
         vio_us = ev0.elapsed_time(ev1) * 1e3 / K
-        del tmp
         lio_bytes = LIO_BYTES_PER_POINT * args.points
         vio_bytes = VIO_BYTES_PER_PATCH * args.patches
         dom = "lio18_pass_kernel" if lio_us >= vio_us else "vio_pass_kernel"

@@ -1,0 +1,144 @@
+"""CPU tests of the product's own arithmetic (fast-livo_amd/csrc/fl_math.h, fl_ikfom_math.h compiled
+for the host by tests/host_emul -- test-only, never shipped) against the oracle, and of the sharded
+orchestration over gloo with world_size 2."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import TOL_SUMS_REL, assert_delta_close, p, sums_to_HTH
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _emul_lio(E, fr, nbr, valid):
+    n = fr.n
+    plane = np.zeros((n, 4), np.float32)
+    ok = np.zeros(n, np.uint8)
+    E.emul_fit_planes(p(nbr, C.c_float), n, p(plane, C.c_float), p(ok, C.c_uint8))
+    return plane, (valid & ok).astype(np.uint8)
+
+
+@pytest.mark.parametrize("n", [1, 257, 6000])
+def test_plane_fit_gates_rows_and_solve_match_oracle(oracle_lib, emul_lib, scene, n):
+    from fast_livo_amd import synth
+    orc, E = oracle_lib, emul_lib
+    fr = synth.make_lio_frame(n, scene=scene)
+    nbr, valid = synth.knn5(scene, fr.world_at(fr.R_prior, fr.p_prior))
+    x = orc.state18_from_frame(fr)
+    xp = x.copy()
+    sel_o = valid.copy()
+    r = orc.lio18_iterate(x, xp, fr.body_xyz, nbr, sel_o, fr.R_LI, fr.t_LI, fr.laser_point_cov)
+    plane, sel_e = _emul_lio(E, fr, nbr, valid)
+    x0 = xp.vec().copy()
+    sums = np.zeros(32)
+    nv = np.zeros((n, 4), np.float32)
+    RLI = np.ascontiguousarray(fr.R_LI.reshape(9))
+    tLI = np.ascontiguousarray(fr.t_LI)
+    E.emul_lio18_accumulate(p(fr.body_xyz, C.c_float), p(plane, C.c_float), p(sel_e, C.c_uint8), n, p(x0, C.c_double),
+                            p(RLI, C.c_double), p(tLI, C.c_double), p(sums, C.c_double), p(nv, C.c_float))
+    assert np.array_equal(sel_e, sel_o)                                  # zero selection flips
+    assert np.array_equal(nv[sel_o != 0], r["normvec"][sel_o != 0])      # bit-identical planes / pd2
+    assert int(sums[27]) == r["out"].effct_feat_num
+    if r["out"].effct_feat_num:
+        S, HTz = sums_to_HTH(sums)
+        HTH_o = np.array(r["out"].HTH).reshape(6, 6)
+        assert np.abs(S - HTH_o).max() <= TOL_SUMS_REL * np.abs(HTH_o).max()
+    for fn in (E.emul_solve18, E.emul_solve18_fast):                     # push-through and LDL^T forms
+        xe = x0.copy()
+        G6 = np.zeros(108)
+        d = np.zeros(18)
+        P = np.ascontiguousarray(fr.cov18.reshape(-1))
+        st = fn(p(xe, C.c_double), p(xp.vec().copy(), C.c_double), p(P, C.c_double), C.c_double(fr.laser_point_cov),
+                p(sums, C.c_double), C.c_double(1.0), p(G6, C.c_double), p(d, C.c_double))
+        assert st == 0
+        assert_delta_close(d, np.array(r["out"].solution))
+        assert np.abs(xe - x.vec()).max() <= 1e-9
+        assert np.abs(G6.reshape(18, 6) - r["G"][:, :6]).max() <= 1e-9
+
+
+def test_degenerate_neighbours_never_selected(emul_lib):
+    E = emul_lib
+    nb = np.zeros((3, 5, 3), dtype=np.float32)
+    nb[0] = 1.0                                        # five identical points
+    nb[1, :, 0] = np.arange(5)                         # collinear
+    nb[2] = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0.5], [0.5, 0.5, -0.5]])  # not planar within 0.1
+    plane = np.zeros((3, 4), np.float32)
+    ok = np.zeros(3, np.uint8)
+    E.emul_fit_planes(p(nb, C.c_float), 3, p(plane, C.c_float), p(ok, C.c_uint8))
+    body = np.ones((3, 3), np.float32)
+    sel = np.ones(3, np.uint8)
+    x = np.concatenate([np.eye(3).reshape(9), np.zeros(15)])
+    sums = np.zeros(32)
+    eye = np.eye(3).reshape(9).copy()
+    z3 = np.zeros(3)
+    E.emul_lio18_accumulate(p(body, C.c_float), p(plane, C.c_float), p(sel, C.c_uint8), 3, p(x, C.c_double), p(eye, C.c_double),
+                            p(z3, C.c_double), p(sums, C.c_double), None)
+    assert ok[2] == 0
+    assert sums[27] <= 1.0 and np.isfinite(sums).all()  # NaN planes flow to "not selected", never into the sums
+
+
+def test_mode23_iteration_matches_oracle(oracle_lib, emul_lib, scene):
+    from fast_livo_amd import synth
+    orc, E = oracle_lib, emul_lib
+    for n, max_iter in ((15, 4), (3000, 4)):
+        fr = synth.make_lio_frame(n, scene=scene)
+        knn = lambda w: synth.knn5(scene, w)  # noqa: E731
+        x23 = orc.state23_from_frame(fr, synth.quat_from_R)
+        P = fr.cov23.copy()
+        x0 = x23.vec().copy()
+        ro = orc.ikfom_update(x23, P, fr.body_xyz, 0.001, max_iter, knn)
+        x = x0.copy()
+        Pw = np.zeros((23, 23))
+        Pprop = fr.cov23.copy()
+        limit = np.full(23, 0.001)
+        ctl = np.array([-1, 0, 1, 0, max_iter, 0], dtype=np.int32)
+        plane = np.zeros((n, 4), np.float32)
+        ok = np.zeros(n, np.uint8)
+        sel = np.zeros(n, np.uint8)
+        sums = np.zeros(96)
+        dx = np.zeros(23)
+        iters = 0
+        while not ctl[3] and ctl[0] < max_iter:
+            if ctl[2]:
+                w = np.zeros((n, 3), np.float32)
+                E.emul_world_points23(p(x, C.c_double), p(fr.body_xyz, C.c_float), n, p(w, C.c_float))
+                nbr, valid = knn(w)
+                nbr = np.ascontiguousarray(nbr)
+                E.emul_fit_planes(p(nbr, C.c_float), n, p(plane, C.c_float), p(ok, C.c_uint8))
+                sel = (valid & ok).astype(np.uint8)
+            E.emul_h_share_sums(p(x, C.c_double), p(fr.body_xyz, C.c_float), p(plane, C.c_float), p(sel, C.c_uint8), n,
+                                p(sums, C.c_double), None)
+            E.emul_ikfom_iterate(p(x, C.c_double), p(x0, C.c_double), p(Pprop, C.c_double), p(Pw, C.c_double), p(limit, C.c_double),
+                                 C.c_double(0.001), p(sums, C.c_double), p(ctl, C.c_int32), p(dx, C.c_double))
+            iters += 1
+        assert iters == ro["out"].iterations
+        assert int(sums[90]) == ro["out"].effct_feat_num
+        assert np.abs(x - x23.vec()).max() <= 1e-9
+        assert np.abs(Pw - P).max() <= 1e-10
+        assert np.abs(dx - np.array(ro["out"].dx)).max() <= 1e-9
+
+
+def test_shard_ranges_cover_everything():
+    import fastlivo  # noqa: F401
+    from fast_livo_amd.sharded import shard_range
+    for n in (1, 7, 50000, 200001):
+        for world in (1, 2, 3, 8):
+            edges = [shard_range(n, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+
+
+def test_sharded_pass_gloo_world2(oracle_lib, emul_lib):
+    """N>1 path on CPU: 2 gloo ranks, point-range shards, all-reduce of the 32-double record, redundant
+    solve -> both ranks hold the same state, equal to the unsharded oracle."""
+    script = os.path.join(ROOT, "tests", "gloo_sharded_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", script],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "RANK0 OK" in out.stdout and "RANK1 OK" in out.stdout, out.stdout[-2000:]
