@@ -184,8 +184,19 @@ def main():
         dom = "lio18_pass_kernel" if lio_us >= vio_us else "vio_pass_kernel"
         dom_bytes, dom_us = (lio_bytes, lio_us) if lio_us >= vio_us else (vio_bytes, vio_us)
         ach = dom_bytes / (dom_us * 1e-6) / 1e9
+        traffic, traffic_src = None, None
+        try:   # PMC bytes are collected in separate rocprofv3 --pmc passes and committed under profiles/
+            import glob
+            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))[-1]
+            pm = json.load(open(latest))["kernels"]
+            for kname, d in pm.items():
+                if dom in kname:
+                    traffic = d["read_bytes_x2_corrected"] + d["write_bytes_raw"]
+                    traffic_src = os.path.basename(latest)
+        except Exception:
+            pass
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us,
                 "method": f"HIP events around {K} back-to-back launches on the launch stream (includes the "
                           "inter-kernel boundary)",

@@ -118,6 +118,7 @@ SYMBOLS = {
     "fl_ikfom_begin": (C.c_int32, [_H, C.POINTER(State23), _dp, _dp]),
     "fl_h_share_model_sums": (C.c_int32, [_H, C.POINTER(State23), _dp, _dp, _i32p, _dp]),
     "fl_h_share_model_rows": (C.c_int32, [_H, C.POINTER(State23), _dp, _dp, _i32p]),
+    "fl_ikfom_world_points": (C.c_int32, [_H, C.POINTER(State23), _fp]),
     "fl_ikfom_iterate": (C.c_int32, [_H, C.c_int32, C.c_int32, C.POINTER(IterInfo)]),
     "fl_ikfom_get": (C.c_int32, [_H, C.POINTER(State23), _dp]),
     "fl_ikfom_update_iterated": (C.c_int32, [_H, C.POINTER(State23), _dp, _fp, C.c_int32, C.c_double, _dp, KNN_FN,
@@ -426,6 +427,11 @@ def _ikfom_methods():
                                                   _p(limit, C.c_double), cbf, None, C.byref(info)), "fl_ikfom_update_iterated")
         return info
 
+    def ikfom_world_points(self, s23, n):
+        w = np.zeros((n, 3), dtype=np.float32)
+        self._chk(self.L.fl_ikfom_world_points(self.h, C.byref(s23), _p(w, C.c_float)), "fl_ikfom_world_points")
+        return w
+
     def ikfom_accumulate(self, d_sums_ptr, flags=0):
         self._chk(self.L.fl_ikfom_accumulate(self.h, C.c_void_p(d_sums_ptr), flags), "fl_ikfom_accumulate")
 
@@ -435,7 +441,7 @@ def _ikfom_methods():
                   "fl_ikfom_solve")
         return info
 
-    for f in (ikfom_begin, ikfom_iterate, ikfom_get, h_share_model_sums, h_share_model_rows, ikfom_update_iterated,
+    for f in (ikfom_world_points, ikfom_begin, ikfom_iterate, ikfom_get, h_share_model_sums, h_share_model_rows, ikfom_update_iterated,
               ikfom_accumulate, ikfom_solve):
         setattr(Handle, f.__name__, f)
 

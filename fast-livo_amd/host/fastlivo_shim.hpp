@@ -1,0 +1,196 @@
+// fastlivo_shim.hpp -- host-side bodies for the reference's entry points, over the C ABI.
+//
+// These are the functions whose bodies a maintainer replaces in the reference:
+//   h_share_model(state_ikfom&, esekfom::dyn_share_datastruct<double>&)   src/laserMapping.cpp:961
+//   the Mode-18 LIO block of main()                                       src/laserMapping.cpp:1504-1733
+//   LidarSelector::ComputeJ(cv::Mat)                                      src/lidar_selection.cpp:967
+// Names, argument meaning and error behaviour follow the reference (void / silent in the reference;
+// here the int32 status of the C ABI is kept in last_status and never thrown).
+#pragma once
+
+#include "../../include/fastlivo_hip.h"
+#include "fastlivo_types.hpp"
+
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace fastlivo_host {
+
+inline void to_abi(const StatesGroup &s, fl_state18 &o)
+{
+    std::memcpy(o.rot, s.rot_end.m, sizeof o.rot);
+    std::memcpy(o.pos, s.pos_end.v, sizeof o.pos);
+    std::memcpy(o.vel, s.vel_end.v, sizeof o.vel);
+    std::memcpy(o.bg, s.bias_g.v, sizeof o.bg);
+    std::memcpy(o.ba, s.bias_a.v, sizeof o.ba);
+    std::memcpy(o.grav, s.gravity.v, sizeof o.grav);
+    std::memcpy(o.cov, s.cov, sizeof o.cov);
+}
+inline void from_abi(const fl_state18 &o, StatesGroup &s)
+{
+    std::memcpy(s.rot_end.m, o.rot, sizeof o.rot);
+    std::memcpy(s.pos_end.v, o.pos, sizeof o.pos);
+    std::memcpy(s.vel_end.v, o.vel, sizeof o.vel);
+    std::memcpy(s.bias_g.v, o.bg, sizeof o.bg);
+    std::memcpy(s.bias_a.v, o.ba, sizeof o.ba);
+    std::memcpy(s.gravity.v, o.grav, sizeof o.grav);
+    std::memcpy(s.cov, o.cov, sizeof o.cov);
+}
+inline void to_abi(const state_ikfom &s, fl_state23 &o)
+{
+    std::memcpy(o.pos, s.pos.v, sizeof o.pos);
+    o.rot[0] = s.rot.x; o.rot[1] = s.rot.y; o.rot[2] = s.rot.z; o.rot[3] = s.rot.w;
+    o.offset_R_L_I[0] = s.offset_R_L_I.x; o.offset_R_L_I[1] = s.offset_R_L_I.y; o.offset_R_L_I[2] = s.offset_R_L_I.z; o.offset_R_L_I[3] = s.offset_R_L_I.w;
+    std::memcpy(o.offset_T_L_I, s.offset_T_L_I.v, sizeof o.offset_T_L_I);
+    std::memcpy(o.vel, s.vel.v, sizeof o.vel);
+    std::memcpy(o.bg, s.bg.v, sizeof o.bg);
+    std::memcpy(o.ba, s.ba.v, sizeof o.ba);
+    std::memcpy(o.grav, s.grav.v, sizeof o.grav);
+}
+
+// Symmetric eigen-decomposition (cyclic Jacobi) of a 12x12 matrix: A = V diag(w) V^T.
+inline void jacobi_eig12(const double *A_in, double *w, double *V)
+{
+    const int n = 12;
+    double A[144];
+    std::memcpy(A, A_in, sizeof A);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0;
+        for (int i = 0; i < n; i++)
+            for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; p++)
+            for (int q = p + 1; q < n; q++) {
+                const double apq = A[p * n + q];
+                if (std::fabs(apq) < 1e-300) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; k++) {
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; i++) w[i] = A[i * n + i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// h_share_model, "sum-compat" body: signature unchanged; laserMapping.cpp and
+// esekfom.hpp stay untouched. The IKFoM updater consumes h_x only through h_x^T h_x and h_x^T h when
+// rows >= 23 (esekfom.hpp:1781,1801,1806), so the callback returns a 23x12 surrogate S with
+// S^T S = H^T H (rows 0..11 = sqrt(Lambda) V^T, rows 12..22 zero) and h with S^T h = H^T z.
+// The kNN of the `converge` pass stays on the host (ikd-Tree) and is staged through the handle.
+// ------------------------------------------------------------------------------------------------
+struct HShareContext {
+    fl_handle handle = nullptr;
+    fl_knn_fn knn = nullptr;          // stands for ikdtree.Nearest_Search over all points
+    void *knn_ctx = nullptr;
+    int n = 0;
+    std::vector<float> world, nbr;
+    std::vector<uint8_t> valid;
+    int32_t last_status = 0;
+    int effct_feat_num = 0;
+    double total_residual = 0.0;
+};
+
+inline void h_share_model(state_ikfom &s, esekfom::dyn_share_datastruct<double> &ekfom_data, HShareContext &ctx)
+{
+    fl_state23 st;
+    to_abi(s, st);
+    double HTH[144], HTh[12];
+    if (ekfom_data.converge) {   // laserMapping.cpp:994-1013: redo the kNN at the current state
+        ctx.world.resize((size_t)ctx.n * 3); ctx.nbr.resize((size_t)ctx.n * 15); ctx.valid.resize((size_t)ctx.n);
+        ctx.last_status = fl_ikfom_world_points(ctx.handle, &st, ctx.world.data());       // :980-984 on the device
+        ctx.knn(ctx.knn_ctx, ctx.world.data(), ctx.n, ctx.nbr.data(), ctx.valid.data());  // ikdtree.Nearest_Search
+        ctx.last_status |= fl_lio_set_neighbours(ctx.handle, ctx.nbr.data(), ctx.valid.data(), ctx.n);
+    }
+    int32_t neff = 0;
+    ctx.last_status |= fl_h_share_model_sums(ctx.handle, &st, HTH, HTh, &neff, &ctx.total_residual);
+    ctx.effct_feat_num = neff;
+    if (neff < 1) { ekfom_data.valid = false; return; }
+    double w[12], V[144];
+    jacobi_eig12(HTH, w, V);
+    ekfom_data.h_x.resize(23, 12);
+    ekfom_data.h.resize(23);
+    for (int k = 0; k < 12; k++) {
+        const double lam = w[k] > 0 ? w[k] : 0.0, sq = std::sqrt(lam);
+        double proj = 0.0;                       // (V^T HTz)_k
+        for (int j = 0; j < 12; j++) {
+            ekfom_data.h_x(k, j) = sq * V[j * 12 + k];
+            proj += V[j * 12 + k] * HTh[j];
+        }
+        ekfom_data.h(k) = (sq > 1e-150) ? proj / sq : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mode-18 LIO block of main(): `if(lidar_en){ for(iterCount=-1; ...) {...} }`, laserMapping.cpp:1504-1733
+// ------------------------------------------------------------------------------------------------
+struct LioMode18 {
+    fl_handle handle = nullptr;
+    fl_knn_fn knn = nullptr;
+    void *knn_ctx = nullptr;
+    int32_t last_status = 0;
+    int effct_feat_num = 0;
+    double total_residual = 0.0;
+    int iterCount = 0;
+
+    // state is updated in place like the reference's global `state`; state_propagat = state on entry
+    void update(StatesGroup &state, const float *feats_down_body_xyz, int feats_down_size)
+    {
+        fl_state18 st;
+        to_abi(state, st);
+        fl_iter_info info;
+        last_status = fl_lio_frame18(handle, &st, feats_down_body_xyz, feats_down_size, knn, knn_ctx, &info);
+        if (last_status < 0) return;                      // HIP/usage error: leave the state untouched
+        from_abi(st, state);
+        effct_feat_num = info.effct_feat_num;
+        total_residual = info.total_residual;
+        iterCount = info.iterations - 1;
+        last_status = info.status;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// LidarSelector::ComputeJ(cv::Mat img) -> UpdateState(img, err, level) x 3, lidar_selection.cpp:967-983
+// ------------------------------------------------------------------------------------------------
+struct VioUpdater {
+    fl_handle handle = nullptr;
+    int32_t last_status = 0;
+
+    void ComputeJ(const uint8_t *img, int width, int height, SubSparseMapView &sub_sparse_map, StatesGroup &state,
+                  const StatesGroup &state_propagat)
+    {
+        const int total_points = (int)sub_sparse_map.search_levels.size();
+        if (total_points == 0) return;                    // lidar_selection.cpp:969-970
+        last_status = fl_vio_set_frame(handle, img, width, height, width);
+        last_status |= fl_vio_set_patches(handle, sub_sparse_map.patch.data(), sub_sparse_map.pos.data(),
+                                          sub_sparse_map.search_levels.data(), total_points);
+        if (last_status < 0) return;
+        fl_state18 st, sp;
+        to_abi(state, st);
+        to_abi(state_propagat, sp);
+        last_status = fl_vio_compute_j(handle, &st, &sp, nullptr);
+        if (last_status < 0) return;
+        from_abi(st, state);
+        sub_sparse_map.errors.resize((size_t)total_points);
+        last_status |= fl_vio_get_errors(handle, sub_sparse_map.errors.data());
+    }
+};
+
+}  // namespace fastlivo_host

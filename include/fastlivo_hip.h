@@ -201,6 +201,9 @@ int32_t fl_h_share_model_sums(fl_handle h, const fl_state23 *s, double *HTH12, d
  * reference's order (ascending point index). h_x/h must hold n rows. */
 int32_t fl_h_share_model_rows(fl_handle h, const fl_state23 *s, double *h_x, double *hvec,
                               int32_t *effct_feat_num);
+/* feats_down_world at state s (the transform at src/laserMapping.cpp:980-984): what the host kNN of a
+ * `converge` pass searches with. Does not touch the filter state of the handle. */
+int32_t fl_ikfom_world_points(fl_handle h, const fl_state23 *s, float *world_xyz);
 /* `count` passes of the body of update_iterated_dyn_share_modified's loop on the device. */
 int32_t fl_ikfom_iterate(fl_handle h, int32_t count, int32_t flags, fl_iter_info *info);
 /* The final covariance block (esekfom.hpp:1831-1924) runs inside the pass that finishes; this

@@ -1,0 +1,58 @@
+"""The C++ host mirror (fast-livo_amd/host: StatesGroup / state_ikfom / dyn_share_datastruct stand-ins and
+the shim bodies of INTEGRATION.md) driven from a plain C++ program over the C ABI, compared with the
+ctypes path on the same frame and the same (replayed) kNN results."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_host_mirror_matches_ctypes_path(gpu_lib, scene, tmp_path):
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    demo = os.path.join(ROOT, "fast-livo_amd", "host", "demo_host")
+    if not os.path.exists(demo):
+        subprocess.check_call(["make", "-C", os.path.dirname(demo), "-s"])
+    n, max_iter = 8000, 5
+    fr = synth.make_lio_frame(n, scene=scene)
+    recorded = []
+
+    def knn(w):
+        nb, va = synth.knn5(scene, w)
+        recorded.append((nb.copy(), va.copy()))
+        return nb, va
+    h = capi.Handle(capi.config_from_frames(fr, max_iterations=max_iter))
+    x = capi.state18_from_frame(fr)
+    info = h.lio_frame18(x, fr.body_xyz, knn)
+    h.close()
+    f = tmp_path / "frame.bin"
+    with open(f, "wb") as fh:
+        fh.write(struct.pack("<iii", n, len(recorded), max_iter))
+        fh.write(np.asarray(fr.R_LI, dtype="<f8").tobytes())
+        fh.write(np.asarray(fr.t_LI, dtype="<f8").tobytes())
+        x0 = capi.state18_from_frame(fr)
+        fh.write(x0.vec().astype("<f8").tobytes())
+        fh.write(np.asarray(x0.cov_np(), dtype="<f8").tobytes())
+        fh.write(fr.body_xyz.astype("<f4").tobytes())
+        for nb, va in recorded:
+            fh.write(nb.astype("<f4").tobytes())
+            fh.write(va.astype("u1").tobytes())
+    out = subprocess.run([demo, str(f)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    head = lines[0].split()
+    assert int(head[1]) == 0                                  # status
+    assert int(head[5]) == info.effct_feat_num
+    vals = np.array(lines[1].split(), dtype=np.float64)
+    assert np.abs(vals - x.vec()[:12]).max() <= 1e-13          # rot + pos after the frame
+    diag = np.array(lines[2].split(), dtype=np.float64)
+    assert np.abs(diag - np.diag(x.cov_np())).max() <= 1e-15
+    # h_share_model surrogate: 23 x 12 with S^T S = H^T H and S^T h = H^T z
+    sur = lines[3].split()
+    assert int(sur[2]) == 23 and int(sur[4]) == 1
+    assert float(sur[8]) <= 1e-12 and float(sur[10]) <= 1e-9 * max(1.0, float(sur[12]))
