@@ -229,12 +229,28 @@ static int32_t ensure_points(fl_handle h, int n)
     return FL_OK;
 }
 
-// producers + 1 solver workgroup (handoff.h)
+// producers + 1 solver workgroup (handoff.h). FL_MAX_PRODUCERS (env, tuning aid) caps the producers.
+static int fl_max_producers()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("FL_MAX_PRODUCERS");
+        v = e ? atoi(e) : (FL_MAX_BLOCKS - 1);
+        if (v < 1 || v > FL_MAX_BLOCKS - 1) v = FL_MAX_BLOCKS - 1;
+    }
+    return v;
+}
 static inline int lio_grid(int n)
 {
     int b = (n + FL_LIO_NT - 1) / FL_LIO_NT;
     if (b < 1) b = 1;
-    if (b > FL_MAX_BLOCKS - 1) b = FL_MAX_BLOCKS - 1;
+    // One gather sweep covers 256 records (handoff.h): keep small/medium scans to a single sweep and
+    // let each lane take several points; spread over more workgroups only when the point loop
+    // dominates (measured crossover, bench.py --sweep: 200k pts 9.8 us @255 vs 14.4 us @1023;
+    // 1M pts 17.5 us @511; 8M pts 75 us @1023).
+    int cap = (n <= 300000) ? 255 : ((n <= 2000000) ? 511 : (FL_MAX_BLOCKS - 1));
+    if (cap > fl_max_producers()) cap = fl_max_producers();
+    if (b > cap) b = cap;
     return b + 1;
 }
 
@@ -244,6 +260,8 @@ int32_t fl_lio_set_points(fl_handle h, const float *body_xyz, int32_t n)
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int32_t st = ensure_points(h, n);
     if (st) return st;
+    if (n != h->n)   // the grid (number of records) changes: stale records must not carry a live tag
+        HIPCHK(h, hipMemsetAsync(h->d_records, 0, (size_t)16 * FL_MAX_BLOCKS * FL_SUMS23, h->stream));
     h->n = n;
     h->have_nbr = false;
     HIPCHK(h, hipMemcpyAsync(h->d_body, body_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, h->stream));
@@ -456,7 +474,7 @@ int32_t fl_lio_solve18(fl_handle h, const double *d_sums, int32_t flags, fl_iter
 {
     if (!h || !d_sums) return fail_arg(h, "fl_lio_solve18: null argument");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(eskf18_solve_kernel, dim3(1), dim3(FL_BLOCK), 0, h->stream, h->d_dev, d_sums, 0, (int)flags);
+    hipLaunchKernelGGL(eskf18_solve_kernel, dim3(1), dim3(FL_BLOCK), 0, h->stream, h->d_dev, d_sums, 0, (int)flags, (const FlVioConst *)h->d_vc);
     HIPCHK(h, hipGetLastError());
     if (info) return read_info18(h, info);
     return FL_OK;

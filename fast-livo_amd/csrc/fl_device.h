@@ -35,6 +35,8 @@ struct FlDev18 {
     double Q[36];       // (P66/meas_cov)^-1, per-frame prepare (fl_math.h fl_prepare18)
     double T[108];      // (P[:,0:6]/meas_cov) Q, 18x6 row-major
     double sums_acc[FL_SUMS18]; // record of the last executed (LIO) / accepted (VIO) pass: source of G
+    double Rcw[9];      // VIO: camera pose derived from x, refreshed by whoever writes x (vio_derive_pose)
+    double Pcw[3];
     double R_LI[9];
     double t_LI[3];
     double solution[24];
@@ -207,6 +209,65 @@ __device__ __forceinline__ void wave_transpose_reduce32(double (&v)[32], int lan
         v[0] = keep + dpp_f64<FL_DPP_QUAD_XOR2>(send);
     }
     v[0] = v[0] + dpp_f64<FL_DPP_QUAD_XOR1>(v[0]);
+}
+
+// Wave totals of 6 values (w[6], w[7] must be 0): transposing steps for masks 32/16/8, plain butterfly
+// for 4/2/1, then the 6 totals are read back with v_readlane (they end up wave-uniform, in SGPRs).
+__device__ __forceinline__ void wave_sum6(double (&w)[8], int lane, double (&T)[6])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) { swap32_f64(w[i], w[i + 4]); w[i] = w[i] + w[i + 4]; }
+#pragma unroll
+    for (int i = 0; i < 2; i++) { swap16_f64(w[i], w[i + 2]); w[i] = w[i] + w[i + 2]; }
+    {
+        const bool upper = (lane & 8) != 0;
+        const double send = upper ? w[0] : w[1];
+        const double keep = upper ? w[1] : w[0];
+        w[0] = keep + dpp_f64<FL_DPP_ROW_ROR8>(send);
+    }
+    w[0] = w[0] + __shfl_xor(w[0], 4, FL_WAVE);
+    w[0] = w[0] + dpp_f64<FL_DPP_QUAD_XOR2>(w[0]);
+    w[0] = w[0] + dpp_f64<FL_DPP_QUAD_XOR1>(w[0]);
+    // lane L now holds the total of value ((L>>5)&1)*4 + ((L>>4)&1)*2 + ((L>>3)&1)
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int src = ((k >> 2) & 1) * 32 + ((k >> 1) & 1) * 16 + (k & 1) * 8;
+        const unsigned lo = __builtin_amdgcn_readlane(f64_lo(w[0]), src);
+        const unsigned hi = __builtin_amdgcn_readlane(f64_hi(w[0]), src);
+        T[k] = f64_make(lo, hi);
+    }
+}
+
+// Same for the two 32-lane halves of a wave independently (one patch per half-wave): totals of the 6
+// values over the lanes of the caller's half, returned in every lane of that half.
+__device__ __forceinline__ void half_sum6(double (&w)[8], int lane, double (&T)[6])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) { swap16_f64(w[i], w[i + 4]); w[i] = w[i] + w[i + 4]; }
+    {
+        const bool upper = (lane & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const double send = upper ? w[i] : w[i + 2];
+            const double keep = upper ? w[i + 2] : w[i];
+            w[i] = keep + dpp_f64<FL_DPP_ROW_ROR8>(send);
+        }
+    }
+    {
+        const bool upper = (lane & 4) != 0;
+        const double send = upper ? w[0] : w[1];
+        const double keep = upper ? w[1] : w[0];
+        w[0] = keep + __shfl_xor(send, 4, FL_WAVE);
+    }
+    w[0] = w[0] + dpp_f64<FL_DPP_QUAD_XOR2>(w[0]);
+    w[0] = w[0] + dpp_f64<FL_DPP_QUAD_XOR1>(w[0]);
+    // lane L holds the total (over its half) of value ((L>>4)&1)*4 + ((L>>3)&1)*2 + ((L>>2)&1)
+    const int base = lane & 32;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int src = base + ((k >> 2) & 1) * 16 + ((k >> 1) & 1) * 8 + (k & 1) * 4;
+        T[k] = __shfl(w[0], src, FL_WAVE);
+    }
 }
 
 __device__ __forceinline__ double wave_sum(double x)

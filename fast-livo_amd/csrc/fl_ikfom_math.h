@@ -281,6 +281,7 @@ FL_HD int fl_gates_from_pw(const float *pb, const float *pl, const float *pw, fl
 // row = [n, A, B, C] (laserMapping.cpp:1063-1089): C = R^T n, A = p_i x C, B = p_b x (R_LI^T C)
 FL_HD void fl_row23(const double *x, const float *pb, const double *p_i, const float *pl, float pd2, double *row /*12*/, double *z)
 {
+    FL_FP_CONTRACT
     const double nv[3] = {(double)pl[0], (double)pl[1], (double)pl[2]};
     const double b[3] = {(double)pb[0], (double)pb[1], (double)pb[2]};
     double C[3], D[3];
@@ -298,6 +299,7 @@ FL_HD void fl_row23(const double *x, const float *pb, const double *p_i, const f
 }
 FL_HD void fl_accum12(double *v /*96*/, const double *row, double z)
 {
+    FL_FP_CONTRACT
     int k = 0;
 #pragma unroll
     for (int i = 0; i < 12; i++)

@@ -16,6 +16,16 @@
 #include <math.h>
 #include <stdint.h>
 
+// FMA contraction is OFF for everything that feeds a gate (world point, plane fit, pd2, s, bilinear
+// taps: they must round like the reference's FMA-less x86-64 build) and switched ON, function by
+// function, only for fp64 arithmetic whose results are compared by tolerance (Jacobian rows, their
+// accumulation, the gain solve): half the instructions for the dominant fp64 work.
+#if defined(__HIPCC__)
+#define FL_FP_CONTRACT _Pragma("clang fp contract(fast)")
+#else
+#define FL_FP_CONTRACT
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // esti_plane<float> (include/common_lib.h:448-493): least-squares plane through 5 neighbours by
 // column-pivoted Householder QR (Eigen ColPivHouseholderQR, float), normal n = x/|x|, d = 1/|x|,
@@ -217,6 +227,7 @@ FL_HD int fl_point_gates(const float *pb, const float *pl /*plane n,d*/, const d
 // Mode-18 Jacobian row (src/laserMapping.cpp:1611-1629): row = [ [p_i]x R^T n , n ], z = -pd2.
 FL_HD void fl_row18(const double *p_i, const float *pl, float pd2, const double *R, double *row /*6*/, double *z)
 {
+    FL_FP_CONTRACT
     const double n0 = (double)pl[0], n1 = (double)pl[1], n2 = (double)pl[2];
     const double c0 = R[0] * n0 + R[3] * n1 + R[6] * n2;   // C = R^T n
     const double c1 = R[1] * n0 + R[4] * n1 + R[7] * n2;
@@ -231,6 +242,7 @@ FL_HD void fl_row18(const double *p_i, const float *pl, float pd2, const double 
 // Accumulate one measurement row into a reduction record (layout in fl_device.h).
 FL_HD void fl_accum6(double *v /*32*/, const double *row, double z)
 {
+    FL_FP_CONTRACT
     int k = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++)
@@ -451,11 +463,6 @@ struct FlLdl6 {
     double L[6][6];
     double dinv[6];
 };
-#if defined(__HIPCC__)
-#define FL_FP_CONTRACT _Pragma("clang fp contract(fast)")
-#else
-#define FL_FP_CONTRACT
-#endif
 FL_HD int fl_ldl6(const double (&C)[6][6], FlLdl6 &f)
 {
     FL_FP_CONTRACT   // the solve is compared to the oracle by tolerance, never bitwise

@@ -6,33 +6,39 @@
 // in block-index order (results never depend on arrival order) and runs the solve. No atomics, no
 // fences, no ticket:
 //
-//   publish : each double travels as one 16-byte write-through (sc1) store {epoch, lo, hi, epoch}.
-//             A 16-byte store can tear only into its two 8-byte halves and each half carries the
-//             tag, so "both tags == epoch" proves both payload words belong to this launch
-//             (data-tagged granules, cdna_hip_programming.md Guideline 16 recipe R2). The producer
-//             never waits: the stores drain while the workgroup exits.
+//   publish : a record is NV doubles, 8 bytes each, stored write-through (sc1), fire-and-forget (the
+//             stores drain while the workgroup exits). Every 8-byte word validates itself: its 6
+//             lowest mantissa bits carry tag = 1 + epoch % 63 (never 0, the value of never-written
+//             memory). An aligned 8-byte store is single-copy atomic, so a word whose tag matches
+//             belongs to this launch (cdna_hip_programming.md Guideline 16, recipe R2 "the data IS the flag").
+//             Cost: the partial sums keep 46 of 52 mantissa bits (relative 1.4e-14, two orders below
+//             the 1e-12 the parity tests allow for fp64 re-ordering; the inputs are float32).
+//             Stale words are always from the previous launch (every launch rewrites every record
+//             of its grid; the host zeroes the buffer whenever the grid size changes), i.e. tag-1.
 //   gather  : the solver workgroup re-reads the records with 16-byte sc1 buffer loads (L1-bypass, a
-//             whole sweep in flight together). A half-wave reads one whole record, so one load
-//             instruction of a wave covers two records; each WAVE polls its own records with a
-//             wave-uniform "still missing" mask (built from ballots): later sweeps skip complete
-//             pairs with scalar branches. One workgroup barrier at the end, none per sweep. Spins are
-//             bounded: a timeout sets status bit 8 instead of hanging the GPU.
+//             whole sweep in flight together). A 16-lane row reads one 32-value group of a record, so
+//             one load instruction of a wave covers four records; each WAVE polls its own records
+//             with a wave-uniform "still missing" mask built from ballots: later sweeps skip complete
+//             records with scalar branches. Spins are bounded: a timeout sets status bit 8 instead of
+//             hanging the GPU.
 //   epoch   : a device word, read by every workgroup at kernel start and incremented by the solver at
-//             the end of the pass (graph-replay safe: not a kernel argument). Never 0; the record
-//             buffer is zeroed at fl_create.
+//             the end of the pass (graph-replay safe: not a kernel argument).
 //
-// Measured alternatives on MI355X (tools/kwall.py, 50k points, 196 producers), per pass:
-//   last-arriver ticket (write-through store, vmcnt(0) drain, returning atomic, re-read)  8.9 us
-//     -- the atomics serialise at ~12 ns per arrival and every step is a full memory round trip;
-//   this scheme                                                                         8.0-8.5 us
-//   raw 8-byte words + one XOR checksum per record (half the bytes)                      11.4 us
-//     -- the gather is latency-, not byte-bound, and the checksum costs the producers an LDS pass.
+// Why 8-byte self-tagged words: tools/gather_bench.hip shows one workgroup reads freshly written
+// data at 0.8 us for <= 32 KB and ~0.4 us per further 32 KB (in-flight limit of one CU, ~50-80 GB/s),
+// so a sweep over 196 records costs 2.0 us at 512 B/record ({epoch,lo,hi,epoch} per double, the first
+// version of this scheme) and 1.25 us at 256 B/record. Measured per LIO pass (50k points): arrival
+// ticket + atomics 8.9 us; 16-byte tagged granules 8.5 us; XOR-checksummed raw words 11.4 us (the
+// producers pay an LDS pass); this form: see DESIGN.md section 4.1.
 #pragma once
 
 #include "fl_device.h"
 
 #define FL_GATHER_SPIN_LIMIT (1 << 15)
 #define FL_NUM_TIMEOUT 8
+#define FL_TAG_MASK 0x3Fu
+
+__device__ __forceinline__ unsigned fl_epoch_tag(unsigned epoch) { return 1u + epoch % 63u; }
 
 // Block-level reduction: on return thread tid < NV holds the workgroup total of value tid.
 template <int NT, int NV>
@@ -60,54 +66,57 @@ __device__ __forceinline__ double block_reduce_record(double (&v)[NV], double *l
 
 // Fire-and-forget publication of this workgroup's record (thread tid < NV holds value tid).
 template <int NV>
-__device__ __forceinline__ void publish_record(double mine, unsigned epoch, void *records, int nrecords)
+__device__ __forceinline__ void publish_record(double mine, unsigned epoch, void *records)
 {
     const int tid = threadIdx.x;
     if (tid < NV) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(records, 0, nrecords * NV * 16, 0x00020000);
-        fl_u4 g;
-        g.x = epoch; g.y = f64_lo(mine); g.z = f64_hi(mine); g.w = epoch;
-        __builtin_amdgcn_raw_buffer_store_b128(g, rs, (blockIdx.x * NV + tid) * 16, 0, 16 /* sc1: write-through */);
+        unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
+        bits = (bits & ~(unsigned long long)FL_TAG_MASK) | fl_epoch_tag(epoch);
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(records) + (size_t)blockIdx.x * NV + tid, bits, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);   // sc1 write-through
     }
 }
+
+__device__ __forceinline__ double fl_untag(unsigned lo, unsigned hi) { return f64_make(lo & ~FL_TAG_MASK, hi); }
 
 // Solver workgroup: gather nprod records and leave the totals in out_lds[NV]. Returns 0, or
 // FL_NUM_TIMEOUT if some record never showed up (all threads agree).
 template <int NT, int NV>
-__device__ __forceinline__ int gather_records(const void *records, int nprod, unsigned epoch, double *lds /* >= NT */,
+__device__ __forceinline__ int gather_records(const void *records, int nprod, unsigned epoch, double *lds /* >= 2*NT */,
                                               double *out_lds /* NV */)
 {
-    constexpr int GROUPS = NT / 32;       // records covered by one load instruction of the workgroup
-    constexpr int BATCH = 32;             // up to GROUPS*32 producers per sweep (256 @ NT=256)
+    constexpr int ROWS = NT / 16;         // records covered by one load instruction of the workgroup
+    constexpr int BATCH = 16;             // up to ROWS*16 producers per sweep (256 @ NT=256)
     const int tid = threadIdx.x;
-    const int kk = tid & 31, grp = tid >> 5;
+    const int kp = tid & 15, row = tid >> 4;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)records, 0, nprod * NV * 16, 0x00020000);
+    const unsigned tag = fl_epoch_tag(epoch);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)records, 0, nprod * NV * 8, 0x00020000);
     int timeout = 0;
 #pragma unroll
     for (int g = 0; g < NV / 32; g++) {
-        double s = 0.0;
-        for (int base = 0; base < nprod; base += GROUPS * BATCH) {   // trip count uniform over the workgroup
-            const int b0 = base + grp;
+        double s0 = 0.0, s1 = 0.0;
+        for (int base = 0; base < nprod; base += ROWS * BATCH) {   // trip count uniform over the workgroup
+            const int b0 = base + row;
             fl_u4 t[BATCH];
-            unsigned need = 0u;                                       // wave-uniform
+            unsigned need = 0u;                                     // wave-uniform
 #pragma unroll
-            for (int j = 0; j < BATCH; j++) need |= ((base + 2 * wave_u + j * GROUPS) < nprod) ? (1u << j) : 0u;
+            for (int j = 0; j < BATCH; j++) need |= ((base + 4 * wave_u + j * ROWS) < nprod) ? (1u << j) : 0u;
 #pragma unroll
             for (int j = 0; j < BATCH; j++) { t[j].x = 0u; t[j].y = 0u; t[j].z = 0u; t[j].w = 0u; }
             for (int spin = 0; need != 0u; spin++) {
 #pragma unroll
                 for (int j = 0; j < BATCH; j++) {
                     if (need & (1u << j)) {
-                        const int b = b0 + j * GROUPS;
-                        t[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (b * NV + g * 32 + kk) * 16, 0, 16 /* sc1 */);
+                        const int b = b0 + j * ROWS;
+                        t[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (b * NV + g * 32 + kp * 2) * 8, 0, 16 /* sc1 */);
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < BATCH; j++) {
                     if (need & (1u << j)) {
-                        const int b = b0 + j * GROUPS;
-                        const bool ok = (b >= nprod) || (t[j].x == epoch && t[j].w == epoch);
+                        const int b = b0 + j * ROWS;
+                        const bool ok = (b >= nprod) || (((t[j].x & FL_TAG_MASK) == tag) && ((t[j].z & FL_TAG_MASK) == tag));
                         if (__ballot(ok) == ~0ull) need &= ~(1u << j);
                     }
                 }
@@ -118,16 +127,20 @@ __device__ __forceinline__ int gather_records(const void *records, int nprod, un
             }
 #pragma unroll
             for (int j = 0; j < BATCH; j++) {
-                const int b = b0 + j * GROUPS;
-                s += (b < nprod) ? f64_make(t[j].y, t[j].z) : 0.0;
+                const int b = b0 + j * ROWS;
+                if (b < nprod) {
+                    s0 += fl_untag(t[j].x, t[j].y);
+                    s1 += fl_untag(t[j].z, t[j].w);
+                }
             }
         }
-        lds[tid] = s;
+        lds[tid * 2] = s0;
+        lds[tid * 2 + 1] = s1;
         __syncthreads();
         if (tid < 32) {
             double t2 = lds[tid];
 #pragma unroll
-            for (int j = 1; j < GROUPS; j++) t2 += lds[j * 32 + tid];
+            for (int j = 1; j < ROWS; j++) t2 += lds[j * 32 + tid];
             out_lds[g * 32 + tid] = t2;
         }
         __syncthreads();

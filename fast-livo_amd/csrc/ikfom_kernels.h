@@ -76,7 +76,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float *__res
     const int nprod = gridDim.x - 1;
 
     if (blockIdx.x == nprod) {
-        __shared__ double s_fin[NT];
+        __shared__ double s_fin[2 * NT];
         __shared__ double s_sums[FL_SUMS23];
         __shared__ double s_P[529];
         __shared__ double s_work[FL_IKFOM_WORK];
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float *__res
         }
     }
     const double mine = block_reduce_record<NT, FL_SUMS23>(v, s_red);
-    publish_record<FL_SUMS23>(mine, epoch, records, nprod);
+    publish_record<FL_SUMS23>(mine, epoch, records);
 }
 
 // Solve from an externally reduced record (sharded form).

@@ -70,9 +70,24 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_pass_kernel(const float *__re
 {
     constexpr int NT = FL_LIO_NT;
     if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();
+    const int nprod = gridDim.x - 1;
+    // Software prefetch: the first point's inputs do not depend on the state, so their (vector)
+    // loads are issued BEFORE the scalar loads of the control words and the state -- one memory
+    // round trip instead of two on the producers' critical path (harmless if the pass is a no-op).
+    const int i_first = blockIdx.x * NT + threadIdx.x;
+    const bool have_first = (blockIdx.x != nprod) && (i_first < n);
+    uint8_t pf_sel = 0;
+    float pf_b0 = 0.f, pf_b1 = 0.f, pf_b2 = 0.f;
+    float4 pf_pl = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (have_first) {
+        pf_sel = sel[i_first];
+        pf_b0 = body[i_first * 3 + 0]; pf_b1 = body[i_first * 3 + 1]; pf_b2 = body[i_first * 3 + 2];
+        pf_pl = plane[i_first];
+    }
+    double pf_solver = 0.0;
+    if (MODE == 0 && blockIdx.x == nprod) pf_solver = eskf18_prefetch_issue(D);
     if (!(flags & FL_ITER_FORCE) && (D->stop || D->need_search)) return;
     const unsigned epoch = *epoch_ptr;
-    const int nprod = gridDim.x - 1;
 
     if (blockIdx.x == nprod) {
         // ------------------------------------------------------------------ solver workgroup
@@ -80,7 +95,7 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_pass_kernel(const float *__re
         __shared__ double s_sums[FL_SUMS18];
         __shared__ FlSolveLds s_solve;
         fl_stamp(flags, 8);
-        if (MODE == 0) eskf18_prefetch(D, s_solve);
+        if (MODE == 0) eskf18_prefetch_commit(pf_solver, s_solve);
         fl_stamp(flags, 9);
         const int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
         fl_stamp(flags, 10);
@@ -107,10 +122,18 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_pass_kernel(const float *__re
     for (int k = 0; k < FL_SUMS18; k++) v[k] = 0.0;
     if (blockIdx.x == 0) fl_stamp(flags, 0);
 
-    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += nprod * NT) {
-        if (!sel[i]) continue;
-        const float pb[3] = {body[i * 3 + 0], body[i * 3 + 1], body[i * 3 + 2]};
-        const float4 plq = plane[i];
+    for (int i = i_first; i < n; i += nprod * NT) {
+        const bool first = (i == i_first);
+        if (!(first ? pf_sel : sel[i])) continue;
+        float pb[3];
+        float4 plq;
+        if (first) {
+            pb[0] = pf_b0; pb[1] = pf_b1; pb[2] = pf_b2;
+            plq = pf_pl;
+        } else {
+            pb[0] = body[i * 3 + 0]; pb[1] = body[i * 3 + 1]; pb[2] = body[i * 3 + 2];
+            plq = plane[i];
+        }
         const float pl[4] = {plq.x, plq.y, plq.z, plq.w};
         double p_i[3];
         float pw[3], pd2;
@@ -129,15 +152,17 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_pass_kernel(const float *__re
     }
     if (blockIdx.x == 0) fl_stamp(flags, 1);
     const double mine = block_reduce_record<NT, FL_SUMS18>(v, s_red);
-    publish_record<FL_SUMS18>(mine, epoch, records, nprod);
+    publish_record<FL_SUMS18>(mine, epoch, records);
     if (blockIdx.x == 0) fl_stamp(flags, 2);
     if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();
 }
 
 // -------------------------------------------------------------------------------------------- K3
 // Solve from an externally reduced record (sharded form). vio != 0 selects the VIO epilogue.
+struct FlVioConst;
+__device__ __forceinline__ void vio_derive_pose(const double *xn, const FlVioConst *__restrict__ VC, FlDev18 *__restrict__ D);
 __global__ __launch_bounds__(FL_BLOCK) void eskf18_solve_kernel(FlDev18 *__restrict__ D, const double *__restrict__ sums_in,
-                                                               int vio, int flags)
+                                                               int vio, int flags, const FlVioConst *__restrict__ VC)
 {
     if (!(flags & FL_ITER_FORCE) && (D->stop || (!vio && D->need_search))) return;
     __shared__ double s_sums[FL_SUMS18];
@@ -145,8 +170,13 @@ __global__ __launch_bounds__(FL_BLOCK) void eskf18_solve_kernel(FlDev18 *__restr
     if (threadIdx.x < FL_SUMS18) s_sums[threadIdx.x] = sums_in[threadIdx.x];
     eskf18_prefetch(D, s_solve);
     __syncthreads();
-    if (vio) eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, 0);
-    else eskf18_solve_block<FL_EPI_LIO>(D, s_sums, s_solve, 0);
+    if (vio) {
+        eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, 0);
+        __syncthreads();
+        vio_derive_pose(s_solve.xn, VC, D);
+    } else {
+        eskf18_solve_block<FL_EPI_LIO>(D, s_sums, s_solve, 0);
+    }
 }
 
 // -------------------------------------------------------------------------------------------- K4

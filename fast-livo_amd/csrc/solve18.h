@@ -25,6 +25,7 @@ struct FlSolveLds {
     double xp[24];
     double vec[18];
     double delta[18];
+    double xn[12];      // rotation (9) and position (3) after the pass: input of the VIO derived pose
     float last_error;
     int accept;
     int st;
@@ -34,14 +35,26 @@ struct FlSolveLds {
 enum { FL_EPI_LIO = 0, FL_EPI_VIO = 1 };
 
 // Stage 0 (before the gather): stage the solve inputs in LDS and form vec = x_prop (-) x.
-__device__ __forceinline__ void eskf18_prefetch(const FlDev18 *__restrict__ D, FlSolveLds &L)
+// Split in two so that the loads can be issued before the kernel's control-word round trip.
+__device__ __forceinline__ double eskf18_prefetch_issue(const FlDev18 *__restrict__ D)
 {
     const int tid = threadIdx.x;
-    if (tid < 36) L.Q[tid] = D->Q[tid];
-    else if (tid < 144) L.T[tid - 36] = D->T[tid - 36];
-    else if (tid < 168) L.x[tid - 144] = D->x[tid - 144];
-    else if (tid < 192) L.xp[tid - 168] = D->xprop[tid - 168];
-    else if (tid == 192) L.last_error = D->last_error;
+    double v = 0.0;
+    if (tid < 36) v = D->Q[tid];
+    else if (tid < 144) v = D->T[tid - 36];
+    else if (tid < 168) v = D->x[tid - 144];
+    else if (tid < 192) v = D->xprop[tid - 168];
+    else if (tid == 192) v = (double)D->last_error;
+    return v;
+}
+__device__ __forceinline__ void eskf18_prefetch_commit(double v, FlSolveLds &L)
+{
+    const int tid = threadIdx.x;
+    if (tid < 36) L.Q[tid] = v;
+    else if (tid < 144) L.T[tid - 36] = v;
+    else if (tid < 168) L.x[tid - 144] = v;
+    else if (tid < 192) L.xp[tid - 168] = v;
+    else if (tid == 192) L.last_error = (float)v;
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     if (wave == 1) {
@@ -61,6 +74,10 @@ __device__ __forceinline__ void eskf18_prefetch(const FlDev18 *__restrict__ D, F
         L.vec[2] = fk * (rd[3] - rd[1]);
     }
     // visibility of L.vec to wave 0 is ensured by the __syncthreads inside the gather / before the solve
+}
+__device__ __forceinline__ void eskf18_prefetch(const FlDev18 *__restrict__ D, FlSolveLds &L)
+{
+    eskf18_prefetch_commit(eskf18_prefetch_issue(D), L);
 }
 
 // Solve + state update + judgement. All threads of the workgroup call it (NT >= 256); s_sums in LDS.
@@ -85,7 +102,11 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
         }
         __syncthreads();
         if (!L.accept) {   // revert: state = old_state ; EKF_end (:888-892)
-            if (tid < 24) D->x[tid] = D->xold[tid];
+            if (tid < 24) {
+                const double xo = D->xold[tid];
+                D->x[tid] = xo;
+                if (tid < 12) L.xn[tid] = xo;
+            }
             if (tid == 64) {
                 D->iters_run = D->iters_run + 1;
                 D->stop = 1;
@@ -160,10 +181,17 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
                     acc += L.x[i * 3 + k] * ekj;
                 }
                 D->x[lane] = acc;
+                L.xn[lane] = acc;
+            } else {
+                L.xn[lane] = L.x[lane];
             }
         }
     } else if (wave == 1) {
-        if (lane < 15) D->x[9 + lane] = L.x[9 + lane] + L.delta[3 + lane];
+        if (lane < 15) {
+            const double nv = L.x[9 + lane] + L.delta[3 + lane];
+            D->x[9 + lane] = nv;
+            if (lane < 3) L.xn[9 + lane] = nv;
+        }
     } else if (wave == 2) {
         if (lane == 0) {
             const double rn = sqrt(L.delta[0] * L.delta[0] + L.delta[1] * L.delta[1] + L.delta[2] * L.delta[2]);

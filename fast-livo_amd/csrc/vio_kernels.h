@@ -95,11 +95,101 @@ FL_HD void fl_pixel_row(const FlPatchGeom &g, const float t[4][4], float ref, co
     *res_out = (double)(wtl * t[1][1] + wtr * t[1][2] + wbl * t[2][1] + wbr * t[2][2] - ref);
 }
 
-#define FL_VIO_NT 512
+// ---- per-patch factorisation of the photometric rows --------------------------------------------
+// Every pixel row of a patch is  row = [du dv] * M  with ONE 2x6 matrix per patch
+//     M = (1/scale) [ Jdpi (p_hat Jdphi_dR - Jdp_dR) | -Jdpi Jdp_dt ]          (lidar_selection.cpp:830-835)
+// so the patch's contribution to the normal equations is  M^T G M  and  M^T g  with the 2x2 Gram
+// matrix G = sum [du dv]^T [du dv] and g = sum [du dv]^T res over its 64 pixels. A lane therefore
+// accumulates 6 numbers instead of forming a 1x6 row and 27 products; the wave reduces the 6 numbers
+// and the (wave-uniform) 6x6 update is done once per patch. Algebraically identical to summing the
+// rows; compared with the oracle by tolerance.
+FL_HD void fl_patch_M(const FlPatchGeom &g, const double *Jdphi_dR, const double *Jdp_dR, const double *Jdp_dt, double (&M)[2][6])
+{
+    FL_FP_CONTRACT
+    const double px = g.pf[0], py = g.pf[1], pz = g.pf[2];
+    const double ph[9] = {0.0, -pz, py, pz, 0.0, -px, -py, px, 0.0};
+    double B[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            B[i * 3 + j] = (ph[i * 3 + 0] * Jdphi_dR[0 * 3 + j] + ph[i * 3 + 1] * Jdphi_dR[1 * 3 + j] + ph[i * 3 + 2] * Jdphi_dR[2 * 3 + j]) - Jdp_dR[i * 3 + j];
+    const double inv_s = 1.0 / g.scale;
+    const double a = g.Jdpi[0] * inv_s, c = g.Jdpi[2] * inv_s, b = g.Jdpi[4] * inv_s, d = g.Jdpi[5] * inv_s;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        M[0][j] = a * B[0 * 3 + j] + c * B[2 * 3 + j];
+        M[1][j] = b * B[1 * 3 + j] + d * B[2 * 3 + j];
+        M[0][3 + j] = -(a * Jdp_dt[0 * 3 + j] + c * Jdp_dt[2 * 3 + j]);
+        M[1][3 + j] = -(b * Jdp_dt[1 * 3 + j] + d * Jdp_dt[2 * 3 + j]);
+    }
+}
+// float part of one pixel, reference operation order (lidar_selection.cpp:826-829,837)
+FL_HD void fl_pixel_grad(const FlPatchGeom &g, const float t[4][4], float ref, float *du_o, float *dv_o, float *res_o)
+{
+    const float wtl = g.wtl, wtr = g.wtr, wbl = g.wbl, wbr = g.wbr;
+    *du_o = 0.5f * ((wtl * t[1][2] + wtr * t[1][3] + wbl * t[2][2] + wbr * t[2][3])
+                  - (wtl * t[1][0] + wtr * t[1][1] + wbl * t[2][0] + wbr * t[2][1]));
+    *dv_o = 0.5f * ((wtl * t[2][1] + wtr * t[2][2] + wbl * t[3][1] + wbr * t[3][2])
+                  - (wtl * t[0][1] + wtr * t[0][2] + wbl * t[1][1] + wbr * t[1][2]));
+    *res_o = wtl * t[1][1] + wtr * t[1][2] + wbl * t[2][1] + wbr * t[2][2] - ref;
+}
+// record += M^T G M, M^T gz, counts (all arguments wave-uniform)
+FL_HD void fl_patch_accum(double *v /*32*/, const double (&M)[2][6], const double *T /*Suu,Suv,Svv,Sur,Svr,Srr*/)
+{
+    FL_FP_CONTRACT
+    double GM0[6], GM1[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        GM0[j] = T[0] * M[0][j] + T[1] * M[1][j];
+        GM1[j] = T[1] * M[0][j] + T[2] * M[1][j];
+    }
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++) { v[k] += M[0][i] * GM0[j] + M[1][i] * GM1[j]; k++; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) v[21 + i] += M[0][i] * T[3] + M[1][i] * T[4];
+    v[27] += 64.0;
+    v[28] += T[5];
+}
+
+// Camera pose of the current state, Rcw = Rci Rwi^T, Pcw = -Rci Rwi^T Pwi + Pci (lidar_selection.cpp:780-784),
+// in exactly the reference's operation order (it feeds the float sub-pixel weights). Threads 0..11 of
+// the calling workgroup each form one element from xn = {rot(9), pos(3)}.
+__device__ __forceinline__ void vio_derive_pose(const double *xn, const FlVioConst *__restrict__ VC, FlDev18 *__restrict__ D)
+{
+    const int t = threadIdx.x;
+    if (t < 9) {
+        const int i = t / 3, j = t % 3;   // Rcw[i][j] = sum_k Rci[i][k] * Rwi[j][k]
+        D->Rcw[t] = VC->Rci[i * 3 + 0] * xn[j * 3 + 0] + VC->Rci[i * 3 + 1] * xn[j * 3 + 1] + VC->Rci[i * 3 + 2] * xn[j * 3 + 2];
+    } else if (t < 12) {
+        const int i = t - 9;              // T = (-Rci) Rwi^T ; Pcw = T Pwi + Pci
+        double T[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            T[j] = (-VC->Rci[i * 3 + 0]) * xn[j * 3 + 0] + (-VC->Rci[i * 3 + 1]) * xn[j * 3 + 1] + (-VC->Rci[i * 3 + 2]) * xn[j * 3 + 2];
+        D->Pcw[i] = (T[0] * xn[9] + T[1] * xn[10] + T[2] * xn[11]) + VC->Pci[i];
+    }
+}
+__global__ void vio_derive_kernel(FlDev18 *__restrict__ D, const FlVioConst *__restrict__ VC)
+{
+    __shared__ double xn[12];
+    if (threadIdx.x < 12) xn[threadIdx.x] = D->x[threadIdx.x];
+    __syncthreads();
+    vio_derive_pose(xn, VC, D);
+}
+
+#define FL_VIO_NT 256
 
 // grid = producers + 1 ; MODE 0: fused pass ; MODE 1: accumulate only (sums -> sums_out).
-// 512-thread workgroups (8 patches in flight per workgroup): 2000 patches -> 250 records, which the
-// solver workgroup gathers in a single sweep.
+// Mapping: ONE HALF-WAVE PER PATCH, two pixels per lane (rows x and x+4 of the 8x8 patch). The
+// per-patch work that is uniform over a patch (projection with its fp64 divisions, the 2x6 matrix M,
+// the 6x6 update) dominates the instruction count and costs the same for 32 or 64 lanes, so two
+// patches per wavefront halve it: 2000 patches = 1000 waves = one wave per SIMD of the chip instead of
+// two sharing each SIMD (measured: producers 5.5 us -> see DESIGN.md). 256-thread workgroups, 8
+// patches each: 250 records, gathered in a single sweep.
 template <int MODE>
 __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__restrict__ img, const float *__restrict__ ref,
                                                             const double *__restrict__ pos, const int32_t *__restrict__ slevel,
@@ -110,9 +200,29 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
 {
     constexpr int NT = FL_VIO_NT;
     constexpr int WPB = NT / 64;
+    const int nprod = gridDim.x - 1;
+    if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();
+    // Software prefetch (see lio18_pass_kernel): the first patch's position, search level and
+    // reference row do not depend on the state; issue their loads before the state round trip.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, hl = lane & 31;
+    const int i_first = (blockIdx.x * WPB + wave) * 2 + half;
+    const bool have_first = (blockIdx.x != nprod) && (i_first < m);
+    int pf_slevel = 0;
+    double pf_pos0 = 0.0, pf_pos1 = 0.0, pf_pos2 = 0.0;
+    float pf_ref[2] = {0.f, 0.f};
+    if (have_first) {
+        pf_slevel = slevel[i_first];
+        pf_pos0 = pos[i_first * 3 + 0]; pf_pos1 = pos[i_first * 3 + 1]; pf_pos2 = pos[i_first * 3 + 2];
+        if (level_arg >= 0) {
+            pf_ref[0] = ref[(size_t)i_first * 192 + 64 * level_arg + hl];
+            pf_ref[1] = ref[(size_t)i_first * 192 + 64 * level_arg + hl + 32];
+        }
+    }
+    double pf_solver = 0.0;
+    if (MODE == 0 && blockIdx.x == nprod) pf_solver = eskf18_prefetch_issue(D);
     if (!(flags & FL_ITER_FORCE) && D->stop) return;
     const unsigned epoch = *epoch_ptr;
-    const int nprod = gridDim.x - 1;
 
     if (blockIdx.x == nprod) {
         // ------------------------------------------------------------------ solver workgroup
@@ -120,13 +230,15 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
         __shared__ double s_sums[FL_SUMS18];
         __shared__ FlSolveLds s_solve;
         fl_stamp(flags, 8);
-        if (MODE == 0) eskf18_prefetch(D, s_solve);
+        if (MODE == 0) eskf18_prefetch_commit(pf_solver, s_solve);
         fl_stamp(flags, 9);
         const int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
         fl_stamp(flags, 10);
         if (threadIdx.x == 0) *epoch_ptr = epoch + 1u;
         if (MODE == 0) {
             eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, gst);
+            __syncthreads();
+            vio_derive_pose(s_solve.xn, VC, D);      // camera pose for the next pass's producers
         } else {
             if (threadIdx.x < FL_SUMS18) sums_out[threadIdx.x] = s_sums[threadIdx.x];
         }
@@ -135,27 +247,18 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     }
 
     // -------------------------------------------------------------------- producer workgroups
-    __shared__ double s_red[WPB * FL_SUMS18];
+    __shared__ double s_red[2 * WPB * FL_SUMS18];
     const int level = (level_arg >= 0) ? level_arg : D->level;
 
-    // wave-uniform camera pose: Rcw = Rci Rwi^T, Pcw = -Rci Rwi^T Pwi + Pci  (:780-784)
+    // wave-uniform camera pose, derived from the state by the previous pass's solver (vio_derive_pose)
     const FlVioConst vc = *VC;
-    double Rwi[9], Rwit[9], Rcw[9], nRci[9], T[9], Pcw[3], Pwi[3];
+    double Rcw[9], Pcw[3];
 #pragma unroll
-    for (int i = 0; i < 9; i++) Rwi[i] = D->x[i];
+    for (int i = 0; i < 9; i++) Rcw[i] = D->Rcw[i];
 #pragma unroll
-    for (int i = 0; i < 3; i++) Pwi[i] = D->x[9 + i];
-    m3_tr(Rwi, Rwit);
-    m3_mul(vc.Rci, Rwit, Rcw);
-#pragma unroll
-    for (int i = 0; i < 9; i++) nRci[i] = -vc.Rci[i];
-    m3_mul(nRci, Rwit, T);
-    m3_vec(T, Pwi, Pcw);
-#pragma unroll
-    for (int i = 0; i < 3; i++) Pcw[i] = Pcw[i] + vc.Pci[i];
+    for (int i = 0; i < 3; i++) Pcw[i] = D->Pcw[i];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int xr = lane >> 3, yc = lane & 7;
+    const int xr = hl >> 3, yc = hl & 7;          // this lane's pixels: (xr, yc) and (xr + 4, yc)
     const int W = vc.stride, Hm1 = vc.height - 1, Wm1 = vc.width - 1;
 
     double v[FL_SUMS18];
@@ -163,44 +266,94 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     for (int k = 0; k < FL_SUMS18; k++) v[k] = 0.0;
 
     if (blockIdx.x == 0) fl_stamp(flags, 0);
-    for (int i = blockIdx.x * WPB + wave; i < m; i += nprod * WPB) {
-        const int scale = 1 << (level + slevel[i]);
-        const double ps[3] = {pos[i * 3 + 0], pos[i * 3 + 1], pos[i * 3 + 2]};
+    // trip count uniform over the wave: both halves iterate together, an inactive half (odd m) computes
+    // on patch 0 and contributes nothing
+    for (int ib = (blockIdx.x * WPB + wave) * 2; ib < m; ib += nprod * WPB * 2) {
+        const int i = ib + half;
+        const bool active = i < m;
+        const int ii = active ? i : 0;
+        const bool first = (i == i_first) && have_first;
+        const int scale = 1 << (level + (first ? pf_slevel : slevel[ii]));
+        double ps[3];
+        if (first) { ps[0] = pf_pos0; ps[1] = pf_pos1; ps[2] = pf_pos2; }
+        else { ps[0] = pos[ii * 3 + 0]; ps[1] = pos[ii * 3 + 1]; ps[2] = pos[ii * 3 + 2]; }
         FlPatchGeom g;
         fl_patch_geom(vc, Rcw, Pcw, ps, scale, g);
-        const int row0 = g.v_i + (xr - 4) * scale;
         const int col0 = g.u_i + (yc - 4) * scale;
-        float t[4][4];
+        float t[2][4][4];
+        // taps span [anchor - 5*scale, anchor + 5*scale]: no clamping needed inside the image
+        const bool inside = (g.v_i - 5 * scale >= 0) && (g.v_i + 5 * scale <= Hm1) && (g.u_i - 5 * scale >= 0) && (g.u_i + 5 * scale <= Wm1);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            int rr = row0 + (r - 1) * scale;
-            rr = rr < 0 ? 0 : (rr > Hm1 ? Hm1 : rr);          // the reference reads unchecked; clamp instead of faulting
+        for (int px = 0; px < 2; px++) {
+            const int row0 = g.v_i + (xr + 4 * px - 4) * scale;
+            if (inside) {
+                const uint8_t *q = img + row0 * W + col0;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const bool used = !((r == 0 && (c == 0 || c == 3)) || (r == 3 && (c == 0 || c == 3)));
-                if (used) {
-                    int cc = col0 + (c - 1) * scale;
-                    cc = cc < 0 ? 0 : (cc > Wm1 ? Wm1 : cc);
-                    t[r][c] = (float)img[rr * W + cc];
-                } else {
-                    t[r][c] = 0.f;
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const bool used = !((r == 0 && (c == 0 || c == 3)) || (r == 3 && (c == 0 || c == 3)));
+                        t[px][r][c] = used ? (float)q[(r - 1) * scale * W + (c - 1) * scale] : 0.f;
+                    }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int rr = row0 + (r - 1) * scale;
+                    rr = rr < 0 ? 0 : (rr > Hm1 ? Hm1 : rr);  // the reference reads unchecked; clamp instead of faulting
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const bool used = !((r == 0 && (c == 0 || c == 3)) || (r == 3 && (c == 0 || c == 3)));
+                        if (used) {
+                            int cc = col0 + (c - 1) * scale;
+                            cc = cc < 0 ? 0 : (cc > Wm1 ? Wm1 : cc);
+                            t[px][r][c] = (float)img[rr * W + cc];
+                        } else {
+                            t[px][r][c] = 0.f;
+                        }
+                    }
                 }
             }
         }
-        const float refv = ref[(size_t)i * 192 + 64 * level + lane];
-        double row[6], res;
-        fl_pixel_row(g, t, refv, vc.Jdphi_dR, vc.Jdp_dR, Rcw, row, &res);
-        fl_accum6(v, row, res);
-        v[FL_S_NEFF] += 1.0;
-        const double r2 = res * res;
-        v[FL_S_RES] += r2;
-        const double pe = wave_sum(r2);
-        if (lane == 0) errors[i] = (float)pe;
+        float refv[2];
+        if (first && level_arg >= 0) { refv[0] = pf_ref[0]; refv[1] = pf_ref[1]; }
+        else {
+            refv[0] = ref[(size_t)ii * 192 + 64 * level + hl];
+            refv[1] = ref[(size_t)ii * 192 + 64 * level + hl + 32];
+        }
+        double M[2][6];
+        fl_patch_M(g, vc.Jdphi_dR, vc.Jdp_dR, Rcw, M);          // uniform per half-wave, overlaps the tap loads
+        double w8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int px = 0; px < 2; px++) {
+            float du, dv, resf;
+            fl_pixel_grad(g, t[px], refv[px], &du, &dv, &resf);
+            const double dud = (double)du, dvd = (double)dv, res = (double)resf;
+            w8[0] += dud * dud; w8[1] += dud * dvd; w8[2] += dvd * dvd;
+            w8[3] += dud * res; w8[4] += dvd * res; w8[5] += res * res;
+        }
+        double T6[6];
+        half_sum6(w8, lane, T6);
+        if (active) {
+            fl_patch_accum(v, M, T6);
+            if (hl == 0) errors[i] = (float)T6[5];
+        }
     }
     if (blockIdx.x == 0) fl_stamp(flags, 1);
-    const double mine = block_reduce_record<NT, FL_SUMS18>(v, s_red);
-    publish_record<FL_SUMS18>(mine, epoch, records, nprod);
+    // every lane of a half-wave holds the same record: lanes 0 and 32 store it, 32 threads add them up
+    if (hl == 0) {
+#pragma unroll
+        for (int k = 0; k < FL_SUMS18; k++) s_red[(wave * 2 + half) * FL_SUMS18 + k] = v[k];
+    }
+    __syncthreads();
+    double mine = 0.0;
+    if (threadIdx.x < FL_SUMS18) {
+        mine = s_red[threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < 2 * WPB; w++) mine += s_red[w * FL_SUMS18 + threadIdx.x];
+    }
+    publish_record<FL_SUMS18>(mine, epoch, records);
     if (blockIdx.x == 0) fl_stamp(flags, 2);
+    if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();
 }
 
 // UpdateState prologue: old_state = *state, last_error = total_residual (:747,756); per-level counters.
