@@ -92,9 +92,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ESKF hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("FL_BENCH_FORCE_SHARDED") == "1"   # the env var exercises the N>1 code path on one GPU
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29617")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import fastlivo  # noqa: F401
@@ -207,7 +210,7 @@ def main():
             sweep(capi, synth, scene, cfg, x0, sys.stderr)
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline and not distributed:
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline(fr, vf, nbr, valid, args.cpu_seconds)
 
     hl.close()

@@ -38,30 +38,9 @@ struct FlDev23 {
     int32_t pad;
 };
 
-#define FL_IK_NT 256
+#include "ikfom_solve_block.h"
 
-__device__ __forceinline__ void ikfom_solver_serial(FlDev23 *__restrict__ D, const double *s_sums, double *s_P, double *s_work, int gst)
-{
-    // one thread; big arrays live in LDS (s_P, s_work), Pprop is read from HBM
-    double x[FL_X23_LEN], xp[FL_X23_LEN], dx[23];
-    for (int i = 0; i < FL_X23_LEN; i++) { x[i] = D->x[i]; xp[i] = D->xprop[i]; }
-    FlIkfomCtl c;
-    c.iter_i = D->iter_i; c.t_count = D->t_count; c.converge = 0; c.finished = 0; c.max_iter = D->max_iter; c.status = gst;
-    fl_ikfom_iterate(x, xp, D->Pprop, s_P, D->limit, D->meas_cov, s_sums, &c, dx, s_work);
-    for (int i = 0; i < FL_X23_LEN; i++) D->x[i] = x[i];
-    for (int i = 0; i < 23; i++) D->solution[i] = dx[i];
-    for (int i = 0; i < 529; i++) D->P[i] = s_P[i];
-    for (int i = 0; i < FL_SUMS23; i++) D->sums[i] = s_sums[i];
-    D->iter_i = c.iter_i;
-    D->t_count = c.t_count;
-    D->need_search = c.converge;
-    D->converged = c.converge;
-    D->stop = (c.finished || c.iter_i >= c.max_iter) ? 1 : 0;
-    D->neff = (int)s_sums[FL_S23_NEFF];
-    D->total_residual = s_sums[FL_S23_RES];
-    D->status = c.status;
-    D->iters_run = D->iters_run + 1;
-}
+#define FL_IK_NT 256
 
 template <int MODE>
 __global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float *__restrict__ body, const float4 *__restrict__ plane,
@@ -78,16 +57,13 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float *__res
     if (blockIdx.x == nprod) {
         __shared__ double s_fin[2 * NT];
         __shared__ double s_sums[FL_SUMS23];
-        __shared__ double s_P[529];
-        __shared__ double s_work[FL_IKFOM_WORK];
+        __shared__ FlIkLds s_ik;
         const int gst = gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums);
-        if (threadIdx.x == 0) {
-            *epoch_ptr = epoch + 1u;
-            if (MODE == 0) {
-                ikfom_solver_serial(D, s_sums, s_P, s_work, gst);
-            } else {
-                for (int k = 0; k < FL_SUMS23; k++) sums_out[k] = s_sums[k];
-            }
+        if (threadIdx.x == 0) *epoch_ptr = epoch + 1u;
+        if (MODE == 0) {
+            ikfom_solver_block(D, s_sums, s_ik, gst);
+        } else {
+            if (threadIdx.x < FL_SUMS23) sums_out[threadIdx.x] = s_sums[threadIdx.x];
         }
         return;
     }
@@ -129,11 +105,10 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_solve_kernel(FlDev23 *__restri
 {
     if (!(flags & FL_ITER_FORCE) && (D->stop || D->need_search)) return;
     __shared__ double s_sums[FL_SUMS23];
-    __shared__ double s_P[529];
-    __shared__ double s_work[FL_IKFOM_WORK];
+    __shared__ FlIkLds s_ik;
     if (threadIdx.x < FL_SUMS23) s_sums[threadIdx.x] = sums_in[threadIdx.x];
     __syncthreads();
-    if (threadIdx.x == 0) ikfom_solver_serial(D, s_sums, s_P, s_work, 0);
+    ikfom_solver_block(D, s_sums, s_ik, 0);
 }
 
 // world points at the current state_ikfom (laserMapping.cpp:980-984) for the host kNN

@@ -49,4 +49,13 @@ res = {
   "fit_planes_us": timeit(lambda: hl.lio_set_neighbours(nbr, valid), reps=20) if a.points <= 200000 else None,
   "points": a.points, "patches": a.patches,
 }
+# Mode-23 pass
+hi = capi.Handle(cfg); hi.set_stream(s.cuda_stream)
+hi.lio_set_points(body)
+x23 = capi.state23_from_frame(fr)
+hi.ikfom_begin(x23, fr.cov23.copy())
+hi.lio_set_neighbours(nbr, valid)
+res["ikfom_fused_us"] = timeit(lambda: hi.ikfom_iterate(1, F, want_info=False), reps=100)
+t96 = torch.zeros(96, dtype=torch.float64, device="cuda")
+res["ikfom_accumulate_us"] = timeit(lambda: hi.ikfom_accumulate(t96.data_ptr(), F), reps=100)
 print(json.dumps(res))
