@@ -1,0 +1,67 @@
+"""One handle across several frames of different sizes: the record tags/epoch, the geometric buffer
+growth and the per-frame prepare must not leak state from one frame (or grid size) into the next."""
+import numpy as np
+import pytest
+
+from helpers import assert_delta_close
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lio_and_vio_frames_of_changing_size_on_one_handle(gpu_lib, oracle_lib, scene):
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    knn = lambda w: synth.knn5(scene, w)  # noqa: E731
+    h = None
+    for k, (n, m) in enumerate([(3000, 64), (70000, 700), (257, 9), (70000, 700), (1, 1), (12000, 333)]):
+        fr = synth.make_lio_frame(n, scene=scene, point_seed=100 + k)
+        vf = synth.make_vio_frame(m, fr, patch_seed=200 + k)
+        if h is None:
+            h = capi.Handle(capi.config_from_frames(fr, vf, max_iterations=4))
+        vf.max_iterations = 4
+        # LIO frame
+        xo = orc.state18_from_frame(fr)
+        ro = orc.lio18_frame(xo, fr.body_xyz, fr.R_LI, fr.t_LI, fr.laser_point_cov, 4, knn)
+        xg = capi.state18_from_frame(fr)
+        info = h.lio_frame18(xg, fr.body_xyz, knn)
+        assert info.iterations == ro["out"].iterations, (k, n)
+        assert info.effct_feat_num == ro["out"].effct_feat_num, (k, n)
+        assert (info.status & 8) == 0                     # no record time-out
+        assert np.abs(xg.vec() - xo.vec()).max() <= 1e-9, (k, n)
+        assert np.abs(xg.cov_np() - xo.cov_np()).max() <= 1e-12
+        # VIO ComputeJ on the same handle
+        xo = orc.state18_from_frame(fr)
+        rv = orc.vio_compute_j(vf, xo, xo.copy())
+        xg = capi.state18_from_frame(fr)
+        h.vio_set_frame(vf.img)
+        h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+        infos = h.vio_compute_j(xg, xg.copy())
+        for lv in (2, 1, 0):
+            assert infos[lv].iterations == rv["outs"][lv].iterations, (k, m, lv)
+        assert np.abs(xg.vec() - xo.vec()).max() <= 1e-9, (k, m)
+        assert np.abs(xg.cov_np() - xo.cov_np()).max() <= 1e-12
+    h.close()
+
+
+def test_border_patches_are_clamped_not_faulting(gpu_lib, scene):
+    """Patches whose footprint leaves the image: the reference reads unchecked memory (UB); the device
+    clamps the taps. No parity claim, only: no fault, finite results."""
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    fr = synth.make_lio_frame(256, scene=scene)
+    vf = synth.make_vio_frame(64, fr)
+    Rcw, Pcw = synth.cam_pose(vf.Rcl, vf.Pcl, vf.R_LI, vf.t_LI, fr.R_true, fr.p_true)
+    # move 16 points so that they project 2 px from the image corner / edges
+    for j, (u, v) in enumerate([(2, 2), (637, 2), (2, 509), (637, 509)] * 4):
+        d = 5.0 + j
+        xyc = np.array([(u - vf.cam["cx"]) / vf.cam["fx"] * d, (v - vf.cam["cy"]) / vf.cam["fy"] * d, d])
+        vf.pos[j] = Rcw.T @ (xyc - Pcw)
+    h = capi.Handle(capi.config_from_frames(fr, vf, max_iterations=3))
+    h.vio_set_frame(vf.img)
+    h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+    xg = capi.state18_from_frame(fr)
+    infos = h.vio_compute_j(xg, xg.copy())
+    assert np.isfinite(xg.vec()).all() and np.isfinite(xg.cov_np()).all()
+    assert np.isfinite(h.vio_get_errors(vf.m)).all()
+    assert all(infos[lv].iterations >= 1 for lv in (0, 1, 2))
+    h.close()
