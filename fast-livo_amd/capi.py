@@ -125,6 +125,11 @@ SYMBOLS = {
                                              C.c_void_p, C.POINTER(IterInfo)]),
     "fl_ikfom_accumulate": (C.c_int32, [_H, C.c_void_p, C.c_int32]),
     "fl_ikfom_solve": (C.c_int32, [_H, C.c_void_p, C.c_int32, C.POINTER(IterInfo)]),
+    "fl_map_set_points": (C.c_int32, [_H, _fp, C.c_int32, C.c_float]),
+    "fl_lio_search18": (C.c_int32, [_H, _fp, _u8p]),
+    "fl_ikfom_search": (C.c_int32, [_H, _fp, _u8p]),
+    "fl_lio_frame18_dev": (C.c_int32, [_H, C.POINTER(State18), _fp, C.c_int32, C.POINTER(IterInfo)]),
+    "fl_ikfom_update_iterated_dev": (C.c_int32, [_H, C.POINTER(State23), _dp, _fp, C.c_int32, C.c_double, _dp, C.POINTER(IterInfo)]),
 }
 
 _lib = None
@@ -462,3 +467,45 @@ def state23_from_frame(fr):
     g = np.asarray(fr.grav, dtype=np.float64)
     s.grav[:] = g / np.linalg.norm(g) * 9.809
     return s
+
+
+# ------------------------------------------------------------------------------------ device k-NN
+def _knn_methods():
+    def map_set_points(self, map_xyz, cell_size=0.5):
+        m = np.ascontiguousarray(map_xyz, dtype=np.float32)
+        self._chk(self.L.fl_map_set_points(self.h, _p(m, C.c_float), m.shape[0], cell_size), "fl_map_set_points")
+
+    def lio_search18(self, n, want=True):
+        nbr = np.zeros((n, 5, 3), dtype=np.float32)
+        valid = np.zeros(n, dtype=np.uint8)
+        self._chk(self.L.fl_lio_search18(self.h, _p(nbr, C.c_float) if want else None, _p(valid, C.c_uint8) if want else None),
+                  "fl_lio_search18")
+        return nbr, valid
+
+    def ikfom_search(self, n, want=True):
+        nbr = np.zeros((n, 5, 3), dtype=np.float32)
+        valid = np.zeros(n, dtype=np.uint8)
+        self._chk(self.L.fl_ikfom_search(self.h, _p(nbr, C.c_float) if want else None, _p(valid, C.c_uint8) if want else None),
+                  "fl_ikfom_search")
+        return nbr, valid
+
+    def lio_frame18_dev(self, state, body):
+        body = np.ascontiguousarray(body, dtype=np.float32)
+        info = IterInfo()
+        self._chk(self.L.fl_lio_frame18_dev(self.h, C.byref(state), _p(body, C.c_float), body.shape[0], C.byref(info)),
+                  "fl_lio_frame18_dev")
+        return info
+
+    def ikfom_update_iterated_dev(self, x23, P, body, R, limit=None):
+        body = np.ascontiguousarray(body, dtype=np.float32)
+        limit = np.full(23, 0.001) if limit is None else np.ascontiguousarray(limit, dtype=np.float64)
+        info = IterInfo()
+        self._chk(self.L.fl_ikfom_update_iterated_dev(self.h, C.byref(x23), _p(P, C.c_double), _p(body, C.c_float), body.shape[0], R,
+                                                      _p(limit, C.c_double), C.byref(info)), "fl_ikfom_update_iterated_dev")
+        return info
+
+    for f in (map_set_points, lio_search18, ikfom_search, lio_frame18_dev, ikfom_update_iterated_dev):
+        setattr(Handle, f.__name__, f)
+
+
+_knn_methods()

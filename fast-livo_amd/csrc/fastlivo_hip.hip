@@ -8,8 +8,10 @@
 #include "lio_kernels.h"
 #include "vio_kernels.h"
 #include "ikfom_kernels.h"
+#include "knn_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <math.h>
 #include <stddef.h>
@@ -49,6 +51,16 @@ struct fl_context {
     // Mode-23
     FlDev23 *d_dev23 = nullptr;
     FlDev23 *h_dev23 = nullptr;
+    // device map grid for the k-NN (knn_kernels.h)
+    float *d_map_raw = nullptr;
+    float4 *d_map_pts = nullptr;
+    unsigned long long *d_map_keys = nullptr, *d_map_keys_tmp = nullptr, *d_map_hkeys = nullptr;
+    unsigned *d_map_idx = nullptr, *d_map_idx_tmp = nullptr, *d_map_hstart = nullptr;
+    void *d_map_sort_tmp = nullptr;
+    size_t map_sort_bytes = 0;
+    int map_cap = 0, map_n = 0, map_max_ring = 0;
+    unsigned map_hcap = 0;
+    float map_cell = 0.f;
     // misc
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
@@ -165,6 +177,8 @@ int32_t fl_destroy(fl_handle h)
     hipFree(h->d_plane); hipFree(h->d_normvec); hipFree(h->d_dev); hipFree(h->d_dev23); hipFree(h->d_records);
     hipFree(h->d_epoch); hipFree(h->d_sums_tmp); hipFree(h->d_vc); hipFree(h->d_img); hipFree(h->d_ref);
     hipFree(h->d_errors); hipFree(h->d_pos); hipFree(h->d_slevel);
+    hipFree(h->d_map_raw); hipFree(h->d_map_pts); hipFree(h->d_map_keys); hipFree(h->d_map_keys_tmp); hipFree(h->d_map_idx);
+    hipFree(h->d_map_idx_tmp); hipFree(h->d_map_hkeys); hipFree(h->d_map_hstart); hipFree(h->d_map_sort_tmp);
     if (h->h_dev) hipHostFree(h->h_dev);
     if (h->h_dev23) hipHostFree(h->h_dev23);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -501,5 +515,6 @@ int32_t fl_debug_get_wall(fl_handle h, long long *out2048)
 
 #include "api_vio.inc"
 #include "api_ikfom.inc"
+#include "api_knn.inc"
 
 }  // extern "C"

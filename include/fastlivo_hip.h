@@ -216,6 +216,27 @@ int32_t fl_ikfom_update_iterated(fl_handle h, fl_state23 *x_io, double *P_io, co
 int32_t fl_ikfom_accumulate(fl_handle h, double *d_sums, int32_t flags);
 int32_t fl_ikfom_solve(fl_handle h, const double *d_sums, int32_t flags, fl_iter_info *info);
 
+/* ------------------------------------------------------------------------------------------------
+ * Device k-NN: the LiDAR-map search of the 2 search passes per frame
+ * on the GPU instead of the host ikd-Tree (KD_TREE::Nearest_Search, include/ikd-Tree/ikd_Tree.cpp:350-380;
+ * call sites src/laserMapping.cpp:1543 and :1002). Exact 5-NN with the tree's float distance
+ * (ikd_Tree.cpp:1291-1295), ascending; exact ties are broken by the lower map index.
+ * ---------------------------------------------------------------------------------------------- */
+/* Mirror of the host map on the device: call after ikdtree.Build (:1411-1419) and after map_incremental
+ * (:692-706) with the current map points (k x 3 floats). cell_size (m) is the voxel edge of the device
+ * grid (0.5 is a good default for filter_size_map 0.15-0.5). */
+int32_t fl_map_set_points(fl_handle h, const float *map_xyz, int32_t k, float cell_size);
+/* One search pass at the current device state (after fl_lio_begin18 / fl_ikfom_begin): neighbours ->
+ * planes -> selection flags, nothing leaves the device. nbr_xyz_out (n x 5 x 3) / valid_out (n) are
+ * optional read-backs for parity checks. */
+int32_t fl_lio_search18(fl_handle h, float *nbr_xyz_out, uint8_t *valid_out);
+int32_t fl_ikfom_search(fl_handle h, float *nbr_xyz_out, uint8_t *valid_out);
+/* fl_lio_frame18 / fl_ikfom_update_iterated with the search on the device: the whole frame is enqueued
+ * at once ([search-if-asked, pass] x (max_iterations + 1)), one host synchronisation per frame. */
+int32_t fl_lio_frame18_dev(fl_handle h, fl_state18 *state_io, const float *body_xyz, int32_t n, fl_iter_info *info);
+int32_t fl_ikfom_update_iterated_dev(fl_handle h, fl_state23 *x_io, double *P_io, const float *body_xyz, int32_t n, double R,
+                                     const double *limit, fl_iter_info *info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,11 @@ int orc_lio18_frame(orc_state18 *x, const float *body_xyz, int n, const double *
                     void *knn_ctx, int nthreads, uint8_t *sel_out, float *normvec_out,
                     orc_lio_frame_out *out);
 
+/* Exact brute-force 5-NN with the ikd-Tree's float distance (ikd_Tree.cpp:1291-1295), ascending, ties by
+ * lower map index; valid = 5 found && sqdist[4] <= 5 (laserMapping.cpp:1549,1567). */
+int orc_knn5(const float *map_xyz, int k, const float *query_xyz, int n, float *nbr_xyz, float *sqdist, uint8_t *valid,
+             int32_t *nbr_idx, int nthreads);
+
 /* ---------------------------------------------------------------- VIO (lidar_selection.cpp) */
 typedef struct orc_vio_config {
     double Rcl[9], Pcl[3];    /* camera <- lidar extrinsic (avia.yaml:42-45)            */

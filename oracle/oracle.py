@@ -130,6 +130,8 @@ def lib():
         L.orc_ikfom_update_iterated.restype = C.c_int
         L.orc_ikfom_update_iterated.argtypes = [C.POINTER(State23), dp, fp, C.c_int, C.c_double, C.c_int, dp,
                                                 KNN_FN, C.c_void_p, C.c_int, u8p, fp, C.POINTER(IkfomOut)]
+        L.orc_knn5.restype = C.c_int
+        L.orc_knn5.argtypes = [fp, C.c_int, fp, C.c_int, fp, fp, u8p, i32p, C.c_int]
         L.orc_state23_boxplus.restype = None
         L.orc_state23_boxplus.argtypes = [C.POINTER(State23), dp]
         L.orc_state23_boxminus.restype = None
@@ -252,3 +254,17 @@ def ikfom_update(x, P, body, R, max_iter, scene_knn, limit=None, nthreads=4):
                                          _p(limit, C.c_double), cb, None, nthreads, _p(sel, C.c_uint8),
                                          _p(normvec, C.c_float), C.byref(out))
     return dict(status=st, out=out, sel=sel, normvec=normvec)
+
+
+def knn5_bruteforce(map_xyz, query_xyz, nthreads=8):
+    """Exact float-distance 5-NN (oracle/orc_knn.c): nbr (n,5,3), sqdist (n,5), valid (n,), idx (n,5)."""
+    map_xyz = np.ascontiguousarray(map_xyz, dtype=np.float32)
+    q = np.ascontiguousarray(query_xyz, dtype=np.float32)
+    n = q.shape[0]
+    nbr = np.zeros((n, 5, 3), dtype=np.float32)
+    sq = np.zeros((n, 5), dtype=np.float32)
+    valid = np.zeros(n, dtype=np.uint8)
+    idx = np.zeros((n, 5), dtype=np.int32)
+    lib().orc_knn5(_p(map_xyz, C.c_float), map_xyz.shape[0], _p(q, C.c_float), n, _p(nbr, C.c_float), _p(sq, C.c_float),
+                   _p(valid, C.c_uint8), _p(idx, C.c_int32), nthreads)
+    return nbr, sq, valid, idx
