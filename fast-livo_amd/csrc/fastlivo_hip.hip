@@ -54,8 +54,9 @@ struct fl_context {
     // device map grid for the k-NN (knn_kernels.h)
     float *d_map_raw = nullptr;
     float4 *d_map_pts = nullptr;
-    unsigned long long *d_map_keys = nullptr, *d_map_keys_tmp = nullptr, *d_map_hkeys = nullptr;
-    unsigned *d_map_idx = nullptr, *d_map_idx_tmp = nullptr, *d_map_hstart = nullptr;
+    unsigned long long *d_map_keys = nullptr, *d_map_keys_tmp = nullptr;
+    struct FlCellEntry *d_map_htab = nullptr;
+    unsigned *d_map_idx = nullptr, *d_map_idx_tmp = nullptr;
     void *d_map_sort_tmp = nullptr;
     size_t map_sort_bytes = 0;
     int map_cap = 0, map_n = 0, map_max_ring = 0;
@@ -178,7 +179,7 @@ int32_t fl_destroy(fl_handle h)
     hipFree(h->d_epoch); hipFree(h->d_sums_tmp); hipFree(h->d_vc); hipFree(h->d_img); hipFree(h->d_ref);
     hipFree(h->d_errors); hipFree(h->d_pos); hipFree(h->d_slevel);
     hipFree(h->d_map_raw); hipFree(h->d_map_pts); hipFree(h->d_map_keys); hipFree(h->d_map_keys_tmp); hipFree(h->d_map_idx);
-    hipFree(h->d_map_idx_tmp); hipFree(h->d_map_hkeys); hipFree(h->d_map_hstart); hipFree(h->d_map_sort_tmp);
+    hipFree(h->d_map_idx_tmp); hipFree(h->d_map_htab); hipFree(h->d_map_sort_tmp);
     if (h->h_dev) hipHostFree(h->h_dev);
     if (h->h_dev23) hipHostFree(h->h_dev23);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -369,11 +370,12 @@ static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_sta
     D->iterCount = -1;
     D->rematch_num = 0;
     D->need_search = 1;
+    D->searched_at = -1;
     D->stop = 0;
     D->max_iter = h->cfg.max_iterations;
     D->last_error = 1e10f;
     HIPCHK(h, hipMemcpyAsync(h->d_dev, D, sizeof(FlDev18), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(eskf18_prepare_kernel, dim3(1), dim3(64), 0, h->stream, h->d_dev);
+    hipLaunchKernelGGL(eskf18_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev);
     HIPCHK(h, hipGetLastError());
     return FL_OK;
 }

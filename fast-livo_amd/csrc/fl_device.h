@@ -56,7 +56,7 @@ struct FlDev18 {
     int32_t accepted;
     int32_t max_iter;
     int32_t level;      // VIO pyramid level of the current UpdateState
-    int32_t pad;
+    int32_t searched_at; // device k-NN: value of iters_run the last search was made for (-1: none)
 };
 
 // VIO constants (lidar_selection.cpp:35-59 + camera), computed on the host once per handle.

@@ -35,7 +35,7 @@ struct FlDev23 {
     int32_t status;
     int32_t iters_run;
     int32_t max_iter;
-    int32_t pad;
+    int32_t searched_at;      // device k-NN: value of iters_run the last search was made for (-1: none)
 };
 
 #include "ikfom_solve_block.h"
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float *__res
                                                              int flags)
 {
     constexpr int NT = FL_IK_NT;
-    if (!(flags & FL_ITER_FORCE) && (D->stop || D->need_search)) return;
+    if (!(flags & FL_ITER_FORCE) && (D->stop || (D->need_search && D->searched_at != D->iters_run))) return;
     const unsigned epoch = *epoch_ptr;
     const int nprod = gridDim.x - 1;
 
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float *__res
 // Solve from an externally reduced record (sharded form).
 __global__ __launch_bounds__(FL_IK_NT) void ikfom_solve_kernel(FlDev23 *__restrict__ D, const double *__restrict__ sums_in, int flags)
 {
-    if (!(flags & FL_ITER_FORCE) && (D->stop || D->need_search)) return;
+    if (!(flags & FL_ITER_FORCE) && (D->stop || (D->need_search && D->searched_at != D->iters_run))) return;
     __shared__ double s_sums[FL_SUMS23];
     __shared__ FlIkLds s_ik;
     if (threadIdx.x < FL_SUMS23) s_sums[threadIdx.x] = sums_in[threadIdx.x];

@@ -22,17 +22,26 @@
 #include "fl_ikfom_math.h"
 
 #define FL_KNN_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define FL_KNN_QPB 64            // queries per workgroup of the search kernel
+#define FL_KNN_NT 256
+#define FL_KNN_BATCH 8           // point loads in flight per lane
+
+// hash-table entry: cell key, first sorted point of the cell, number of points in the cell
+struct __attribute__((aligned(16))) FlCellEntry {
+    unsigned long long key;
+    unsigned start;
+    unsigned count;
+};
 
 struct FlMapGrid {
     const float4 *pts;               // sorted by cell key: xyz + original index (as int bits) in w
-    const unsigned long long *keys;  // sorted cell key of every point
-    const unsigned long long *hkeys; // hash table: cell key or FL_KNN_EMPTY
-    const unsigned *hstart;          // hash table: index of the cell's first sorted point
+    const float *raw;                // the map as staged (k x 3), addressed by original index
+    const FlCellEntry *htab;         // open-addressing table, key == FL_KNN_EMPTY: free slot
     unsigned hmask;                  // table size - 1 (power of two)
     int npts;
     float cell;                      // edge length
     float inv_cell;
-    int max_ring;                    // smallest r with (r*cell)^2 > 5
+    int max_ring;                    // smallest r with (r*cell)^2 > 5 (+1 for the margin of the stop rule)
 };
 
 __device__ __forceinline__ unsigned long long fl_cell_key(int ix, int iy, int iz)
@@ -40,10 +49,15 @@ __device__ __forceinline__ unsigned long long fl_cell_key(int ix, int iy, int iz
     return ((unsigned long long)(unsigned)(ix + (1 << 20)) << 42) | ((unsigned long long)(unsigned)(iy + (1 << 20)) << 21) |
            (unsigned long long)(unsigned)(iz + (1 << 20));
 }
+// table slot of a cell. The three 21-bit biased coordinates are mixed with full-rate 24-bit multiplies (the 64-bit
+// multiplies of a general-purpose mixer are quarter rate and the search kernel is VALU bound).
 __device__ __forceinline__ unsigned fl_hash64(unsigned long long k)
 {
-    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
-    return (unsigned)k;
+    const unsigned z = (unsigned)k & 0x1FFFFFu, y = (unsigned)(k >> 21) & 0x1FFFFFu, x = (unsigned)(k >> 42) & 0x1FFFFFu;
+    unsigned h = __umul24(x, 0x9E3779u) ^ __umul24(y, 0x85EBCBu) ^ __umul24(z, 0xC2B2AFu);
+    h ^= h >> 15;
+    h = __umul24(h & 0xFFFFFFu, 0x27D4EBu) ^ (h >> 11);
+    return h;
 }
 
 __global__ __launch_bounds__(FL_BLOCK) void knn_keys_kernel(const float *__restrict__ map_xyz, int k, float inv_cell,
@@ -59,37 +73,50 @@ __global__ __launch_bounds__(FL_BLOCK) void knn_keys_kernel(const float *__restr
 
 __global__ __launch_bounds__(FL_BLOCK) void knn_build_kernel(const float *__restrict__ map_xyz, const unsigned long long *__restrict__ skeys,
                                                             const unsigned *__restrict__ sidx, int k, float4 *__restrict__ pts,
-                                                            unsigned long long *__restrict__ hkeys, unsigned *__restrict__ hstart,
-                                                            unsigned hmask)
+                                                            FlCellEntry *__restrict__ htab, unsigned hmask)
 {
     const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
     if (i >= k) return;
     const unsigned o = sidx[i];
     pts[i] = make_float4(map_xyz[o * 3], map_xyz[o * 3 + 1], map_xyz[o * 3 + 2], __int_as_float((int)o));
     const unsigned long long key = skeys[i];
-    if (i == 0 || skeys[i - 1] != key) {          // first point of its cell: claim a slot
+    if (i == 0 || skeys[i - 1] != key) {          // first point of its cell: claim a slot, count the cell
+        int e = i + 1;
+        while (e < k && skeys[e] == key) e++;
         unsigned h = fl_hash64(key) & hmask;
         while (true) {
-            const unsigned long long prev = atomicCAS((unsigned long long *)&hkeys[h], FL_KNN_EMPTY, key);
-            if (prev == FL_KNN_EMPTY || prev == key) { hstart[h] = (unsigned)i; break; }
+            const unsigned long long prev = atomicCAS((unsigned long long *)&htab[h].key, FL_KNN_EMPTY, key);
+            if (prev == FL_KNN_EMPTY || prev == key) { htab[h].start = (unsigned)i; htab[h].count = (unsigned)(e - i); break; }
             h = (h + 1) & hmask;
         }
     }
 }
 
+// Sorted best-5 list of keys. key bits = (float bits of the squared distance + 0x00100000) << 32 | original map
+// index. Squared distances are non-negative floats, so the unsigned order of the keys is (distance, then lower map
+// index) -- the tie rule of oracle/orc_knn.c. The bit pattern is handled as a positive, normal, finite DOUBLE (the
+// bias keeps the exponent field in 1..0x7F9), whose IEEE order equals the unsigned order: a compare-exchange is one
+// v_min_f64 + one v_max_f64, both exact selections.
 struct FlTop5 {
-    float d[5];
-    int id[5];      // original map index (tie-break)
-    int at[5];      // position in the sorted array
+    double key[5];
 };
-__device__ __forceinline__ void fl_top5_insert(FlTop5 &t, float d, int id, int at)
+__device__ __forceinline__ double fl_knn_key(float d, int id) { return __hiloint2double((int)(__float_as_uint(d) + 0x00100000u), id); }
+__device__ __forceinline__ float fl_knn_key_d(double key) { return __uint_as_float((unsigned)__double2hiint(key) - 0x00100000u); }
+__device__ __forceinline__ int fl_knn_key_id(double key) { return __double2loint(key); }
+#define FL_KNN_NO_ID 0x7fffffff
+__device__ __forceinline__ void fl_top5_clear(FlTop5 &t)
 {
-    if (!(d < t.d[4] || (d == t.d[4] && id < t.id[4]))) return;
 #pragma unroll
-    for (int p = 4; p >= 0; p--) {
-        const bool before_prev = (p > 0) && (d < t.d[p - 1] || (d == t.d[p - 1] && id < t.id[p - 1]));
-        if (before_prev) { t.d[p] = t.d[p - 1]; t.id[p] = t.id[p - 1]; t.at[p] = t.at[p - 1]; }
-        else { t.d[p] = d; t.id[p] = id; t.at[p] = at; break; }
+    for (int k = 0; k < 5; k++) t.key[k] = fl_knn_key(INFINITY, FL_KNN_NO_ID);
+}
+// branch-free insertion: 5 compare-exchanges carry the displaced key down the list
+__device__ __forceinline__ void fl_top5_insert(FlTop5 &t, double key)
+{
+#pragma unroll
+    for (int p = 0; p < 5; p++) {
+        const double lo = fmin(key, t.key[p]);
+        key = fmax(key, t.key[p]);
+        t.key[p] = lo;
     }
 }
 
@@ -97,99 +124,233 @@ __device__ __forceinline__ void fl_scan_cell(const FlMapGrid &G, int ix, int iy,
 {
     const unsigned long long key = fl_cell_key(ix, iy, iz);
     unsigned h = fl_hash64(key) & G.hmask;
+    unsigned start, count;
     while (true) {
-        const unsigned long long hk = G.hkeys[h];
+        const uint4 e = *reinterpret_cast<const uint4 *>(&G.htab[h]);
+        const unsigned long long hk = ((unsigned long long)e.y << 32) | e.x;
         if (hk == FL_KNN_EMPTY) return;
-        if (hk == key) break;
+        if (hk == key) { start = e.z; count = e.w; break; }
         h = (h + 1) & G.hmask;
     }
-    for (int j = (int)G.hstart[h]; j < G.npts && G.keys[j] == key; j++) {
+    for (unsigned j = start; j < start + count; j++) {
         const float4 p = G.pts[j];
         const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
         const float d = dx * dx + dy * dy + dz * dz;        // ikd_Tree.cpp:1293 (no contraction)
-        fl_top5_insert(t, d, __float_as_int(p.w), j);
+        fl_top5_insert(t, fl_knn_key(d, __float_as_int(p.w)));
     }
 }
 
-// MODE 18: world point from FlDev18 ; MODE 23: from FlDev23. `cond` != 0: run only when the device
-// raised need_search and not stop (the frame drivers enqueue it before every pass).
-template <int MODE, typename DEV>
-__global__ __launch_bounds__(FL_BLOCK) void lio_search_fit_kernel(const float *__restrict__ body, int n, FlMapGrid G, DEV *__restrict__ D,
-                                                                 float4 *__restrict__ plane, uint8_t *__restrict__ sel,
-                                                                 float *__restrict__ nbr_out /* nullable n x 15 */,
-                                                                 uint8_t *__restrict__ valid_out /* nullable */, int cond)
+// ---- quad (4 lanes) cross-lane helpers -------------------------------------------------------
+__device__ __forceinline__ double quad_min_f64(double v)
 {
-    if (cond && (!D->need_search || D->stop)) return;
-    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
-    if (i < n) {
-        const float pb[3] = {body[i * 3], body[i * 3 + 1], body[i * 3 + 2]};
-        float pw[3];
-        if constexpr (MODE == 18) {
-            const FlDev18 *D18 = D;
-            const double b0 = (double)pb[0], b1 = (double)pb[1], b2 = (double)pb[2];
-            const double q0 = (D18->R_LI[0] * b0 + D18->R_LI[1] * b1 + D18->R_LI[2] * b2) + D18->t_LI[0];
-            const double q1 = (D18->R_LI[3] * b0 + D18->R_LI[4] * b1 + D18->R_LI[5] * b2) + D18->t_LI[1];
-            const double q2 = (D18->R_LI[6] * b0 + D18->R_LI[7] * b1 + D18->R_LI[8] * b2) + D18->t_LI[2];
-            pw[0] = (float)((D18->x[0] * q0 + D18->x[1] * q1 + D18->x[2] * q2) + D18->x[9]);
-            pw[1] = (float)((D18->x[3] * q0 + D18->x[4] * q1 + D18->x[5] * q2) + D18->x[10]);
-            pw[2] = (float)((D18->x[6] * q0 + D18->x[7] * q1 + D18->x[8] * q2) + D18->x[11]);
-        } else {
-            double x[FL_X23_LEN], p_i[3];
+    v = fmin(v, dpp_f64<FL_DPP_QUAD_XOR1>(v));
+    return fmin(v, dpp_f64<FL_DPP_QUAD_XOR2>(v));
+}
+__device__ __forceinline__ unsigned quad_sum_u32(unsigned v)
+{
+    v += __builtin_amdgcn_update_dpp(0u, v, FL_DPP_QUAD_XOR1, 0xf, 0xf, false);
+    return v + __builtin_amdgcn_update_dpp(0u, v, FL_DPP_QUAD_XOR2, 0xf, 0xf, false);
+}
+
+// Merge the 4 lanes' sorted local lists into the quad's global best 5 (same in the 4 lanes). Keys are unique
+// per map point, so a round has one winner (or only INF keys are left).
+__device__ __forceinline__ void quad_merge_top5(const FlTop5 &loc, FlTop5 &g)
+{
+    FlTop5 w = loc;
 #pragma unroll
-            for (int k = 0; k < FL_X23_LEN; k++) x[k] = D->x[k];
-            fl_world_point23(x, pb, p_i, pw);
+    for (int k = 0; k < 5; k++) {
+        const double best = quad_min_f64(w.key[0]);
+        const bool win = (w.key[0] == best);
+        g.key[k] = best;
+#pragma unroll
+        for (int p = 0; p < 4; p++) w.key[p] = win ? w.key[p + 1] : w.key[p];
+        w.key[4] = win ? fl_knn_key(INFINITY, FL_KNN_NO_ID) : w.key[4];
+    }
+}
+
+// hash lookup of one cell: returns count (0: empty) and start
+__device__ __forceinline__ unsigned fl_cell_lookup(const FlMapGrid &G, unsigned long long key, uint4 first, unsigned h, unsigned *start)
+{
+    uint4 e = first;
+    while (true) {
+        const unsigned long long hk = ((unsigned long long)e.y << 32) | e.x;
+        if (hk == FL_KNN_EMPTY) return 0u;
+        if (hk == key) { *start = e.z; return e.w; }
+        h = (h + 1) & G.hmask;
+        e = *reinterpret_cast<const uint4 *>(&G.htab[h]);
+    }
+}
+
+// MODE 18: world point from FlDev18 ; MODE 23: from FlDev23. `cond` != 0: run only when the device raised
+// need_search and not stop (the frame drivers enqueue it before every pass).
+//
+// Workgroup = 256 threads = 64 queries, one quad (4 lanes) per query -- 50 k scan points alone are fewer
+// than one wave per SIMD, so a lane-per-query kernel is purely latency bound; 4 lanes per query give
+// 3+ waves per SIMD and short dependent chains. Phase 1a: the quad looks up the 27 cells of rings 0..1
+// (7 independent table loads per lane). Phase 1b: the ~100 candidate points of those cells are split
+// evenly over the 4 lanes (prefix over the cell counts in LDS) -- the cells themselves are very unevenly
+// filled, a plane crosses 9 of the 27. Each lane keeps a sorted local best-5; 5 rounds of a quad DPP
+// min-reduction over (distance, index) keys merge them. Farther rings (sparse regions only) are scanned
+// cell-round-robin. Phase 2: one lane per query gathers the 5 neighbours and fits the plane (K0 fused) on
+// full waves.
+template <int MODE, typename DEV>
+__global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *__restrict__ body, int n, FlMapGrid G, DEV *__restrict__ D,
+                                                                  float4 *__restrict__ plane, uint8_t *__restrict__ sel,
+                                                                  float *__restrict__ nbr_out /* nullable n x 15 */,
+                                                                  uint8_t *__restrict__ valid_out /* nullable */, int cond)
+{
+    if ((cond & 1) && (!D->need_search || D->stop)) return;
+    const bool stamp = (cond & 2) && threadIdx.x == 0 && blockIdx.x < 512;
+    if (stamp) g_fl_wall[blockIdx.x] = (long long)wall_clock64();
+    __shared__ int s_at[FL_KNN_QPB][5];
+    __shared__ float s_d5[FL_KNN_QPB];
+    __shared__ unsigned s_cstart[FL_KNN_QPB][28];
+    __shared__ unsigned s_ccnt[FL_KNN_QPB][28];
+    const int ql = (int)(threadIdx.x >> 2), j = (int)(threadIdx.x & 3u);
+    const int q0 = blockIdx.x * FL_KNN_QPB;
+    const int i = min(q0 + ql, n - 1);                // tail quads repeat the last query (results unused)
+
+    const float pb[3] = {body[i * 3], body[i * 3 + 1], body[i * 3 + 2]};
+    float pw[3];
+    if constexpr (MODE == 18) {
+        const FlDev18 *D18 = D;
+        const double b0 = (double)pb[0], b1 = (double)pb[1], b2 = (double)pb[2];
+        const double u0 = (D18->R_LI[0] * b0 + D18->R_LI[1] * b1 + D18->R_LI[2] * b2) + D18->t_LI[0];
+        const double u1 = (D18->R_LI[3] * b0 + D18->R_LI[4] * b1 + D18->R_LI[5] * b2) + D18->t_LI[1];
+        const double u2 = (D18->R_LI[6] * b0 + D18->R_LI[7] * b1 + D18->R_LI[8] * b2) + D18->t_LI[2];
+        pw[0] = (float)((D18->x[0] * u0 + D18->x[1] * u1 + D18->x[2] * u2) + D18->x[9]);
+        pw[1] = (float)((D18->x[3] * u0 + D18->x[4] * u1 + D18->x[5] * u2) + D18->x[10]);
+        pw[2] = (float)((D18->x[6] * u0 + D18->x[7] * u1 + D18->x[8] * u2) + D18->x[11]);
+    } else {
+        double xs[FL_X23_LEN], p_i[3];
+#pragma unroll
+        for (int k = 0; k < FL_X23_LEN; k++) xs[k] = D->x[k];
+        fl_world_point23(xs, pb, p_i, pw);
+    }
+    const int cx = (int)floorf(pw[0] * G.inv_cell), cy = (int)floorf(pw[1] * G.inv_cell), cz = (int)floorf(pw[2] * G.inv_cell);
+
+    // ---- phase 1a: rings 0..1, cells c = j, j+4, ... < 27 ; c = (dz+1)*9 + (dy+1)*3 + (dx+1)
+    {
+        unsigned long long key[7];
+        unsigned hs[7];
+        uint4 first[7];
+#pragma unroll
+        for (int m = 0; m < 7; m++) {
+            const int c = min(j + 4 * m, 26);
+            key[m] = fl_cell_key(cx + (c % 3) - 1, cy + ((c / 3) % 3) - 1, cz + (c / 9) - 1);
+            hs[m] = fl_hash64(key[m]) & G.hmask;
+            first[m] = *reinterpret_cast<const uint4 *>(&G.htab[hs[m]]);
         }
-        const int cx = (int)floorf(pw[0] * G.inv_cell), cy = (int)floorf(pw[1] * G.inv_cell), cz = (int)floorf(pw[2] * G.inv_cell);
-        FlTop5 t;
+        // compact the occupied cells (a plane crosses ~9 of the 27) into the quad's LDS list, in cell order:
+        // rank = occupied cells of the earlier rows m + occupied cells of the lower lanes in this row
+        unsigned mysum = 0;
+        int nocc = 0;
+        const int quad_shift = (int)(threadIdx.x & 60u);
 #pragma unroll
-        for (int k = 0; k < 5; k++) { t.d[k] = INFINITY; t.id[k] = 0x7fffffff; t.at[k] = -1; }
-        for (int r = 0; r <= G.max_ring; r++) {
-            for (int dz = -r; dz <= r; dz++)
-                for (int dy = -r; dy <= r; dy++) {
-                    const bool face = (dz == -r || dz == r || dy == -r || dy == r);
-                    if (face) {
-                        for (int dx = -r; dx <= r; dx++) fl_scan_cell(G, cx + dx, cy + dy, cz + dz, pw[0], pw[1], pw[2], t);
-                    } else {            // only the two x-faces of the shell
-                        fl_scan_cell(G, cx - r, cy + dy, cz + dz, pw[0], pw[1], pw[2], t);
-                        fl_scan_cell(G, cx + r, cy + dy, cz + dz, pw[0], pw[1], pw[2], t);
-                    }
-                }
-            // 1 mm safety margin: cell boundaries are evaluated in float (floorf(x * inv_cell)), exact to
-            // well under a millimetre for maps of several kilometres
-            const float reach = (float)r * G.cell - 1e-3f;
-            if (reach > 0.f && t.d[4] <= reach * reach) break;
+        for (int m = 0; m < 7; m++) {
+            unsigned st = 0;
+            unsigned cn = fl_cell_lookup(G, key[m], first[m], hs[m], &st);
+            if (j + 4 * m >= 27) cn = 0;
+            const unsigned bits = (unsigned)(__ballot(cn != 0u) >> quad_shift) & 0xFu;
+            const int r = nocc + __popc(bits & ((1u << j) - 1u));
+            if (cn != 0u) { s_cstart[ql][r] = st; s_ccnt[ql][r] = cn; }
+            nocc += __popc(bits);
+            mysum += cn;
         }
-        const int found5 = t.at[4] >= 0;
-        const int valid = found5 && !(t.d[4] > 5.0f);
-        float nb[15];
+        if (j == 0) s_ccnt[ql][nocc] = 0x40000000u;      // terminator: the walk never advances past it
+        const unsigned T = quad_sum_u32(mysum);
+        __syncthreads();
+        if (stamp) g_fl_wall[512 + blockIdx.x] = (long long)wall_clock64();
+        // ---- phase 1b: the T candidates of the concatenated cell ranges are split evenly over the 4 lanes, lane j
+        // takes [j*T/4, (j+1)*T/4) -- balanced however unevenly the cells are filled. One flat loop over the
+        // candidates (the 16 queries of a wave have their points in different cells: a loop over cells would run
+        // every cell's longest range for the whole wave); every listed cell holds >= 1 point, so stepping to the
+        // next candidate crosses at most one cell boundary (branch-free). Loads are issued FL_KNN_BATCH at a time.
+        const unsigned seg_b = (T * (unsigned)j) >> 2, seg_e = (T * (unsigned)(j + 1)) >> 2;
+        FlTop5 t, g;
+        fl_top5_clear(t);
+        int c = 0;
+        unsigned cell_end = s_ccnt[ql][0], base = s_cstart[ql][0];
+        while (seg_b >= cell_end) {                      // position on the cell of the first candidate
+            c++;
+            base = s_cstart[ql][c] - cell_end;
+            cell_end += s_ccnt[ql][c];
+        }
+        for (unsigned k0 = seg_b; k0 < seg_e; k0 += FL_KNN_BATCH) {
+            unsigned pos[FL_KNN_BATCH];
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            if (t.at[k] >= 0) {
-                const float4 p = G.pts[t.at[k]];
-                nb[k * 3] = p.x; nb[k * 3 + 1] = p.y; nb[k * 3 + 2] = p.z;
-            } else {
-                nb[k * 3] = 0.f; nb[k * 3 + 1] = 0.f; nb[k * 3 + 2] = 0.f;
+            for (int u = 0; u < FL_KNN_BATCH; u++) {
+                const unsigned k = min(k0 + (unsigned)u, seg_e - 1u);
+                const bool adv = k >= cell_end;
+                c += adv ? 1 : 0;
+                const unsigned nst = s_cstart[ql][c], ncn = s_ccnt[ql][c];
+                base = adv ? nst - cell_end : base;
+                cell_end = adv ? cell_end + ncn : cell_end;
+                pos[u] = base + k;
+            }
+            float4 p[FL_KNN_BATCH];
+#pragma unroll
+            for (int u = 0; u < FL_KNN_BATCH; u++) p[u] = G.pts[pos[u]];
+#pragma unroll
+            for (int u = 0; u < FL_KNN_BATCH; u++) {
+                const bool live = k0 + (unsigned)u < seg_e;      // the tail of a batch repeats the last candidate: never inserted
+                const float dx = pw[0] - p[u].x, dy = pw[1] - p[u].y, dz = pw[2] - p[u].z;
+                const float d = dx * dx + dy * dy + dz * dz;        // ikd_Tree.cpp:1293 (no contraction)
+                fl_top5_insert(t, fl_knn_key(live ? d : INFINITY, live ? __float_as_int(p[u].w) : FL_KNN_NO_ID));
             }
         }
-        float pl[4];
-        const int ok = fl_esti_plane(nb, pl);
-        plane[i] = make_float4(pl[0], pl[1], pl[2], pl[3]);
-        sel[i] = (uint8_t)(valid && ok);
-        if (nbr_out) {
-#pragma unroll
-            for (int k = 0; k < 15; k++) nbr_out[(size_t)i * 15 + k] = nb[k];
+        quad_merge_top5(t, g);
+        // 1 mm safety margin: cell boundaries are evaluated in float (floorf(x * inv_cell)), exact to
+        // well under a millimetre for maps of several kilometres
+        float reach = G.cell - 1e-3f;
+        if (!(fl_knn_key_d(g.key[4]) <= reach * reach)) {
+            for (int r = 2; r <= G.max_ring; r++) {
+                const int s = 2 * r + 1, s3 = s * s * s;
+                for (int c = j; c < s3; c += 4) {
+                    const int dz = c / (s * s) - r, rem = c % (s * s), dy = rem / s - r, dx = rem % s - r;
+                    if (max(max(abs(dx), abs(dy)), abs(dz)) < r) continue;      // visited by the previous rings
+                    fl_scan_cell(G, cx + dx, cy + dy, cz + dz, pw[0], pw[1], pw[2], t);
+                }
+                quad_merge_top5(t, g);
+                reach = (float)r * G.cell - 1e-3f;
+                if (fl_knn_key_d(g.key[4]) <= reach * reach) break;
+            }
         }
-        if (valid_out) valid_out[i] = (uint8_t)valid;
+        if (j == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) s_at[ql][k] = fl_knn_key_id(g.key[k]);
+            s_d5[ql] = fl_knn_key_d(g.key[4]);
+        }
     }
-    // the search pass is done: nearest_search_en = false for the passes that follow. All threads of the
-    // grid read need_search before anyone clears it only if the clear happens in a later launch, so the
-    // flag is cleared by a separate tiny kernel (knn_clear_flag_kernel) enqueued right after this one.
-}
+    __syncthreads();
+    if (stamp) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();
 
-template <typename DEV>
-__global__ void knn_clear_flag_kernel(DEV *__restrict__ D, int cond)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (cond && (!D->need_search || D->stop)) return;
-    D->need_search = 0;
+    // "the search for pass iters_run has been made": the pass kernels run when need_search is down or
+    // searched_at == iters_run. No workgroup of this kernel reads searched_at, so one of them may write it.
+    if (blockIdx.x == 0 && threadIdx.x == 0) D->searched_at = D->iters_run;
+    const int qf = (int)threadIdx.x;
+    const int iq = q0 + qf;
+    if (qf >= FL_KNN_QPB || iq >= n) return;
+    const int found5 = s_at[qf][4] != FL_KNN_NO_ID;
+    const int valid = found5 && !(s_d5[qf] > 5.0f);
+    float nb[15];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int id = s_at[qf][k];                    // original map index of the k-th neighbour
+        if (id != FL_KNN_NO_ID) {
+            nb[k * 3] = G.raw[(size_t)id * 3]; nb[k * 3 + 1] = G.raw[(size_t)id * 3 + 1]; nb[k * 3 + 2] = G.raw[(size_t)id * 3 + 2];
+        } else {
+            nb[k * 3] = 0.f; nb[k * 3 + 1] = 0.f; nb[k * 3 + 2] = 0.f;
+        }
+    }
+    float pl[4];
+    const int ok = fl_esti_plane(nb, pl);
+    plane[iq] = make_float4(pl[0], pl[1], pl[2], pl[3]);
+    sel[iq] = (uint8_t)(valid && ok);
+    if (nbr_out) {
+#pragma unroll
+        for (int k = 0; k < 15; k++) nbr_out[(size_t)iq * 15 + k] = nb[k];
+    }
+    if (valid_out) valid_out[iq] = (uint8_t)valid;
+    if (stamp) g_fl_wall[1536 + blockIdx.x] = (long long)wall_clock64();
 }

@@ -48,15 +48,44 @@ __global__ __launch_bounds__(FL_BLOCK) void lio_fit_planes_kernel(const float *_
     sel[i] = (uint8_t)((valid[i] != 0) && ok);
 }
 
-// Per-frame prepare: Q and T of fl_math.h (depends on P and the measurement covariance only).
-__global__ void eskf18_prepare_kernel(FlDev18 *__restrict__ D)
+// Per-frame prepare: Q and T of fl_math.h (depends on P and the measurement covariance only). One workgroup of
+// 128 threads; the arithmetic per output element is fl_prepare18's (threads 0..5 each eliminate one column of the
+// 6x6 inverse -- the pivoting depends on the matrix only, so a column solved alone is bit-identical to the same
+// column solved with the others; threads 0..107 each form one element of T).
+__global__ __launch_bounds__(128) void eskf18_prepare_kernel(FlDev18 *__restrict__ D)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double Q[36], T[108];
-    const int st = fl_prepare18(D->P, D->meas_cov, Q, T);
-    for (int i = 0; i < 36; i++) D->Q[i] = Q[i];
-    for (int i = 0; i < 108; i++) D->T[i] = T[i];
-    D->status = st;
+    __shared__ double s_B[36], s_Q[36];
+    __shared__ int s_st[6];
+    const int t = (int)threadIdx.x;
+    const double meas_cov = D->meas_cov;
+    if (t < 6) {
+        double M[6][6], B[6][1];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) M[i][j] = 0.5 * (D->P[i * 18 + j] + D->P[j * 18 + i]) / meas_cov;   // symmetrised A66
+            B[i][0] = (i == t) ? 1.0 : 0.0;
+        }
+        s_st[t] = fl_gauss_solve<6, 1>(M, B);
+#pragma unroll
+        for (int i = 0; i < 6; i++) s_B[i * 6 + t] = B[i][0];
+    }
+    __syncthreads();
+    if (t < 36) {
+        const int i = t / 6, j = t % 6;
+        const double q = 0.5 * (s_B[i * 6 + j] + s_B[j * 6 + i]);
+        s_Q[t] = q;
+        D->Q[t] = q;
+    }
+    __syncthreads();
+    if (t < 108) {
+        const int r = t / 6, c = t % 6;
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += (D->P[r * 18 + k] / meas_cov) * s_Q[k * 6 + c];
+        D->T[t] = s;
+    }
+    if (t == 0) D->status = s_st[0] | s_st[1] | s_st[2] | s_st[3] | s_st[4] | s_st[5];
 }
 
 // -------------------------------------------------------------------------------------------- K1
@@ -86,7 +115,7 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_pass_kernel(const float *__re
     }
     double pf_solver = 0.0;
     if (MODE == 0 && blockIdx.x == nprod) pf_solver = eskf18_prefetch_issue(D);
-    if (!(flags & FL_ITER_FORCE) && (D->stop || D->need_search)) return;
+    if (!(flags & FL_ITER_FORCE) && (D->stop || (D->need_search && D->searched_at != D->iters_run))) return;
     const unsigned epoch = *epoch_ptr;
 
     if (blockIdx.x == nprod) {
@@ -164,7 +193,7 @@ __device__ __forceinline__ void vio_derive_pose(const double *xn, const FlVioCon
 __global__ __launch_bounds__(FL_BLOCK) void eskf18_solve_kernel(FlDev18 *__restrict__ D, const double *__restrict__ sums_in,
                                                                int vio, int flags, const FlVioConst *__restrict__ VC)
 {
-    if (!(flags & FL_ITER_FORCE) && (D->stop || (!vio && D->need_search))) return;
+    if (!(flags & FL_ITER_FORCE) && (D->stop || (!vio && D->need_search && D->searched_at != D->iters_run))) return;
     __shared__ double s_sums[FL_SUMS18];
     __shared__ FlSolveLds s_solve;
     if (threadIdx.x < FL_SUMS18) s_sums[threadIdx.x] = sums_in[threadIdx.x];
