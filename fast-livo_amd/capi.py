@@ -91,6 +91,9 @@ SYMBOLS = {
     "fl_last_error_string": (C.c_char_p, [_H]),
     "fl_set_stream": (C.c_int32, [_H, C.c_void_p]),
     "fl_sync": (C.c_int32, [_H]),
+    "fl_host_alloc": (C.c_int32, [_H, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "fl_host_free": (C.c_int32, [_H, C.c_void_p]),
+    "fl_debug_get_wall": (C.c_int32, [_H, C.POINTER(C.c_longlong)]),
     "fl_set_timing": (C.c_int32, [_H, C.c_int32]),
     "fl_get_last_kernel_ms": (C.c_int32, [_H, _fp]),
     "fl_debug_get_stamps": (C.c_int32, [_H, C.POINTER(C.c_longlong)]),
@@ -232,6 +235,22 @@ class Handle:
 
     def sync(self):
         self._chk(self.L.fl_sync(self.h), "fl_sync")
+
+    def host_alloc(self, shape, dtype=np.float32):
+        """numpy view of page-locked host memory owned by the library (free with host_free)."""
+        dt = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dt.itemsize
+        p = C.c_void_p()
+        self._chk(self.L.fl_host_alloc(self.h, nbytes, C.byref(p)), "fl_host_alloc")
+        buf = (C.c_char * nbytes).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dt).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr):
+        p = self._pinned.pop(arr.ctypes.data)
+        self._chk(self.L.fl_host_free(self.h, C.c_void_p(p)), "fl_host_free")
 
     def set_timing(self, on):
         self._chk(self.L.fl_set_timing(self.h, 1 if on else 0), "fl_set_timing")

@@ -206,6 +206,21 @@ int32_t fl_sync(fl_handle h)
     return FL_OK;
 }
 
+int32_t fl_host_alloc(fl_handle h, size_t bytes, void **out)
+{
+    if (!h || !out || bytes == 0) return fail_arg(h, "fl_host_alloc: bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return FL_OK;
+}
+
+int32_t fl_host_free(fl_handle h, void *p)
+{
+    if (!h) return fail_arg(nullptr, "null handle");
+    if (p) HIPCHK(h, hipHostFree(p));
+    return FL_OK;
+}
+
 int32_t fl_set_timing(fl_handle h, int32_t enable)
 {
     if (!h) return fail_arg(nullptr, "null handle");

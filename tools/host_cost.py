@@ -28,4 +28,9 @@ keep = capi.state18_from_frame(fr)
 def frame2():
     C.memmove(C.byref(xg), C.byref(keep), C.sizeof(xg)); return h.lio_frame18_dev(xg, fr.body_xyz)
 res["frame18_dev_ctypes_only_us"] = med(frame2)
+pin = h.host_alloc(fr.body_xyz.shape, np.float32); pin[:] = fr.body_xyz
+res["set_points_pinned+sync_us"] = med(lambda: (h.lio_set_points(pin), h.sync()))
+def frame3():
+    C.memmove(C.byref(xg), C.byref(keep), C.sizeof(xg)); return h.lio_frame18_dev(xg, pin)
+res["frame18_dev_pinned_us"] = med(frame3)
 print(json.dumps(res))
