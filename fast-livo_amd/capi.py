@@ -91,6 +91,8 @@ SYMBOLS = {
     "fl_last_error_string": (C.c_char_p, [_H]),
     "fl_set_stream": (C.c_int32, [_H, C.c_void_p]),
     "fl_sync": (C.c_int32, [_H]),
+    "fl_scan_voxel_filter": (C.c_int32, [_H, _fp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32, _fp, C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32)]),
     "fl_host_alloc": (C.c_int32, [_H, C.c_size_t, C.POINTER(C.c_void_p)]),
     "fl_host_free": (C.c_int32, [_H, C.c_void_p]),
     "fl_debug_get_wall": (C.c_int32, [_H, C.POINTER(C.c_longlong)]),
@@ -235,6 +237,17 @@ class Handle:
 
     def sync(self):
         self._chk(self.L.fl_sync(self.h), "fl_sync")
+
+    def scan_voxel_filter(self, xyzi, leaf, stage_as_scan=False, want=True):
+        """pcl::VoxelGrid on the device. Returns (centroids (m,4) or None, m, leaf_too_small)."""
+        xyzi = np.ascontiguousarray(xyzi, np.float32)
+        n = xyzi.shape[0]
+        leaf = (leaf, leaf, leaf) if np.isscalar(leaf) else tuple(leaf)
+        out = np.empty((n, 4), np.float32) if want else None
+        m = C.c_int32(0); small = C.c_int32(0)
+        self._chk(self.L.fl_scan_voxel_filter(self.h, xyzi.ctypes.data_as(_fp), n, leaf[0], leaf[1], leaf[2], 1 if stage_as_scan else 0,
+                                              out.ctypes.data_as(_fp) if want else None, C.byref(m), C.byref(small)), "fl_scan_voxel_filter")
+        return (out[:m.value].copy() if want else None), m.value, bool(small.value)
 
     def host_alloc(self, shape, dtype=np.float32):
         """numpy view of page-locked host memory owned by the library (free with host_free)."""
@@ -509,8 +522,12 @@ def _knn_methods():
         return nbr, valid
 
     def lio_frame18_dev(self, state, body):
-        body = np.ascontiguousarray(body, dtype=np.float32)
+        """body None: use the scan already staged on the device (lio_set_points / scan_voxel_filter)."""
         info = IterInfo()
+        if body is None:
+            self._chk(self.L.fl_lio_frame18_dev(self.h, C.byref(state), None, 0, C.byref(info)), "fl_lio_frame18_dev")
+            return info
+        body = np.ascontiguousarray(body, dtype=np.float32)
         self._chk(self.L.fl_lio_frame18_dev(self.h, C.byref(state), _p(body, C.c_float), body.shape[0], C.byref(info)),
                   "fl_lio_frame18_dev")
         return info

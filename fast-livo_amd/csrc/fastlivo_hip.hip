@@ -9,6 +9,7 @@
 #include "vio_kernels.h"
 #include "ikfom_kernels.h"
 #include "knn_kernels.h"
+#include "voxel_kernels.h"
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -62,6 +63,14 @@ struct fl_context {
     int map_cap = 0, map_n = 0, map_max_ring = 0;
     unsigned map_hcap = 0;
     float map_cell = 0.f;
+    // scan voxel filter (voxel_kernels.h)
+    float4 *d_vox_in = nullptr, *d_vox_out = nullptr;
+    unsigned *d_vox_keys = nullptr, *d_vox_keys_s = nullptr, *d_vox_vals = nullptr, *d_vox_vals_s = nullptr;
+    unsigned *d_vox_heads = nullptr, *d_vox_slot = nullptr;
+    FlVoxCtl *d_vox_ctl = nullptr;
+    void *d_vox_tmp = nullptr;
+    size_t vox_tmp_bytes = 0;
+    int vox_cap = 0;
     // misc
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
@@ -169,6 +178,8 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
     return FL_OK;
 }
 
+static void vox_free(fl_handle h);
+
 int32_t fl_destroy(fl_handle h)
 {
     if (!h) return FL_OK;
@@ -180,6 +191,7 @@ int32_t fl_destroy(fl_handle h)
     hipFree(h->d_errors); hipFree(h->d_pos); hipFree(h->d_slevel);
     hipFree(h->d_map_raw); hipFree(h->d_map_pts); hipFree(h->d_map_keys); hipFree(h->d_map_keys_tmp); hipFree(h->d_map_idx);
     hipFree(h->d_map_idx_tmp); hipFree(h->d_map_htab); hipFree(h->d_map_sort_tmp);
+    vox_free(h);
     if (h->h_dev) hipHostFree(h->h_dev);
     if (h->h_dev23) hipHostFree(h->h_dev23);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -533,5 +545,6 @@ int32_t fl_debug_get_wall(fl_handle h, long long *out2048)
 #include "api_vio.inc"
 #include "api_ikfom.inc"
 #include "api_knn.inc"
+#include "api_voxel.inc"
 
 }  // extern "C"

@@ -241,10 +241,24 @@ int32_t fl_map_set_points(fl_handle h, const float *map_xyz, int32_t k, float ce
 int32_t fl_lio_search18(fl_handle h, float *nbr_xyz_out, uint8_t *valid_out);
 int32_t fl_ikfom_search(fl_handle h, float *nbr_xyz_out, uint8_t *valid_out);
 /* fl_lio_frame18 / fl_ikfom_update_iterated with the search on the device: the whole frame is enqueued
- * at once ([search-if-asked, pass] x (max_iterations + 1)), one host synchronisation per frame. */
+ * at once ([search-if-asked, pass] x (max_iterations + 1)), one host synchronisation per frame.
+ * body_xyz == NULL: use the scan already staged on the device (fl_lio_set_points / fl_scan_voxel_filter). */
 int32_t fl_lio_frame18_dev(fl_handle h, fl_state18 *state_io, const float *body_xyz, int32_t n, fl_iter_info *info);
 int32_t fl_ikfom_update_iterated_dev(fl_handle h, fl_state23 *x_io, double *P_io, const float *body_xyz, int32_t n, double R,
                                      const double *limit, fl_iter_info *info);
+
+/* ------------------------------------------------------------------------------------------------
+ * Scan voxel down-sampling on the device: pcl::VoxelGrid<PointType>::filter as called at
+ * src/laserMapping.cpp:1398-1399 (downSizeFilterSurf, leaf = filter_size_surf, :1186) and
+ * src/lidar_selection.cpp:352-353 (leaf 0.2, :7). xyzi: n x 4 floats (x, y, z, intensity). One output point per
+ * occupied voxel, in ascending voxel index (PCL's output order): the centroid of its points, summed in float in
+ * ascending input index (PCL's std::sort leaves that order unspecified) and divided by the count.
+ * stage_as_scan != 0: the centroids become the staged scan of this handle, exactly as if fl_lio_set_points had been
+ * called with them (feats_down_body never visits the host). out_xyzi (nullable) has room for n points.
+ * leaf_too_small (nullable) reports PCL's "Leaf size is too small for the input dataset" case (output = input).
+ * ---------------------------------------------------------------------------------------------- */
+int32_t fl_scan_voxel_filter(fl_handle h, const float *xyzi, int32_t n, float leaf_x, float leaf_y, float leaf_z,
+                             int32_t stage_as_scan, float *out_xyzi, int32_t *out_n, int32_t *leaf_too_small);
 
 #ifdef __cplusplus
 }

@@ -76,6 +76,11 @@ int orc_lio18_frame(orc_state18 *x, const float *body_xyz, int n, const double *
 int orc_knn5(const float *map_xyz, int k, const float *query_xyz, int n, float *nbr_xyz, float *sqdist, uint8_t *valid,
              int32_t *nbr_idx, int nthreads);
 
+/* pcl::VoxelGrid::applyFilter as used at laserMapping.cpp:1398-1399 / lidar_selection.cpp:352-353 (orc_voxel.c).
+ * xyzi: n x 4 floats (x, y, z, intensity); out_xyzi has room for n points; centroids in ascending voxel index. */
+int orc_voxel_grid(const float *xyzi, int n, float leaf_x, float leaf_y, float leaf_z, float *out_xyzi, int32_t *out_n,
+                   int32_t *leaf_too_small);
+
 /* ---------------------------------------------------------------- VIO (lidar_selection.cpp) */
 typedef struct orc_vio_config {
     double Rcl[9], Pcl[3];    /* camera <- lidar extrinsic (avia.yaml:42-45)            */

@@ -268,3 +268,21 @@ def knn5_bruteforce(map_xyz, query_xyz, nthreads=8):
     lib().orc_knn5(_p(map_xyz, C.c_float), map_xyz.shape[0], _p(q, C.c_float), n, _p(nbr, C.c_float), _p(sq, C.c_float),
                    _p(valid, C.c_uint8), _p(idx, C.c_int32), nthreads)
     return nbr, sq, valid, idx
+
+
+def voxel_grid(xyzi, leaf):
+    """pcl::VoxelGrid restatement (oracle/orc_voxel.c): returns (centroids (m,4) float32, leaf_too_small)."""
+    xyzi = np.ascontiguousarray(xyzi, dtype=np.float32)
+    n = xyzi.shape[0]
+    leaf = (leaf, leaf, leaf) if np.isscalar(leaf) else tuple(leaf)
+    out = np.zeros((max(n, 1), 4), dtype=np.float32)
+    m = C.c_int32(0)
+    small = C.c_int32(0)
+    L = lib()
+    L.orc_voxel_grid.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float),
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.orc_voxel_grid.restype = C.c_int
+    rc = L.orc_voxel_grid(_p(xyzi, C.c_float), n, leaf[0], leaf[1], leaf[2], _p(out, C.c_float), C.byref(m), C.byref(small))
+    if rc != 0:
+        raise RuntimeError("orc_voxel_grid failed")
+    return out[:m.value].copy(), bool(small.value)
