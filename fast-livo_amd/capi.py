@@ -79,6 +79,43 @@ class IterInfo(C.Structure):
                 ("need_search", C.c_int32), ("stop", C.c_int32), ("accepted", C.c_int32), ("reserved", C.c_int32)]
 
 
+class ImuSample(C.Structure):
+    _fields_ = [("t", C.c_double), ("gyr", C.c_double * 3), ("acc", C.c_double * 3)]
+
+
+class Pose6d(C.Structure):
+    _fields_ = [("offset_time", C.c_double), ("acc", C.c_double * 3), ("gyr", C.c_double * 3), ("vel", C.c_double * 3),
+                ("pos", C.c_double * 3), ("rot", C.c_double * 9)]
+
+
+class ImuProc(C.Structure):
+    """ImuProcess members used by UndistortPcl (IMU_Processing.cpp:611-809)."""
+    _fields_ = [("cov_gyr", C.c_double * 3), ("cov_acc", C.c_double * 3), ("cov_bias_gyr", C.c_double * 3),
+                ("cov_bias_acc", C.c_double * 3), ("mean_acc", C.c_double * 3), ("Lid_rot_to_IMU", C.c_double * 9),
+                ("Lid_offset_to_IMU", C.c_double * 3), ("acc_s_last", C.c_double * 3), ("angvel_last", C.c_double * 3),
+                ("last_imu", ImuSample), ("last_lidar_end_time", C.c_double)]
+
+
+def imu_proc_from_frame(f):
+    """f: synth.ImuFrame"""
+    p = ImuProc()
+    p.cov_gyr[:] = f.cov_gyr; p.cov_acc[:] = f.cov_acc; p.cov_bias_gyr[:] = f.cov_bias_gyr; p.cov_bias_acc[:] = f.cov_bias_acc
+    p.mean_acc[:] = f.mean_acc
+    p.Lid_rot_to_IMU[:] = np.asarray(f.R_LI, np.float64).reshape(9); p.Lid_offset_to_IMU[:] = f.t_LI
+    p.acc_s_last[:] = f.acc_s_last; p.angvel_last[:] = f.angvel_last
+    p.last_imu.t = f.last_imu[0]; p.last_imu.gyr[:] = f.last_imu[1:4]; p.last_imu.acc[:] = f.last_imu[4:7]
+    p.last_lidar_end_time = f.last_lidar_end_time
+    return p
+
+
+def imu_samples(arr):
+    """(k,7) array [t, gyr xyz, acc xyz] -> ctypes array of ImuSample"""
+    arr = np.ascontiguousarray(arr, np.float64)
+    out = (ImuSample * arr.shape[0])()
+    C.memmove(out, arr.ctypes.data, arr.nbytes)
+    return out
+
+
 KNN_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_uint8))
 
 _dp, _fp, _u8p, _i32p = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
@@ -93,6 +130,8 @@ SYMBOLS = {
     "fl_sync": (C.c_int32, [_H]),
     "fl_scan_voxel_filter": (C.c_int32, [_H, _fp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32, _fp, C.POINTER(C.c_int32),
                                          C.POINTER(C.c_int32)]),
+    "fl_imu_undistort": (C.c_int32, [_H, C.POINTER(ImuProc), C.POINTER(State18), C.POINTER(ImuSample), C.c_int32, C.c_double, C.c_double,
+                                     _fp, C.c_int32, _fp, C.POINTER(Pose6d), C.POINTER(C.c_int32)]),
     "fl_host_alloc": (C.c_int32, [_H, C.c_size_t, C.POINTER(C.c_void_p)]),
     "fl_host_free": (C.c_int32, [_H, C.c_void_p]),
     "fl_debug_get_wall": (C.c_int32, [_H, C.POINTER(C.c_longlong)]),
@@ -248,6 +287,28 @@ class Handle:
         self._chk(self.L.fl_scan_voxel_filter(self.h, xyzi.ctypes.data_as(_fp), n, leaf[0], leaf[1], leaf[2], 1 if stage_as_scan else 0,
                                               out.ctypes.data_as(_fp) if want else None, C.byref(m), C.byref(small)), "fl_scan_voxel_filter")
         return (out[:m.value].copy() if want else None), m.value, bool(small.value)
+
+    def imu_undistort(self, proc, state, imu, pcl_beg_time, pcl_end_time, pts_xyzt, want=True):
+        """ImuProcess::UndistortPcl on the device. imu: (k,7) array or ImuSample array. Returns (cloud (n,4) or None, poses list)."""
+        samples = imu if not isinstance(imu, np.ndarray) else imu_samples(imu)
+        k = len(samples)
+        pts = np.ascontiguousarray(pts_xyzt, np.float32)
+        n = pts.shape[0]
+        out = np.empty((n, 4), np.float32) if want else None
+        poses = (Pose6d * (k + 1))()
+        npz = C.c_int32(0)
+        self._chk(self.L.fl_imu_undistort(self.h, C.byref(proc), C.byref(state), samples, k, pcl_beg_time, pcl_end_time,
+                                          pts.ctypes.data_as(_fp) if n else None, n, out.ctypes.data_as(_fp) if (want and n) else None,
+                                          poses, C.byref(npz)), "fl_imu_undistort")
+        return out, [poses[i] for i in range(npz.value)]
+
+    def scan_voxel_filter_resident(self, n, leaf, stage_as_scan=True):
+        """VoxelGrid of the n-point cloud fl_imu_undistort left on the device; result staged as the scan."""
+        leaf = (leaf, leaf, leaf) if np.isscalar(leaf) else tuple(leaf)
+        m = C.c_int32(0); small = C.c_int32(0)
+        self._chk(self.L.fl_scan_voxel_filter(self.h, None, n, leaf[0], leaf[1], leaf[2], 1 if stage_as_scan else 0, None, C.byref(m),
+                                              C.byref(small)), "fl_scan_voxel_filter")
+        return None, m.value, bool(small.value)
 
     def host_alloc(self, shape, dtype=np.float32):
         """numpy view of page-locked host memory owned by the library (free with host_free)."""

@@ -10,6 +10,7 @@
 #include "ikfom_kernels.h"
 #include "knn_kernels.h"
 #include "voxel_kernels.h"
+#include "imu_kernels.h"
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -71,6 +72,13 @@ struct fl_context {
     void *d_vox_tmp = nullptr;
     size_t vox_tmp_bytes = 0;
     int vox_cap = 0;
+    int vox_resident = 0;          // points left in d_vox_in by fl_imu_undistort
+    // IMU propagation / undistortion (imu_kernels.h)
+    FlImuDev *d_imu = nullptr, *h_imu = nullptr;
+    FlImuSample *d_imu_samples = nullptr;
+    FlPose6 *d_imu_poses = nullptr;
+    int *d_imu_head = nullptr, *d_imu_blockmin = nullptr;
+    int imu_cap_samples = 0, imu_cap_points = 0;
     // misc
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
@@ -179,6 +187,7 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
 }
 
 static void vox_free(fl_handle h);
+static void imu_free(fl_handle h);
 
 int32_t fl_destroy(fl_handle h)
 {
@@ -192,6 +201,7 @@ int32_t fl_destroy(fl_handle h)
     hipFree(h->d_map_raw); hipFree(h->d_map_pts); hipFree(h->d_map_keys); hipFree(h->d_map_keys_tmp); hipFree(h->d_map_idx);
     hipFree(h->d_map_idx_tmp); hipFree(h->d_map_htab); hipFree(h->d_map_sort_tmp);
     vox_free(h);
+    imu_free(h);
     if (h->h_dev) hipHostFree(h->h_dev);
     if (h->h_dev23) hipHostFree(h->h_dev23);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -546,5 +556,6 @@ int32_t fl_debug_get_wall(fl_handle h, long long *out2048)
 #include "api_ikfom.inc"
 #include "api_knn.inc"
 #include "api_voxel.inc"
+#include "api_imu.inc"
 
 }  // extern "C"

@@ -1,0 +1,340 @@
+// imu_kernels.h -- SURVEY.md section 8(f) row N4: ImuProcess::UndistortPcl (src/IMU_Processing.cpp:611-809) on the device.
+//
+//  imu_forward_kernel      one workgroup: forward propagation of state and 18x18 covariance over the IMU samples
+//                          (:656-741: F_x, cov_w, cov = F cov F^T + cov_w -- dense 18-term dot products in the order of
+//                          the oracle, one covariance element per lane), the IMUpose list, the frame-end prediction
+//                          (:743-759) and the extrinsic products (:764-765).
+//  undistort_heads_kernel  per point: the latest IMU interval (head >= 1) that starts before the point's time
+//  undistort_scan_kernel   suffix minimum of those heads over the cloud = the interval the reference's backward
+//                          double loop (:778-808) is in when it reaches the point. The loop walks the cloud from the
+//                          last point and only ever moves to EARLIER intervals, so for an unsorted cloud a point can be
+//                          handled by an earlier interval than its own time asks for; the suffix minimum reproduces
+//                          that exactly. It also ends for good at the first point (from the back) that is not later
+//                          than IMUpose[0] (offset 0): every point before it stays uncompensated (`term`).
+//  undistort_apply_kernel  per point compensation (:792-800) in double, stored as float. Point 0 is special: after
+//                          compensating it the reference breaks the inner loop WITHOUT stepping back (:803), so each
+//                          earlier interval compensates it again from its already-rewritten coordinates; replicated.
+#pragma once
+
+#include "fl_device.h"
+
+struct FlImuSample { double t, gyr[3], acc[3]; };
+struct FlPose6 { double offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]; };
+
+struct FlImuDev {
+    // in/out state (StatesGroup)
+    double rot[9], pos[3], vel[3], bg[3], ba[3], grav[3];
+    double P[324];
+    // ImuProcess members
+    double cov_gyr[3], cov_acc[3], cov_bias_gyr[3], cov_bias_acc[3];
+    double mean_acc_norm;
+    double R_LI[9], t_LI[3];           // Lid_rot_to_IMU, Lid_offset_to_IMU
+    double acc_s_last[3], angvel_last[3];
+    double last_lidar_end_time, pcl_beg_time, pcl_end_time;
+    // products for the backward pass
+    double extR_Ri[9], exrR_extT[3];
+    int32_t n_poses;
+    int32_t term;                      // highest point index the backward loop does not reach (-1: none)
+};
+
+__device__ __forceinline__ void fl_m3_mul(const double *A, const double *B, double *C)
+{
+    double T[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) T[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; i++) C[i] = T[i];
+}
+__device__ __forceinline__ void fl_m3_mv(const double *A, const double *x, double *o)
+{
+    double t[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) t[i] = A[i * 3] * x[0] + A[i * 3 + 1] * x[1] + A[i * 3 + 2] * x[2];
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
+}
+// include/so3_math.h:31-52, Exp(ang_vel, dt)
+__device__ __forceinline__ void fl_so3_exp_dt(const double *w, double dt, double *R)
+{
+    const double n = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    if (n > 0.0000001) {
+        const double a[3] = {w[0] / n, w[1] / n, w[2] / n};
+        const double K[9] = {0.0, -a[2], a[1], a[2], 0.0, -a[0], -a[1], a[0], 0.0};
+        const double ang = n * dt;
+        const double s = sin(ang), c1 = 1.0 - cos(ang);
+        double cK[9], cKK[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) cK[i] = c1 * K[i];
+        fl_m3_mul(cK, K, cKK);
+#pragma unroll
+        for (int i = 0; i < 9; i++) R[i] = (R[i] + s * K[i]) + cKK[i];
+    }
+}
+
+#define FL_IMU_NT 384
+// element (i, j) of F_x (:700-709) and cov_w (:701, :711-714) from the step's 3x3 pieces
+struct FlImuStep {
+    double Exp_m[9], RAdt[9], Rdt[9], Cacc[9];   // Exp(w,-dt), R*[a]x*dt, R*dt, R diag(cov_acc) R^T dt^2
+    double dt, dt2;
+};
+__device__ __forceinline__ void fl_imu_FC(const FlImuStep &S, const double *cg, const double *cbg, const double *cba, int i, int j, double &F,
+                                          double &C)
+{
+    const int bi = i / 3, bj = j / 3, r = i % 3, c = j % 3;
+    const double eye = (r == c) ? 1.0 : 0.0;
+    F = (i == j) ? 1.0 : 0.0;
+    C = 0.0;
+    if (bi == 0) {
+        if (bj == 0) { F = S.Exp_m[r * 3 + c]; C = (r == c) ? cg[r] * S.dt * S.dt : 0.0; }
+        else if (bj == 3) F = (r == c) ? -S.dt : 0.0;
+    } else if (bi == 1) {
+        if (bj == 2) F = eye * S.dt;
+    } else if (bi == 2) {
+        if (bj == 0) F = -S.RAdt[r * 3 + c];
+        else if (bj == 4) F = -S.Rdt[r * 3 + c];
+        else if (bj == 5) F = eye * S.dt;
+        else if (bj == 2) C = S.Cacc[r * 3 + c];
+    } else if (bi == 3) {
+        if (bj == 3) C = (r == c) ? cbg[r] * S.dt * S.dt : 0.0;
+    } else if (bi == 4) {
+        if (bj == 4) C = (r == c) ? cba[r] * S.dt * S.dt : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(FL_IMU_NT) void imu_forward_kernel(FlImuDev *__restrict__ D, const FlImuSample *__restrict__ v, int nv,
+                                                               FlPose6 *__restrict__ poses)
+{
+    __shared__ double sF[324], sP[324], sT[324], sC[324];
+    __shared__ FlImuStep sS;
+    __shared__ double s_R[9], s_vel[3], s_pos[3], s_acc[3], s_w[3];
+    __shared__ int s_go, s_K;
+    __shared__ FlImuSample s_v[256];          // samples staged once: a global load per step costs ~1 us of latency
+    const int t = (int)threadIdx.x;
+    const int ti = t / 18, tj = t % 18;
+    if (t < 324) sP[t] = D->P[t];
+    const bool staged = nv <= 256;
+    if (staged) {
+        const double *src = reinterpret_cast<const double *>(v);
+        double *dst = reinterpret_cast<double *>(s_v);
+        for (int k = t; k < nv * 7; k += FL_IMU_NT) dst[k] = src[k];
+    }
+    const FlImuSample *vs = staged ? s_v : v;
+    // per-frame constants in registers (every lane: the F/C construction below reads them)
+    double bg[3], ba[3], grav[3], cg[3], ca[3], cbg[3], cba[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        bg[k] = D->bg[k]; ba[k] = D->ba[k]; grav[k] = D->grav[k];
+        cg[k] = D->cov_gyr[k]; ca[k] = D->cov_acc[k]; cbg[k] = D->cov_bias_gyr[k]; cba[k] = D->cov_bias_acc[k];
+    }
+    const double mean_acc_norm = D->mean_acc_norm, last_end = D->last_lidar_end_time, beg = D->pcl_beg_time;
+    if (t == 0) {
+        for (int k = 0; k < 9; k++) s_R[k] = D->rot[k];
+        for (int k = 0; k < 3; k++) { s_vel[k] = D->vel[k]; s_pos[k] = D->pos[k]; s_acc[k] = D->acc_s_last[k]; s_w[k] = D->angvel_last[k]; }
+        FlPose6 p;
+        p.offset_time = 0.0;
+        for (int k = 0; k < 3; k++) { p.acc[k] = s_acc[k]; p.gyr[k] = s_w[k]; p.vel[k] = s_vel[k]; p.pos[k] = s_pos[k]; }
+        for (int k = 0; k < 9; k++) p.rot[k] = s_R[k];
+        poses[0] = p;                                                              // :656
+        s_K = 1;
+    }
+    __syncthreads();
+    for (int it = 0; it + 1 < nv; it++) {
+        if (t == 0) {
+            const FlImuSample head = vs[it], tail = vs[it + 1];
+            const int go = !(tail.t < last_end);                                   // :666
+            if (go) {
+                double w[3], a[3];
+                for (int k = 0; k < 3; k++) {
+                    w[k] = 0.5 * (head.gyr[k] + tail.gyr[k]);
+                    a[k] = 0.5 * (head.acc[k] + tail.acc[k]);
+                }
+                for (int k = 0; k < 3; k++) {
+                    w[k] -= bg[k];                                                 // :684
+                    a[k] = a[k] * 9.81 / mean_acc_norm - ba[k];                    // :685
+                }
+                const double dt = (head.t < last_end) ? (tail.t - last_end) : (tail.t - head.t);   // :687-694
+                double Exp_f[9], Exp_m[9], RA[9], R[9];
+                for (int k = 0; k < 9; k++) R[k] = s_R[k];
+                fl_so3_exp_dt(w, dt, Exp_f);
+                fl_so3_exp_dt(w, -dt, Exp_m);                                      // :703
+                const double askew[9] = {0.0, -a[2], a[1], a[2], 0.0, -a[0], -a[1], a[0], 0.0};
+                fl_m3_mul(R, askew, RA);
+                for (int k = 0; k < 9; k++) { sS.Exp_m[k] = Exp_m[k]; sS.RAdt[k] = RA[k] * dt; sS.Rdt[k] = R[k] * dt; }   // :707-708
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++) {                                  // :712
+                        double q = 0.0;
+                        for (int k = 0; k < 3; k++) q += R[i * 3 + k] * ca[k] * R[j * 3 + k];
+                        sS.Cacc[i * 3 + j] = q * dt * dt;
+                    }
+                sS.dt = dt;
+                fl_m3_mul(R, Exp_f, R);                                            // :719
+                double Ra[3], acc[3];
+                fl_m3_mv(R, a, Ra);
+                for (int k = 0; k < 3; k++) acc[k] = Ra[k] + grav[k];              // :722
+                for (int k = 0; k < 3; k++) s_pos[k] = s_pos[k] + s_vel[k] * dt + 0.5 * acc[k] * dt * dt;   // :725
+                for (int k = 0; k < 3; k++) s_vel[k] = s_vel[k] + acc[k] * dt;     // :728
+                for (int k = 0; k < 9; k++) s_R[k] = R[k];
+                for (int k = 0; k < 3; k++) { s_acc[k] = acc[k]; s_w[k] = w[k]; }   // :731-732
+                FlPose6 p;
+                p.offset_time = tail.t - beg;                                      // :733
+                for (int k = 0; k < 3; k++) { p.acc[k] = acc[k]; p.gyr[k] = w[k]; p.vel[k] = s_vel[k]; p.pos[k] = s_pos[k]; }
+                for (int k = 0; k < 9; k++) p.rot[k] = R[k];
+                poses[s_K] = p;
+                s_K = s_K + 1;
+            }
+            s_go = go;
+        }
+        __syncthreads();
+        if (s_go) {                                                                // :716  cov = F cov F^T + cov_w
+            if (t < 324) {
+                double f, c;
+                fl_imu_FC(sS, cg, cbg, cba, ti, tj, f, c);
+                sF[t] = f; sC[t] = c;
+            }
+            __syncthreads();
+            if (t < 324) {
+                double q = 0.0;
+#pragma unroll
+                for (int k = 0; k < 18; k++) q += sF[ti * 18 + k] * sP[k * 18 + tj];
+                sT[t] = q;
+            }
+            __syncthreads();
+            if (t < 324) {
+                double q = 0.0;
+#pragma unroll
+                for (int k = 0; k < 18; k++) q += sT[ti * 18 + k] * sF[tj * 18 + k];
+                sP[t] = q + sC[t];
+            }
+        }
+        __syncthreads();
+    }
+    if (t < 324) D->P[t] = sP[t];
+    if (t == 0) {
+        const double imu_end_time = v[nv - 1].t, end = D->pcl_end_time;
+        double note, dt;                                                           // :743-759
+        if (imu_end_time > beg) { note = end > imu_end_time ? 1.0 : -1.0; dt = note * (end - imu_end_time); }
+        else { note = end > beg ? 1.0 : -1.0; dt = note * (end - beg); }
+        double w[3] = {note * s_w[0], note * s_w[1], note * s_w[2]}, E[9], R[9], Rend[9];
+        for (int k = 0; k < 9; k++) R[k] = s_R[k];
+        fl_so3_exp_dt(w, dt, E);
+        fl_m3_mul(R, E, Rend);
+        for (int k = 0; k < 3; k++) D->vel[k] = s_vel[k] + note * s_acc[k] * dt;
+        for (int k = 0; k < 9; k++) D->rot[k] = Rend[k];
+        for (int k = 0; k < 3; k++) D->pos[k] = s_pos[k] + note * s_vel[k] * dt + note * 0.5 * s_acc[k] * dt * dt;
+        for (int k = 0; k < 3; k++) { D->acc_s_last[k] = s_acc[k]; D->angvel_last[k] = s_w[k]; }
+        double LT[9], RT[9], X[9], o[3];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) { LT[i * 3 + j] = D->R_LI[j * 3 + i]; RT[i * 3 + j] = Rend[j * 3 + i]; }
+        fl_m3_mul(LT, RT, X);                                                      // :764
+        fl_m3_mv(LT, D->t_LI, o);                                                  // :765
+        for (int k = 0; k < 9; k++) D->extR_Ri[k] = X[k];
+        for (int k = 0; k < 3; k++) D->exrR_extT[k] = o[k];
+        D->n_poses = s_K;
+        D->term = -1;
+    }
+}
+
+// latest head k in [1, K-2] with offset_time[k] < t (those offsets increase with k), 0 if none
+__device__ __forceinline__ int fl_imu_head(const FlPose6 *poses, int K, double t)
+{
+    int lo = 1, hi = K - 1;            // count of k in [1, K-2] with offset < t, found by bisection
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (poses[mid].offset_time < t) lo = mid + 1; else hi = mid;
+    }
+    return lo - 1;
+}
+
+__global__ __launch_bounds__(FL_BLOCK) void undistort_heads_kernel(const float4 *__restrict__ pts, int n, const FlImuDev *__restrict__ D,
+                                                                  const FlPose6 *__restrict__ poses, int *__restrict__ head,
+                                                                  int *__restrict__ blockmin)
+{
+    __shared__ int s_min[FL_BLOCK / 64];
+    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
+    const int K = D->n_poses;
+    int v = 0x7fffffff;
+    if (i < n) {
+        v = fl_imu_head(poses, K, (double)pts[i].w / 1000.0);
+        head[i] = v;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = min(v, __shfl_xor(v, s));
+    if ((threadIdx.x & 63u) == 0) s_min[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < FL_BLOCK / 64; w++) v = min(v, s_min[w]);
+        blockmin[blockIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(FL_BLOCK) void undistort_scan_kernel(const float4 *__restrict__ pts, int n, FlImuDev *__restrict__ D,
+                                                                 const FlPose6 *__restrict__ poses, int *__restrict__ head,
+                                                                 const int *__restrict__ blockmin, int nblocks)
+{
+    __shared__ int s_v[FL_BLOCK];
+    __shared__ int s_later[FL_BLOCK / 64];
+    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
+    // minimum over all later workgroups
+    int later = 0x7fffffff;
+    for (int b = blockIdx.x + 1 + (int)threadIdx.x; b < nblocks; b += FL_BLOCK) later = min(later, blockmin[b]);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) later = min(later, __shfl_xor(later, s));
+    if ((threadIdx.x & 63u) == 0) s_later[threadIdx.x >> 6] = later;
+    s_v[threadIdx.x] = (i < n) ? head[i] : 0x7fffffff;
+    __syncthreads();
+    later = s_later[0];
+    for (int w = 1; w < FL_BLOCK / 64; w++) later = min(later, s_later[w]);
+    // suffix minimum inside the workgroup (Hillis-Steele from the right)
+    for (int d = 1; d < FL_BLOCK; d <<= 1) {
+        const int mine = s_v[threadIdx.x];
+        const int other = (threadIdx.x + d < FL_BLOCK) ? s_v[threadIdx.x + d] : 0x7fffffff;
+        __syncthreads();
+        s_v[threadIdx.x] = min(mine, other);
+        __syncthreads();
+    }
+    if (i < n) {
+        const int m = min(s_v[threadIdx.x], later);
+        head[i] = m;
+        // at head 0 the point must be later than IMUpose[0] (offset 0.0); otherwise the reference's loops end here
+        if (m == 0 && !((double)pts[i].w / 1000.0 > poses[0].offset_time)) atomicMax(&D->term, i);
+    }
+}
+
+__device__ __forceinline__ void fl_undistort_point(const FlImuDev *D, const FlPose6 &hd, double t, float &x, float &y, float &z)
+{
+    const double dt = t - hd.offset_time;                                          // :790
+    double E[9], R_i[9], T_ei[3], P_i[3] = {(double)x, (double)y, (double)z}, a[3], b[3], c[3];
+    fl_so3_exp_dt(hd.gyr, dt, E);
+    fl_m3_mul(hd.rot, E, R_i);                                                     // :796
+#pragma unroll
+    for (int k = 0; k < 3; k++) T_ei[k] = hd.pos[k] + hd.vel[k] * dt + 0.5 * hd.acc[k] * dt * dt - D->pos[k];   // :797
+    fl_m3_mv(D->R_LI, P_i, a);
+#pragma unroll
+    for (int k = 0; k < 3; k++) a[k] += D->t_LI[k];
+    fl_m3_mv(R_i, a, b);
+#pragma unroll
+    for (int k = 0; k < 3; k++) b[k] += T_ei[k];
+    fl_m3_mv(D->extR_Ri, b, c);                                                    // :800
+    x = (float)(c[0] - D->exrR_extT[0]); y = (float)(c[1] - D->exrR_extT[1]); z = (float)(c[2] - D->exrR_extT[2]);
+}
+
+__global__ __launch_bounds__(FL_BLOCK) void undistort_apply_kernel(float4 *__restrict__ pts, int n, const FlImuDev *__restrict__ D,
+                                                                  const FlPose6 *__restrict__ poses, const int *__restrict__ head)
+{
+    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int K = D->n_poses;
+    if (K < 2 || i <= D->term) return;
+    float4 p = pts[i];
+    const double t = (double)p.w / 1000.0;
+    const int hd = head[i];
+    fl_undistort_point(D, poses[hd], t, p.x, p.y, p.z);
+    if (i == 0) {
+        for (int k = hd - 1; k >= 0; k--)                                          // :803: no step back after the first point
+            if (t > poses[k].offset_time) fl_undistort_point(D, poses[k], t, p.x, p.y, p.z);
+    }
+    pts[i] = p;
+}

@@ -311,3 +311,66 @@ def make_vio_frame(m, lio: LioFrame, seed=SEED, cam=None, Rcl=AVIA_RCL, Pcl=AVIA
     return VioFrame(m=m, img=img, ref_patch=np.ascontiguousarray(ref), pos=np.ascontiguousarray(pos),
                     search_level=np.zeros(m, dtype=np.int32), cam=cam, Rcl=np.array(Rcl), Pcl=np.array(Pcl),
                     R_LI=lio.R_LI, t_LI=lio.t_LI, img_point_cov=img_point_cov, max_iterations=max_iterations)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# IMU frame for ImuProcess::UndistortPcl: one 100 ms LiDAR frame with a 200 Hz IMU
+@dataclasses.dataclass
+class ImuFrame:
+    imu: np.ndarray              # (k,7) float64 [t, gyr xyz, acc xyz] = meas.imu
+    last_imu: np.ndarray         # (7,) last_imu_
+    last_lidar_end_time: float
+    pcl_beg_time: float
+    pcl_end_time: float
+    pts_xyzt: np.ndarray         # float32 (n,4): x, y, z, curvature (offset from pcl_beg_time in ms)
+    R_LI: np.ndarray
+    t_LI: np.ndarray
+    cov_gyr: np.ndarray
+    cov_acc: np.ndarray
+    cov_bias_gyr: np.ndarray
+    cov_bias_acc: np.ndarray
+    mean_acc: np.ndarray
+    acc_s_last: np.ndarray
+    angvel_last: np.ndarray
+    lio: LioFrame                # state (prior) and scene
+
+
+def make_imu_frame(n, n_imu=20, seed=SEED, time_sorted=True, imu_before_frame=True, first_point_late=False, lio=None, quiet=False):
+    rng = np.random.default_rng(seed + 77)
+    lio = lio if lio is not None else make_lio_frame(max(n, 16), seed=seed)
+    t0 = 1000.0                                    # pcl_beg_time
+    dur = 0.1
+    dt_imu = dur / n_imu
+    # last_imu_ a little before the frame; with imu_before_frame the first samples straddle last_lidar_end_time_
+    t_last = t0 - 0.6 * dt_imu if imu_before_frame else t0 + 0.1 * dt_imu
+    times = t_last + dt_imu * np.arange(1, n_imu + 1)
+    def sample(t):
+        w = np.array([0.3 * np.sin(7 * t), -0.2 * np.cos(5 * t), 0.25 * np.sin(3 * t + 1)]) + rng.normal(0, 0.01, 3)
+        a = np.array([0.02 * np.sin(11 * t), 0.03 * np.cos(13 * t), 1.0 + 0.01 * np.sin(17 * t)]) + rng.normal(0, 0.002, 3)   # Livox: unit g
+        return np.concatenate([[t], w, a])
+    imu = np.stack([sample(t) for t in times])
+    last_imu = sample(t_last)
+    mean_acc = np.array([0.01, -0.02, 0.999])
+    if quiet:
+        # sensor almost at rest: specific force cancels gravity at the prior attitude, tiny rates. The scan then stays on the
+        # scene's planes after undistortion (used by the whole-pipeline benchmark, where the LIO update must converge)
+        rest = (np.asarray(lio.R_prior, float).T @ (-np.asarray(lio.grav, float))) / 9.81 * np.linalg.norm(mean_acc) + np.asarray(lio.ba, float) * np.linalg.norm(mean_acc) / 9.81
+        for row in (last_imu, *imu):
+            row[1:4] = row[1:4] * 0.01 + np.asarray(lio.bg, float)
+            row[4:7] = rest + rng.normal(0, 1e-5, 3)
+    pts = np.empty((n, 4), np.float32)
+    src = lio.body_xyz[rng.integers(0, lio.n, n)] if n else np.zeros((0, 3), np.float32)
+    pts[:, :3] = src
+    tt = rng.uniform(0.0, dur * 1000.0, n).astype(np.float32)
+    if time_sorted:
+        tt = np.sort(tt)
+    if n > 3 and not first_point_late:
+        tt[:2] = 0.0                                # the first returns carry offset 0 (never later than IMUpose[0])
+    if n > 3 and first_point_late:
+        tt = np.maximum(tt, np.float32(3.5 * dt_imu * 1000.0))   # frame tail only: the first point lies in a later IMU interval
+    pts[:, 3] = tt
+    return ImuFrame(imu=imu, last_imu=last_imu, last_lidar_end_time=t0 - 0.2 * dt_imu, pcl_beg_time=t0,
+                    pcl_end_time=t0 + float(tt.max()) / 1000.0 if n else t0 + dur, pts_xyzt=pts, R_LI=lio.R_LI, t_LI=lio.t_LI,
+                    cov_gyr=np.array([0.1, 0.1, 0.1]) * 1e-2, cov_acc=np.array([0.1, 0.12, 0.09]) * 96.2, cov_bias_gyr=np.full(3, 1e-4),
+                    cov_bias_acc=np.full(3, 1e-4), mean_acc=mean_acc,
+                    acc_s_last=np.array([0.05, -0.03, 0.02]) * (0.0 if quiet else 1.0), angvel_last=np.array([0.01, 0.02, -0.015]) * (0.0 if quiet else 1.0), lio=lio)

@@ -255,10 +255,38 @@ int32_t fl_ikfom_update_iterated_dev(fl_handle h, fl_state23 *x_io, double *P_io
  * ascending input index (PCL's std::sort leaves that order unspecified) and divided by the count.
  * stage_as_scan != 0: the centroids become the staged scan of this handle, exactly as if fl_lio_set_points had been
  * called with them (feats_down_body never visits the host). out_xyzi (nullable) has room for n points.
+ * xyzi == NULL: filter the n-point cloud that fl_imu_undistort left on the device.
  * leaf_too_small (nullable) reports PCL's "Leaf size is too small for the input dataset" case (output = input).
  * ---------------------------------------------------------------------------------------------- */
 int32_t fl_scan_voxel_filter(fl_handle h, const float *xyzi, int32_t n, float leaf_x, float leaf_y, float leaf_z,
                              int32_t stage_as_scan, float *out_xyzi, int32_t *out_n, int32_t *leaf_too_small);
+
+/* ------------------------------------------------------------------------------------------------
+ * IMU forward propagation + point undistortion on the device:
+ * ImuProcess::UndistortPcl(LidarMeasureGroup&, StatesGroup&, PointCloudXYZI&), src/IMU_Processing.cpp:611-809,
+ * as called from Process2 (:875). The choice of the frame's points and of pcl_beg_time / pcl_end_time (:620-648)
+ * is bookkeeping on LidarMeasureGroup and stays with the caller.
+ * fl_imu_proc holds the ImuProcess members the function reads and writes (include/IMU_Processing.h); imu = meas.imu
+ * (n_imu >= 1 samples, last_imu_ is taken from proc). pts_xyzt: n x 4 floats (x, y, z, curvature = offset in ms).
+ * On return: state (rot/pos/vel = *_end, cov propagated), proc (acc_s_last, angvel_last, last_imu_,
+ * last_lidar_end_time_), out_xyzt (nullable) the compensated cloud, poses_out (nullable, room for n_imu + 1) the
+ * IMUpose list. The compensated cloud also stays on the device: fl_scan_voxel_filter(h, NULL, n, ...) continues
+ * from it. Unsorted clouds, points not later than IMUpose[0] and the repeated compensation of the first point
+ * behave exactly as the reference's backward loops do (see imu_kernels.h).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fl_imu_sample { double t; double gyr[3]; double acc[3]; } fl_imu_sample;   /* sensor_msgs::Imu fields used */
+typedef struct fl_pose6d { double offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]; } fl_pose6d;  /* Pose6D, common_lib.h:396-412 */
+typedef struct fl_imu_proc {
+    double cov_gyr[3], cov_acc[3], cov_bias_gyr[3], cov_bias_acc[3];   /* IMU_Processing.cpp:15-20, after IMU_init scaling (:829-836) */
+    double mean_acc[3];                                                /* :21, :113 */
+    double Lid_rot_to_IMU[9], Lid_offset_to_IMU[3];                    /* set_extrinsic :59-63 */
+    double acc_s_last[3], angvel_last[3];
+    fl_imu_sample last_imu;
+    double last_lidar_end_time;
+} fl_imu_proc;
+int32_t fl_imu_undistort(fl_handle h, fl_imu_proc *proc_io, fl_state18 *state_io, const fl_imu_sample *imu, int32_t n_imu,
+                         double pcl_beg_time, double pcl_end_time, const float *pts_xyzt, int32_t n, float *out_xyzt,
+                         fl_pose6d *poses_out, int32_t *n_poses_out);
 
 #ifdef __cplusplus
 }

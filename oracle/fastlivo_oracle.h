@@ -81,6 +81,23 @@ int orc_knn5(const float *map_xyz, int k, const float *query_xyz, int n, float *
 int orc_voxel_grid(const float *xyzi, int n, float leaf_x, float leaf_y, float leaf_z, float *out_xyzi, int32_t *out_n,
                    int32_t *leaf_too_small);
 
+/* ------------------------------------------------------------ IMU propagation + undistortion (orc_imu.c) */
+typedef struct orc_imu_sample { double t; double gyr[3]; double acc[3]; } orc_imu_sample;   /* sensor_msgs::Imu fields used */
+typedef struct orc_pose6d { double offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]; } orc_pose6d;  /* Pose6D, common_lib.h:396-412 */
+typedef struct orc_imu_proc {          /* members of ImuProcess read/written by UndistortPcl (IMU_Processing.h) */
+    double cov_gyr[3], cov_acc[3], cov_bias_gyr[3], cov_bias_acc[3];
+    double mean_acc[3];
+    double Lid_rot_to_IMU[9], Lid_offset_to_IMU[3];
+    double acc_s_last[3], angvel_last[3];
+    orc_imu_sample last_imu;
+    double last_lidar_end_time;
+} orc_imu_proc;
+/* ImuProcess::UndistortPcl, IMU_Processing.cpp:611-809. imu = meas.imu (n_imu samples, without last_imu_);
+ * pts_xyzt: n x 4 floats (x, y, z, curvature = offset in ms), compensated in place; poses_out (nullable) has
+ * room for n_imu + 1 poses. state: rot/pos/vel = *_end, cov propagated. */
+int orc_imu_undistort(orc_imu_proc *proc, orc_state18 *state, const orc_imu_sample *imu, int n_imu, double pcl_beg_time,
+                      double pcl_end_time, float *pts_xyzt, int n, orc_pose6d *poses_out, int32_t *n_poses_out);
+
 /* ---------------------------------------------------------------- VIO (lidar_selection.cpp) */
 typedef struct orc_vio_config {
     double Rcl[9], Pcl[3];    /* camera <- lidar extrinsic (avia.yaml:42-45)            */

@@ -154,6 +154,43 @@ def knn_callback(scene_knn):
     return KNN_FN(cb)
 
 
+class ImuSample(C.Structure):
+    _fields_ = [("t", C.c_double), ("gyr", C.c_double * 3), ("acc", C.c_double * 3)]
+
+
+class Pose6d(C.Structure):
+    _fields_ = [("offset_time", C.c_double), ("acc", C.c_double * 3), ("gyr", C.c_double * 3), ("vel", C.c_double * 3),
+                ("pos", C.c_double * 3), ("rot", C.c_double * 9)]
+
+
+class ImuProc(C.Structure):
+    """ImuProcess members used by UndistortPcl (IMU_Processing.cpp:611-809)."""
+    _fields_ = [("cov_gyr", C.c_double * 3), ("cov_acc", C.c_double * 3), ("cov_bias_gyr", C.c_double * 3),
+                ("cov_bias_acc", C.c_double * 3), ("mean_acc", C.c_double * 3), ("Lid_rot_to_IMU", C.c_double * 9),
+                ("Lid_offset_to_IMU", C.c_double * 3), ("acc_s_last", C.c_double * 3), ("angvel_last", C.c_double * 3),
+                ("last_imu", ImuSample), ("last_lidar_end_time", C.c_double)]
+
+
+def imu_proc_from_frame(f):
+    """f: synth.ImuFrame"""
+    p = ImuProc()
+    p.cov_gyr[:] = f.cov_gyr; p.cov_acc[:] = f.cov_acc; p.cov_bias_gyr[:] = f.cov_bias_gyr; p.cov_bias_acc[:] = f.cov_bias_acc
+    p.mean_acc[:] = f.mean_acc
+    p.Lid_rot_to_IMU[:] = np.asarray(f.R_LI, np.float64).reshape(9); p.Lid_offset_to_IMU[:] = f.t_LI
+    p.acc_s_last[:] = f.acc_s_last; p.angvel_last[:] = f.angvel_last
+    p.last_imu.t = f.last_imu[0]; p.last_imu.gyr[:] = f.last_imu[1:4]; p.last_imu.acc[:] = f.last_imu[4:7]
+    p.last_lidar_end_time = f.last_lidar_end_time
+    return p
+
+
+def imu_samples(arr):
+    """(k,7) array [t, gyr xyz, acc xyz] -> ctypes array of ImuSample"""
+    arr = np.ascontiguousarray(arr, np.float64)
+    out = (ImuSample * arr.shape[0])()
+    C.memmove(out, arr.ctypes.data, arr.nbytes)
+    return out
+
+
 def state18_from_frame(fr, R=None, p=None):
     return State18.make(fr.R_prior if R is None else R, fr.p_prior if p is None else p,
                         fr.vel, fr.bg, fr.ba, fr.grav, fr.cov18)
@@ -286,3 +323,21 @@ def voxel_grid(xyzi, leaf):
     if rc != 0:
         raise RuntimeError("orc_voxel_grid failed")
     return out[:m.value].copy(), bool(small.value)
+
+
+def imu_undistort(proc, state, imu, pcl_beg_time, pcl_end_time, pts_xyzt):
+    """ImuProcess::UndistortPcl restatement (oracle/orc_imu.c). Returns (compensated cloud (n,4), poses list)."""
+    samples = imu if not isinstance(imu, np.ndarray) else imu_samples(imu)
+    k = len(samples)
+    pts = np.array(pts_xyzt, dtype=np.float32, order="C", copy=True)
+    n = pts.shape[0]
+    poses = (Pose6d * (k + 1))()
+    npz = C.c_int32(0)
+    L = lib()
+    L.orc_imu_undistort.argtypes = [C.POINTER(ImuProc), C.POINTER(State18), C.POINTER(ImuSample), C.c_int, C.c_double, C.c_double,
+                                    C.POINTER(C.c_float), C.c_int, C.POINTER(Pose6d), C.POINTER(C.c_int32)]
+    L.orc_imu_undistort.restype = C.c_int
+    rc = L.orc_imu_undistort(C.byref(proc), C.byref(state), samples, k, pcl_beg_time, pcl_end_time, _p(pts, C.c_float), n, poses, C.byref(npz))
+    if rc != 0:
+        raise RuntimeError("orc_imu_undistort failed")
+    return pts, [poses[i] for i in range(npz.value)]
