@@ -116,6 +116,26 @@ def imu_samples(arr):
     return out
 
 
+class PatchCandidate(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("px_ref", C.c_double * 2), ("f_ref", C.c_double * 3), ("R_ref", C.c_double * 9),
+                ("t_ref", C.c_double * 3), ("keyframe_id", C.c_int32), ("level_ref", C.c_int32), ("grid_index", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+def patch_candidates(sf, kf_ids=None):
+    """ctypes array of candidates from a synth.SelectFrame; kf_ids maps keyframe index -> registered id."""
+    m = sf.cand_pos.shape[0]
+    arr = (PatchCandidate * m)()
+    for i in range(m):
+        c = arr[i]
+        k = int(sf.cand_kf[i])
+        c.pos[:] = sf.cand_pos[i]; c.px_ref[:] = sf.cand_px[i]; c.f_ref[:] = sf.cand_f[i]
+        c.R_ref[:] = sf.kf_R[k].reshape(9); c.t_ref[:] = sf.kf_t[k]
+        c.keyframe_id = int(kf_ids[k]) if kf_ids is not None else k
+        c.level_ref = 0; c.grid_index = i
+    return arr
+
+
 KNN_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_uint8))
 
 _dp, _fp, _u8p, _i32p = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
@@ -132,6 +152,10 @@ SYMBOLS = {
                                          C.POINTER(C.c_int32)]),
     "fl_imu_undistort": (C.c_int32, [_H, C.POINTER(ImuProc), C.POINTER(State18), C.POINTER(ImuSample), C.c_int32, C.c_double, C.c_double,
                                      _fp, C.c_int32, _fp, C.POINTER(Pose6d), C.POINTER(C.c_int32)]),
+    "fl_vio_add_keyframe": (C.c_int32, [_H, _u8p, C.c_int32, C.c_int32, C.c_int32, _i32p]),
+    "fl_vio_drop_keyframe": (C.c_int32, [_H, C.c_int32]),
+    "fl_vio_select_patches": (C.c_int32, [_H, _dp, _dp, _fp, C.c_int32, C.POINTER(PatchCandidate), C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                          _i32p, _fp, _i32p, _i32p, _i32p, _fp, _fp]),
     "fl_host_alloc": (C.c_int32, [_H, C.c_size_t, C.POINTER(C.c_void_p)]),
     "fl_host_free": (C.c_int32, [_H, C.c_void_p]),
     "fl_debug_get_wall": (C.c_int32, [_H, C.POINTER(C.c_longlong)]),
@@ -309,6 +333,36 @@ class Handle:
         self._chk(self.L.fl_scan_voxel_filter(self.h, None, n, leaf[0], leaf[1], leaf[2], 1 if stage_as_scan else 0, None, C.byref(m),
                                               C.byref(small)), "fl_scan_voxel_filter")
         return None, m.value, bool(small.value)
+
+    def vio_add_keyframe(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        kid = C.c_int32(-1)
+        self._chk(self.L.fl_vio_add_keyframe(self.h, img.ctypes.data_as(_u8p), img.shape[1], img.shape[0], img.shape[1], C.byref(kid)),
+                  "fl_vio_add_keyframe")
+        return kid.value
+
+    def vio_drop_keyframe(self, kid):
+        self._chk(self.L.fl_vio_drop_keyframe(self.h, kid), "fl_vio_drop_keyframe")
+
+    def vio_select_patches(self, Rcw, Pcw, scan_world, cand, ncc_en=False, ncc_thre=0.0, outlier_threshold=300.0, want_patches=True,
+                           want_depth=False):
+        """Returns dict(idx, errors, levels, reason, patches, depth); the accepted patches stay staged for vio_compute_j."""
+        Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(9); Pcw = np.ascontiguousarray(Pcw, np.float64)
+        scan = np.ascontiguousarray(scan_world, np.float32)
+        m = len(cand)
+        idx = np.zeros(max(m, 1), np.int32); err = np.zeros(max(m, 1), np.float32); lvl = np.zeros(max(m, 1), np.int32)
+        reason = np.zeros(max(m, 1), np.int32)
+        patches = np.zeros((max(m, 1), 192), np.float32) if want_patches else None
+        depth = np.zeros((self.cfg.img_height, self.cfg.img_width), np.float32) if want_depth else None
+        na = C.c_int32(0)
+        self._chk(self.L.fl_vio_select_patches(self.h, Rcw.ctypes.data_as(_dp), Pcw.ctypes.data_as(_dp), scan.ctypes.data_as(_fp) if len(scan) else None,
+                                               len(scan), cand, m, 1 if ncc_en else 0, ncc_thre, outlier_threshold, idx.ctypes.data_as(_i32p),
+                                               err.ctypes.data_as(_fp), lvl.ctypes.data_as(_i32p), C.byref(na), reason.ctypes.data_as(_i32p),
+                                               patches.ctypes.data_as(_fp) if want_patches else None,
+                                               depth.ctypes.data_as(_fp) if want_depth else None), "fl_vio_select_patches")
+        k = na.value
+        return dict(idx=idx[:k].copy(), errors=err[:k].copy(), levels=lvl[:k].copy(), reason=reason[:m].copy(),
+                    patches=patches[:k].copy() if want_patches else None, depth=depth)
 
     def host_alloc(self, shape, dtype=np.float32):
         """numpy view of page-locked host memory owned by the library (free with host_free)."""

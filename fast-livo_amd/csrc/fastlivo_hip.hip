@@ -11,6 +11,7 @@
 #include "knn_kernels.h"
 #include "voxel_kernels.h"
 #include "imu_kernels.h"
+#include "select_kernels.h"
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -79,6 +80,18 @@ struct fl_context {
     FlPose6 *d_imu_poses = nullptr;
     int *d_imu_head = nullptr, *d_imu_blockmin = nullptr;
     int imu_cap_samples = 0, imu_cap_points = 0;
+    // VIO patch selection (select_kernels.h)
+    std::vector<uint8_t *> kf_ptrs;            // device copies of the reference images (Feature::img), by keyframe id
+    uint8_t **d_kf_table = nullptr;
+    int kf_table_cap = 0;
+    bool kf_table_dirty = true;
+    unsigned long long *d_depth64 = nullptr;
+    struct FlPatchCandidate *d_sel_cand = nullptr;
+    struct FlSelectParams *d_sel_prm = nullptr;
+    float *d_sel_patches = nullptr, *d_sel_errors = nullptr, *d_sel_acc_err = nullptr, *d_sel_scan = nullptr;
+    int32_t *d_sel_slevel = nullptr, *d_sel_reason = nullptr, *d_sel_slot = nullptr, *d_sel_count = nullptr, *d_sel_acc_idx = nullptr,
+            *d_sel_acc_lvl = nullptr;
+    int sel_cap = 0, sel_scan_cap = 0;
     // misc
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
@@ -188,6 +201,7 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
 
 static void vox_free(fl_handle h);
 static void imu_free(fl_handle h);
+static void select_free(fl_handle h);
 
 int32_t fl_destroy(fl_handle h)
 {
@@ -202,6 +216,7 @@ int32_t fl_destroy(fl_handle h)
     hipFree(h->d_map_idx_tmp); hipFree(h->d_map_htab); hipFree(h->d_map_sort_tmp);
     vox_free(h);
     imu_free(h);
+    select_free(h);
     if (h->h_dev) hipHostFree(h->h_dev);
     if (h->h_dev23) hipHostFree(h->h_dev23);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -557,5 +572,6 @@ int32_t fl_debug_get_wall(fl_handle h, long long *out2048)
 #include "api_knn.inc"
 #include "api_voxel.inc"
 #include "api_imu.inc"
+#include "api_select.inc"
 
 }  // extern "C"

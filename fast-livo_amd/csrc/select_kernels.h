@@ -1,0 +1,232 @@
+// select_kernels.h -- SURVEY.md section 8(f) row N2, pixel-level part of LidarSelector::addFromSparseMap
+// (src/lidar_selection.cpp:346-587): depth image of the scan (:376-410) and, per grid winner, the depth-continuity test
+// (:484-506), getWarpMatrixAffine (:232-256), getBestSearchLevel (:315-329), warpAffine for 3 pyramid levels (:258-296),
+// getpatch of the current image (:119-140), the NCC gate (:298-313, :559-563) and the squared-error gate (:565-570).
+// The accepted patches are written straight into the VIO patch tensor of the handle (d_ref/d_pos/d_slevel, the layout
+// UpdateState reads) in ascending candidate order (:572-579): the 768-byte patches never visit the host.
+// The voxel lookups / grid competition (:412-466) and Point::getCloseViewObs (src/point.cpp:141-178) walk the
+// pointer-linked visual map and stay with the caller, who hands in one candidate per winning grid cell.
+//
+//  vio_depth_kernel     1 lane = 1 scan point; the reference overwrites a pixel in scan order (last point wins), here
+//                       a 64-bit atomicMax of (point index << 32 | depth bits) gives the same winner.
+//  vio_select_kernel    1 wavefront = 1 candidate, 1 lane = 1 patch pixel. Doubles/floats in the oracle's order; the
+//                       squared error is summed sequentially in float by one lane (the gate compares it to a threshold).
+//  vio_select_compact_kernel / vio_select_scatter_kernel   exclusive scan of the accept flags, copy to the patch tensor.
+#pragma once
+
+#include "fl_device.h"
+#include "vio_kernels.h"
+
+struct FlPatchCandidate {      // == fl_patch_candidate (C ABI)
+    double pos[3], px_ref[2], f_ref[3], R_ref[9], t_ref[3];
+    int32_t keyframe_id, level_ref, grid_index, reserved;
+};
+
+struct FlSelectParams {
+    double Rcw[9], Pcw[3];
+    double ncc_thre, outlier_threshold;
+    int32_t ncc_en, m;
+};
+
+__global__ __launch_bounds__(FL_BLOCK) void vio_depth_kernel(const float *__restrict__ scan, int n, const FlSelectParams *__restrict__ S,
+                                                            const FlVioConst *__restrict__ VC, unsigned long long *__restrict__ depth64)
+{
+    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double pw[3] = {(double)scan[3 * i], (double)scan[3 * i + 1], (double)scan[3 * i + 2]};
+    double pc[3];
+    pc[0] = (S->Rcw[0] * pw[0] + S->Rcw[1] * pw[1] + S->Rcw[2] * pw[2]) + S->Pcw[0];
+    pc[1] = (S->Rcw[3] * pw[0] + S->Rcw[4] * pw[1] + S->Rcw[5] * pw[2]) + S->Pcw[1];
+    pc[2] = (S->Rcw[6] * pw[0] + S->Rcw[7] * pw[1] + S->Rcw[8] * pw[2]) + S->Pcw[2];
+    if (!(pc[2] > 0)) return;
+    const double px0 = VC->fx_abs * pc[0] / pc[2] + VC->cx, px1 = VC->fy_abs * pc[1] / pc[2] + VC->cy;      // :398-399
+    const int u = (int)px0, v = (int)px1, W = VC->width, H = VC->height, b = 40;                                // (patch_size_half+1)*8
+    if (!(u >= b && u < W - b && v >= b && v < H - b)) return;
+    const unsigned long long key = ((unsigned long long)(unsigned)i << 32) | (unsigned long long)__float_as_uint((float)pc[2]);
+    atomicMax(&depth64[(size_t)W * v + u], key);
+}
+
+__device__ __forceinline__ void fl_cam2world(const FlVioConst &c, double u, double v, double *f)
+{
+    const double x = (u - c.cx) / c.fx, y = (v - c.cy) / c.fy, z = 1.0;
+    const double n = sqrt(x * x + y * y + z * z);
+    f[0] = x / n; f[1] = y / n; f[2] = z / n;
+}
+__device__ __forceinline__ void fl_se3_apply(const double *R, const double *t, const double *x, double *o)
+{
+    o[0] = (R[0] * x[0] + R[1] * x[1] + R[2] * x[2]) + t[0];
+    o[1] = (R[3] * x[0] + R[4] * x[1] + R[5] * x[2]) + t[1];
+    o[2] = (R[6] * x[0] + R[7] * x[1] + R[8] * x[2]) + t[2];
+}
+// vk::interpolateMat_8u (rpg_vikit vision.h, restated -- see oracle/orc_select.c)
+__device__ __forceinline__ float fl_interpolate_8u(const uint8_t *__restrict__ img, int stride, float u, float v)
+{
+    const int x = (int)floorf(u), y = (int)floorf(v);
+    const float sx = u - x, sy = v - y;
+    const float w00 = (1.0f - sx) * (1.0f - sy), w01 = (1.0f - sx) * sy, w10 = sx * (1.0f - sy);
+    const float w11 = 1.0f - w00 - w01 - w10;
+    const uint8_t *p = img + (size_t)y * stride + x;
+    return w00 * p[0] + w01 * p[stride] + w10 * p[1] + w11 * p[stride + 1];
+}
+
+#define FL_SEL_NT 256
+// reason: 0 accepted, 1 depth discontinuity, 3 NCC gate, 4 outlier gate
+__global__ __launch_bounds__(FL_SEL_NT) void vio_select_kernel(const FlPatchCandidate *__restrict__ cand, const FlSelectParams *__restrict__ S,
+                                                              const FlVioConst *__restrict__ VCp, const uint8_t *__restrict__ cur_img,
+                                                              const uint8_t *const *__restrict__ keyframes,
+                                                              const unsigned long long *__restrict__ depth64, float *__restrict__ patches /* m x 192 */,
+                                                              float *__restrict__ errors, int32_t *__restrict__ slevel, int32_t *__restrict__ reason)
+{
+    __shared__ float s_d2[FL_SEL_NT / 64][64];
+    const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+    const int ci = blockIdx.x * (FL_SEL_NT / 64) + wv;
+    if (ci >= S->m) return;                                    // whole wavefront
+    const FlVioConst &VC = *VCp;
+    const FlPatchCandidate &c = cand[ci];
+    const int W = VC.width, H = VC.height, half = 4, ps = 8, pst = 64;
+    double pt_cam[3], pc[2];
+    fl_se3_apply(S->Rcw, S->Pcw, c.pos, pt_cam);
+    fl_world2cam(VC, pt_cam, pc);                                                                        // :480-481
+    // depth continuity :484-506 -- 80 neighbours of the 9x9 window, two per lane
+    const int pu = min(max((int)pc[0], half), W - 1 - half), pv = min(max((int)pc[1], half), H - 1 - half);   // clamp: the reference reads unchecked
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int k = lane + 64 * r;
+        if (k < 81 && k != 40) {
+            const int u = k / 9 - half, v = k % 9 - half;
+            const float d = __uint_as_float((unsigned)depth64[(size_t)W * (v + pv) + u + pu]);
+            if (d != 0.f && fabs(pt_cam[2] - (double)d) > 1.5) bad = true;
+        }
+    }
+    if (__any(bad)) { if (lane == 0) reason[ci] = 1; return; }
+    // getWarpMatrixAffine :232-256 (every lane, same values)
+    double Rt[9], ref_pos[3], T_R[9], T_t[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Rt[i * 3 + j] = c.R_ref[j * 3 + i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) ref_pos[i] = -(Rt[i * 3] * c.t_ref[0] + Rt[i * 3 + 1] * c.t_ref[1] + Rt[i * 3 + 2] * c.t_ref[2]);   // Feature::pos()
+    const double dv0 = ref_pos[0] - c.pos[0], dv1 = ref_pos[1] - c.pos[1], dv2 = ref_pos[2] - c.pos[2];
+    const double depth_ref = sqrt(dv0 * dv0 + dv1 * dv1 + dv2 * dv2);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) T_R[i * 3 + j] = S->Rcw[i * 3] * Rt[j] + S->Rcw[i * 3 + 1] * Rt[3 + j] + S->Rcw[i * 3 + 2] * Rt[6 + j];
+    fl_se3_apply(S->Rcw, S->Pcw, ref_pos, T_t);
+    const double xyz_ref[3] = {c.f_ref[0] * depth_ref, c.f_ref[1] * depth_ref, c.f_ref[2] * depth_ref};
+    double du[3], dw[3];
+    fl_cam2world(VC, c.px_ref[0] + (double)half, c.px_ref[1], du);
+    fl_cam2world(VC, c.px_ref[0], c.px_ref[1] + (double)half, dw);
+    const double su = xyz_ref[2] / du[2], sw = xyz_ref[2] / dw[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { du[k] *= su; dw[k] *= sw; }
+    double q[3], px_cur[2], px_du[2], px_dv[2];
+    fl_se3_apply(T_R, T_t, xyz_ref, q); fl_world2cam(VC, q, px_cur);
+    fl_se3_apply(T_R, T_t, du, q);      fl_world2cam(VC, q, px_du);
+    fl_se3_apply(T_R, T_t, dw, q);      fl_world2cam(VC, q, px_dv);
+    const double A00 = (px_du[0] - px_cur[0]) / half, A10 = (px_du[1] - px_cur[1]) / half;
+    const double A01 = (px_dv[0] - px_cur[0]) / half, A11 = (px_dv[1] - px_cur[1]) / half;
+    int search_level = 0;                                                                                // :315-329
+    const double det = A00 * A11 - A01 * A10;
+    double D = det;
+    while (D > 3.0 && search_level < 2) { search_level += 1; D *= 0.25; }
+    // warpAffine :258-296, lane = y*8 + x
+    const double invdet = 1.0 / det;
+    const float B00 = (float)(A11 * invdet), B01 = (float)(-A01 * invdet), B10 = (float)(-A10 * invdet), B11 = (float)(A00 * invdet);
+    const uint8_t *ref = keyframes[c.keyframe_id];
+    const int x = lane & 7, y = lane >> 3;
+    float P0 = 0.f;
+    float *Pout = patches + (size_t)ci * 192;
+#pragma unroll
+    for (int lvl = 0; lvl <= 2; lvl++) {
+        float val = 0.f;
+        if (!isnan(B00)) {
+            float p0 = (float)(x - half), p1 = (float)(y - half);
+            p0 *= (float)(1 << search_level); p1 *= (float)(1 << search_level);
+            p0 *= (float)(1 << lvl); p1 *= (float)(1 << lvl);
+            const float u = (B00 * p0 + B01 * p1) + (float)c.px_ref[0];
+            const float v = (B10 * p0 + B11 * p1) + (float)c.px_ref[1];
+            if (!(u < 0 || v < 0 || u >= W - 1 || v >= H - 1)) val = fl_interpolate_8u(ref, W, u, v);
+        }
+        Pout[pst * lvl + lane] = val;
+        if (lvl == 0) P0 = val;
+    }
+    // getpatch(img, pc, patch_cache, 0) :119-140 ; lane = x_row*8 + y_col
+    float cur;
+    {
+        const float u_ref = (float)pc[0], v_ref = (float)pc[1];
+        const int u_i = min(max((int)floorf((float)pc[0]), half), W - 2 - half), v_i = min(max((int)floorf((float)pc[1]), half), H - 2 - half);
+        const float su_ = u_ref - (int)floorf((float)pc[0]), sv_ = v_ref - (int)floorf((float)pc[1]);
+        const float w_tl = (float)((1.0 - su_) * (1.0 - sv_)), w_tr = (float)(su_ * (1.0 - sv_)), w_bl = (float)((1.0 - su_) * sv_), w_br = su_ * sv_;
+        const uint8_t *ip = cur_img + (size_t)(v_i - half + y) * W + (u_i - half) + x;
+        cur = w_tl * ip[0] + w_tr * ip[1] + w_bl * ip[W] + w_br * ip[W + 1];
+    }
+    if (S->ncc_en) {                                                                                     // :298-313 (doubles)
+        const double sr = wave_sum((double)P0), sc = wave_sum((double)cur);
+        const double mr = sr / pst, mc = sc / pst;
+        const double num = wave_sum(((double)P0 - mr) * ((double)cur - mc));
+        const double d1 = wave_sum(((double)P0 - mr) * ((double)P0 - mr));
+        const double d2 = wave_sum(((double)cur - mc) * ((double)cur - mc));
+        if (num / sqrt(d1 * d2 + 1e-10) < S->ncc_thre) { if (lane == 0) reason[ci] = 3; return; }
+    }
+    s_d2[wv][lane] = (P0 - cur) * (P0 - cur);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the LDS writes of this wavefront have landed
+    if (lane == 0) {
+        float error = 0.0f;
+        for (int i = 0; i < pst; i++) error += s_d2[wv][i];                                              // :565-569, sequential float sum
+        const bool out = (double)error > S->outlier_threshold * pst;
+        reason[ci] = out ? 4 : 0;
+        errors[ci] = error;
+        slevel[ci] = search_level;
+    }
+    (void)ps;
+}
+
+// one workgroup: exclusive scan of (reason == 0) over the m candidates -> slot, count
+__global__ __launch_bounds__(1024) void vio_select_compact_kernel(const int32_t *__restrict__ reason, int m, int32_t *__restrict__ slot,
+                                                                 int32_t *__restrict__ count)
+{
+    __shared__ int s_cnt[1024];
+    const int t = (int)threadIdx.x;
+    const int chunk = (m + 1023) / 1024;
+    const int b = t * chunk, e = min(b + chunk, m);
+    int cnt = 0;
+    for (int i = b; i < e; i++) cnt += (reason[i] == 0);
+    s_cnt[t] = cnt;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = (t >= d) ? s_cnt[t - d] : 0;
+        __syncthreads();
+        s_cnt[t] += v;
+        __syncthreads();
+    }
+    int run = s_cnt[t] - cnt;
+    for (int i = b; i < e; i++) {
+        const int acc = (reason[i] == 0);
+        slot[i] = acc ? run : -1;
+        run += acc;
+    }
+    if (t == 1023) *count = s_cnt[1023];
+}
+
+// 1 wavefront per candidate: copy the accepted patch and its metadata to the VIO patch tensor
+__global__ __launch_bounds__(64) void vio_select_scatter_kernel(const FlPatchCandidate *__restrict__ cand, const int32_t *__restrict__ slot,
+                                                               const float *__restrict__ patches, const float *__restrict__ errors,
+                                                               const int32_t *__restrict__ slevel, float *__restrict__ d_ref,
+                                                               double *__restrict__ d_pos, int32_t *__restrict__ d_slevel,
+                                                               float *__restrict__ d_errors, int32_t *__restrict__ accepted_idx,
+                                                               float *__restrict__ acc_errors, int32_t *__restrict__ acc_slevel)
+{
+    const int ci = blockIdx.x, lane = (int)threadIdx.x;
+    const int s = slot[ci];
+    if (s < 0) return;
+#pragma unroll
+    for (int k = 0; k < 3; k++) d_ref[(size_t)s * 192 + 64 * k + lane] = patches[(size_t)ci * 192 + 64 * k + lane];
+    if (lane < 3) d_pos[(size_t)s * 3 + lane] = cand[ci].pos[lane];
+    if (lane == 3) { d_slevel[s] = slevel[ci]; acc_slevel[s] = slevel[ci]; }
+    if (lane == 4) { d_errors[s] = errors[ci]; acc_errors[s] = errors[ci]; }
+    if (lane == 5) accepted_idx[s] = ci;
+}

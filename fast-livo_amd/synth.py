@@ -374,3 +374,69 @@ def make_imu_frame(n, n_imu=20, seed=SEED, time_sorted=True, imu_before_frame=Tr
                     cov_gyr=np.array([0.1, 0.1, 0.1]) * 1e-2, cov_acc=np.array([0.1, 0.12, 0.09]) * 96.2, cov_bias_gyr=np.full(3, 1e-4),
                     cov_bias_acc=np.full(3, 1e-4), mean_acc=mean_acc,
                     acc_s_last=np.array([0.05, -0.03, 0.02]) * (0.0 if quiet else 1.0), angvel_last=np.array([0.01, 0.02, -0.015]) * (0.0 if quiet else 1.0), lio=lio)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Patch-selection frame for LidarSelector::addFromSparseMap: current image + pose, reference keyframes,
+# one candidate (map point + chosen reference observation) per "grid cell", and a scan for the depth image
+@dataclasses.dataclass
+class SelectFrame:
+    vio: VioFrame
+    Rcw: np.ndarray
+    Pcw: np.ndarray
+    keyframes: list               # uint8 (H,W) images; keyframe 0 is the current image seen from the current pose
+    kf_R: np.ndarray              # (K,3,3) T_f_w rotation of each keyframe
+    kf_t: np.ndarray              # (K,3)
+    cand_pos: np.ndarray          # (m,3)
+    cand_kf: np.ndarray           # (m,) int32
+    cand_px: np.ndarray           # (m,2) ref_ftr->px
+    cand_f: np.ndarray            # (m,3) ref_ftr->f
+    scan_world: np.ndarray        # float32 (n,3)
+    lio: LioFrame = None
+    outlier_threshold: float = 300.0
+
+
+def make_select_frame(m, seed=SEED, n_keyframes=3, discont_frac=0.1, lio=None):
+    rng = np.random.default_rng(seed + 501)
+    lio = lio if lio is not None else make_lio_frame(2000, seed=seed)
+    vf = make_vio_frame(m, lio, seed=seed)
+    cam = vf.cam
+    Rcw, Pcw = cam_pose(vf.Rcl, vf.Pcl, lio.R_LI, lio.t_LI, lio.R_true, lio.p_true)
+    kfs, kR, kt = [vf.img], [Rcw.copy()], [Pcw.copy()]
+    for k in range(1, n_keyframes):
+        dR = exp_so3(rng.uniform(-0.02, 0.02, 3))
+        Rk = dR @ Rcw
+        tk = dR @ Pcw + rng.uniform(-0.15, 0.15, 3)
+        img = np.roll(vf.img, (3 * k, -2 * k), axis=(0, 1)) if k % 2 else make_image(cam["width"], cam["height"], seed + 17 * k)
+        kfs.append(np.ascontiguousarray(img)); kR.append(Rk); kt.append(tk)
+    kR = np.stack(kR); kt = np.stack(kt)
+    pos = vf.pos
+    ckf = (np.arange(m) % n_keyframes).astype(np.int32)
+    cpx = np.zeros((m, 2)); cf = np.zeros((m, 3))
+    for i in range(m):
+        for attempt in (ckf[i], 0):
+            pf = kR[attempt] @ pos[i] + kt[attempt]
+            px = world2cam(cam, pf[None])[0]
+            if pf[2] > 0.5 and 45 < px[0] < cam["width"] - 45 and 45 < px[1] < cam["height"] - 45:
+                ckf[i] = attempt
+                break
+        cpx[i] = px
+        b = np.array([(px[0] - cam["cx"]) / cam["fx"], (px[1] - cam["cy"]) / cam["fy"], 1.0])
+        cf[i] = b / np.linalg.norm(b)
+    # scan: around every candidate a few returns at (almost) its depth; for some a return 3 m behind inside the 9x9 window
+    pf = pos @ Rcw.T + Pcw
+    scan_c = []
+    for i in range(m):
+        for _ in range(3):
+            d = pf[i] * (1.0 + rng.normal(0, 0.002))
+            d[:2] += rng.normal(0, 0.004, 2) * pf[i, 2]
+            scan_c.append(d)
+        if rng.uniform() < discont_frac:
+            scan_c.append(pf[i] * (1.0 + 3.0 / pf[i, 2]) + np.array([0.002 * pf[i, 2], 0.0, 0.0]))
+    scan_c = np.array(scan_c)
+    scan_w = (scan_c - Pcw) @ Rcw
+    extra = lio.world_at(lio.R_true, lio.p_true)[:1000]
+    scan_w = np.concatenate([scan_w, extra]).astype(np.float32)
+    scan_w = scan_w[rng.permutation(len(scan_w))]
+    return SelectFrame(vio=vf, Rcw=Rcw, Pcw=Pcw, keyframes=kfs, kf_R=kR, kf_t=kt, cand_pos=np.ascontiguousarray(pos), cand_kf=ckf,
+                       cand_px=cpx, cand_f=cf, scan_world=np.ascontiguousarray(scan_w), lio=lio)

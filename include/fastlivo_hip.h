@@ -288,6 +288,38 @@ int32_t fl_imu_undistort(fl_handle h, fl_imu_proc *proc_io, fl_state18 *state_io
                          double pcl_beg_time, double pcl_end_time, const float *pts_xyzt, int32_t n, float *out_xyzt,
                          fl_pose6d *poses_out, int32_t *n_poses_out);
 
+/* ------------------------------------------------------------------------------------------------
+ * VIO patch selection + affine warp on the device (pixel-level part of
+ * LidarSelector::addFromSparseMap, src/lidar_selection.cpp:346-587): depth image of the scan (:376-410) and, per
+ * candidate, depth-continuity test (:484-506), getWarpMatrixAffine (:232-256), getBestSearchLevel (:315-329),
+ * warpAffine x 3 levels (:258-296), getpatch of the current image (:119-140), NCC gate (:298-313, :559-563),
+ * squared-error gate (:565-570). The caller keeps the walk over the visual map: voxel lookups + grid competition
+ * (:412-466) and Point::getCloseViewObs (src/point.cpp:141-178) produce one candidate per winning grid cell, in
+ * ascending grid index. Reference images (Feature::img) are registered once with fl_vio_add_keyframe and stay in
+ * HBM until dropped. The current image is the one staged by fl_vio_set_frame; Rcw/Pcw = new_frame_->T_f_w_.
+ * Accepted candidates (ascending input order, :572-579) become the staged VIO patch set, exactly as after
+ * fl_vio_set_patches(ref = warped patches, pos = pt->pos_, search_level): fl_vio_compute_j can follow directly and
+ * the 768-byte patches never visit the host. Outputs (all nullable except n_accepted): accepted_idx / errors /
+ * search_levels (room for m), reason (m: 0 accepted, 1 depth discontinuity, 3 NCC, 4 outlier), patches_out
+ * (m x 192 floats, parity checks), depth_out (width x height floats). Only the distortion-free camera is supported.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fl_patch_candidate {
+    double pos[3];             /* pt->pos_ */
+    double px_ref[2];          /* ref_ftr->px */
+    double f_ref[3];           /* ref_ftr->f */
+    double R_ref[9], t_ref[3]; /* ref_ftr->T_f_w_ */
+    int32_t keyframe_id;       /* id of ref_ftr->img from fl_vio_add_keyframe */
+    int32_t level_ref;         /* ref_ftr->level (not read by warpAffine) */
+    int32_t grid_index;        /* caller's bookkeeping */
+    int32_t reserved;
+} fl_patch_candidate;
+int32_t fl_vio_add_keyframe(fl_handle h, const uint8_t *gray, int32_t width, int32_t height, int32_t stride, int32_t *keyframe_id);
+int32_t fl_vio_drop_keyframe(fl_handle h, int32_t keyframe_id);
+int32_t fl_vio_select_patches(fl_handle h, const double *Rcw, const double *Pcw, const float *scan_world_xyz, int32_t n_scan,
+                              const fl_patch_candidate *cand, int32_t m, int32_t ncc_en, double ncc_thre, double outlier_threshold,
+                              int32_t *accepted_idx, float *errors, int32_t *search_levels, int32_t *n_accepted, int32_t *reason,
+                              float *patches_out, float *depth_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,6 +134,27 @@ int orc_vio_compute_j(const orc_vio_config *cfg, orc_state18 *x, const orc_state
                       const int32_t *search_level, int m, float *errors,
                       orc_vio_level_out *out3 /* [3], index = level */);
 
+/* Pixel-level part of LidarSelector::addFromSparseMap (orc_select.c). A candidate = the map point a grid cell
+ * chose (:441-466) plus the reference observation Point::getCloseViewObs picked for it (point.cpp:141-178). */
+typedef struct orc_patch_candidate {
+    double pos[3];        /* pt->pos_ */
+    double px_ref[2];     /* ref_ftr->px */
+    double f_ref[3];      /* ref_ftr->f */
+    double R_ref[9], t_ref[3]; /* ref_ftr->T_f_w_ */
+    int32_t keyframe_id;  /* which image is ref_ftr->img */
+    int32_t level_ref;    /* ref_ftr->level (ignored by warpAffine, :258-296) */
+    int32_t grid_index;
+    int32_t reserved;
+} orc_patch_candidate;
+void orc_vio_depth_image(const orc_vio_config *cfg, const double *Rcw, const double *Pcw, const float *scan_world_xyz, int n,
+                         float *depth);
+/* patches: room for m x 3 x 64; accepted_idx/errors/search_levels: room for m; reason (nullable, m):
+ * 0 accepted, 1 depth discontinuity, 3 NCC gate, 4 outlier gate. Returns -2 if cfg has distortion. */
+int orc_vio_select(const orc_vio_config *cfg, const double *Rcw, const double *Pcw, const uint8_t *cur_img,
+                   const uint8_t *const *keyframes, const float *depth, const orc_patch_candidate *cand, int m,
+                   int ncc_en, double ncc_thre, double outlier_threshold, int32_t *accepted_idx, float *patches,
+                   float *errors, int32_t *search_levels, int32_t *n_accepted, int32_t *reason);
+
 /* vk::PinholeCamera::world2cam (rpg_vikit, unpinned master; restated from memory). */
 void orc_world2cam(const orc_vio_config *cfg, const double *xyz_c, double *px);
 

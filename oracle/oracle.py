@@ -191,6 +191,26 @@ def imu_samples(arr):
     return out
 
 
+class PatchCandidate(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("px_ref", C.c_double * 2), ("f_ref", C.c_double * 3), ("R_ref", C.c_double * 9),
+                ("t_ref", C.c_double * 3), ("keyframe_id", C.c_int32), ("level_ref", C.c_int32), ("grid_index", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+def patch_candidates(sf, kf_ids=None):
+    """ctypes array of candidates from a synth.SelectFrame; kf_ids maps keyframe index -> registered id."""
+    m = sf.cand_pos.shape[0]
+    arr = (PatchCandidate * m)()
+    for i in range(m):
+        c = arr[i]
+        k = int(sf.cand_kf[i])
+        c.pos[:] = sf.cand_pos[i]; c.px_ref[:] = sf.cand_px[i]; c.f_ref[:] = sf.cand_f[i]
+        c.R_ref[:] = sf.kf_R[k].reshape(9); c.t_ref[:] = sf.kf_t[k]
+        c.keyframe_id = int(kf_ids[k]) if kf_ids is not None else k
+        c.level_ref = 0; c.grid_index = i
+    return arr
+
+
 def state18_from_frame(fr, R=None, p=None):
     return State18.make(fr.R_prior if R is None else R, fr.p_prior if p is None else p,
                         fr.vel, fr.bg, fr.ba, fr.grav, fr.cov18)
@@ -341,3 +361,40 @@ def imu_undistort(proc, state, imu, pcl_beg_time, pcl_end_time, pts_xyzt):
     if rc != 0:
         raise RuntimeError("orc_imu_undistort failed")
     return pts, [poses[i] for i in range(npz.value)]
+
+
+def vio_depth_image(cfg, Rcw, Pcw, scan_world):
+    Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(9); Pcw = np.ascontiguousarray(Pcw, np.float64)
+    scan = np.ascontiguousarray(scan_world, np.float32)
+    depth = np.zeros((cfg.height, cfg.width), np.float32)
+    L = lib()
+    L.orc_vio_depth_image.argtypes = [C.POINTER(VioConfig), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_int,
+                                      C.POINTER(C.c_float)]
+    L.orc_vio_depth_image.restype = None
+    L.orc_vio_depth_image(C.byref(cfg), _p(Rcw, C.c_double), _p(Pcw, C.c_double), _p(scan, C.c_float), scan.shape[0], _p(depth, C.c_float))
+    return depth
+
+
+def vio_select(cfg, Rcw, Pcw, cur_img, keyframes, depth, cand, ncc_en=False, ncc_thre=0.0, outlier_threshold=300.0):
+    """orc_vio_select: returns dict(idx, errors, levels, reason, patches)."""
+    Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(9); Pcw = np.ascontiguousarray(Pcw, np.float64)
+    cur = np.ascontiguousarray(cur_img, np.uint8)
+    kfs = [np.ascontiguousarray(k, np.uint8) for k in keyframes]
+    ptrs = (C.POINTER(C.c_uint8) * len(kfs))(*[k.ctypes.data_as(C.POINTER(C.c_uint8)) for k in kfs])
+    m = len(cand)
+    idx = np.zeros(max(m, 1), np.int32); err = np.zeros(max(m, 1), np.float32); lvl = np.zeros(max(m, 1), np.int32)
+    reason = np.zeros(max(m, 1), np.int32); patches = np.zeros((max(m, 1), 192), np.float32)
+    na = C.c_int32(0)
+    L = lib()
+    L.orc_vio_select.argtypes = [C.POINTER(VioConfig), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint8),
+                                 C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_float), C.POINTER(PatchCandidate), C.c_int, C.c_int,
+                                 C.c_double, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.orc_vio_select.restype = C.c_int
+    rc = L.orc_vio_select(C.byref(cfg), _p(Rcw, C.c_double), _p(Pcw, C.c_double), _p(cur, C.c_uint8), ptrs, _p(depth, C.c_float), cand, m,
+                          1 if ncc_en else 0, ncc_thre, outlier_threshold, _p(idx, C.c_int32), _p(patches, C.c_float), _p(err, C.c_float),
+                          _p(lvl, C.c_int32), C.byref(na), _p(reason, C.c_int32))
+    if rc != 0:
+        raise RuntimeError("orc_vio_select failed: %d" % rc)
+    k = na.value
+    return dict(idx=idx[:k].copy(), errors=err[:k].copy(), levels=lvl[:k].copy(), reason=reason[:m].copy(), patches=patches[:k].copy())
