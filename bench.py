@@ -130,10 +130,32 @@ def main():
     lio_pass = ShardedPass(GpuLioBackend(hl, F), dist)      # accumulate -> all_reduce(32 doubles) -> solve
     vio_pass = ShardedPass(GpuVioBackend(hv, VIO_LEVEL, F), dist)
 
+    # N > 1: the exchange is done natively (ncclAllReduce on the handle's stream between accumulate and solve, api_comm.inc);
+    # the unique ids travel over torch.distributed. If RCCL cannot be bound, fall back to torch.distributed.all_reduce.
+    exchange = "none"
+    if distributed:
+        exchange = "torch.distributed.all_reduce"
+        if os.environ.get("FL_BENCH_TORCH_EXCHANGE") != "1":
+            try:
+                for h_ in (hl, hv):
+                    uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                    if rank == 0:
+                        uid.copy_(torch.frombuffer(bytearray(h_.comm_unique_id()), dtype=torch.uint8))
+                    dist.broadcast(uid, 0)
+                    torch.cuda.synchronize()
+                    h_.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, max(world, 1))
+                exchange = "ncclAllReduce on the pass stream (native)"
+            except Exception as e:   # noqa: BLE001
+                print(f"[bench] native RCCL exchange unavailable ({e}); using torch.distributed", file=sys.stderr)
+    native = exchange.startswith("ncclAllReduce")
+
     def step():
         if not distributed:
             hl.lio_iterate18(1, F, want_info=False)          # fused pass kernel (reduce + solve in-launch)
             hv.vio_iterate(VIO_LEVEL, 1, F, want_info=False)
+        elif native:
+            hl.lio_iterate18_sharded(1, F, want_info=False)  # accumulate -> ncclAllReduce(32 doubles) -> solve
+            hv.vio_iterate_sharded(VIO_LEVEL, 1, F, want_info=False)
         else:
             lio_pass.step()
             vio_pass.step()
@@ -237,7 +259,7 @@ def main():
                        "iteration_definition": "one LIO pass + one VIO pass, each = residuals + Jacobian rows + "
                                                "normal equations + gain solve + state update",
                        "parallelism": f"point/patch-range shards x{world}, all-reduce of the 32-double normal-equation "
-                                      "record per pass" if world > 1 else "single GPU, fused pass kernels"},
+                                      f"record per pass ({exchange})" if world > 1 else "single GPU, fused pass kernels"},
             "frame_iterations_per_s": frame_it_s,
             "state_finite": finite,
             "roofline": roof,

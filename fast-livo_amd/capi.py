@@ -156,6 +156,12 @@ SYMBOLS = {
     "fl_vio_drop_keyframe": (C.c_int32, [_H, C.c_int32]),
     "fl_vio_select_patches": (C.c_int32, [_H, _dp, _dp, _fp, C.c_int32, C.POINTER(PatchCandidate), C.c_int32, C.c_int32, C.c_double, C.c_double,
                                           _i32p, _fp, _i32p, _i32p, _i32p, _fp, _fp]),
+    "fl_comm_unique_id": (C.c_int32, [_H, C.c_void_p]),
+    "fl_comm_init": (C.c_int32, [_H, C.c_void_p, C.c_int32, C.c_int32]),
+    "fl_comm_destroy": (C.c_int32, [_H]),
+    "fl_lio_iterate18_sharded": (C.c_int32, [_H, C.c_int32, C.c_int32, C.POINTER(IterInfo)]),
+    "fl_vio_iterate_sharded": (C.c_int32, [_H, C.c_int32, C.c_int32, C.c_int32, C.POINTER(IterInfo)]),
+    "fl_ikfom_iterate_sharded": (C.c_int32, [_H, C.c_int32, C.c_int32, C.POINTER(IterInfo)]),
     "fl_host_alloc": (C.c_int32, [_H, C.c_size_t, C.POINTER(C.c_void_p)]),
     "fl_host_free": (C.c_int32, [_H, C.c_void_p]),
     "fl_debug_get_wall": (C.c_int32, [_H, C.POINTER(C.c_longlong)]),
@@ -363,6 +369,33 @@ class Handle:
         k = na.value
         return dict(idx=idx[:k].copy(), errors=err[:k].copy(), levels=lvl[:k].copy(), reason=reason[:m].copy(),
                     patches=patches[:k].copy() if want_patches else None, depth=depth)
+
+    def comm_unique_id(self):
+        buf = (C.c_char * 128)()
+        self._chk(self.L.fl_comm_unique_id(self.h, buf), "fl_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, uid, rank, world):
+        buf = (C.c_char * 128).from_buffer_copy(uid)
+        self._chk(self.L.fl_comm_init(self.h, buf, rank, world), "fl_comm_init")
+
+    def comm_destroy(self):
+        self._chk(self.L.fl_comm_destroy(self.h), "fl_comm_destroy")
+
+    def lio_iterate18_sharded(self, count=1, flags=0, want_info=True):
+        info = IterInfo()
+        self._chk(self.L.fl_lio_iterate18_sharded(self.h, count, flags, C.byref(info) if want_info else None), "fl_lio_iterate18_sharded")
+        return info if want_info else None
+
+    def vio_iterate_sharded(self, level, count=1, flags=0, want_info=True):
+        info = IterInfo()
+        self._chk(self.L.fl_vio_iterate_sharded(self.h, level, count, flags, C.byref(info) if want_info else None), "fl_vio_iterate_sharded")
+        return info if want_info else None
+
+    def ikfom_iterate_sharded(self, count=1, flags=0, want_info=True):
+        info = IterInfo()
+        self._chk(self.L.fl_ikfom_iterate_sharded(self.h, count, flags, C.byref(info) if want_info else None), "fl_ikfom_iterate_sharded")
+        return info if want_info else None
 
     def host_alloc(self, shape, dtype=np.float32):
         """numpy view of page-locked host memory owned by the library (free with host_free)."""

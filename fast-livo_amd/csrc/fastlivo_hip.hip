@@ -92,6 +92,9 @@ struct fl_context {
     int32_t *d_sel_slevel = nullptr, *d_sel_reason = nullptr, *d_sel_slot = nullptr, *d_sel_count = nullptr, *d_sel_acc_idx = nullptr,
             *d_sel_acc_lvl = nullptr;
     int sel_cap = 0, sel_scan_cap = 0;
+    // native exchange of the sharded form (api_comm.inc)
+    void *comm = nullptr;          // ncclComm_t
+    int comm_world = 0, comm_rank = 0;
     // misc
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
@@ -202,6 +205,7 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
 static void vox_free(fl_handle h);
 static void imu_free(fl_handle h);
 static void select_free(fl_handle h);
+extern "C" int32_t fl_comm_destroy(fl_handle h);
 
 int32_t fl_destroy(fl_handle h)
 {
@@ -217,6 +221,7 @@ int32_t fl_destroy(fl_handle h)
     vox_free(h);
     imu_free(h);
     select_free(h);
+    fl_comm_destroy(h);
     if (h->h_dev) hipHostFree(h->h_dev);
     if (h->h_dev23) hipHostFree(h->h_dev23);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -573,5 +578,6 @@ int32_t fl_debug_get_wall(fl_handle h, long long *out2048)
 #include "api_voxel.inc"
 #include "api_imu.inc"
 #include "api_select.inc"
+#include "api_comm.inc"
 
 }  // extern "C"

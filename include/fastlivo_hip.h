@@ -320,6 +320,21 @@ int32_t fl_vio_select_patches(fl_handle h, const double *Rcw, const double *Pcw,
                               int32_t *accepted_idx, float *errors, int32_t *search_levels, int32_t *n_accepted, int32_t *reason,
                               float *patches_out, float *depth_out);
 
+/* ------------------------------------------------------------------------------------------------
+ * Sharded form with the exchange done natively: each rank stages its contiguous range of the scan
+ * points / patches; a pass = accumulate (this rank's range) -> ncclAllReduce of the 32-double (Mode-23: 96) record
+ * on the handle's stream (RCCL over xGMI) -> solve, replicated on bitwise-identical inputs. Three enqueues, no host
+ * work in between. fl_comm_unique_id on one rank, distributed to all by the caller (e.g. torch.distributed
+ * broadcast), then fl_comm_init on every rank (collective: blocks until all ranks have called it).
+ * RCCL is bound at run time (the librccl.so.1 already loaded in the process, else /opt/rocm/lib).
+ * ---------------------------------------------------------------------------------------------- */
+int32_t fl_comm_unique_id(fl_handle h, void *id128 /* 128 bytes out */);
+int32_t fl_comm_init(fl_handle h, const void *id128, int32_t rank, int32_t world);
+int32_t fl_comm_destroy(fl_handle h);
+int32_t fl_lio_iterate18_sharded(fl_handle h, int32_t count, int32_t flags, fl_iter_info *info);
+int32_t fl_vio_iterate_sharded(fl_handle h, int32_t level, int32_t count, int32_t flags, fl_iter_info *info);
+int32_t fl_ikfom_iterate_sharded(fl_handle h, int32_t count, int32_t flags, fl_iter_info *info);
+
 #ifdef __cplusplus
 }
 #endif
