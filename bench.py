@@ -267,9 +267,15 @@ def main():
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
-        print(json.dumps(out))
     if distributed:
-        dist.destroy_process_group()
+        dist.destroy_process_group()       # (the handles' own communicators went with hl.close() / hv.close())
+    if rank == 0:
+        # RCCL writes its version banner to the C stdout when NCCL_DEBUG=VERSION is set in the environment: drain it first so
+        # that the JSON line is the last line of this rank's stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 def sweep(capi, synth, scene, cfg, x0, fh):
