@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 N_POINTS = 50000
 N_PATCHES = 2000
+PASSES_PER_LAUNCH = 10   # avia.yaml max_iteration
 VIO_LEVEL = 0
 # algorithmic HBM bytes per unit and launch
 LIO_BYTES_PER_POINT = 12 + 16 + 1      # body xyz + cached plane (n,d) + selection flag
@@ -149,16 +150,26 @@ def main():
                 print(f"[bench] native RCCL exchange unavailable ({e}); using torch.distributed", file=sys.stderr)
     native = exchange.startswith("ncclAllReduce")
 
-    def step():
+    # A frame of the reference runs its passes back to back (<= max_iteration + 1 LIO passes, <= max_iteration VIO passes per
+    # pyramid level): the single-GPU path enqueues PASSES_PER_LAUNCH consecutive passes as one multi-pass launch (pose handed
+    # from the solver to the producers inside the kernel); every pass still does the full work of a step.
+    def steps(k):
+        """k steps = k LIO passes + k VIO passes"""
         if not distributed:
-            hl.lio_iterate18(1, F, want_info=False)          # fused pass kernel (reduce + solve in-launch)
-            hv.vio_iterate(VIO_LEVEL, 1, F, want_info=False)
+            done = 0
+            while done < k:
+                c = min(PASSES_PER_LAUNCH, k - done)
+                hl.lio_iterate18(c, F, want_info=False)      # fused passes (reduce + solve + pose broadcast in-launch)
+                hv.vio_iterate(VIO_LEVEL, c, F, want_info=False)
+                done += c
         elif native:
-            hl.lio_iterate18_sharded(1, F, want_info=False)  # accumulate -> ncclAllReduce(32 doubles) -> solve
-            hv.vio_iterate_sharded(VIO_LEVEL, 1, F, want_info=False)
+            for _ in range(k):
+                hl.lio_iterate18_sharded(1, F, want_info=False)  # accumulate -> ncclAllReduce(32 doubles) -> solve
+                hv.vio_iterate_sharded(VIO_LEVEL, 1, F, want_info=False)
         else:
-            lio_pass.step()
-            vio_pass.step()
+            for _ in range(k):
+                lio_pass.step()
+                vio_pass.step()
 
     def fence():
         torch.cuda.synchronize()
@@ -166,12 +177,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    steps(args.warmup)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -187,27 +196,31 @@ def main():
     # ---- roofline of the dominant kernel (LIO pass), HIP events on the launch stream
     roof = None
     if rank == 0:
-        K = max(200, min(args.steps, 2000))
+        # the kernels of the timed region: one launch = PASSES_PER_LAUNCH passes (multi-pass kernels); average launch duration
+        # from events on the launch stream around K back-to-back launches
+        C = PASSES_PER_LAUNCH
+        K = max(50, min(args.steps // C, 300))
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(50):
-            hl.lio_iterate18(1, F, want_info=False)
+        for _ in range(10):
+            hl.lio_iterate18(C, F, want_info=False)
         torch.cuda.synchronize()
         ev0.record()
         for _ in range(K):
-            hl.lio_iterate18(1, F, want_info=False)
+            hl.lio_iterate18(C, F, want_info=False)
         ev1.record()
         torch.cuda.synchronize()
-        lio_us = ev0.elapsed_time(ev1) * 1e3 / K
+        lio_launch_us = ev0.elapsed_time(ev1) * 1e3 / K
         ev0.record()
         for _ in range(K):
-            hv.vio_iterate(VIO_LEVEL, 1, F, want_info=False)
+            hv.vio_iterate(VIO_LEVEL, C, F, want_info=False)
         ev1.record()
         torch.cuda.synchronize()
-        vio_us = ev0.elapsed_time(ev1) * 1e3 / K
-        lio_bytes = LIO_BYTES_PER_POINT * args.points
-        vio_bytes = VIO_BYTES_PER_PATCH * args.patches
-        dom = "lio18_pass_kernel" if lio_us >= vio_us else "vio_pass_kernel"
-        dom_bytes, dom_us = (lio_bytes, lio_us) if lio_us >= vio_us else (vio_bytes, vio_us)
+        vio_launch_us = ev0.elapsed_time(ev1) * 1e3 / K
+        lio_us, vio_us = lio_launch_us / C, vio_launch_us / C
+        lio_bytes = LIO_BYTES_PER_POINT * args.points * C      # algorithmic bytes per launch = per pass x passes per launch
+        vio_bytes = VIO_BYTES_PER_PATCH * args.patches * C
+        dom = "lio18_multipass_kernel" if lio_us >= vio_us else "vio_multipass_kernel"
+        dom_bytes, dom_us = (lio_bytes, lio_launch_us) if lio_us >= vio_us else (vio_bytes, vio_launch_us)
         ach = dom_bytes / (dom_us * 1e-6) / 1e9
         traffic, traffic_src = None, None
         try:   # PMC bytes are collected in separate rocprofv3 --pmc passes and committed under profiles/
@@ -225,9 +238,9 @@ def main():
                 "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us,
                 "method": f"HIP events around {K} back-to-back launches on the launch stream (includes the "
                           "inter-kernel boundary)",
-                "lio_pass_us": lio_us, "vio_pass_us": vio_us,
-                "note": "latency-bound at BASELINE sizes: 1.45 MB/launch is 0.18 us at 8 TB/s, below one kernel boundary "
-                        "(SURVEY.md fact 5); see DESIGN.md size sweep"}
+                "passes_per_launch": C, "lio_pass_us": lio_us, "vio_pass_us": vio_us,
+                "note": "latency-bound at BASELINE sizes: a pass moves 1.45 MB (LIO) / 0.82 MB (VIO) = 0.2 us at 8 TB/s, against "
+                        "two cross-workgroup hand-offs of ~2 us each per pass (SURVEY.md fact 5); see the DESIGN.md size sweep"}
         if args.sweep:
             sweep(capi, synth, scene, cfg, x0, sys.stderr)
 
@@ -259,7 +272,8 @@ def main():
                        "iteration_definition": "one LIO pass + one VIO pass, each = residuals + Jacobian rows + "
                                                "normal equations + gain solve + state update",
                        "parallelism": f"point/patch-range shards x{world}, all-reduce of the 32-double normal-equation "
-                                      f"record per pass ({exchange})" if world > 1 else "single GPU, fused pass kernels"},
+                                      f"record per pass ({exchange})" if world > 1 else
+                                      f"single GPU, fused multi-pass kernels ({PASSES_PER_LAUNCH} consecutive passes per launch, as in one frame)"},
             "frame_iterations_per_s": frame_it_s,
             "state_finite": finite,
             "roofline": roof,

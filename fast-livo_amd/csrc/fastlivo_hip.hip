@@ -41,6 +41,7 @@ struct fl_context {
     void *d_records = nullptr;      // tagged per-workgroup records (handoff.h)
     unsigned *d_epoch = nullptr;    // launch epoch of the records, advanced on the device
     double *d_sums_tmp = nullptr;
+    unsigned long long *d_bcast = nullptr;   // pose broadcast words of the multi-pass kernels (handoff.h)
     // VIO
     FlVioConst *d_vc = nullptr;
     FlVioConst h_vc;
@@ -185,6 +186,8 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
     HIPCHK(h, hipMalloc(&h->d_records, (size_t)16 * FL_MAX_BLOCKS * FL_SUMS23));
     HIPCHK(h, hipMalloc(&h->d_epoch, 64));
     HIPCHK(h, hipMalloc(&h->d_sums_tmp, sizeof(double) * FL_SUMS23));
+    HIPCHK(h, hipMalloc(&h->d_bcast, sizeof(unsigned long long) * 64));
+    HIPCHK(h, hipMemset(h->d_bcast, 0, sizeof(unsigned long long) * 64));
     HIPCHK(h, hipMalloc(&h->d_vc, sizeof(FlVioConst)));
     HIPCHK(h, hipMemset(h->d_records, 0, (size_t)16 * FL_MAX_BLOCKS * FL_SUMS23));
     {
@@ -214,7 +217,7 @@ int32_t fl_destroy(fl_handle h)
     hipStreamSynchronize(h->stream);
     hipFree(h->d_body); hipFree(h->d_nbr); hipFree(h->d_world); hipFree(h->d_valid); hipFree(h->d_sel);
     hipFree(h->d_plane); hipFree(h->d_normvec); hipFree(h->d_dev); hipFree(h->d_dev23); hipFree(h->d_records);
-    hipFree(h->d_epoch); hipFree(h->d_sums_tmp); hipFree(h->d_vc); hipFree(h->d_img); hipFree(h->d_ref);
+    hipFree(h->d_epoch); hipFree(h->d_sums_tmp); hipFree(h->d_bcast); hipFree(h->d_vc); hipFree(h->d_img); hipFree(h->d_ref);
     hipFree(h->d_errors); hipFree(h->d_pos); hipFree(h->d_slevel);
     hipFree(h->d_map_raw); hipFree(h->d_map_pts); hipFree(h->d_map_keys); hipFree(h->d_map_keys_tmp); hipFree(h->d_map_idx);
     hipFree(h->d_map_idx_tmp); hipFree(h->d_map_htab); hipFree(h->d_map_sort_tmp);
@@ -466,6 +469,26 @@ static int32_t read_info18(fl_handle h, fl_iter_info *info)
     return FL_OK;
 }
 
+// `count` passes: one multi-pass launch when the grid is certainly co-resident (<= 256 workgroups, one per CU at most),
+// else one launch per pass. FL_NO_MULTIPASS=1 (env) forces the latter (A/B measurements).
+static bool fl_multipass_enabled()
+{
+    static int v = -1;
+    if (v < 0) v = getenv("FL_NO_MULTIPASS") ? 0 : 1;
+    return v == 1;
+}
+static void launch_lio_passes(fl_handle h, int grid, int count, int flags)
+{
+    if (count > 1 && grid <= 256 && fl_multipass_enabled()) {
+        hipLaunchKernelGGL(lio18_multipass_kernel, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_body, h->d_plane, h->d_sel, h->d_normvec,
+                           h->n, h->d_dev, h->d_records, h->d_epoch, h->d_bcast, (int)count, (int)flags);
+        return;
+    }
+    for (int i = 0; i < count; i++)
+        hipLaunchKernelGGL(lio18_pass_kernel<0>, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_body, h->d_plane, h->d_sel,
+                           h->d_normvec, h->n, h->d_dev, h->d_records, h->d_epoch, (double *)nullptr, (int)flags);
+}
+
 int32_t fl_lio_iterate18(fl_handle h, int32_t count, int32_t flags, fl_iter_info *info)
 {
     if (!h || count < 0) return fail_arg(h, "fl_lio_iterate18: bad argument");
@@ -473,9 +496,7 @@ int32_t fl_lio_iterate18(fl_handle h, int32_t count, int32_t flags, fl_iter_info
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int grid = lio_grid(h->n);
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    for (int i = 0; i < count; i++)
-        hipLaunchKernelGGL(lio18_pass_kernel<0>, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_body, h->d_plane, h->d_sel,
-                           h->d_normvec, h->n, h->d_dev, h->d_records, h->d_epoch, (double *)nullptr, (int)flags);
+    launch_lio_passes(h, grid, count, flags);
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipGetLastError());
     h->last_launches = count;

@@ -147,3 +147,49 @@ __device__ __forceinline__ int gather_records(const void *records, int nprod, un
     }
     return __syncthreads_or(timeout) ? FL_NUM_TIMEOUT : 0;
 }
+
+
+// ---- state broadcast of the multi-pass kernels: solver workgroup -> every producer workgroup, inside one launch.
+// The new pose (12 doubles) + a control word travel as 25 self-validating 8-byte words: high 32 bits = payload (one
+// half of a double, or the control bits), low 32 bits = the pass epoch the word belongs to. An aligned 8-byte store
+// is single-copy atomic and written through (sc1); a reader that sees the expected epoch in a word has that word's
+// payload -- no fence, no flag ordering (Guideline 16 "the data IS the flag"), and the doubles arrive bit-exact.
+#define FL_BCAST_WORDS 25
+__device__ __forceinline__ void bcast_publish(unsigned long long *words, const double *x12 /* LDS */, int ctrl, unsigned epoch)
+{
+    const int tid = threadIdx.x;
+    if (tid < FL_BCAST_WORDS) {
+        unsigned payload;
+        if (tid < 24) {
+            const double v = x12[tid >> 1];
+            payload = (tid & 1) ? f64_hi(v) : f64_lo(v);
+        } else {
+            payload = (unsigned)ctrl;
+        }
+        __hip_atomic_store(words + tid, ((unsigned long long)payload << 32) | (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// Wave 0 of a producer workgroup polls; on return (after the caller's __syncthreads) out13[0..11] = pose, *ctrl_out = control
+// bits. Returns 0, or FL_NUM_TIMEOUT when the words never showed up (bounded spin).
+__device__ __forceinline__ int bcast_wait(const unsigned long long *words, unsigned epoch, double *out12 /* LDS */, int *ctrl_out /* LDS */)
+{
+    const int tid = threadIdx.x;
+    int timeout = 0;
+    if (tid < 64) {
+        unsigned long long w = 0ull;
+        bool ok = tid >= FL_BCAST_WORDS;
+        for (int spin = 0; ; spin++) {
+            if (!ok) {
+                w = __hip_atomic_load(words + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ((unsigned)w == epoch);
+            }
+            if (__ballot(ok) == ~0ull) break;
+            if (spin > FL_GATHER_SPIN_LIMIT) { timeout = FL_NUM_TIMEOUT; break; }
+        }
+        const unsigned payload = (unsigned)(w >> 32);
+        const unsigned other = (unsigned)__shfl_xor((int)payload, 1, 64);
+        if (tid < 24 && (tid & 1) == 0) out12[tid >> 1] = f64_make(payload, other);
+        if (tid == 24) *ctrl_out = timeout ? 5 : (int)payload;
+    }
+    return timeout;
+}

@@ -186,6 +186,125 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_pass_kernel(const float *__re
     if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();
 }
 
+// -------------------------------------------------------------------------------------------- K1m
+// Up to `count` passes in ONE launch (the LIO block of a frame between two searches): the kernel boundary (~1.5 us), the
+// launch prologue and the no-op launches after stop/need_search disappear. Per pass the producers wait for the pose of the
+// previous solve (bcast_wait, handoff.h), the solver gathers the records, solves, and broadcasts the new pose together with
+// the stop / search-wanted bits, so every workgroup leaves the loop at the same pass. The points' loads do not depend on the
+// pose and are issued before the wait. Requires every workgroup co-resident: the host uses it only for grids <= 256
+// workgroups (<= 1 per CU) and falls back to one launch per pass otherwise; every spin is bounded.
+// Arithmetic per pass is that of lio18_pass_kernel<0>: states are bit-identical.
+__global__ __launch_bounds__(FL_LIO_NT) void lio18_multipass_kernel(const float *__restrict__ body, const float4 *__restrict__ plane,
+                                                                   uint8_t *__restrict__ sel, float4 *__restrict__ normvec, int n,
+                                                                   FlDev18 *__restrict__ D, void *__restrict__ records,
+                                                                   unsigned *__restrict__ epoch_ptr, unsigned long long *__restrict__ bcast,
+                                                                   int count, int flags)
+{
+    constexpr int NT = FL_LIO_NT;
+    const int nprod = gridDim.x - 1;
+    const bool force = (flags & FL_ITER_FORCE) != 0;
+    if (!force && (D->stop || (D->need_search && D->searched_at != D->iters_run))) return;
+    const unsigned epoch0 = *epoch_ptr;
+
+    if (blockIdx.x == nprod) {
+        // ------------------------------------------------------------------ solver workgroup
+        __shared__ double s_fin[2 * NT];
+        __shared__ double s_sums[FL_SUMS18];
+        __shared__ FlSolveLds s_solve;
+        eskf18_prefetch(D, s_solve);
+        int done = 0;
+        for (int p = 0; p < count; p++) {
+            const unsigned epoch = epoch0 + (unsigned)p;
+            if (p == 5) fl_stamp(flags, 16);
+            const int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
+            if (p == 5) fl_stamp(flags, 17);
+            eskf18_solve_block<FL_EPI_LIO>(D, s_sums, s_solve, gst, bcast, epoch + 1u);   // publishes pose + control word
+            __syncthreads();
+            if (p == 5) fl_stamp(flags, 18);
+            done = p + 1;
+            const int ctrl = s_solve.ctrl;                       // bit 2: a gather timeout ends the launch
+            if (!force && (ctrl & 3)) break;
+            if (ctrl & 4) break;
+            if (p + 1 < count) eskf18_restage(s_solve);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *epoch_ptr = epoch0 + (unsigned)done;
+        return;
+    }
+
+    // -------------------------------------------------------------------- producer workgroups
+    __shared__ double s_red[(NT / 64) * FL_SUMS18];
+    __shared__ double s_pose[12];
+    __shared__ int s_ctrl;
+    double R[9], p[3], RLI[9], tLI[3];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { R[i] = D->x[i]; RLI[i] = D->R_LI[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { p[i] = D->x[9 + i]; tLI[i] = D->t_LI[i]; }
+    const int i_first = blockIdx.x * NT + threadIdx.x;
+
+    for (int ps = 0; ps < count; ps++) {
+        const unsigned epoch = epoch0 + (unsigned)ps;
+        // this pass's first point: loads issued before the wait for the pose
+        uint8_t pf_sel = 0;
+        float pf_b0 = 0.f, pf_b1 = 0.f, pf_b2 = 0.f;
+        float4 pf_pl = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i_first < n) {
+            pf_sel = sel[i_first];
+            pf_b0 = body[i_first * 3 + 0]; pf_b1 = body[i_first * 3 + 1]; pf_b2 = body[i_first * 3 + 2];
+            pf_pl = plane[i_first];
+        }
+        if (ps > 0) {
+            if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 20 + 4 * (ps - 5));
+            bcast_wait(bcast, epoch, s_pose, &s_ctrl);
+            __syncthreads();
+            if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 21 + 4 * (ps - 5));
+            if (!force && (s_ctrl & 3)) break;
+            if (s_ctrl & 4) break;
+#pragma unroll
+            for (int i = 0; i < 9; i++) R[i] = s_pose[i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) p[i] = s_pose[9 + i];
+        }
+        double v[FL_SUMS18];
+#pragma unroll
+        for (int k = 0; k < FL_SUMS18; k++) v[k] = 0.0;
+        for (int i = i_first; i < n; i += nprod * NT) {
+            const bool first = (i == i_first);
+            if (!(first ? pf_sel : sel[i])) continue;
+            float pb[3];
+            float4 plq;
+            if (first) {
+                pb[0] = pf_b0; pb[1] = pf_b1; pb[2] = pf_b2;
+                plq = pf_pl;
+            } else {
+                pb[0] = body[i * 3 + 0]; pb[1] = body[i * 3 + 1]; pb[2] = body[i * 3 + 2];
+                plq = plane[i];
+            }
+            const float pl[4] = {plq.x, plq.y, plq.z, plq.w};
+            double p_i[3];
+            float pw[3], pd2;
+            int eff;
+            const int s = fl_point_gates(pb, pl, R, p, RLI, tLI, p_i, pw, &pd2, &eff);
+            if (!s) sel[i] = 0;
+            if ((flags & FL_ITER_KEEP_NORMVEC) && s) normvec[i] = make_float4(pl[0], pl[1], pl[2], pd2);
+            if (eff) {
+                double row[6], z;
+                fl_row18(p_i, pl, pd2, R, row, &z);
+                fl_accum6(v, row, z);
+                v[FL_S_NEFF] += 1.0;
+                v[FL_S_RES] += (double)fabsf(pd2);
+                v[FL_S_RES2] += (double)pd2 * (double)pd2;
+            }
+        }
+        if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 22 + 4 * (ps - 5));
+        const double mine = block_reduce_record<NT, FL_SUMS18>(v, s_red);
+        publish_record<FL_SUMS18>(mine, epoch, records);
+        __syncthreads();          // s_red / s_pose are reused by the next pass
+        if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 23 + 4 * (ps - 5));
+    }
+}
+
 // -------------------------------------------------------------------------------------------- K3
 // Solve from an externally reduced record (sharded form). vio != 0 selects the VIO epilogue.
 struct FlVioConst;

@@ -26,6 +26,9 @@ struct FlSolveLds {
     double vec[18];
     double delta[18];
     double xn[12];      // rotation (9) and position (3) after the pass: input of the VIO derived pose
+    double xadd[15];    // the additive states (pos, vel, bg, ba, grav) after the pass (multi-pass kernels restage from LDS)
+    int ctrl;           // multi-pass kernels: bit0 stop, bit1 search wanted (written by the judging lane)
+    int pad2;
     float last_error;
     int accept;
     int st;
@@ -82,8 +85,16 @@ __device__ __forceinline__ void eskf18_prefetch(const FlDev18 *__restrict__ D, F
 
 // Solve + state update + judgement. All threads of the workgroup call it (NT >= 256); s_sums in LDS.
 // FMA contraction is allowed here (compared to the oracle by tolerance, never bitwise).
+// bcast != nullptr (multi-pass kernels): the lanes that form the new pose publish it themselves the moment it exists
+// (self-validating words of handoff.h, tagged bepoch), the judging lane publishes the control word.
+__device__ __forceinline__ void fl_bcast_store(unsigned long long *bcast, int idx, double v, unsigned bepoch)
+{
+    __hip_atomic_store(bcast + 2 * idx, ((unsigned long long)f64_lo(v) << 32) | (unsigned long long)bepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(bcast + 2 * idx + 1, ((unsigned long long)f64_hi(v) << 32) | (unsigned long long)bepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <int KIND>
-__device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, const double *s_sums, FlSolveLds &L, int gather_status)
+__device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, const double *s_sums, FlSolveLds &L, int gather_status,
+                                                   unsigned long long *bcast = nullptr, unsigned bepoch = 0u)
 {
 #pragma clang fp contract(fast)
     const int tid = threadIdx.x;
@@ -106,10 +117,12 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
                 const double xo = D->xold[tid];
                 D->x[tid] = xo;
                 if (tid < 12) L.xn[tid] = xo;
+                if (tid >= 9) L.xadd[tid - 9] = xo;
             }
             if (tid == 64) {
                 D->iters_run = D->iters_run + 1;
                 D->stop = 1;
+                L.ctrl = 1;
                 D->converged = 1;
                 D->neff = (int)s_sums[FL_S_NEFF];
                 D->total_residual = (double)L.last_error;
@@ -182,15 +195,21 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
                 }
                 D->x[lane] = acc;
                 L.xn[lane] = acc;
+                if (KIND == FL_EPI_LIO && bcast) fl_bcast_store(bcast, lane, acc, bepoch);
             } else {
                 L.xn[lane] = L.x[lane];
+                if (KIND == FL_EPI_LIO && bcast) fl_bcast_store(bcast, lane, L.x[lane], bepoch);
             }
         }
     } else if (wave == 1) {
         if (lane < 15) {
             const double nv = L.x[9 + lane] + L.delta[3 + lane];
             D->x[9 + lane] = nv;
-            if (lane < 3) L.xn[9 + lane] = nv;
+            L.xadd[lane] = nv;
+            if (lane < 3) {
+                L.xn[9 + lane] = nv;
+                if (KIND == FL_EPI_LIO && bcast) fl_bcast_store(bcast, 9 + lane, nv, bepoch);
+            }
         }
     } else if (wave == 2) {
         if (lane == 0) {
@@ -216,6 +235,10 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
                 D->neff = (int)s_sums[FL_S_NEFF];
                 D->total_residual = s_sums[FL_S_RES];
                 D->status = st | ((s_sums[FL_S_NEFF] < 1.0) ? 4 : 0);
+                L.ctrl = (stop ? 1 : 0) | (need_search ? 2 : 0) | (gather_status ? 4 : 0);
+                if (bcast)
+                    __hip_atomic_store(bcast + 24, ((unsigned long long)(unsigned)L.ctrl << 32) | (unsigned long long)bepoch, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 // lidar_selection.cpp:883-899
                 int stop = ((rn * 57.3f < 0.001f) && (tn * 100.0f < 0.001f)) ? 1 : 0;
@@ -228,7 +251,34 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
                 D->neff = (int)s_sums[FL_S_NEFF];
                 D->total_residual = (double)L.last_error;
                 D->status = st;
+                L.ctrl = stop ? 1 : 0;
             }
         }
+    }
+}
+
+// Multi-pass kernels: after eskf18_solve_block (and a __syncthreads) make the new state the solve input of the next
+// pass without a global round trip: x <- x (+) delta from LDS, vec = x_prop (-) x as in eskf18_prefetch_commit.
+__device__ __forceinline__ void eskf18_restage(FlSolveLds &L)
+{
+    const int tid = threadIdx.x;
+    if (tid < 9) L.x[tid] = L.xn[tid];
+    else if (tid < 24) L.x[tid] = L.xadd[tid - 9];
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    if (wave == 1) {
+        if (lane < 15) L.vec[3 + lane] = L.xp[9 + lane] - L.x[9 + lane];
+    } else if (wave == 2 && lane == 0) {
+        double rd[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) rd[i * 3 + j] = L.x[0 * 3 + i] * L.xp[0 * 3 + j] + L.x[1 * 3 + i] * L.xp[1 * 3 + j] + L.x[2 * 3 + i] * L.xp[2 * 3 + j];
+        const double tr = rd[0] + rd[4] + rd[8];
+        const double theta = (tr > 3.0 - 1e-6) ? 0.0 : acos(0.5 * (tr - 1));
+        const double fk = (fabs(theta) < 0.001) ? 0.5 : (0.5 * theta / sin(theta));
+        L.vec[0] = fk * (rd[7] - rd[5]);
+        L.vec[1] = fk * (rd[2] - rd[6]);
+        L.vec[2] = fk * (rd[3] - rd[1]);
     }
 }

@@ -190,74 +190,48 @@ __global__ void vio_derive_kernel(FlDev18 *__restrict__ D, const FlVioConst *__r
 // patches per wavefront halve it: 2000 patches = 1000 waves = one wave per SIMD of the chip instead of
 // two sharing each SIMD (measured: producers 5.5 us -> see DESIGN.md). 256-thread workgroups, 8
 // patches each: 250 records, gathered in a single sweep.
-template <int MODE>
-__global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__restrict__ img, const float *__restrict__ ref,
-                                                            const double *__restrict__ pos, const int32_t *__restrict__ slevel,
-                                                            float *__restrict__ errors, int m, int level_arg,
-                                                            const FlVioConst *__restrict__ VC, FlDev18 *__restrict__ D,
-                                                            void *__restrict__ records, unsigned *__restrict__ epoch_ptr,
-                                                            double *__restrict__ sums_out, int flags)
+// The first patch's inputs do not depend on the state: their loads are issued before the state round trip.
+struct FlVioFirst {
+    int slevel;
+    double pos0, pos1, pos2;
+    float ref0, ref1;
+    bool have;
+};
+__device__ __forceinline__ FlVioFirst vio_prefetch_first(const float *__restrict__ ref, const double *__restrict__ pos,
+                                                        const int32_t *__restrict__ slevel, int m, int level_arg, int nprod)
 {
-    constexpr int NT = FL_VIO_NT;
-    constexpr int WPB = NT / 64;
-    const int nprod = gridDim.x - 1;
-    if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();
-    // Software prefetch (see lio18_pass_kernel): the first patch's position, search level and
-    // reference row do not depend on the state; issue their loads before the state round trip.
+    constexpr int WPB = FL_VIO_NT / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, hl = lane & 31;
     const int i_first = (blockIdx.x * WPB + wave) * 2 + half;
-    const bool have_first = (blockIdx.x != nprod) && (i_first < m);
-    int pf_slevel = 0;
-    double pf_pos0 = 0.0, pf_pos1 = 0.0, pf_pos2 = 0.0;
-    float pf_ref[2] = {0.f, 0.f};
-    if (have_first) {
-        pf_slevel = slevel[i_first];
-        pf_pos0 = pos[i_first * 3 + 0]; pf_pos1 = pos[i_first * 3 + 1]; pf_pos2 = pos[i_first * 3 + 2];
+    FlVioFirst f;
+    f.have = (blockIdx.x != nprod) && (i_first < m);
+    f.slevel = 0; f.pos0 = 0.0; f.pos1 = 0.0; f.pos2 = 0.0; f.ref0 = 0.f; f.ref1 = 0.f;
+    if (f.have) {
+        f.slevel = slevel[i_first];
+        f.pos0 = pos[i_first * 3 + 0]; f.pos1 = pos[i_first * 3 + 1]; f.pos2 = pos[i_first * 3 + 2];
         if (level_arg >= 0) {
-            pf_ref[0] = ref[(size_t)i_first * 192 + 64 * level_arg + hl];
-            pf_ref[1] = ref[(size_t)i_first * 192 + 64 * level_arg + hl + 32];
+            f.ref0 = ref[(size_t)i_first * 192 + 64 * level_arg + hl];
+            f.ref1 = ref[(size_t)i_first * 192 + 64 * level_arg + hl + 32];
         }
     }
-    double pf_solver = 0.0;
-    if (MODE == 0 && blockIdx.x == nprod) pf_solver = eskf18_prefetch_issue(D);
-    if (!(flags & FL_ITER_FORCE) && D->stop) return;
-    const unsigned epoch = *epoch_ptr;
+    return f;
+}
 
-    if (blockIdx.x == nprod) {
-        // ------------------------------------------------------------------ solver workgroup
-        __shared__ double s_fin[2 * NT];
-        __shared__ double s_sums[FL_SUMS18];
-        __shared__ FlSolveLds s_solve;
-        fl_stamp(flags, 8);
-        if (MODE == 0) eskf18_prefetch_commit(pf_solver, s_solve);
-        fl_stamp(flags, 9);
-        const int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
-        fl_stamp(flags, 10);
-        if (threadIdx.x == 0) *epoch_ptr = epoch + 1u;
-        if (MODE == 0) {
-            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, gst);
-            __syncthreads();
-            vio_derive_pose(s_solve.xn, VC, D);      // camera pose for the next pass's producers
-        } else {
-            if (threadIdx.x < FL_SUMS18) sums_out[threadIdx.x] = s_sums[threadIdx.x];
-        }
-        fl_stamp(flags, 11);
-        return;
-    }
-
-    // -------------------------------------------------------------------- producer workgroups
-    __shared__ double s_red[2 * WPB * FL_SUMS18];
-    const int level = (level_arg >= 0) ? level_arg : D->level;
-
-    // wave-uniform camera pose, derived from the state by the previous pass's solver (vio_derive_pose)
-    const FlVioConst vc = *VC;
-    double Rcw[9], Pcw[3];
-#pragma unroll
-    for (int i = 0; i < 9; i++) Rcw[i] = D->Rcw[i];
-#pragma unroll
-    for (int i = 0; i < 3; i++) Pcw[i] = D->Pcw[i];
-
+// One producer workgroup's share of a pass: residuals, rows, 6x6 update for its patches, reduced to one record and published.
+__device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, const float *__restrict__ ref, const double *__restrict__ pos,
+                                            const int32_t *__restrict__ slevel, float *__restrict__ errors, int m, int level_arg, int level,
+                                            const FlVioConst &vc, const double (&Rcw)[9], const double (&Pcw)[3], const FlVioFirst &pf,
+                                            int nprod, double *s_red, unsigned epoch, void *__restrict__ records, int flags)
+{
+    constexpr int WPB = FL_VIO_NT / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, hl = lane & 31;
+    const int i_first = (blockIdx.x * WPB + wave) * 2 + half;
+    const bool have_first = pf.have;
+    const int pf_slevel = pf.slevel;
+    const double pf_pos0 = pf.pos0, pf_pos1 = pf.pos1, pf_pos2 = pf.pos2;
+    const float pf_ref[2] = {pf.ref0, pf.ref1};
     const int xr = hl >> 3, yc = hl & 7;          // this lane's pixels: (xr, yc) and (xr + 4, yc)
     const int W = vc.stride, Hm1 = vc.height - 1, Wm1 = vc.width - 1;
 
@@ -352,8 +326,133 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
         for (int w = 1; w < 2 * WPB; w++) mine += s_red[w * FL_SUMS18 + threadIdx.x];
     }
     publish_record<FL_SUMS18>(mine, epoch, records);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__restrict__ img, const float *__restrict__ ref,
+                                                            const double *__restrict__ pos, const int32_t *__restrict__ slevel,
+                                                            float *__restrict__ errors, int m, int level_arg,
+                                                            const FlVioConst *__restrict__ VC, FlDev18 *__restrict__ D,
+                                                            void *__restrict__ records, unsigned *__restrict__ epoch_ptr,
+                                                            double *__restrict__ sums_out, int flags)
+{
+    constexpr int NT = FL_VIO_NT;
+    constexpr int WPB = NT / 64;
+    const int nprod = gridDim.x - 1;
+    if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();
+    const FlVioFirst pf = vio_prefetch_first(ref, pos, slevel, m, level_arg, nprod);
+    double pf_solver = 0.0;
+    if (MODE == 0 && blockIdx.x == nprod) pf_solver = eskf18_prefetch_issue(D);
+    if (!(flags & FL_ITER_FORCE) && D->stop) return;
+    const unsigned epoch = *epoch_ptr;
+
+    if (blockIdx.x == nprod) {
+        // ------------------------------------------------------------------ solver workgroup
+        __shared__ double s_fin[2 * NT];
+        __shared__ double s_sums[FL_SUMS18];
+        __shared__ FlSolveLds s_solve;
+        fl_stamp(flags, 8);
+        if (MODE == 0) eskf18_prefetch_commit(pf_solver, s_solve);
+        fl_stamp(flags, 9);
+        const int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
+        fl_stamp(flags, 10);
+        if (threadIdx.x == 0) *epoch_ptr = epoch + 1u;
+        if (MODE == 0) {
+            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, gst);
+            __syncthreads();
+            vio_derive_pose(s_solve.xn, VC, D);      // camera pose for the next pass's producers
+        } else {
+            if (threadIdx.x < FL_SUMS18) sums_out[threadIdx.x] = s_sums[threadIdx.x];
+        }
+        fl_stamp(flags, 11);
+        return;
+    }
+
+    // -------------------------------------------------------------------- producer workgroups
+    __shared__ double s_red[2 * WPB * FL_SUMS18];
+    const int level = (level_arg >= 0) ? level_arg : D->level;
+    // wave-uniform camera pose, derived from the state by the previous pass's solver (vio_derive_pose)
+    const FlVioConst vc = *VC;
+    double Rcw[9], Pcw[3];
+#pragma unroll
+    for (int i = 0; i < 9; i++) Rcw[i] = D->Rcw[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) Pcw[i] = D->Pcw[i];
+    vio_produce(img, ref, pos, slevel, errors, m, level_arg, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags);
     if (blockIdx.x == 0) fl_stamp(flags, 2);
     if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();
+}
+
+// Up to `count` passes of one pyramid level in ONE launch (see lio18_multipass_kernel): the solver broadcasts the derived camera
+// pose (Rcw, Pcw: what the producers consume) and the stop bit; a rejected solve (error went up, lidar_selection.cpp:888-892)
+// reverts and stops like the reference. Bit-identical to `count` launches of vio_pass_kernel<0>.
+__global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t *__restrict__ img, const float *__restrict__ ref,
+                                                                 const double *__restrict__ pos, const int32_t *__restrict__ slevel,
+                                                                 float *__restrict__ errors, int m, int level,
+                                                                 const FlVioConst *__restrict__ VC, FlDev18 *__restrict__ D,
+                                                                 void *__restrict__ records, unsigned *__restrict__ epoch_ptr,
+                                                                 unsigned long long *__restrict__ bcast, int count, int flags)
+{
+    constexpr int NT = FL_VIO_NT;
+    constexpr int WPB = NT / 64;
+    const int nprod = gridDim.x - 1;
+    const bool force = (flags & FL_ITER_FORCE) != 0;
+    if (!force && D->stop) return;
+    const unsigned epoch0 = *epoch_ptr;
+
+    if (blockIdx.x == nprod) {
+        __shared__ double s_fin[2 * NT];
+        __shared__ double s_sums[FL_SUMS18];
+        __shared__ FlSolveLds s_solve;
+        __shared__ double s_cam[12];
+        eskf18_prefetch(D, s_solve);
+        int done = 0;
+        for (int p = 0; p < count; p++) {
+            const unsigned epoch = epoch0 + (unsigned)p;
+            const int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
+            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, gst);
+            __syncthreads();
+            vio_derive_pose(s_solve.xn, VC, D);
+            // the same 12 threads publish what they just derived (D->Rcw / D->Pcw are their own stores)
+            if (threadIdx.x < 12) s_cam[threadIdx.x] = (threadIdx.x < 9) ? D->Rcw[threadIdx.x] : D->Pcw[threadIdx.x - 9];
+            __syncthreads();
+            done = p + 1;
+            const int ctrl = s_solve.ctrl | (gst ? 4 : 0);
+            bcast_publish(bcast, s_cam, ctrl, epoch + 1u);
+            if (!force && (ctrl & 3)) break;
+            if (ctrl & 4) break;
+            if (p + 1 < count) eskf18_restage(s_solve);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *epoch_ptr = epoch0 + (unsigned)done;
+        return;
+    }
+
+    __shared__ double s_red[2 * WPB * FL_SUMS18];
+    __shared__ double s_pose[12];
+    __shared__ int s_ctrl;
+    const FlVioConst vc = *VC;
+    double Rcw[9], Pcw[3];
+#pragma unroll
+    for (int i = 0; i < 9; i++) Rcw[i] = D->Rcw[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) Pcw[i] = D->Pcw[i];
+    for (int ps = 0; ps < count; ps++) {
+        const unsigned epoch = epoch0 + (unsigned)ps;
+        const FlVioFirst pf = vio_prefetch_first(ref, pos, slevel, m, level, nprod);
+        if (ps > 0) {
+            bcast_wait(bcast, epoch, s_pose, &s_ctrl);
+            __syncthreads();
+            if (!force && (s_ctrl & 3)) break;
+            if (s_ctrl & 4) break;
+#pragma unroll
+            for (int i = 0; i < 9; i++) Rcw[i] = s_pose[i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) Pcw[i] = s_pose[9 + i];
+        }
+        vio_produce(img, ref, pos, slevel, errors, m, level, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags);
+        __syncthreads();
+    }
 }
 
 // UpdateState prologue: old_state = *state, last_error = total_residual (:747,756); per-level counters.

@@ -1,0 +1,131 @@
+"""Multi-pass LIO kernel (several ESKF passes in one launch, pose broadcast in-kernel) vs one launch per pass: bit-identical
+states, selections and counters, with and without the convergence logic; whole all-device frame vs the per-pass path
+(FL_NO_MULTIPASS=1 in a child process)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _prep(capi, synth, scene, n, max_iter=10):
+    fr = synth.make_lio_frame(n, scene=scene)
+    nbr, valid = synth.knn5(scene, fr.world_at(fr.R_prior, fr.p_prior))
+    h = capi.Handle(capi.config_from_frames(fr, max_iterations=max_iter))
+    x0 = capi.state18_from_frame(fr)
+    h.lio_set_points(fr.body_xyz); h.lio_begin18(x0, x0); h.lio_set_neighbours(nbr, valid)
+    return fr, h
+
+
+@pytest.mark.parametrize("n", [300, 20000, 60000])
+def test_forced_multipass_equals_single_launches(gpu_lib, scene, n):
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    F = capi.FL_ITER_FORCE | capi.FL_ITER_KEEP_NORMVEC
+    fr, h1 = _prep(capi, synth, scene, n)
+    for _ in range(7):
+        i1 = h1.lio_iterate18(1, F)
+    fr, h2 = _prep(capi, synth, scene, n)
+    i2 = h2.lio_iterate18(7, F)
+    assert np.array_equal(h1.lio_get_state18().vec(), h2.lio_get_state18().vec())
+    assert i1.iterations == i2.iterations == 7 and i1.effct_feat_num == i2.effct_feat_num
+    assert list(i1.solution) == list(i2.solution)
+    m1, v1 = h1.lio_get_selection(n); m2, v2 = h2.lio_get_selection(n)
+    assert np.array_equal(m1, m2) and np.array_equal(v1.view(np.uint32), v2.view(np.uint32))
+    # and a second multi-pass launch continues where the first stopped
+    h1.lio_iterate18(1, F); h1.lio_iterate18(1, F)
+    h2.lio_iterate18(2, F)
+    assert np.array_equal(h1.lio_get_state18().vec(), h2.lio_get_state18().vec())
+
+
+def test_convergence_logic_stops_the_launch(gpu_lib, scene):
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    fr, h1 = _prep(capi, synth, scene, 20000)
+    infos = []
+    for _ in range(11):
+        infos.append(h1.lio_iterate18(1, 0))
+        if infos[-1].need_search or infos[-1].stop:
+            break
+    fr, h2 = _prep(capi, synth, scene, 20000)
+    i2 = h2.lio_iterate18(11, 0)
+    assert i2.iterations == infos[-1].iterations and i2.need_search == infos[-1].need_search and i2.stop == infos[-1].stop
+    assert np.array_equal(h1.lio_get_state18().vec(), h2.lio_get_state18().vec())
+    # a further launch without a new search is a no-op, exactly like single launches
+    before = h2.lio_get_state18().vec()
+    i3 = h2.lio_iterate18(5, 0)
+    assert i3.iterations == i2.iterations and np.array_equal(before, h2.lio_get_state18().vec())
+
+
+_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import fastlivo
+from fast_livo_amd import capi, synth
+fr = synth.make_lio_frame(30000)
+h = capi.Handle(capi.config_from_frames(fr, max_iterations=10))
+h.map_set_points(fr.scene.map_xyz, 0.5)
+x = capi.state18_from_frame(fr)
+info = h.lio_frame18_dev(x, fr.body_xyz)
+m, v = h.lio_get_selection(fr.n)
+sys.stdout.buffer.write(bytes(x) + np.int32([info.iterations, info.effct_feat_num]).tobytes() + m.tobytes() + v.tobytes())
+"""
+
+
+def test_all_device_frame_same_with_and_without_multipass(gpu_lib):
+    outs = []
+    for env in ({}, {"FL_NO_MULTIPASS": "1"}):
+        e = dict(os.environ); e.update(env)
+        outs.append(subprocess.run([sys.executable, "-c", _CHILD % ROOT], env=e, check=True, capture_output=True).stdout)
+    assert len(outs[0]) > 1000 and outs[0] == outs[1]
+
+
+def _prep_vio(capi, synth, m, max_iter=10):
+    lio = synth.make_lio_frame(2000)
+    vf = synth.make_vio_frame(m, lio)
+    h = capi.Handle(capi.config_from_frames(lio, vf, max_iterations=max_iter))
+    x0 = capi.state18_from_frame(lio)
+    h.vio_set_frame(vf.img); h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level); h.vio_begin(x0, x0)
+    return lio, vf, h
+
+
+@pytest.mark.parametrize("m,level", [(7, 0), (500, 1), (2000, 0)])
+def test_vio_forced_multipass_equals_single_launches(gpu_lib, m, level):
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    F = capi.FL_ITER_FORCE
+    _, _, h1 = _prep_vio(capi, synth, m)
+    for _ in range(6):
+        i1 = h1.vio_iterate(level, 1, F)
+    _, _, h2 = _prep_vio(capi, synth, m)
+    i2 = h2.vio_iterate(level, 6, F)
+    assert np.array_equal(h1.vio_get_state18().vec(), h2.vio_get_state18().vec())
+    assert list(i1.solution) == list(i2.solution) and i1.accepted == i2.accepted and i1.iterations == i2.iterations
+    assert np.array_equal(h1.vio_get_errors(m).view(np.uint32), h2.vio_get_errors(m).view(np.uint32))
+
+
+def test_vio_compute_j_same_with_and_without_multipass(gpu_lib):
+    """ComputeJ (3 levels x up to max_iterations passes, accept/revert/stop logic) in a child process per mode."""
+    child = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import fastlivo
+from fast_livo_amd import capi, synth
+lio = synth.make_lio_frame(2000)
+vf = synth.make_vio_frame(1500, lio)
+h = capi.Handle(capi.config_from_frames(lio, vf, max_iterations=10))
+x = capi.state18_from_frame(lio); xp = capi.state18_from_frame(lio)
+h.vio_set_frame(vf.img); h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+infos = h.vio_compute_j(x, xp)
+e = h.vio_get_errors(vf.m)
+sys.stdout.buffer.write(bytes(x) + np.int32([i.iterations for i in infos] + [i.accepted for i in infos]).tobytes() + e.tobytes())
+''' % ROOT
+    outs = []
+    for env in ({}, {"FL_NO_MULTIPASS": "1"}):
+        e = dict(os.environ); e.update(env)
+        outs.append(subprocess.run([sys.executable, "-c", child], env=e, check=True, capture_output=True).stdout)
+    assert len(outs[0]) > 1000 and outs[0] == outs[1]
