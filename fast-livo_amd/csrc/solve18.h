@@ -28,7 +28,8 @@ struct FlSolveLds {
     double xn[12];      // rotation (9) and position (3) after the pass: input of the VIO derived pose
     double xadd[15];    // the additive states (pos, vel, bg, ba, grav) after the pass (multi-pass kernels restage from LDS)
     int ctrl;           // multi-pass kernels: bit0 stop, bit1 search wanted (written by the judging lane)
-    int pad2;
+    // loop counters of the judgement, staged with the solve inputs so that the judging lane does not wait for global loads
+    int rematch, iterCount, max_iter, iters_run, accepted;
     float last_error;
     int accept;
     int st;
@@ -36,6 +37,36 @@ struct FlSolveLds {
 };
 
 enum { FL_EPI_LIO = 0, FL_EPI_VIO = 1 };
+
+// sin(x) and 1 - cos(x) of the rotation update. The increments of an ESKF pass are tiny (|x| << 0.5): a Taylor/Horner form
+// (truncation < 1e-17 relative for |x| <= 0.5, and 1 - cos without cancellation) replaces two library calls of several hundred
+// dependent cycles each on the solver workgroup's critical path; larger angles use the library. The solve is compared to the
+// oracle by tolerance (1e-9), never bitwise.
+__device__ __forceinline__ void fl_sin_omc(double x, double *s, double *omc)
+{
+    if (fabs(x) <= 0.5) {
+        const double x2 = x * x;
+        double ps = -1.0 / 1307674368000.0;
+        ps = ps * x2 + 1.0 / 6227020800.0;
+        ps = ps * x2 - 1.0 / 39916800.0;
+        ps = ps * x2 + 1.0 / 362880.0;
+        ps = ps * x2 - 1.0 / 5040.0;
+        ps = ps * x2 + 1.0 / 120.0;
+        ps = ps * x2 - 1.0 / 6.0;
+        *s = x + x * (x2 * ps);
+        double pc = 1.0 / 87178291200.0;
+        pc = pc * x2 - 1.0 / 479001600.0;
+        pc = pc * x2 + 1.0 / 3628800.0;
+        pc = pc * x2 - 1.0 / 40320.0;
+        pc = pc * x2 + 1.0 / 720.0;
+        pc = pc * x2 - 1.0 / 24.0;
+        pc = pc * x2 + 0.5;
+        *omc = x2 * pc;
+    } else {
+        *s = sin(x);
+        *omc = 1.0 - cos(x);
+    }
+}
 
 // Stage 0 (before the gather): stage the solve inputs in LDS and form vec = x_prop (-) x.
 // Split in two so that the loads can be issued before the kernel's control-word round trip.
@@ -48,6 +79,11 @@ __device__ __forceinline__ double eskf18_prefetch_issue(const FlDev18 *__restric
     else if (tid < 168) v = D->x[tid - 144];
     else if (tid < 192) v = D->xprop[tid - 168];
     else if (tid == 192) v = (double)D->last_error;
+    else if (tid == 193) v = (double)D->rematch_num;
+    else if (tid == 194) v = (double)D->iterCount;
+    else if (tid == 195) v = (double)D->max_iter;
+    else if (tid == 196) v = (double)D->iters_run;
+    else if (tid == 197) v = (double)D->accepted;
     return v;
 }
 __device__ __forceinline__ void eskf18_prefetch_commit(double v, FlSolveLds &L)
@@ -58,6 +94,11 @@ __device__ __forceinline__ void eskf18_prefetch_commit(double v, FlSolveLds &L)
     else if (tid < 168) L.x[tid - 144] = v;
     else if (tid < 192) L.xp[tid - 168] = v;
     else if (tid == 192) L.last_error = (float)v;
+    else if (tid == 193) L.rematch = (int)v;
+    else if (tid == 194) L.iterCount = (int)v;
+    else if (tid == 195) L.max_iter = (int)v;
+    else if (tid == 196) L.iters_run = (int)v;
+    else if (tid == 197) L.accepted = (int)v;
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     if (wave == 1) {
@@ -120,7 +161,8 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
                 if (tid >= 9) L.xadd[tid - 9] = xo;
             }
             if (tid == 64) {
-                D->iters_run = D->iters_run + 1;
+                L.iters_run = L.iters_run + 1;
+                D->iters_run = L.iters_run;
                 D->stop = 1;
                 L.ctrl = 1;
                 D->converged = 1;
@@ -180,7 +222,8 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
             if (nrm > 0.00001) {
                 const double r0 = d0 / nrm, r1 = d1 / nrm, r2 = d2 / nrm;
                 const double K[9] = {0.0, -r2, r1, r2, 0.0, -r0, -r1, r0, 0.0};
-                const double s = sin(nrm), c = 1.0 - cos(nrm);
+                double s, c;
+                fl_sin_omc(nrm, &s, &c);
                 double acc = 0.0;
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
@@ -222,16 +265,17 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
             if (KIND == FL_EPI_LIO) {
                 // laserMapping.cpp:1688-1728
                 const int converged = (rn * 57.3 < 0.01) && (tn * 100 < 0.015);
-                int rematch = D->rematch_num, need_search = 0, stop = 0;
-                const int it = D->iterCount;
-                if (converged || ((rematch == 0) && (it == (D->max_iter - 2)))) { need_search = 1; rematch++; }
-                if (rematch >= 2 || (it == D->max_iter - 1)) stop = 1;
+                int rematch = L.rematch, need_search = 0, stop = 0;
+                const int it = L.iterCount;
+                if (converged || ((rematch == 0) && (it == (L.max_iter - 2)))) { need_search = 1; rematch++; }
+                if (rematch >= 2 || (it == L.max_iter - 1)) stop = 1;
+                L.rematch = rematch; L.iterCount = it + 1; L.iters_run = L.iters_run + 1;
                 D->converged = converged;
                 D->rematch_num = rematch;
                 D->need_search = need_search;
                 D->stop = stop;
                 D->iterCount = it + 1;
-                D->iters_run = D->iters_run + 1;
+                D->iters_run = L.iters_run;
                 D->neff = (int)s_sums[FL_S_NEFF];
                 D->total_residual = s_sums[FL_S_RES];
                 D->status = st | ((s_sums[FL_S_NEFF] < 1.0) ? 4 : 0);
@@ -243,10 +287,12 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
                 // lidar_selection.cpp:883-899
                 int stop = ((rn * 57.3f < 0.001f) && (tn * 100.0f < 0.001f)) ? 1 : 0;
                 D->converged = stop;
-                D->accepted = D->accepted + 1;
-                const int it = D->iters_run + 1;
+                L.accepted = L.accepted + 1;
+                D->accepted = L.accepted;
+                const int it = L.iters_run + 1;
+                L.iters_run = it;
                 D->iters_run = it;
-                if (it >= D->max_iter) stop = 1;
+                if (it >= L.max_iter) stop = 1;
                 D->stop = stop;
                 D->neff = (int)s_sums[FL_S_NEFF];
                 D->total_residual = (double)L.last_error;
