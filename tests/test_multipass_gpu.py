@@ -21,7 +21,7 @@ def _prep(capi, synth, scene, n, max_iter=10):
     return fr, h
 
 
-@pytest.mark.parametrize("n", [300, 20000, 60000])
+@pytest.mark.parametrize("n", [300, 20000, 60000, 120000])   # 120000: grid-stride producers (255 workgroups)
 def test_forced_multipass_equals_single_launches(gpu_lib, scene, n):
     capi = gpu_lib
     from fast_livo_amd import synth
