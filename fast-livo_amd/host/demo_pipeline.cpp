@@ -1,0 +1,61 @@
+// demo_pipeline.cpp -- the LiDAR front of a frame through the host mirror, from plain C++ over the C ABI:
+// ImuProcessDev::UndistortPcl -> VoxelGridDev::filter_to_scan -> LioMode18Dev::update (map search on the device).
+// Input: little-endian binary written by tests/test_host_mirror_gpu.py; output: the updated StatesGroup as text.
+#include "fastlivo_shim.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+using namespace fastlivo_host;
+template <typename T> static void rd(FILE *f, T *p, size_t n) { if (fread(p, sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } }
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: demo_pipeline frame.bin\n"); return 2; }
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) { perror("open"); return 2; }
+    int32_t n, n_imu, k_map, max_iter;
+    float leaf, cell;
+    double beg, end;
+    rd(f, &n, 1); rd(f, &n_imu, 1); rd(f, &k_map, 1); rd(f, &max_iter, 1); rd(f, &leaf, 1); rd(f, &cell, 1); rd(f, &beg, 1); rd(f, &end, 1);
+    fl_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.device = 0; cfg.max_iterations = max_iter; cfg.img_width = 640; cfg.img_height = 512; cfg.patch_size = 8;
+    rd(f, cfg.R_LI, 9); rd(f, cfg.t_LI, 3);
+    for (int i = 0; i < 9; i++) cfg.Rcl[i] = (i % 4 == 0);
+    cfg.fx = cfg.fy = 400; cfg.cx = 320; cfg.cy = 256;
+    cfg.laser_point_cov = 0.001; cfg.img_point_cov = 100;
+    StatesGroup state;
+    rd(f, state.rot_end.m, 9); rd(f, state.pos_end.v, 3); rd(f, state.vel_end.v, 3); rd(f, state.bias_g.v, 3);
+    rd(f, state.bias_a.v, 3); rd(f, state.gravity.v, 3); rd(f, state.cov, 324);
+    ImuProcessDev imu;
+    rd(f, &imu.proc, 1);
+    std::vector<fl_imu_sample> samples((size_t)n_imu);
+    rd(f, samples.data(), samples.size());
+    std::vector<float> pts((size_t)n * 4), map((size_t)k_map * 3);
+    rd(f, pts.data(), pts.size()); rd(f, map.data(), map.size());
+    fclose(f);
+
+    fl_handle h = nullptr;
+    int32_t st = fl_create(&cfg, &h);
+    if (st) { fprintf(stderr, "fl_create: %d %s\n", st, fl_last_error_string(nullptr)); return 1; }
+    imu.handle = h;
+    VoxelGridDev vg; vg.handle = h; vg.setLeafSize(leaf, leaf, leaf);
+    LioMode18Dev lio; lio.handle = h;
+    if (lio.set_map(map.data(), k_map, cell)) { fprintf(stderr, "set_map: %s\n", fl_last_error_string(h)); return 1; }
+    imu.UndistortPcl(samples, beg, end, state, pts, /*keep_on_device=*/true);
+    vg.setInputCloudOnDevice(n);
+    const int feats_down_size = vg.filter_to_scan();
+    lio.update(state, nullptr, 0);
+    if (imu.last_status < 0 || vg.last_status < 0 || lio.last_status < 0) { fprintf(stderr, "error: %s\n", fl_last_error_string(h)); return 1; }
+    printf("status %d iter %d neff %d scan %d\n", lio.last_status, lio.iterCount, lio.effct_feat_num, feats_down_size);
+    for (int i = 0; i < 9; i++) printf("%.17g ", state.rot_end.m[i]);
+    for (int i = 0; i < 3; i++) printf("%.17g ", state.pos_end.v[i]);
+    for (int i = 0; i < 3; i++) printf("%.17g ", state.vel_end.v[i]);
+    printf("\n");
+    for (int i = 0; i < 18; i++) printf("%.17g ", state.cov[i * 18 + i]);
+    printf("\n%.17g %.17g\n", imu.proc.last_lidar_end_time, imu.proc.acc_s_last[2]);
+    fl_destroy(h);
+    return 0;
+}

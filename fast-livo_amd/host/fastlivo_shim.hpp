@@ -167,6 +167,96 @@ struct LioMode18 {
 };
 
 // ------------------------------------------------------------------------------------------------
+// The same block with the map search on the device: ikdtree.Nearest_Search leaves the loop. `set_map` is
+// called where the reference's tree content changes (ikdtree.Build :1416, map_incremental :692-706 / :1758).
+// update(state, nullptr, 0) consumes a scan already staged on the device (VoxelGridDev::filter_to_scan below).
+// ------------------------------------------------------------------------------------------------
+struct LioMode18Dev {
+    fl_handle handle = nullptr;
+    int32_t last_status = 0;
+    int effct_feat_num = 0;
+    double total_residual = 0.0;
+    int iterCount = 0;
+
+    int32_t set_map(const float *map_xyz, int k, float cell_size = 0.5f) { return last_status = fl_map_set_points(handle, map_xyz, k, cell_size); }
+
+    void update(StatesGroup &state, const float *feats_down_body_xyz, int feats_down_size)
+    {
+        fl_state18 st;
+        to_abi(state, st);
+        fl_iter_info info;
+        last_status = fl_lio_frame18_dev(handle, &st, feats_down_body_xyz, feats_down_size, &info);
+        if (last_status < 0) return;
+        from_abi(st, state);
+        effct_feat_num = info.effct_feat_num;
+        total_residual = info.total_residual;
+        iterCount = info.iterations - 1;
+        last_status = info.status;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// pcl::VoxelGrid<PointType> as the reference drives it (setLeafSize / setInputCloud / filter), laserMapping.cpp:1186,1398-1399
+// ------------------------------------------------------------------------------------------------
+struct VoxelGridDev {
+    fl_handle handle = nullptr;
+    float leaf[3] = {0.5f, 0.5f, 0.5f};
+    const float *input = nullptr;     // x, y, z, intensity per point; nullptr: the cloud fl_imu_undistort left on the device
+    int input_n = 0;
+    int32_t last_status = 0;
+    bool leaf_too_small = false;
+
+    void setLeafSize(float lx, float ly, float lz) { leaf[0] = lx; leaf[1] = ly; leaf[2] = lz; }
+    void setInputCloud(const float *xyzi, int n) { input = xyzi; input_n = n; }
+    void setInputCloudOnDevice(int n) { input = nullptr; input_n = n; }
+    // filter(*out): centroids to the host
+    int filter(std::vector<float> &out_xyzi)
+    {
+        out_xyzi.resize((size_t)input_n * 4);
+        int32_t m = 0, small = 0;
+        last_status = fl_scan_voxel_filter(handle, input, input_n, leaf[0], leaf[1], leaf[2], 0, out_xyzi.data(), &m, &small);
+        leaf_too_small = small != 0;
+        out_xyzi.resize(last_status < 0 ? 0 : (size_t)m * 4);
+        return m;
+    }
+    // filter(*feats_down_body) without the round trip: the centroids become the staged scan of the LIO block
+    int filter_to_scan()
+    {
+        int32_t m = 0, small = 0;
+        last_status = fl_scan_voxel_filter(handle, input, input_n, leaf[0], leaf[1], leaf[2], 1, nullptr, &m, &small);
+        leaf_too_small = small != 0;
+        return last_status < 0 ? 0 : m;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// ImuProcess: the members UndistortPcl uses + the call, IMU_Processing.cpp:611-809 (Process2 :875)
+// ------------------------------------------------------------------------------------------------
+struct ImuProcessDev {
+    fl_handle handle = nullptr;
+    fl_imu_proc proc{};               // cov_gyr, cov_acc, cov_bias_*, mean_acc, Lid_*_to_IMU, acc_s_last, angvel_last, last_imu_, last_lidar_end_time_
+    int32_t last_status = 0;
+
+    void set_extrinsic(const double *transl, const double *rot)   // IMU_Processing.cpp:59-63
+    {
+        for (int i = 0; i < 3; i++) proc.Lid_offset_to_IMU[i] = transl[i];
+        for (int i = 0; i < 9; i++) proc.Lid_rot_to_IMU[i] = rot[i];
+    }
+    // pcl_out in/out: x, y, z, curvature(ms). keep_on_device: skip the read-back (the voxel filter continues on the device)
+    void UndistortPcl(const std::vector<fl_imu_sample> &imu, double pcl_beg_time, double pcl_end_time, StatesGroup &state_inout,
+                      std::vector<float> &pcl_out_xyzt, bool keep_on_device)
+    {
+        fl_state18 st;
+        to_abi(state_inout, st);
+        const int n = (int)(pcl_out_xyzt.size() / 4);
+        last_status = fl_imu_undistort(handle, &proc, &st, imu.data(), (int)imu.size(), pcl_beg_time, pcl_end_time, pcl_out_xyzt.data(), n,
+                                       keep_on_device ? nullptr : pcl_out_xyzt.data(), nullptr, nullptr);
+        if (last_status < 0) return;
+        from_abi(st, state_inout);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
 // LidarSelector::ComputeJ(cv::Mat img) -> UpdateState(img, err, level) x 3, lidar_selection.cpp:967-983
 // ------------------------------------------------------------------------------------------------
 struct VioUpdater {

@@ -56,3 +56,47 @@ def test_cpp_host_mirror_matches_ctypes_path(gpu_lib, scene, tmp_path):
     sur = lines[3].split()
     assert int(sur[2]) == 23 and int(sur[4]) == 1
     assert float(sur[8]) <= 1e-12 and float(sur[10]) <= 1e-9 * max(1.0, float(sur[12]))
+
+
+def test_cpp_device_pipeline_matches_ctypes_path(gpu_lib, tmp_path):
+    """ImuProcessDev::UndistortPcl -> VoxelGridDev::filter_to_scan -> LioMode18Dev::update from plain C++ (demo_pipeline)
+    vs the same three calls through ctypes: identical state."""
+    capi = gpu_lib
+    import ctypes as C
+    from fast_livo_amd import synth
+    hostdir = os.path.join(ROOT, "fast-livo_amd", "host")
+    demo = os.path.join(hostdir, "demo_pipeline")
+    if not os.path.exists(demo):
+        subprocess.check_call(["make", "-C", hostdir, "-s", "demo_pipeline"])
+    n, max_iter, leaf, cell = 30000, 6, 0.2, 0.5
+    lio = synth.make_lio_frame(n)
+    f = synth.make_imu_frame(n, n_imu=20, lio=lio, quiet=True)
+    f.pts_xyzt[:, :3] = lio.body_xyz
+    h = capi.Handle(capi.config_from_frames(lio, max_iterations=max_iter))
+    h.map_set_points(lio.scene.map_xyz, cell)
+    x = capi.state18_from_frame(lio); pr = capi.imu_proc_from_frame(f)
+    pr0 = capi.imu_proc_from_frame(f)
+    h.imu_undistort(pr, x, f.imu, f.pcl_beg_time, f.pcl_end_time, f.pts_xyzt, want=False)
+    _, m, _ = h.scan_voxel_filter_resident(n, leaf)
+    info = h.lio_frame18_dev(x, None)
+    h.close()
+    fn = tmp_path / "pipe.bin"
+    with open(fn, "wb") as fh:
+        fh.write(struct.pack("<iiiiffdd", n, f.imu.shape[0], lio.scene.map_xyz.shape[0], max_iter, leaf, cell, f.pcl_beg_time, f.pcl_end_time))
+        fh.write(np.asarray(lio.R_LI, dtype="<f8").tobytes()); fh.write(np.asarray(lio.t_LI, dtype="<f8").tobytes())
+        x0 = capi.state18_from_frame(lio)
+        fh.write(x0.vec().astype("<f8").tobytes()); fh.write(np.asarray(x0.cov_np(), dtype="<f8").tobytes())
+        fh.write(bytes(pr0))
+        fh.write(np.ascontiguousarray(f.imu, dtype="<f8").tobytes())
+        fh.write(f.pts_xyzt.astype("<f4").tobytes()); fh.write(lio.scene.map_xyz.astype("<f4").tobytes())
+    out = subprocess.run([demo, str(fn)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    head = lines[0].split()
+    assert int(head[1]) == 0 and int(head[5]) == info.effct_feat_num and int(head[7]) == m
+    vals = np.array(lines[1].split(), dtype=np.float64)
+    assert np.array_equal(vals, x.vec()[:15])                 # rot, pos, vel: bit-identical (%.17g round-trips)
+    diag = np.array(lines[2].split(), dtype=np.float64)
+    assert np.array_equal(diag, np.diag(x.cov_np()))
+    tail = np.array(lines[3].split(), dtype=np.float64)
+    assert tail[0] == pr.last_lidar_end_time and tail[1] == pr.acc_s_last[2]
