@@ -105,3 +105,36 @@ def test_all_device_ikfom_update_matches_oracle(gpu_lib, oracle_lib, scene):
     assert np.abs(xg.vec() - xo.vec()).max() <= 1e-9
     assert np.abs(Pg - Po).max() <= 1e-10
     h.close()
+
+
+def test_exact_ties_and_far_from_origin(gpu_lib, oracle_lib, scene):
+    """Lattice map + queries on lattice midpoints: many exactly equal float distances -> the lower map index wins, as in
+    oracle/orc_knn.c; duplicated map points; and the same scene 3 km from the origin (cell assignment margin)."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    fr = synth.make_lio_frame(2000, scene=scene)
+    h = _handle(capi, synth, fr)
+    x = capi.state18_from_frame(fr)
+    g = np.arange(-8, 8, dtype=np.float32) * np.float32(0.25)
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    lattice = np.concatenate([lattice, lattice[::7]])                      # duplicates: equal coordinates, different indices
+    rng = np.random.default_rng(11)
+    q = (rng.integers(-6, 6, (3000, 3)).astype(np.float32) * np.float32(0.25) + np.float32(0.125))     # cell centres: 8-way ties
+    q[::3] -= np.float32(0.125)                                             # on lattice points: 6-way ties at the next shell
+    # queries are handed over as "body" points of an identity pose
+    xi = capi.State18.make(np.eye(3), np.zeros(3), np.zeros(3), np.zeros(3), np.zeros(3), [0, 0, -9.81], np.eye(18) * 1e-3)
+    cfg = capi.make_config(np.eye(3), np.zeros(3), synth.AVIA_RCL, synth.AVIA_PCL, dict(synth.PINHOLE, d=(0.0,) * 5))
+    hi = capi.Handle(cfg)
+    for off in (np.float32(0.0), np.float32(3000.0)):
+        m = lattice + off
+        hi.map_set_points(m, 0.5)
+        hi.lio_set_points(q + off); hi.lio_begin18(xi, xi)
+        nbr_g, valid_g = hi.lio_search18(q.shape[0])
+        world = hi.lio_get_world_points(q.shape[0])
+        assert np.array_equal(world, q + off)
+        nbr_o, sq_o, valid_o, idx_o = orc.knn5_bruteforce(m, world)
+        assert np.array_equal(valid_g, valid_o) and valid_o.all()
+        assert np.array_equal(nbr_g, nbr_o)
+        if off == 0:
+            assert (np.diff(sq_o, axis=1) == 0).mean() > 0.3                # the ties are really there
+    hi.close(); h.close()
