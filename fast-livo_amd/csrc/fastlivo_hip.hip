@@ -52,6 +52,7 @@ struct fl_context {
     int32_t *d_slevel = nullptr;
     int cap_patches = 0, m = 0;
     bool have_img = false;
+    void *d_vio_li = nullptr;      // per-level results of fl_vio_compute_j
     // Mode-23
     FlDev23 *d_dev23 = nullptr;
     FlDev23 *h_dev23 = nullptr;
@@ -218,7 +219,7 @@ int32_t fl_destroy(fl_handle h)
     hipFree(h->d_body); hipFree(h->d_nbr); hipFree(h->d_world); hipFree(h->d_valid); hipFree(h->d_sel);
     hipFree(h->d_plane); hipFree(h->d_normvec); hipFree(h->d_dev); hipFree(h->d_dev23); hipFree(h->d_records);
     hipFree(h->d_epoch); hipFree(h->d_sums_tmp); hipFree(h->d_bcast); hipFree(h->d_vc); hipFree(h->d_img); hipFree(h->d_ref);
-    hipFree(h->d_errors); hipFree(h->d_pos); hipFree(h->d_slevel);
+    hipFree(h->d_errors); hipFree(h->d_pos); hipFree(h->d_slevel); hipFree(h->d_vio_li);
     hipFree(h->d_map_raw); hipFree(h->d_map_pts); hipFree(h->d_map_keys); hipFree(h->d_map_keys_tmp); hipFree(h->d_map_idx);
     hipFree(h->d_map_idx_tmp); hipFree(h->d_map_htab); hipFree(h->d_map_sort_tmp);
     vox_free(h);
