@@ -64,7 +64,8 @@ __device__ __forceinline__ void fl_so3_exp_dt(const double *w, double dt, double
         const double a[3] = {w[0] / n, w[1] / n, w[2] / n};
         const double K[9] = {0.0, -a[2], a[1], a[2], 0.0, -a[0], -a[1], a[0], 0.0};
         const double ang = n * dt;
-        const double s = sin(ang), c1 = 1.0 - cos(ang);
+        double s, c1;
+        fl_sin_omc(ang, &s, &c1);          // Taylor form for |ang| <= 0.5 (always, for IMU intervals), library beyond
         double cK[9], cKK[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) cK[i] = c1 * K[i];

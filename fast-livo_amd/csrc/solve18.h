@@ -38,36 +38,6 @@ struct FlSolveLds {
 
 enum { FL_EPI_LIO = 0, FL_EPI_VIO = 1 };
 
-// sin(x) and 1 - cos(x) of the rotation update. The increments of an ESKF pass are tiny (|x| << 0.5): a Taylor/Horner form
-// (truncation < 1e-17 relative for |x| <= 0.5, and 1 - cos without cancellation) replaces two library calls of several hundred
-// dependent cycles each on the solver workgroup's critical path; larger angles use the library. The solve is compared to the
-// oracle by tolerance (1e-9), never bitwise.
-__device__ __forceinline__ void fl_sin_omc(double x, double *s, double *omc)
-{
-    if (fabs(x) <= 0.5) {
-        const double x2 = x * x;
-        double ps = -1.0 / 1307674368000.0;
-        ps = ps * x2 + 1.0 / 6227020800.0;
-        ps = ps * x2 - 1.0 / 39916800.0;
-        ps = ps * x2 + 1.0 / 362880.0;
-        ps = ps * x2 - 1.0 / 5040.0;
-        ps = ps * x2 + 1.0 / 120.0;
-        ps = ps * x2 - 1.0 / 6.0;
-        *s = x + x * (x2 * ps);
-        double pc = 1.0 / 87178291200.0;
-        pc = pc * x2 - 1.0 / 479001600.0;
-        pc = pc * x2 + 1.0 / 3628800.0;
-        pc = pc * x2 - 1.0 / 40320.0;
-        pc = pc * x2 + 1.0 / 720.0;
-        pc = pc * x2 - 1.0 / 24.0;
-        pc = pc * x2 + 0.5;
-        *omc = x2 * pc;
-    } else {
-        *s = sin(x);
-        *omc = 1.0 - cos(x);
-    }
-}
-
 // Stage 0 (before the gather): stage the solve inputs in LDS and form vec = x_prop (-) x.
 // Split in two so that the loads can be issued before the kernel's control-word round trip.
 __device__ __forceinline__ double eskf18_prefetch_issue(const FlDev18 *__restrict__ D)
