@@ -35,6 +35,7 @@ struct fl_context {
     float4 *d_plane = nullptr, *d_normvec = nullptr;
     int cap_points = 0, n = 0;
     bool have_nbr = false;
+    bool normvec_valid = false;   // a pass with FL_ITER_KEEP_NORMVEC has run on the staged scan
     // 18-state block, reduction scratch
     FlDev18 *d_dev = nullptr;
     FlDev18 *h_dev = nullptr;      // pinned mirror
@@ -340,6 +341,7 @@ int32_t fl_lio_set_points(fl_handle h, const float *body_xyz, int32_t n)
         HIPCHK(h, hipMemsetAsync(h->d_records, 0, (size_t)16 * FL_MAX_BLOCKS * FL_SUMS23, h->stream));
     h->n = n;
     h->have_nbr = false;
+    h->normvec_valid = false;
     HIPCHK(h, hipMemcpyAsync(h->d_body, body_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_sel, 0, (size_t)n, h->stream));
     return FL_OK;
@@ -374,9 +376,10 @@ int32_t fl_lio_get_selection(fl_handle h, uint8_t *mask, float *normvec)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < n; i++) {
         // effective = point_selected_surf && res_last <= 2.0 (laserMapping.cpp:1593)
-        if (mask) mask[i] = (uint8_t)(sel[i] && ((double)fabsf(nv[(size_t)i * 4 + 3]) <= 2.0));
+        // without a FL_ITER_KEEP_NORMVEC pass d_normvec holds nothing: mask = the selection flags, normvec = 0
+        if (mask) mask[i] = (uint8_t)(sel[i] && (!h->normvec_valid || (double)fabsf(nv[(size_t)i * 4 + 3]) <= 2.0));
         if (normvec) {
-            if (sel[i]) memcpy(normvec + (size_t)i * 4, nv.data() + (size_t)i * 4, sizeof(float) * 4);
+            if (sel[i] && h->normvec_valid) memcpy(normvec + (size_t)i * 4, nv.data() + (size_t)i * 4, sizeof(float) * 4);
             else memset(normvec + (size_t)i * 4, 0, sizeof(float) * 4);
         }
     }
@@ -480,6 +483,7 @@ static bool fl_multipass_enabled()
 }
 static void launch_lio_passes(fl_handle h, int grid, int count, int flags)
 {
+    if (flags & FL_ITER_KEEP_NORMVEC) h->normvec_valid = true;
     if (count > 1 && grid <= 256 && fl_multipass_enabled()) {
         hipLaunchKernelGGL(lio18_multipass_kernel, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_body, h->d_plane, h->d_sel, h->d_normvec,
                            h->n, h->d_dev, h->d_records, h->d_epoch, h->d_bcast, (int)count, (int)flags);
@@ -554,6 +558,7 @@ int32_t fl_lio_frame18(fl_handle h, fl_state18 *state_io, const float *body_xyz,
 
 int32_t fl_lio_accumulate18(fl_handle h, double *d_sums, int32_t flags)
 {
+    if (h && (flags & FL_ITER_KEEP_NORMVEC)) h->normvec_valid = true;
     if (!h || !d_sums) return fail_arg(h, "fl_lio_accumulate18: null argument");
     if (h->n <= 0 || !h->have_nbr) return fail_arg(h, "fl_lio_accumulate18: points/neighbours not staged");
     HIPCHK(h, hipSetDevice(h->cfg.device));

@@ -227,14 +227,16 @@ FL_HD int fl_point_gates(const float *pb, const float *pl /*plane n,d*/, const d
 // Mode-18 Jacobian row (src/laserMapping.cpp:1611-1629): row = [ [p_i]x R^T n , n ], z = -pd2.
 FL_HD void fl_row18(const double *p_i, const float *pl, float pd2, const double *R, double *row /*6*/, double *z)
 {
-    FL_FP_CONTRACT
+    // explicit fma(): a fixed operation tree (half the instructions of mul+add), so every kernel that inlines this -- the
+    // per-pass, multi-pass and accumulate-only forms -- produces bit-identical partial sums whatever the surrounding code is
+    // (with `fp contract(fast)` the compiler's choice of what to fuse depended on the inlining context)
     const double n0 = (double)pl[0], n1 = (double)pl[1], n2 = (double)pl[2];
-    const double c0 = R[0] * n0 + R[3] * n1 + R[6] * n2;   // C = R^T n
-    const double c1 = R[1] * n0 + R[4] * n1 + R[7] * n2;
-    const double c2 = R[2] * n0 + R[5] * n1 + R[8] * n2;
-    row[0] = p_i[1] * c2 - p_i[2] * c1;                    // A = p_i x C
-    row[1] = p_i[2] * c0 - p_i[0] * c2;
-    row[2] = p_i[0] * c1 - p_i[1] * c0;
+    const double c0 = fma(R[6], n2, fma(R[3], n1, R[0] * n0));   // C = R^T n
+    const double c1 = fma(R[7], n2, fma(R[4], n1, R[1] * n0));
+    const double c2 = fma(R[8], n2, fma(R[5], n1, R[2] * n0));
+    row[0] = fma(p_i[1], c2, -(p_i[2] * c1));                    // A = p_i x C
+    row[1] = fma(p_i[2], c0, -(p_i[0] * c2));
+    row[2] = fma(p_i[0], c1, -(p_i[1] * c0));
     row[3] = n0; row[4] = n1; row[5] = n2;
     *z = -(double)pd2;
 }
@@ -242,14 +244,13 @@ FL_HD void fl_row18(const double *p_i, const float *pl, float pd2, const double 
 // Accumulate one measurement row into a reduction record (layout in fl_device.h).
 FL_HD void fl_accum6(double *v /*32*/, const double *row, double z)
 {
-    FL_FP_CONTRACT
     int k = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = i; j < 6; j++) { v[k] += row[i] * row[j]; k++; }
+        for (int j = i; j < 6; j++) { v[k] = fma(row[i], row[j], v[k]); k++; }
 #pragma unroll
-    for (int i = 0; i < 6; i++) v[21 + i] += row[i] * z;
+    for (int i = 0; i < 6; i++) v[21 + i] = fma(row[i], z, v[21 + i]);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -151,18 +151,20 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_pass_kernel(const float *__re
     for (int k = 0; k < FL_SUMS18; k++) v[k] = 0.0;
     if (blockIdx.x == 0) fl_stamp(flags, 0);
 
+    // rolling software prefetch: the next point's inputs (same lane, one grid stride ahead) are requested before the current
+    // point's ~150 fp64 instructions, so that with several points per lane (n > 65 k) the loop is bound by issue/HBM, not by
+    // one memory round trip per point
     for (int i = i_first; i < n; i += nprod * NT) {
-        const bool first = (i == i_first);
-        if (!(first ? pf_sel : sel[i])) continue;
-        float pb[3];
-        float4 plq;
-        if (first) {
-            pb[0] = pf_b0; pb[1] = pf_b1; pb[2] = pf_b2;
-            plq = pf_pl;
-        } else {
-            pb[0] = body[i * 3 + 0]; pb[1] = body[i * 3 + 1]; pb[2] = body[i * 3 + 2];
-            plq = plane[i];
+        const uint8_t c_sel = pf_sel;
+        const float pb[3] = {pf_b0, pf_b1, pf_b2};
+        const float4 plq = pf_pl;
+        const int inext = i + nprod * NT;
+        if (inext < n) {
+            pf_sel = sel[inext];
+            pf_b0 = body[inext * 3 + 0]; pf_b1 = body[inext * 3 + 1]; pf_b2 = body[inext * 3 + 2];
+            pf_pl = plane[inext];
         }
+        if (!c_sel) continue;
         const float pl[4] = {plq.x, plq.y, plq.z, plq.w};
         double p_i[3];
         float pw[3], pd2;
@@ -269,18 +271,18 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_multipass_kernel(const float 
         double v[FL_SUMS18];
 #pragma unroll
         for (int k = 0; k < FL_SUMS18; k++) v[k] = 0.0;
+        // rolling software prefetch as in lio18_pass_kernel
         for (int i = i_first; i < n; i += nprod * NT) {
-            const bool first = (i == i_first);
-            if (!(first ? pf_sel : sel[i])) continue;
-            float pb[3];
-            float4 plq;
-            if (first) {
-                pb[0] = pf_b0; pb[1] = pf_b1; pb[2] = pf_b2;
-                plq = pf_pl;
-            } else {
-                pb[0] = body[i * 3 + 0]; pb[1] = body[i * 3 + 1]; pb[2] = body[i * 3 + 2];
-                plq = plane[i];
+            const uint8_t c_sel = pf_sel;
+            const float pb[3] = {pf_b0, pf_b1, pf_b2};
+            const float4 plq = pf_pl;
+            const int inext = i + nprod * NT;
+            if (inext < n) {
+                pf_sel = sel[inext];
+                pf_b0 = body[inext * 3 + 0]; pf_b1 = body[inext * 3 + 1]; pf_b2 = body[inext * 3 + 2];
+                pf_pl = plane[inext];
             }
+            if (!c_sel) continue;
             const float pl[4] = {plq.x, plq.y, plq.z, plq.w};
             double p_i[3];
             float pw[3], pd2;
