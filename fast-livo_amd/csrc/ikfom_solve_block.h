@@ -22,6 +22,8 @@ struct FlIkLds {
     double rhs[12], y[12];
     double J[3][9];      // J_rot, J_off (3x3), J_S2 (2x2 in the first 4 entries)
     int ctl[8];          // 0 t_count, 1 converge, 2 finished, 3 status
+    double limit[23];    // convergence limits, staged once (the judging lane would otherwise walk them with dependent global loads)
+    int cnt[4];          // t_count, iter_i, max_iter, iters_run of D at the start of the pass
 };
 
 // block-diagonal Jf: element (r, a); blk = start index of r's block, bs = its size
@@ -36,30 +38,75 @@ __device__ __forceinline__ double ik_J(const FlIkLds &L, int which, int bs, int 
 {
     return (which < 0) ? 1.0 : L.J[which][r_in * bs + a_in];
 }
-// thread 0..2: the three projection Jacobians for segments of `seg` (dx or dx_)
+// threads 0, 64, 128 (three different wavefronts: divergent lanes of one wave would run one after the other): the three
+// projection Jacobians for segments of `seg` (dx or dx_)
 __device__ __forceinline__ void ik_make_J(FlIkLds &L, const double *seg, int tid)
 {
     if (tid == 0) fl_ikfom_J_so3(seg + 3, L.J[0]);
-    else if (tid == 1) fl_ikfom_J_so3(seg + 6, L.J[1]);
-    else if (tid == 2) fl_ikfom_J_s2(L.x + FL_X23_GRAV, L.xp + FL_X23_GRAV, seg + 21, L.J[2]);
+    else if (tid == 64) fl_ikfom_J_so3(seg + 6, L.J[1]);
+    else if (tid == 128) fl_ikfom_J_s2(L.x + FL_X23_GRAV, L.xp + FL_X23_GRAV, seg + 21, L.J[2]);
+}
+// value of `v` in lane `lane` (compile-time constant) for the whole wave: two v_readlane instead of two ds_bpermute
+__device__ __forceinline__ double ik_lane(double v, int lane /* wave-uniform */)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)f64_lo(v), lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)f64_hi(v), lane);
+    return f64_make(lo, hi);
 }
 
 __device__ __forceinline__ void ikfom_solver_block(FlDev23 *__restrict__ D, const double *s_sums, FlIkLds &L, int gst)
 {
     const int tid = threadIdx.x, NTH = blockDim.x, n = FL_N23;
-    // ---- stage 0: state to LDS
+#ifdef FL_IK_STAMPS
+    if (tid == 0) g_fl_stamps[32] = (long long)wall_clock64();
+#endif
+    // ---- stage 0: state, propagated covariance (into L.L, free until the finishing block), limits and counters to LDS
     if (tid < FL_X23_LEN) { L.x[tid] = D->x[tid]; L.xp[tid] = D->xprop[tid]; }
+    for (int e = tid; e < n * n; e += NTH) L.L[e] = D->Pprop[e];
+    if (tid >= 64 && tid < 64 + 23) L.limit[tid - 64] = D->limit[tid - 64];
+    if (tid == 96) { L.cnt[0] = D->t_count; L.cnt[1] = D->iter_i; L.cnt[2] = D->max_iter; L.cnt[3] = D->iters_run; }
     __syncthreads();
-    // ---- stage 1: dx = x (-) x_prop  (serial, small)
-    if (tid == 0) {
-        double x[FL_X23_LEN], xp[FL_X23_LEN], dx[23];
-        for (int i = 0; i < FL_X23_LEN; i++) { x[i] = L.x[i]; xp[i] = L.xp[i]; }
-        fl_x23_boxminus(x, xp, dx);
-        for (int i = 0; i < 23; i++) { L.dx[i] = dx[i]; L.dxn[i] = dx[i]; }
+#ifdef FL_IK_STAMPS
+    if (tid == 0) g_fl_stamps[33] = (long long)wall_clock64();
+#endif
+    // ---- stage 1: dx = x (-) x_prop and the projection Jacobians at dx. The three manifold segments (SO3 rot, SO3 offset_R,
+    // S2 grav -- each a Log with acos/atan2 and a Jacobian with sin/cos) are independent: one lane of three different waves each
+    if (tid == 0 || tid == 64 || tid == 128) {
+        const double *x = L.x, *o = L.xp;
+        double oc[4], r[4], d3[3];
+        if (tid == 0) {
+            for (int i = 0; i < 3; i++) { const double v = x[FL_X23_POS + i] - o[FL_X23_POS + i]; L.dx[i] = v; L.dxn[i] = v; }
+            oc[0] = -o[FL_X23_ROT]; oc[1] = -o[FL_X23_ROT + 1]; oc[2] = -o[FL_X23_ROT + 2]; oc[3] = o[FL_X23_ROT + 3];
+            flq_mul(oc, x + FL_X23_ROT, r);
+            fl_so3_log(r, d3);
+            for (int i = 0; i < 3; i++) { L.dx[3 + i] = d3[i]; L.dxn[3 + i] = d3[i]; }
+            fl_ikfom_J_so3(d3, L.J[0]);
+        } else if (tid == 64) {
+            oc[0] = -o[FL_X23_ORLI]; oc[1] = -o[FL_X23_ORLI + 1]; oc[2] = -o[FL_X23_ORLI + 2]; oc[3] = o[FL_X23_ORLI + 3];
+            flq_mul(oc, x + FL_X23_ORLI, r);
+            fl_so3_log(r, d3);
+            for (int i = 0; i < 3; i++) {
+                L.dx[6 + i] = d3[i]; L.dxn[6 + i] = d3[i];
+                const double v = x[FL_X23_OTLI + i] - o[FL_X23_OTLI + i]; L.dx[9 + i] = v; L.dxn[9 + i] = v;
+            }
+            fl_ikfom_J_so3(d3, L.J[1]);
+        } else {
+            for (int i = 0; i < 3; i++) {
+                const double v = x[FL_X23_VEL + i] - o[FL_X23_VEL + i], g = x[FL_X23_BG + i] - o[FL_X23_BG + i], a = x[FL_X23_BA + i] - o[FL_X23_BA + i];
+                L.dx[12 + i] = v; L.dxn[12 + i] = v; L.dx[15 + i] = g; L.dxn[15 + i] = g; L.dx[18 + i] = a; L.dxn[18 + i] = a;
+            }
+            double d2[2];
+            fl_s2_boxminus(x + FL_X23_GRAV, o + FL_X23_GRAV, d2);
+            L.dx[21] = d2[0]; L.dx[22] = d2[1]; L.dxn[21] = d2[0]; L.dxn[22] = d2[1];
+            double seg[23];
+            seg[21] = d2[0]; seg[22] = d2[1];
+            fl_ikfom_J_s2(L.x + FL_X23_GRAV, L.xp + FL_X23_GRAV, seg + 21, L.J[2]);
+        }
     }
     __syncthreads();
-    ik_make_J(L, L.dx, tid);
-    __syncthreads();
+#ifdef FL_IK_STAMPS
+    if (tid == 0) g_fl_stamps[34] = (long long)wall_clock64();
+#endif
     // ---- stage 2: P = Jf Pprop Jf^T ; dx_new = Jf dx
     for (int e = tid; e < n * n; e += NTH) {
         const int r = e / n, c = e % n;
@@ -69,7 +116,7 @@ __device__ __forceinline__ void ikfom_solver_block(FlDev23 *__restrict__ D, cons
         double s = 0.0;
         for (int a = 0; a < rs; a++) {
             const double jr = ik_J(L, rw, rs, r - rb, a);
-            for (int b = 0; b < cs; b++) s += jr * D->Pprop[(rb + a) * n + (cb + b)] * ik_J(L, cw, cs, c - cb, b);
+            for (int b = 0; b < cs; b++) s += jr * L.L[(rb + a) * n + (cb + b)] * ik_J(L, cw, cs, c - cb, b);
         }
         L.P[e] = s;
     }
@@ -89,6 +136,9 @@ __device__ __forceinline__ void ikfom_solver_block(FlDev23 *__restrict__ D, cons
         L.S[j * 12 + i] = v;
     }
     __syncthreads();
+#ifdef FL_IK_STAMPS
+    if (tid == 0) g_fl_stamps[35] = (long long)wall_clock64();
+#endif
     const double R = D->meas_cov;
     if (tid < 144) {
         const int i = tid / 12, j = tid % 12;
@@ -120,61 +170,110 @@ __device__ __forceinline__ void ikfom_solver_block(FlDev23 *__restrict__ D, cons
         L.rhs[i] = s;
     }
     __syncthreads();
-    // ---- stage 3: Cholesky of M (12x12), column by column
+#ifdef FL_IK_STAMPS
+    if (tid == 0) g_fl_stamps[36] = (long long)wall_clock64();
+#endif
+    // ---- stage 3: Cholesky of M (12x12) and the solve for y in wave 0: lane i owns row i in registers, pivots and
+    // multipliers are broadcast with v_readlane (right-looking; no workgroup barrier, instead of 24 of them)
     int bad = 0;
-    for (int j = 0; j < 12; j++) {
-        if (tid == 0) {
-            double d = L.M[j * 12 + j];
-            for (int k = 0; k < j; k++) d -= L.M[j * 12 + k] * L.M[j * 12 + k];
-            if (!(d > 0.0)) bad = 1;
-            L.M[j * 12 + j] = sqrt(d);
+    if (tid < 64) {
+        const int i = tid;
+        double a[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) a[k] = (i < 12) ? L.M[i * 12 + k] : 0.0;
+        double yi = 0.0;                                  // y0 = A12 rhs
+        if (i < 12) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) yi += L.A12[i * 12 + k] * L.rhs[k];
         }
-        __syncthreads();
-        if (tid > j && tid < 12) {
-            double v = L.M[tid * 12 + j];
-            for (int k = 0; k < j; k++) v -= L.M[tid * 12 + k] * L.M[j * 12 + k];
-            L.M[tid * 12 + j] = v / L.M[j * 12 + j];
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const double ajj = ik_lane(a[j], j);
+            if (!(ajj > 0.0)) bad = 1;
+            const double ljj = sqrt(ajj);
+            const double lij = (i == j) ? ljj : a[j] / ljj;
+            a[j] = lij;
+#pragma unroll
+            for (int k = j + 1; k < 12; k++) {
+                const double lkj = ik_lane(lij, k);
+                if (i >= k) a[k] -= lij * lkj;
+            }
         }
-        __syncthreads();
+        if (i < 12) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) if (k <= i) L.M[i * 12 + k] = a[k];
+        }
+        // forward substitution L z = y0 (lane i holds component i), then back substitution L^T y = z
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const double zj = ik_lane(yi, j) / ik_lane(a[j], j);      // component j is final once rows < j are eliminated
+            if (i == j) yi = zj;
+            if (i > j) yi -= a[j] * zj;
+        }
+#pragma unroll
+        for (int j = 11; j >= 0; j--) {
+            const double yj = ik_lane(yi, j) / ik_lane(a[j], j);
+            if (i == j) yi = yj;
+#pragma unroll
+            for (int r = 0; r < 12; r++) {
+                if (r < j) {
+                    const double ljr = ik_lane(a[r], j);               // L[j][r] = L^T[r][j]
+                    if (i == r) yi -= ljr * yj;
+                }
+            }
+        }
+        if (i < 12) L.y[i] = yi;
     }
-    if (tid < 12) {                         // y0 = A12 rhs
-        double s = 0.0;
-        for (int k = 0; k < 12; k++) s += L.A12[tid * 12 + k] * L.rhs[k];
-        L.y[tid] = s;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double y[12];
-        for (int i = 0; i < 12; i++) y[i] = L.y[i];
-        fl_chol_solve(L.M, 12, y);
-        for (int i = 0; i < 12; i++) L.y[i] = y[i];
-    }
-    __syncthreads();
+    bad = __syncthreads_or(bad);
+#ifdef FL_IK_STAMPS
+    if (tid == 0) g_fl_stamps[37] = (long long)wall_clock64();
+#endif
     if (tid < n) {                          // dx_ = A[:,0:12] y - dx_new
         double s = 0.0;
         for (int c = 0; c < 12; c++) s += (L.P[tid * n + c] / R) * L.y[c];
         L.dxo[tid] = s - L.dxn[tid];
     }
     __syncthreads();
-    // ---- stage 4: boxplus, convergence bookkeeping (serial, small)
-    if (tid == 0) {
-        double x[FL_X23_LEN], dxo[23];
-        for (int i = 0; i < FL_X23_LEN; i++) x[i] = L.x[i];
-        for (int i = 0; i < 23; i++) dxo[i] = L.dxo[i];
-        fl_x23_boxplus(x, dxo);
+#ifdef FL_IK_STAMPS
+    if (tid == 0) g_fl_stamps[38] = (long long)wall_clock64();
+#endif
+    // ---- stage 4: boxplus on three lanes of three waves (SO3 rot | SO3 offset_R | additive + S2), judgement on a fourth
+    if (tid == 0 || tid == 64 || tid == 128) {
+        double e[4], q[4];
+        if (tid == 0) {
+            for (int i = 0; i < 3; i++) { const double v = L.x[FL_X23_POS + i] + L.dxo[i]; L.x[FL_X23_POS + i] = v; D->x[FL_X23_POS + i] = v; }
+            fl_mtk_exp3(L.dxo + 3, 0.5, e);
+            for (int i = 0; i < 4; i++) q[i] = L.x[FL_X23_ROT + i];
+            flq_mul(q, e, q);
+            for (int i = 0; i < 4; i++) { L.x[FL_X23_ROT + i] = q[i]; D->x[FL_X23_ROT + i] = q[i]; }
+        } else if (tid == 64) {
+            fl_mtk_exp3(L.dxo + 6, 0.5, e);
+            for (int i = 0; i < 4; i++) q[i] = L.x[FL_X23_ORLI + i];
+            flq_mul(q, e, q);
+            for (int i = 0; i < 4; i++) { L.x[FL_X23_ORLI + i] = q[i]; D->x[FL_X23_ORLI + i] = q[i]; }
+            for (int i = 0; i < 3; i++) { const double v = L.x[FL_X23_OTLI + i] + L.dxo[9 + i]; L.x[FL_X23_OTLI + i] = v; D->x[FL_X23_OTLI + i] = v; }
+        } else {
+            for (int i = 0; i < 3; i++) {
+                const double v = L.x[FL_X23_VEL + i] + L.dxo[12 + i], g = L.x[FL_X23_BG + i] + L.dxo[15 + i], a = L.x[FL_X23_BA + i] + L.dxo[18 + i];
+                L.x[FL_X23_VEL + i] = v; D->x[FL_X23_VEL + i] = v; L.x[FL_X23_BG + i] = g; D->x[FL_X23_BG + i] = g;
+                L.x[FL_X23_BA + i] = a; D->x[FL_X23_BA + i] = a;
+            }
+            double gv[3] = {L.x[FL_X23_GRAV], L.x[FL_X23_GRAV + 1], L.x[FL_X23_GRAV + 2]};
+            fl_s2_boxplus(gv, L.dxo + 21);
+            for (int i = 0; i < 3; i++) { L.x[FL_X23_GRAV + i] = gv[i]; D->x[FL_X23_GRAV + i] = gv[i]; }
+        }
+    } else if (tid == 192) {
         int converge = 1, st = gst | bad;
         for (int i = 0; i < n; i++) {
-            if (fabs(dxo[i]) > D->limit[i]) { converge = 0; break; }
+            if (fabs(L.dxo[i]) > L.limit[i]) { converge = 0; break; }
         }
         for (int i = 0; i < n; i++)
-            if (!(fabs(dxo[i]) <= DBL_MAX)) st |= 2;
-        int t = D->t_count;
-        const int i_loop = D->iter_i, max_iter = D->max_iter;
+            if (!(fabs(L.dxo[i]) <= DBL_MAX)) st |= 2;
+        int t = L.cnt[0];
+        const int i_loop = L.cnt[1], max_iter = L.cnt[2];
         if (converge) t++;
         if (!t && i_loop == max_iter - 2) converge = 1;
         const int finishing = (t > 1 || i_loop == max_iter - 1) ? 1 : 0;
-        for (int i = 0; i < FL_X23_LEN; i++) { L.x[i] = x[i]; D->x[i] = x[i]; }
-        for (int i = 0; i < 23; i++) D->solution[i] = dxo[i];
         L.ctl[0] = t; L.ctl[1] = converge; L.ctl[2] = finishing; L.ctl[3] = st;
         D->t_count = t;
         D->need_search = converge;
@@ -184,10 +283,18 @@ __device__ __forceinline__ void ikfom_solver_block(FlDev23 *__restrict__ D, cons
         D->neff = (int)s_sums[FL_S23_NEFF];
         D->total_residual = s_sums[FL_S23_RES];
         D->status = st;
-        D->iters_run = D->iters_run + 1;
+        D->iters_run = L.cnt[3] + 1;
+    } else if (tid >= 200 && tid < 223) {
+        D->solution[tid - 200] = L.dxo[tid - 200];
     }
+#ifdef FL_IK_STAMPS
+    if (tid == 0) g_fl_stamps[39] = (long long)wall_clock64();
+#endif
     if (tid >= 64 && tid < 64 + FL_SUMS23) D->sums[tid - 64] = s_sums[tid - 64];
     __syncthreads();
+#ifdef FL_IK_STAMPS
+    if (tid == 0) g_fl_stamps[40] = (long long)wall_clock64();
+#endif
     if (!L.ctl[2]) {                        // not finishing: publish the projected P_ and return
         for (int e = tid; e < n * n; e += NTH) D->P[e] = L.P[e];
         return;
