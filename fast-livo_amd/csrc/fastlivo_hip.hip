@@ -35,6 +35,7 @@ struct fl_context {
     float4 *d_plane = nullptr, *d_normvec = nullptr;
     int cap_points = 0, n = 0;
     bool have_nbr = false;
+    int num_cus = 0;              // compute units of the device: the multi-pass kernels need every workgroup resident (<= 1 per CU)
     bool normvec_valid = false;   // a pass with FL_ITER_KEEP_NORMVEC has run on the staged scan
     // 18-state block, reduction scratch
     FlDev18 *d_dev = nullptr;
@@ -187,6 +188,11 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
     HIPCHK(h, hipHostMalloc(&h->h_dev23, sizeof(FlDev23)));
     HIPCHK(h, hipMalloc(&h->d_records, (size_t)16 * FL_MAX_BLOCKS * FL_SUMS23));
     HIPCHK(h, hipMalloc(&h->d_epoch, 64));
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(h, hipGetDeviceProperties(&prop, h->cfg.device));
+        h->num_cus = prop.multiProcessorCount;
+    }
     HIPCHK(h, hipMalloc(&h->d_sums_tmp, sizeof(double) * FL_SUMS23));
     HIPCHK(h, hipMalloc(&h->d_bcast, sizeof(unsigned long long) * 64));
     HIPCHK(h, hipMemset(h->d_bcast, 0, sizeof(unsigned long long) * 64));
@@ -484,7 +490,7 @@ static bool fl_multipass_enabled()
 static void launch_lio_passes(fl_handle h, int grid, int count, int flags)
 {
     if (flags & FL_ITER_KEEP_NORMVEC) h->normvec_valid = true;
-    if (count > 1 && grid <= 256 && fl_multipass_enabled()) {
+    if (count > 1 && grid <= h->num_cus && fl_multipass_enabled()) {
         hipLaunchKernelGGL(lio18_multipass_kernel, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_body, h->d_plane, h->d_sel, h->d_normvec,
                            h->n, h->d_dev, h->d_records, h->d_epoch, h->d_bcast, (int)count, (int)flags);
         return;
