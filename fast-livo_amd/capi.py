@@ -152,6 +152,7 @@ SYMBOLS = {
                                          C.POINTER(C.c_int32)]),
     "fl_imu_undistort": (C.c_int32, [_H, C.POINTER(ImuProc), C.POINTER(State18), C.POINTER(ImuSample), C.c_int32, C.c_double, C.c_double,
                                      _fp, C.c_int32, _fp, C.POINTER(Pose6d), C.POINTER(C.c_int32)]),
+    "fl_vio_grid_select": (C.c_int32, [_H, _dp, _dp, _dp, _fp, C.c_int32, C.c_int32, _i32p, _fp, _fp, _i32p, _i32p]),
     "fl_vio_add_keyframe": (C.c_int32, [_H, _u8p, C.c_int32, C.c_int32, C.c_int32, _i32p]),
     "fl_vio_drop_keyframe": (C.c_int32, [_H, C.c_int32]),
     "fl_vio_select_patches": (C.c_int32, [_H, _dp, _dp, _fp, C.c_int32, C.POINTER(PatchCandidate), C.c_int32, C.c_int32, C.c_double, C.c_double,
@@ -339,6 +340,17 @@ class Handle:
         self._chk(self.L.fl_scan_voxel_filter(self.h, None, n, leaf[0], leaf[1], leaf[2], 1 if stage_as_scan else 0, None, C.byref(m),
                                               C.byref(small)), "fl_scan_voxel_filter")
         return None, m.value, bool(small.value)
+
+    def vio_grid_select(self, Rcw, Pcw, pos, value, grid_size):
+        Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(9); Pcw = np.ascontiguousarray(Pcw, np.float64)
+        pos = np.ascontiguousarray(pos, np.float64); value = np.ascontiguousarray(value, np.float32)
+        length = (self.cfg.img_width // grid_size) * (self.cfg.img_height // grid_size)
+        win = np.zeros(length, np.int32); md = np.zeros(length, np.float32); mv = np.zeros(length, np.float32); gn = np.zeros(length, np.int32)
+        ln = C.c_int32(0)
+        self._chk(self.L.fl_vio_grid_select(self.h, Rcw.ctypes.data_as(_dp), Pcw.ctypes.data_as(_dp), pos.ctypes.data_as(_dp),
+                                            value.ctypes.data_as(_fp), pos.shape[0], grid_size, win.ctypes.data_as(_i32p), md.ctypes.data_as(_fp),
+                                            mv.ctypes.data_as(_fp), gn.ctypes.data_as(_i32p), C.byref(ln)), "fl_vio_grid_select")
+        return dict(winner=win, map_dist=md, map_value=mv, grid_num=gn)
 
     def vio_add_keyframe(self, img):
         img = np.ascontiguousarray(img, np.uint8)

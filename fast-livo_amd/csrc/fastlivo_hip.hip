@@ -96,6 +96,13 @@ struct fl_context {
     int32_t *d_sel_slevel = nullptr, *d_sel_reason = nullptr, *d_sel_slot = nullptr, *d_sel_count = nullptr, *d_sel_acc_idx = nullptr,
             *d_sel_acc_lvl = nullptr;
     int sel_cap = 0, sel_scan_cap = 0;
+    double *d_grid_pos = nullptr;
+    float *d_grid_val_in = nullptr;
+    unsigned long long *d_grid_key = nullptr;
+    int *d_grid_val = nullptr;
+    int32_t *d_grid_num = nullptr;
+    void *d_grid_prm = nullptr;
+    int grid_cap_pts = 0, grid_cap_cells = 0;
     // native exchange of the sharded form (api_comm.inc)
     void *comm = nullptr;          // ncclComm_t
     int comm_world = 0, comm_rank = 0;

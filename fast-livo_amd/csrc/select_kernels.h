@@ -230,3 +230,45 @@ __global__ __launch_bounds__(64) void vio_select_scatter_kernel(const FlPatchCan
     if (lane == 4) { d_errors[s] = errors[ci]; acc_errors[s] = errors[ci]; }
     if (lane == 5) accepted_idx[s] = ci;
 }
+
+
+// ---- projection + grid competition over the map points of the visible voxels (lidar_selection.cpp:412-466) ----------------
+// 1 lane = 1 map point of the caller's flat list. The reference keeps, per grid cell, the LAST point of its loop whose distance
+// is <= the running minimum: the point with the smallest float distance, the later one on ties -- a 64-bit atomicMin over
+// (distance bits, ~index). map_value is a running maximum of non-negative scores (atomicMax on the float bits).
+struct FlGridParams {
+    double Rcw[9], Pcw[3], fpos[3];
+    int32_t k, grid_size, gh, length;
+};
+__global__ __launch_bounds__(FL_BLOCK) void vio_grid_init_kernel(unsigned long long *__restrict__ key, int *__restrict__ val, int32_t *__restrict__ gnum,
+                                                                int length)
+{
+    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
+    if (i >= length) return;
+    key[i] = ((unsigned long long)__float_as_uint(10000.f) << 32) | 0xFFFFFFFFull;
+    val[i] = 0;                 // bits of 0.0f
+    gnum[i] = 3;                // TYPE_UNKNOWN
+}
+__global__ __launch_bounds__(FL_BLOCK) void vio_grid_kernel(const double *__restrict__ pos, const float *__restrict__ value,
+                                                           const FlGridParams *__restrict__ G, const FlVioConst *__restrict__ VC,
+                                                           unsigned long long *__restrict__ key, int *__restrict__ val, int32_t *__restrict__ gnum)
+{
+    const int j = blockIdx.x * FL_BLOCK + threadIdx.x;
+    if (j >= G->k) return;
+    const double p[3] = {pos[3 * (size_t)j], pos[3 * (size_t)j + 1], pos[3 * (size_t)j + 2]};
+    double pc3[3], px[2];
+    fl_se3_apply(G->Rcw, G->Pcw, p, pc3);
+    if (pc3[2] < 0) return;
+    fl_world2cam(*VC, pc3, px);
+    const int u = (int)px[0], v = (int)px[1], W = VC->width, H = VC->height, b = 40;
+    if (!(u >= b && u < W - b && v >= b && v < H - b)) return;
+    const int index = (int)(px[0] / G->grid_size) * G->gh + (int)(px[1] / G->grid_size);
+    if (index < 0 || index >= G->length) return;
+    gnum[index] = 1;            // TYPE_MAP
+    const double o0 = G->fpos[0] - p[0], o1 = G->fpos[1] - p[1], o2 = G->fpos[2] - p[2];
+    const float cur_dist = (float)sqrt(o0 * o0 + o1 * o1 + o2 * o2);
+    if (cur_dist <= 10000.f)
+        atomicMin(&key[index], ((unsigned long long)__float_as_uint(cur_dist) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)j));
+    const float cv = value[j];
+    if (cv >= 0.f) atomicMax(&val[index], __float_as_int(cv));
+}

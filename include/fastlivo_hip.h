@@ -313,6 +313,12 @@ typedef struct fl_patch_candidate {
     int32_t grid_index;        /* caller's bookkeeping */
     int32_t reserved;
 } fl_patch_candidate;
+/* Projection + grid competition of addFromSparseMap (:412-466) over a flat list of the map points of the visible voxels, in the
+ * order the reference's loops visit them (pos k x 3 doubles, value k floats = Point::value). Arrays of
+ * length (width/grid_size)*(height/grid_size): winner = index into the list of the point a cell keeps (voxel_points_[index],
+ * the closest one, the later one on equal float distances; -1: none), map_dist, map_value, grid_num (1 TYPE_MAP, 3 TYPE_UNKNOWN). */
+int32_t fl_vio_grid_select(fl_handle h, const double *Rcw, const double *Pcw, const double *pos, const float *value, int32_t k,
+                           int32_t grid_size, int32_t *winner, float *map_dist, float *map_value, int32_t *grid_num, int32_t *length_out);
 int32_t fl_vio_add_keyframe(fl_handle h, const uint8_t *gray, int32_t width, int32_t height, int32_t stride, int32_t *keyframe_id);
 int32_t fl_vio_drop_keyframe(fl_handle h, int32_t keyframe_id);
 int32_t fl_vio_select_patches(fl_handle h, const double *Rcw, const double *Pcw, const float *scan_world_xyz, int32_t n_scan,

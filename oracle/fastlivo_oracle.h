@@ -155,6 +155,10 @@ int orc_vio_select(const orc_vio_config *cfg, const double *Rcw, const double *P
                    int ncc_en, double ncc_thre, double outlier_threshold, int32_t *accepted_idx, float *patches,
                    float *errors, int32_t *search_levels, int32_t *n_accepted, int32_t *reason);
 
+/* lidar_selection.cpp:412-466 on a flat list of map points (orc_select.c); arrays of length (W/grid)*(H/grid); returns it. */
+int orc_vio_grid_select(const orc_vio_config *cfg, const double *Rcw, const double *Pcw, const double *pos, const float *value, int k,
+                        int grid_size, int32_t *winner, float *map_dist, float *map_value, int32_t *grid_num);
+
 /* vk::PinholeCamera::world2cam (rpg_vikit, unpinned master; restated from memory). */
 void orc_world2cam(const orc_vio_config *cfg, const double *xyz_c, double *px);
 

@@ -398,3 +398,18 @@ def vio_select(cfg, Rcw, Pcw, cur_img, keyframes, depth, cand, ncc_en=False, ncc
         raise RuntimeError("orc_vio_select failed: %d" % rc)
     k = na.value
     return dict(idx=idx[:k].copy(), errors=err[:k].copy(), levels=lvl[:k].copy(), reason=reason[:m].copy(), patches=patches[:k].copy())
+
+
+def vio_grid_select(cfg, Rcw, Pcw, pos, value, grid_size):
+    Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(9); Pcw = np.ascontiguousarray(Pcw, np.float64)
+    pos = np.ascontiguousarray(pos, np.float64); value = np.ascontiguousarray(value, np.float32)
+    length = (cfg.width // grid_size) * (cfg.height // grid_size)
+    win = np.zeros(length, np.int32); md = np.zeros(length, np.float32); mv = np.zeros(length, np.float32); gn = np.zeros(length, np.int32)
+    L = lib()
+    L.orc_vio_grid_select.argtypes = [C.POINTER(VioConfig), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                      C.POINTER(C.c_int32)]
+    L.orc_vio_grid_select.restype = C.c_int
+    L.orc_vio_grid_select(C.byref(cfg), _p(Rcw, C.c_double), _p(Pcw, C.c_double), _p(pos, C.c_double), _p(value, C.c_float), pos.shape[0],
+                          grid_size, _p(win, C.c_int32), _p(md, C.c_float), _p(mv, C.c_float), _p(gn, C.c_int32))
+    return dict(winner=win, map_dist=md, map_value=mv, grid_num=gn)

@@ -183,3 +183,36 @@ int orc_vio_select(const orc_vio_config *cfg, const double *Rcw, const double *P
     *n_accepted = na;
     return 0;
 }
+
+/* Projection + grid competition over the map points of the visible voxels, lidar_selection.cpp:412-466, given those points as a
+ * flat list in the order the reference's loops visit them (the walk over sub_feat_map / feat_map stays with the caller).
+ * winner[length]: index into the list of the point each grid cell keeps (voxel_points_[index]), -1 if none; map_dist starts at
+ * 10000 (reset_grid, :85), map_value at 0 (:356), grid_num: 1 = TYPE_MAP where a point projected, else 3 = TYPE_UNKNOWN.
+ * A cell index >= length (possible in the reference when width is not a multiple of grid_size) is skipped. */
+int orc_vio_grid_select(const orc_vio_config *cfg, const double *Rcw, const double *Pcw, const double *pos, const float *value, int k,
+                        int grid_size, int32_t *winner, float *map_dist, float *map_value, int32_t *grid_num)
+{
+    const int W = cfg->width, H = cfg->height, half = cfg->patch_size / 2;
+    const int gw = W / grid_size, gh = H / grid_size, length = gw * gh;
+    for (int i = 0; i < length; i++) { winner[i] = -1; map_dist[i] = 10000.f; map_value[i] = 0.f; grid_num[i] = 3; }
+    double fpos[3];                                    /* new_frame_->pos() = T_f_w_.inverse().translation() = -(Rcw^T Pcw) */
+    for (int i = 0; i < 3; i++) fpos[i] = -(Rcw[i] * Pcw[0] + Rcw[3 + i] * Pcw[1] + Rcw[6 + i] * Pcw[2]);
+    for (int j = 0; j < k; j++) {
+        const double *p = pos + 3 * (size_t)j;
+        double pc3[3], px[2];
+        s_mv(Rcw, p, pc3);
+        pc3[0] += Pcw[0]; pc3[1] += Pcw[1]; pc3[2] += Pcw[2];
+        if (pc3[2] < 0) continue;                                                      /* :430 */
+        orc_world2cam(cfg, pc3, px);                                                   /* :432 */
+        if (!in_frame((int)px[0], (int)px[1], (half + 1) * 8, W, H)) continue;         /* :436 */
+        const int index = (int)(px[0] / grid_size) * gh + (int)(px[1] / grid_size);   /* :438 */
+        if (index < 0 || index >= length) continue;
+        grid_num[index] = 1;
+        const double o0 = fpos[0] - p[0], o1 = fpos[1] - p[1], o2 = fpos[2] - p[2];
+        const float cur_dist = (float)sqrt(o0 * o0 + o1 * o1 + o2 * o2);
+        const float cur_value = value[j];
+        if (cur_dist <= map_dist[index]) { map_dist[index] = cur_dist; winner[index] = j; }      /* :445-449 */
+        if (cur_value >= map_value[index]) map_value[index] = cur_value;                           /* :451-454 */
+    }
+    return length;
+}

@@ -103,3 +103,30 @@ def test_keyframe_pool_reuse_and_errors(gpu_lib):
     # no candidates, no scan
     dev = h.vio_select_patches(sf.Rcw, sf.Pcw, np.zeros((0, 3), np.float32), (capi.PatchCandidate * 0)())
     assert len(dev["idx"]) == 0
+
+
+@pytest.mark.parametrize("k,grid_size", [(1, 40), (500, 40), (30000, 40), (30000, 11), (5000, 64)])
+def test_grid_competition_matches_oracle(gpu_lib, k, grid_size):
+    """Projection + per-cell competition (lidar_selection.cpp:412-466): winners, distances, values and cell types identical,
+    including exact distance ties (duplicated points: the later one of the list wins) and points behind / outside the image."""
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    sf = synth.make_select_frame(8, seed=19)
+    h = capi.Handle(capi.config_from_frames(sf.lio, sf.vio))
+    rng = np.random.default_rng(k + grid_size)
+    cam = sf.vio.cam
+    px = np.stack([rng.uniform(-60, cam["width"] + 60, k), rng.uniform(-60, cam["height"] + 60, k)], -1)
+    depth = rng.uniform(-2.0, 25.0, k)                        # some behind the camera
+    xyc = np.stack([(px[:, 0] - cam["cx"]) / cam["fx"], (px[:, 1] - cam["cy"]) / cam["fy"], np.ones(k)], -1) * depth[:, None]
+    pos = (xyc - sf.Pcw) @ sf.Rcw
+    if k > 100:
+        pos[k // 2:k // 2 + 40] = pos[:40]                    # exact duplicates -> equal float distances
+    value = rng.uniform(0, 500, k).astype(np.float32)
+    ref = orc.vio_grid_select(orc.vio_config(sf.vio), sf.Rcw, sf.Pcw, pos, value, grid_size)
+    dev = h.vio_grid_select(sf.Rcw, sf.Pcw, pos, value, grid_size)
+    for key in ("winner", "grid_num"):
+        assert np.array_equal(dev[key], ref[key]), key
+    for key in ("map_dist", "map_value"):
+        assert np.array_equal(dev[key].view(np.uint32), ref[key].view(np.uint32)), key
+    if k >= 500:
+        assert (ref["winner"] >= 0).sum() > 3
