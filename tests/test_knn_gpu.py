@@ -138,3 +138,32 @@ def test_exact_ties_and_far_from_origin(gpu_lib, oracle_lib, scene):
         if off == 0:
             assert (np.diff(sq_o, axis=1) == 0).mean() > 0.3                # the ties are really there
     hi.close(); h.close()
+
+
+def test_frame_without_any_valid_neighbour(gpu_lib, oracle_lib, scene):
+    """Map 50 m away from the scan: every point is rejected (sqdist[4] > 5), no effective measurement. The reference's loop then
+    solves with H = 0 (prior pull only; here state_propagat == state, so the state stays put) and stops on the convergence rule;
+    the device must do the same, flag status bit 4 and leave the covariance unchanged."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    fr = synth.make_lio_frame(3000, scene=scene)
+    far = scene.map_xyz + np.float32(50.0)
+
+    def knn(w):
+        nb, _, va, _ = orc.knn5_bruteforce(far, w)
+        return nb, va
+    xo = orc.state18_from_frame(fr)
+    ro = orc.lio18_frame(xo, fr.body_xyz, fr.R_LI, fr.t_LI, fr.laser_point_cov, 10, knn)
+    h = _handle(capi, synth, fr, 10)
+    h.map_set_points(far, 0.5)
+    xg = capi.state18_from_frame(fr)
+    x0 = capi.state18_from_frame(fr)
+    info = h.lio_frame18_dev(xg, fr.body_xyz)
+    assert info.effct_feat_num == 0 == ro["out"].effct_feat_num
+    assert info.iterations == ro["out"].iterations
+    assert info.status & 4
+    assert np.abs(xg.vec() - xo.vec()).max() <= 1e-12 and np.abs(xg.vec() - x0.vec()).max() <= 1e-12
+    assert np.abs(xg.cov_np() - xo.cov_np()).max() <= 1e-15
+    mask, _ = h.lio_get_selection(fr.n)
+    assert mask.sum() == 0
+    h.close()
