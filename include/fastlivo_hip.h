@@ -104,6 +104,9 @@ const char *fl_last_error_string(fl_handle h);
  * RCCL all-reduce enqueued by the caller is ordered with the kernels). NULL selects HIP's default
  * (null) stream. Without this call a handle runs on a private non-blocking stream. */
 int32_t fl_set_stream(fl_handle h, void *hip_stream);
+/* Handles on different streams of one device run concurrently. The multi-pass kernels behind fl_*_iterate(count > 1) and the
+ * frame drivers need all their workgroups (<= one per compute unit) resident at once: keep at most 4 such launches in flight per
+ * device. Exceeding that cannot hang -- every in-kernel wait is bounded and reports status bit 8 -- but it is slow. */
 int32_t fl_sync(fl_handle h);
 /* Page-locked host memory for the arrays the caller hands over every frame (scan points, neighbours, patches):
  * a staging call on such memory is a true asynchronous DMA (fl_lio_set_points of 50 k points costs the host
