@@ -63,6 +63,7 @@ struct fl_context {
     float4 *d_map_pts = nullptr;
     unsigned long long *d_map_keys = nullptr, *d_map_keys_tmp = nullptr;
     struct FlCellEntry *d_map_htab = nullptr;
+    unsigned long long *d_map_ckeys = nullptr;
     unsigned *d_map_idx = nullptr, *d_map_idx_tmp = nullptr;
     void *d_map_sort_tmp = nullptr;
     size_t map_sort_bytes = 0;
@@ -235,7 +236,7 @@ int32_t fl_destroy(fl_handle h)
     hipFree(h->d_epoch); hipFree(h->d_sums_tmp); hipFree(h->d_bcast); hipFree(h->d_vc); hipFree(h->d_img); hipFree(h->d_ref);
     hipFree(h->d_errors); hipFree(h->d_pos); hipFree(h->d_slevel); hipFree(h->d_vio_li);
     hipFree(h->d_map_raw); hipFree(h->d_map_pts); hipFree(h->d_map_keys); hipFree(h->d_map_keys_tmp); hipFree(h->d_map_idx);
-    hipFree(h->d_map_idx_tmp); hipFree(h->d_map_htab); hipFree(h->d_map_sort_tmp);
+    hipFree(h->d_map_idx_tmp); hipFree(h->d_map_htab); hipFree(h->d_map_ckeys); hipFree(h->d_map_sort_tmp);
     vox_free(h);
     imu_free(h);
     select_free(h);

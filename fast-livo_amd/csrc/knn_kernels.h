@@ -38,6 +38,8 @@ struct FlMapGrid {
     const float *raw;                // the map as staged (k x 3), addressed by original index
     const FlCellEntry *htab;         // open-addressing table, key == FL_KNN_EMPTY: free slot
     unsigned hmask;                  // table size - 1 (power of two)
+    const unsigned long long *ckeys; // coarse occupancy set: keys of the 4x4x4-cell blocks that hold at least one point
+    unsigned cmask;
     int npts;
     float cell;                      // edge length
     float inv_cell;
@@ -60,6 +62,23 @@ __device__ __forceinline__ unsigned fl_hash64(unsigned long long k)
     return h;
 }
 
+// coarse block (4 x 4 x 4 cells) of a cell, from the biased 21-bit coordinates packed in its key
+__device__ __forceinline__ unsigned long long fl_coarse_key(unsigned long long cell_key)
+{
+    const unsigned long long m = 0x1FFFFFull;
+    return ((((cell_key >> 42) & m) >> 2) << 42) | ((((cell_key >> 21) & m) >> 2) << 21) | ((cell_key & m) >> 2);
+}
+__device__ __forceinline__ bool fl_coarse_occupied(const unsigned long long *ckeys, unsigned cmask, unsigned long long ck)
+{
+    unsigned h = fl_hash64(ck * 0x9E3779B97F4A7C15ull >> 1) & cmask;
+    while (true) {
+        const unsigned long long k = ckeys[h];
+        if (k == ck) return true;
+        if (k == FL_KNN_EMPTY) return false;
+        h = (h + 1) & cmask;
+    }
+}
+
 __global__ __launch_bounds__(FL_BLOCK) void knn_keys_kernel(const float *__restrict__ map_xyz, int k, float inv_cell,
                                                            unsigned long long *__restrict__ keys, unsigned *__restrict__ idx)
 {
@@ -73,7 +92,8 @@ __global__ __launch_bounds__(FL_BLOCK) void knn_keys_kernel(const float *__restr
 
 __global__ __launch_bounds__(FL_BLOCK) void knn_build_kernel(const float *__restrict__ map_xyz, const unsigned long long *__restrict__ skeys,
                                                             const unsigned *__restrict__ sidx, int k, float4 *__restrict__ pts,
-                                                            FlCellEntry *__restrict__ htab, unsigned hmask)
+                                                            FlCellEntry *__restrict__ htab, unsigned hmask,
+                                                            unsigned long long *__restrict__ ckeys, unsigned cmask)
 {
     const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
     if (i >= k) return;
@@ -88,6 +108,13 @@ __global__ __launch_bounds__(FL_BLOCK) void knn_build_kernel(const float *__rest
             const unsigned long long prev = atomicCAS((unsigned long long *)&htab[h].key, FL_KNN_EMPTY, key);
             if (prev == FL_KNN_EMPTY || prev == key) { htab[h].start = (unsigned)i; htab[h].count = (unsigned)(e - i); break; }
             h = (h + 1) & hmask;
+        }
+        const unsigned long long ck = fl_coarse_key(key);     // the cell's 4x4x4 block is occupied
+        unsigned hc = fl_hash64(ck * 0x9E3779B97F4A7C15ull >> 1) & cmask;
+        while (true) {
+            const unsigned long long prev = atomicCAS(&ckeys[hc], FL_KNN_EMPTY, ck);
+            if (prev == FL_KNN_EMPTY || prev == ck) break;
+            hc = (hc + 1) & cmask;
         }
     }
 }
@@ -304,16 +331,37 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
         // well under a millimetre for maps of several kilometres
         float reach = G.cell - 1e-3f;
         if (!(fl_knn_key_d(g.key[4]) <= reach * reach)) {
-            for (int r = 2; r <= G.max_ring; r++) {
-                const int s = 2 * r + 1, s3 = s * s * s;
-                for (int c = j; c < s3; c += 4) {
-                    const int dz = c / (s * s) - r, rem = c % (s * s), dy = rem / s - r, dx = rem % s - r;
-                    if (max(max(abs(dx), abs(dy)), abs(dz)) < r) continue;      // visited by the previous rings
+            // ring 2 cell by cell (98 cells, round-robin over the quad): enough wherever the map is merely a little thin
+            bool done = false;
+            if (G.max_ring >= 2) {
+                for (int c = j; c < 125; c += 4) {
+                    const int dz = c / 25 - 2, rem = c % 25, dy = rem / 5 - 2, dx = rem % 5 - 2;
+                    if (max(max(abs(dx), abs(dy)), abs(dz)) < 2) continue;      // visited by rings 0..1
                     fl_scan_cell(G, cx + dx, cy + dy, cz + dz, pw[0], pw[1], pw[2], t);
                 }
                 quad_merge_top5(t, g);
-                reach = (float)r * G.cell - 1e-3f;
-                if (fl_knn_key_d(g.key[4]) <= reach * reach) break;
+                reach = 2.0f * G.cell - 1e-3f;
+                done = fl_knn_key_d(g.key[4]) <= reach * reach;
+            }
+            // sparse region: everything out to the ring cap, but only inside the 4x4x4-cell blocks that hold points at all (coarse
+            // occupancy set) -- a query with nothing around costs <= 125 coarse probes instead of (2R+1)^3 cell probes
+            if (!done && G.max_ring >= 3) {
+                const int R = G.max_ring, B = 1 << 20;
+                const int lx = (cx - R + B) >> 2, ly = (cy - R + B) >> 2, lz = (cz - R + B) >> 2;
+                const int nx = ((cx + R + B) >> 2) - lx + 1, ny = ((cy + R + B) >> 2) - ly + 1, nz = ((cz + R + B) >> 2) - lz + 1;
+                const int total = nx * ny * nz;
+                for (int cc = j; cc < total; cc += 4) {
+                    const int bz = lz + cc / (nx * ny), brem = cc % (nx * ny), by = ly + brem / nx, bx = lx + brem % nx;
+                    const unsigned long long ck = ((unsigned long long)(unsigned)bx << 42) | ((unsigned long long)(unsigned)by << 21) | (unsigned long long)(unsigned)bz;
+                    if (!fl_coarse_occupied(G.ckeys, G.cmask, ck)) continue;
+                    for (int f = 0; f < 64; f++) {
+                        const int ix = (bx << 2) + (f & 3) - B, iy = (by << 2) + ((f >> 2) & 3) - B, iz = (bz << 2) + (f >> 4) - B;
+                        const int cheb = max(max(abs(ix - cx), abs(iy - cy)), abs(iz - cz));
+                        if (cheb <= 2 || cheb > R) continue;                    // visited already / beyond the cap
+                        fl_scan_cell(G, ix, iy, iz, pw[0], pw[1], pw[2], t);
+                    }
+                }
+                quad_merge_top5(t, g);
             }
         }
         if (j == 0) {
