@@ -129,3 +129,24 @@ sys.stdout.buffer.write(bytes(x) + np.int32([i.iterations for i in infos] + [i.a
         e = dict(os.environ); e.update(env)
         outs.append(subprocess.run([sys.executable, "-c", child], env=e, check=True, capture_output=True).stdout)
     assert len(outs[0]) > 1000 and outs[0] == outs[1]
+
+
+def test_non_finite_state_is_reported_not_hung(gpu_lib, scene):
+    """A NaN in the incoming state poisons the sums: every pass must still terminate (bounded hand-offs) and report status bit 2;
+    the handle stays usable for the next frame."""
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    fr = synth.make_lio_frame(20000, scene=scene)
+    nbr, valid = synth.knn5(scene, fr.world_at(fr.R_prior, fr.p_prior))
+    h = capi.Handle(capi.config_from_frames(fr, max_iterations=10))
+    bad = capi.state18_from_frame(fr)
+    bad.pos[1] = float("nan")
+    h.lio_set_points(fr.body_xyz); h.lio_begin18(bad, bad); h.lio_set_neighbours(nbr, valid)
+    info = h.lio_iterate18(8, capi.FL_ITER_FORCE)
+    assert info.iterations == 8 and (info.status & 2 or info.effct_feat_num == 0)
+    assert not (info.status & 8)                       # no hand-off timeout
+    # next frame on the same handle is clean
+    x = capi.state18_from_frame(fr)
+    h.lio_set_points(fr.body_xyz); h.lio_begin18(x, x); h.lio_set_neighbours(nbr, valid)
+    good = h.lio_iterate18(3, capi.FL_ITER_FORCE)
+    assert good.status == 0 and good.effct_feat_num > 1000 and np.isfinite(h.lio_get_state18().vec()).all()
