@@ -29,6 +29,8 @@
 struct fl_context {
     fl_config cfg;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t aux_stream = nullptr;      // overlapped uploads (api_imu.inc)
+    hipEvent_t aux_event = nullptr;
     // LIO
     float *d_body = nullptr, *d_nbr = nullptr, *d_world = nullptr;
     uint8_t *d_valid = nullptr, *d_sel = nullptr;
@@ -245,6 +247,8 @@ int32_t fl_destroy(fl_handle h)
     if (h->h_dev23) hipHostFree(h->h_dev23);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->aux_event) hipEventDestroy(h->aux_event);
+    if (h->aux_stream) hipStreamDestroy(h->aux_stream);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
     return FL_OK;
