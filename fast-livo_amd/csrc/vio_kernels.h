@@ -383,6 +383,12 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();
 }
 
+struct FlVioLevelInfo {
+    double solution[18];
+    float error;
+    int32_t iterations, n_meas, accepted, status, converged;
+};
+
 // Up to `count` passes of one pyramid level in ONE launch (see lio18_multipass_kernel): the solver broadcasts the derived camera
 // pose (Rcw, Pcw: what the producers consume) and the stop bit; a rejected solve (error went up, lidar_selection.cpp:888-892)
 // reverts and stops like the reference. Bit-identical to `count` launches of vio_pass_kernel<0>.
@@ -391,13 +397,18 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
                                                                  float *__restrict__ errors, int m, int level,
                                                                  const FlVioConst *__restrict__ VC, FlDev18 *__restrict__ D,
                                                                  void *__restrict__ records, unsigned *__restrict__ epoch_ptr,
-                                                                 unsigned long long *__restrict__ bcast, int count, int flags)
+                                                                 unsigned long long *__restrict__ bcast, int count, int flags,
+                                                                 float begin_residual, FlVioLevelInfo *__restrict__ level_info)
 {
+    // begin_residual >= 0: the launch starts a pyramid level, i.e. it first does what vio_level_begin_kernel does (UpdateState
+    // prologue, lidar_selection.cpp:747,756); level_info != nullptr: it ends with what vio_level_end_kernel does. ComputeJ then
+    // needs one launch per level instead of three.
     constexpr int NT = FL_VIO_NT;
     constexpr int WPB = NT / 64;
     const int nprod = gridDim.x - 1;
     const bool force = (flags & FL_ITER_FORCE) != 0;
-    if (!force && D->stop) return;
+    const bool begin = begin_residual >= 0.f;
+    if (!force && !begin && D->stop) return;
     const unsigned epoch0 = *epoch_ptr;
 
     if (blockIdx.x == nprod) {
@@ -406,6 +417,16 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
         __shared__ FlSolveLds s_solve;
         __shared__ double s_cam[12];
         eskf18_prefetch(D, s_solve);
+        if (begin) {
+            __syncthreads();
+            if (threadIdx.x < 24) D->xold[threadIdx.x] = s_solve.x[threadIdx.x];      // old_state = *state
+            if (threadIdx.x == 32) {
+                s_solve.last_error = begin_residual; s_solve.iters_run = 0; s_solve.accepted = 0; s_solve.fragile = 0;
+                D->last_error = begin_residual; D->level = level; D->stop = 0; D->converged = 0; D->iters_run = 0; D->accepted = 0;
+                D->status = 0;
+            }
+            __syncthreads();
+        }
         int done = 0;
         for (int p = 0; p < count; p++) {
             const unsigned epoch = epoch0 + (unsigned)p;
@@ -425,6 +446,14 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
             __syncthreads();
         }
         if (threadIdx.x == 0) *epoch_ptr = epoch0 + (unsigned)done;
+        if (level_info) {
+            __syncthreads();
+            if (threadIdx.x < 18) level_info->solution[threadIdx.x] = D->solution[threadIdx.x];
+            if (threadIdx.x == 32) {
+                level_info->error = D->last_error; level_info->iterations = D->iters_run; level_info->n_meas = D->neff;
+                level_info->accepted = D->accepted; level_info->status = D->status; level_info->converged = D->converged;
+            }
+        }
         return;
     }
 
@@ -469,11 +498,6 @@ __global__ void vio_level_begin_kernel(FlDev18 *__restrict__ D, int level, float
     D->status = 0;
 }
 
-struct FlVioLevelInfo {
-    double solution[18];
-    float error;
-    int32_t iterations, n_meas, accepted, status, converged;
-};
 __global__ void vio_level_end_kernel(const FlDev18 *__restrict__ D, FlVioLevelInfo *__restrict__ out)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;

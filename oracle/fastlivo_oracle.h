@@ -118,6 +118,7 @@ typedef struct orc_vio_level_out {
     int32_t iterations; /* iterations executed at this level */
     int32_t n_meas;
     int32_t accepted;   /* accepted solves */
+    int32_t fragile;    /* test infrastructure: an accept test was decided within float-rounding distance (3e-5 relative) */
 } orc_vio_level_out;
 
 /* LidarSelector::UpdateState(img, total_residual, level), lidar_selection.cpp:743-902.

@@ -76,7 +76,7 @@ class VioConfig(C.Structure):
 class VioLevelOut(C.Structure):
     _fields_ = [("HTH", C.c_double * 36), ("HTz", C.c_double * 6), ("solution", C.c_double * 18),
                 ("error", C.c_float), ("iterations", C.c_int32), ("n_meas", C.c_int32),
-                ("accepted", C.c_int32)]
+                ("accepted", C.c_int32), ("fragile", C.c_int32)]
 
 
 class State23(C.Structure):

@@ -87,7 +87,7 @@ float orc_vio_update_state(const orc_vio_config *cfg, orc_state18 *x, const orc_
     double *H_sub = (double *)calloc((size_t)H_DIM * 6, sizeof(double));
     int EKF_end = 0;
     float error = 0.0f, last_error = total_residual, patch_error = 0.0f;
-    int iters = 0, accepted = 0, n_meas = 0;
+    int iters = 0, accepted = 0, n_meas = 0, fragile = 0;
     double HTH[36], HTz[6], solution[18];
     memset(HTH, 0, sizeof HTH); memset(HTz, 0, sizeof HTz); memset(solution, 0, sizeof solution);
 
@@ -173,6 +173,9 @@ float orc_vio_update_state(const orc_vio_config *cfg, orc_state18 *x, const orc_
         }
         error = error / n_meas;
 
+        /* not part of the reference: note when the test below is decided within the rounding noise of the float running sum
+         * (see solve18.h); the parity tests use it to choose their tolerance */
+        if (last_error < 1e9f && fabsf(error - last_error) <= 3e-5f * fabsf(error)) fragile = 1;
         if (error <= last_error) {
             old_state = *x;
             last_error = error;
@@ -205,6 +208,7 @@ float orc_vio_update_state(const orc_vio_config *cfg, orc_state18 *x, const orc_
         out->iterations = iters;
         out->n_meas = n_meas;
         out->accepted = accepted;
+        out->fragile = fragile;
     }
     free(z); free(H_sub);
     return last_error;

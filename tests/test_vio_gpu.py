@@ -140,3 +140,31 @@ def test_sharded_accumulate_then_solve_equals_fused(gpu_lib, scene):
     for hh in hs:
         hh.close()
     h.close()
+
+
+def test_accept_test_inside_rounding_noise_is_flagged(gpu_lib, oracle_lib):
+    """The reference decides `error <= last_error` on a FLOAT running sum of res^2 (lidar_selection.cpp:849-859): near convergence the
+    two errors agree to ~1e-6 and the outcome depends on the summation order, which a parallel reduction cannot reproduce. Contract:
+    whenever neither side reports such a decision (status bit 16 / oracle `fragile`) the final state agrees to 1e-9; when one does,
+    the two sides may differ by the one step in question, which is below the level's convergence threshold (1.7e-5 rad, 1e-5 m)."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    seen_fragile = 0
+    for seed in range(1, 13):
+        lio = synth.make_lio_frame(500, seed=synth.SEED + seed % 7)
+        vf = synth.make_vio_frame(1000, lio, max_iterations=10, patch_seed=seed * 7919)
+        h = capi.Handle(capi.config_from_frames(lio, vf, max_iterations=10))
+        xg = capi.state18_from_frame(lio); xp = capi.state18_from_frame(lio)
+        h.vio_set_frame(vf.img); h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+        infos = h.vio_compute_j(xg, xp)
+        xo = orc.state18_from_frame(lio)
+        ro = orc.vio_compute_j(vf, xo, xo.copy())
+        fragile = any(i.status & 16 for i in infos) or any(o.fragile for o in ro["outs"])
+        seen_fragile += fragile
+        d = np.abs(xg.vec() - xo.vec()).max()
+        assert d <= (3e-5 if fragile else 1e-9), (seed, d, fragile)
+        same_path = all(infos[l].iterations == ro["outs"][l].iterations and infos[l].accepted == ro["outs"][l].accepted for l in range(3))
+        if same_path:
+            assert d <= 1e-9, (seed, d)
+        h.close()
+    assert seen_fragile >= 1          # the situation does occur on ordinary frames
