@@ -52,6 +52,7 @@ struct fl_context {
     uint8_t *d_img = nullptr;
     size_t cap_img = 0;
     float *d_ref = nullptr, *d_errors = nullptr;
+    unsigned long long *d_err_words = nullptr;   // [2][cap_patches]: per-patch errors of a pass as self-validating words (solve18.h)
     double *d_pos = nullptr;
     int32_t *d_slevel = nullptr;
     int cap_patches = 0, m = 0;
@@ -236,7 +237,7 @@ int32_t fl_destroy(fl_handle h)
     hipFree(h->d_body); hipFree(h->d_nbr); hipFree(h->d_world); hipFree(h->d_valid); hipFree(h->d_sel);
     hipFree(h->d_plane); hipFree(h->d_normvec); hipFree(h->d_dev); hipFree(h->d_dev23); hipFree(h->d_records);
     hipFree(h->d_epoch); hipFree(h->d_sums_tmp); hipFree(h->d_bcast); hipFree(h->d_vc); hipFree(h->d_img); hipFree(h->d_ref);
-    hipFree(h->d_errors); hipFree(h->d_pos); hipFree(h->d_slevel); hipFree(h->d_vio_li);
+    hipFree(h->d_errors); hipFree(h->d_err_words); hipFree(h->d_pos); hipFree(h->d_slevel); hipFree(h->d_vio_li);
     hipFree(h->d_map_raw); hipFree(h->d_map_pts); hipFree(h->d_map_keys); hipFree(h->d_map_keys_tmp); hipFree(h->d_map_idx);
     hipFree(h->d_map_idx_tmp); hipFree(h->d_map_htab); hipFree(h->d_map_ckeys); hipFree(h->d_map_sort_tmp);
     vox_free(h);
@@ -456,6 +457,10 @@ static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_sta
     D->stop = 0;
     D->max_iter = h->cfg.max_iterations;
     D->last_error = 1e10f;
+    D->last_exact = 1e10f;
+    D->last_exact_valid = 1;
+    D->err_words = h->d_err_words;
+    D->err_cap = h->cap_patches;
     HIPCHK(h, hipMemcpyAsync(h->d_dev, D, sizeof(FlDev18), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(eskf18_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev);
     HIPCHK(h, hipGetLastError());

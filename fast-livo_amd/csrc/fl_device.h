@@ -57,6 +57,15 @@ struct FlDev18 {
     int32_t max_iter;
     int32_t level;      // VIO pyramid level of the current UpdateState
     int32_t searched_at; // device k-NN: value of iters_run the last search was made for (-1: none)
+    // VIO: exact emulation of the reference's float error sum (solve18.h). Per-patch errors of the passes of a level, ping-pong by
+    // pass parity, each an 8-byte self-validating word (float bits << 32 | epoch of the pass that wrote it).
+    unsigned long long *err_words;   // [2][err_cap], set by the host
+    int32_t err_cap;
+    int32_t err_acc_buf;             // half that holds the per-patch errors of the last ACCEPTED pass
+    uint32_t err_acc_epoch;          // ... and the epoch they are tagged with
+    int32_t last_exact_valid;        // last_exact is the reference's float value of last_error (not the fp64-reduced one)
+    float last_exact;
+    int32_t pad_e;
 };
 
 // VIO constants (lidar_selection.cpp:35-59 + camera), computed on the host once per handle.

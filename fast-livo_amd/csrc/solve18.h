@@ -29,6 +29,10 @@ struct FlSolveLds {
     double xadd[15];    // the additive states (pos, vel, bg, ba, grav) after the pass (multi-pass kernels restage from LDS)
     int ctrl;           // multi-pass kernels: bit0 stop, bit1 search wanted (written by the judging lane)
     int fragile;        // VIO: sticky FL_NUM_FRAGILE (16) once an accept test was decided within float-rounding distance
+    // VIO exact accept test (see eskf18_solve_block): mirrors of the FlDev18 fields, kept across the passes of a multi-pass launch
+    int need_exact, acc_buf, last_exact_valid, exact_timeout;
+    unsigned acc_epoch;
+    float last_exact, exact_cur;
     // loop counters of the judgement, staged with the solve inputs so that the judging lane does not wait for global loads
     int rematch, iterCount, max_iter, iters_run, accepted;
     float last_error;
@@ -38,6 +42,41 @@ struct FlSolveLds {
 };
 
 enum { FL_EPI_LIO = 0, FL_EPI_VIO = 1 };
+
+// Per-patch errors of one pass for the exact VIO accept test (see eskf18_solve_block)
+struct FlVioExact {
+    const unsigned long long *words;   // [2][cap]
+    int m, cap;
+    unsigned epoch;                    // of the current pass = tag of its words
+    float *scratch;                    // LDS, FL_EXACT_CHUNK floats
+    int enabled;                       // 0: forced passes (FL_ITER_FORCE, benchmark/diagnostic mode) keep the fast test only
+};
+#define FL_EXACT_CHUNK 2048
+// The reference's `error += patch_error` over patches 0..m-1 as one chain of float additions (no contraction). All threads of the
+// workgroup stage the words (polling until their tag says they belong to pass `tag`); thread 0 adds. Result valid in thread 0.
+__device__ __forceinline__ float vio_exact_sum(const unsigned long long *w, int m, unsigned tag, float *scr, int *timeout_flag)
+{
+#pragma clang fp contract(off)
+    const int tid = threadIdx.x, nt = blockDim.x;
+    float f = 0.0f;
+    for (int base = 0; base < m; base += FL_EXACT_CHUNK) {
+        const int cnt = min(FL_EXACT_CHUNK, m - base);
+        for (int k = tid; k < cnt; k += nt) {
+            unsigned long long v = 0ull;
+            int spin = 0;
+            do {
+                v = __hip_atomic_load(w + base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } while ((unsigned)v != tag && ++spin < 4096);
+            if ((unsigned)v != tag) *timeout_flag = 1;
+            scr[k] = __uint_as_float((unsigned)(v >> 32));
+        }
+        __syncthreads();
+        if (tid == 0)
+            for (int k = 0; k < cnt; k++) f = f + scr[k];
+        __syncthreads();
+    }
+    return f;
+}
 
 // Stage 0 (before the gather): stage the solve inputs in LDS and form vec = x_prop (-) x.
 // Split in two so that the loads can be issued before the kernel's control-word round trip.
@@ -56,6 +95,10 @@ __device__ __forceinline__ double eskf18_prefetch_issue(const FlDev18 *__restric
     else if (tid == 196) v = (double)D->iters_run;
     else if (tid == 197) v = (double)D->accepted;
     else if (tid == 198) v = (double)(D->status & 16);
+    else if (tid == 199) v = (double)D->err_acc_buf;
+    else if (tid == 200) v = (double)D->err_acc_epoch;
+    else if (tid == 201) v = (double)D->last_exact_valid;
+    else if (tid == 202) v = (double)D->last_exact;
     return v;
 }
 __device__ __forceinline__ void eskf18_prefetch_commit(double v, FlSolveLds &L)
@@ -72,6 +115,10 @@ __device__ __forceinline__ void eskf18_prefetch_commit(double v, FlSolveLds &L)
     else if (tid == 196) L.iters_run = (int)v;
     else if (tid == 197) L.accepted = (int)v;
     else if (tid == 198) L.fragile = (int)v;
+    else if (tid == 199) L.acc_buf = (int)v;
+    else if (tid == 200) L.acc_epoch = (unsigned)v;
+    else if (tid == 201) L.last_exact_valid = (int)v;
+    else if (tid == 202) L.last_exact = (float)v;
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     if (wave == 1) {
@@ -108,7 +155,7 @@ __device__ __forceinline__ void fl_bcast_store(unsigned long long *bcast, int id
 }
 template <int KIND>
 __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, const double *s_sums, FlSolveLds &L, int gather_status,
-                                                   unsigned long long *bcast = nullptr, unsigned bepoch = 0u)
+                                                   unsigned long long *bcast = nullptr, unsigned bepoch = 0u, const FlVioExact *ex = nullptr)
 {
 #pragma clang fp contract(fast)
     const int tid = threadIdx.x;
@@ -116,18 +163,51 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
     const double sign = (KIND == FL_EPI_VIO) ? -1.0 : 1.0;
 
     if (KIND == FL_EPI_VIO) {
-        // error = sum(res^2) / n_meas ; accept iff error <= last_error (lidar_selection.cpp:857-861)
+        // error = sum(res^2) / n_meas ; accept iff error <= last_error (lidar_selection.cpp:857-861).
+        // The reference forms `error` as a FLOAT running sum: per patch `patch_error += res*res` over its 64 pixels, then
+        // `error += patch_error` over the patches in order (:849-857). Its last digits depend on that order, which no tree reduction
+        // reproduces, and near convergence the test is decided inside that noise. So: the producers leave every patch's
+        // `patch_error` exactly as the reference rounds it (vio_produce), the fast test uses the fp64-reduced sum, and whenever it is
+        // closer than (m + 8) * 2^-24 relative (the worst-case distance between the two sums) the workgroup replays the reference's running sum
+        // over those per-patch floats -- m dependent float additions by one lane, ~5 us, only on such passes -- for this pass and, if
+        // not known yet, for the last accepted one, and decides on the reference's own float values (status bit 16 reports that the
+        // slow path ran). Without the per-patch words (sharded solve kernel: `ex` == nullptr) bit 16 means "may differ".
         if (tid == 0) {
             const float n_meas = (float)s_sums[FL_S_NEFF];
             const float error = (float)s_sums[FL_S_RES] / n_meas;
-            const int acc = (error <= L.last_error) ? 1 : 0;
-            // The reference forms `error` as a float running sum over all patches (lidar_selection.cpp:849-857): its last digits
-            // depend on the summation order, which no parallel reduction can reproduce. When the test is decided inside that noise
-            // (relative 3e-5: sqrt(#pixels) float roundings) the two sides may take different branches; say so (sticky bit 16).
-            if (L.last_error < 1e9f && fabsf(error - L.last_error) <= 3e-5f * fabsf(error)) L.fragile = 16;
+            const float last = L.last_error;
+            // worst-case distance between this fp64-reduced value and the reference's float running sum, for both operands:
+            // m additions of at most half an ulp each, plus the casts and the division
+            const float thr = (n_meas * (1.0f / 64.0f) + 8.0f) * 5.9604645e-8f;
+            L.need_exact = (last < 1e9f && fabsf(error - last) <= thr * fabsf(error)) ? 1 : 0;
+            L.exact_cur = error;
+            L.exact_timeout = 0;
+        }
+        __syncthreads();
+        if (L.need_exact && ex && ex->enabled) {
+            const int cur_buf = L.iters_run & 1;
+            const float fc = vio_exact_sum(ex->words + (size_t)cur_buf * ex->cap, ex->m, ex->epoch, ex->scratch, &L.exact_timeout);
+            if (tid == 0) L.exact_cur = fc / (float)(64 * ex->m);
+            if (!L.last_exact_valid && L.acc_buf != cur_buf) {   // (same half: only when forced passes ran on after a rejection)
+                const float fl = vio_exact_sum(ex->words + (size_t)L.acc_buf * ex->cap, ex->m, L.acc_epoch, ex->scratch, &L.exact_timeout);
+                if (tid == 0) { L.last_exact = fl / (float)(64 * ex->m); L.last_exact_valid = 1; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const bool exact = L.need_exact && ex && ex->enabled && !L.exact_timeout && L.last_exact_valid;
+            const float error = (L.need_exact && !exact) ? (float)s_sums[FL_S_RES] / (float)s_sums[FL_S_NEFF] : L.exact_cur;
+            const float last = exact ? L.last_exact : L.last_error;
+            const int acc = (error <= last) ? 1 : 0;
+            if (L.need_exact) L.fragile = 16;
             L.accept = acc;
             D->error = error;
-            if (acc) { D->last_error = error; L.last_error = error; }
+            if (acc) {
+                D->last_error = error; L.last_error = error;
+                L.acc_buf = L.iters_run & 1; L.acc_epoch = ex ? ex->epoch : 0u;
+                L.last_exact_valid = exact ? 1 : 0; L.last_exact = error;
+                D->err_acc_buf = L.acc_buf; D->err_acc_epoch = L.acc_epoch; D->last_exact_valid = L.last_exact_valid; D->last_exact = error;
+            }
         }
         __syncthreads();
         if (!L.accept) {   // revert: state = old_state ; EKF_end (:888-892)

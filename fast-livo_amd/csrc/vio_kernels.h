@@ -218,11 +218,32 @@ __device__ __forceinline__ FlVioFirst vio_prefetch_first(const float *__restrict
     return f;
 }
 
+// float patch_error of one patch from its 64 residuals in LDS (pixel order x*8+y), by the first lane of the patch's half-wave
+__device__ __forceinline__ void vio_patch_error(const float *r, int hl, bool active, int i, float *__restrict__ errors,
+                                                unsigned long long *__restrict__ err_words, unsigned epoch)
+{
+    if (hl != 0 || !active) return;
+#ifdef FL_NO_PATCH_CHAIN
+    return;
+#endif
+    float pe = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < 64; k++) {
+        const double rd = (double)r[k];
+        pe = (float)((double)pe + rd * rd);          // the product of two floats is exact in double: fused or not, same rounding
+    }
+    errors[i] = pe;
+    if (err_words)
+        __hip_atomic_store(err_words + i, ((unsigned long long)__float_as_uint(pe) << 32) | (unsigned long long)epoch, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // One producer workgroup's share of a pass: residuals, rows, 6x6 update for its patches, reduced to one record and published.
 __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, const float *__restrict__ ref, const double *__restrict__ pos,
                                             const int32_t *__restrict__ slevel, float *__restrict__ errors, int m, int level_arg, int level,
                                             const FlVioConst &vc, const double (&Rcw)[9], const double (&Pcw)[3], const FlVioFirst &pf,
-                                            int nprod, double *s_red, unsigned epoch, void *__restrict__ records, int flags)
+                                            int nprod, double *s_red, unsigned epoch, void *__restrict__ records, int flags,
+                                            unsigned long long *__restrict__ err_words /* this pass's half, nullable */, float *s_res /* LDS */)
 {
     constexpr int WPB = FL_VIO_NT / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -242,6 +263,8 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
     if (blockIdx.x == 0) fl_stamp(flags, 0);
     // trip count uniform over the wave: both halves iterate together, an inactive half (odd m) computes
     // on patch 0 and contributes nothing
+    int def_i = 0;
+    bool def_active = false;
     for (int ib = (blockIdx.x * WPB + wave) * 2; ib < m; ib += nprod * WPB * 2) {
         const int i = ib + half;
         const bool active = i < m;
@@ -301,15 +324,24 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
         for (int px = 0; px < 2; px++) {
             float du, dv, resf;
             fl_pixel_grad(g, t[px], refv[px], &du, &dv, &resf);
+            s_res[(wave * 2 + half) * 64 + 32 * px + hl] = resf;        // pixel order of the reference: x * 8 + y
             const double dud = (double)du, dvd = (double)dv, res = (double)resf;
             w8[0] += dud * dud; w8[1] += dud * dvd; w8[2] += dvd * dvd;
             w8[3] += dud * res; w8[4] += dvd * res; w8[5] += res * res;
         }
         double T6[6];
         half_sum6(w8, lane, T6);
-        if (active) {
-            fl_patch_accum(v, M, T6);
-            if (hl == 0) errors[i] = (float)T6[5];
+        // patch_error exactly as the reference rounds it (lidar_selection.cpp:849: float patch_error; patch_error += res*res with a
+        // double res): one lane per patch replays the 64 additions in pixel order (vio_patch_error). It feeds only the errors[]
+        // output and the rare exact accept test, never the record: for the wave's LAST patch pair it is deferred until the record is
+        // published, off the hand-off's critical path (the residuals wait in LDS).
+        const bool last_iter = (ib + nprod * WPB * 2 >= m);
+        if (active) fl_patch_accum(v, M, T6);
+        if (last_iter) { def_i = i; def_active = active; }
+        else {
+            __builtin_amdgcn_wave_barrier();
+            vio_patch_error(s_res + (wave * 2 + half) * 64, hl, active, i, errors, err_words, epoch);
+            __builtin_amdgcn_wave_barrier();
         }
     }
     if (blockIdx.x == 0) fl_stamp(flags, 1);
@@ -326,6 +358,8 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
         for (int w = 1; w < 2 * WPB; w++) mine += s_red[w * FL_SUMS18 + threadIdx.x];
     }
     publish_record<FL_SUMS18>(mine, epoch, records);
+    __builtin_amdgcn_wave_barrier();
+    vio_patch_error(s_res + (wave * 2 + half) * 64, hl, def_active, def_i, errors, err_words, epoch);
 }
 
 template <int MODE>
@@ -358,7 +392,10 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
         fl_stamp(flags, 10);
         if (threadIdx.x == 0) *epoch_ptr = epoch + 1u;
         if (MODE == 0) {
-            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, gst);
+            __shared__ float s_ex[FL_EXACT_CHUNK];
+            FlVioExact ex;
+            ex.words = D->err_words; ex.m = m; ex.cap = D->err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !(flags & FL_ITER_FORCE);
+            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, gst, nullptr, 0u, ex.words ? &ex : nullptr);
             __syncthreads();
             vio_derive_pose(s_solve.xn, VC, D);      // camera pose for the next pass's producers
         } else {
@@ -378,7 +415,9 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     for (int i = 0; i < 9; i++) Rcw[i] = D->Rcw[i];
 #pragma unroll
     for (int i = 0; i < 3; i++) Pcw[i] = D->Pcw[i];
-    vio_produce(img, ref, pos, slevel, errors, m, level_arg, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags);
+    __shared__ float s_res[2 * WPB * 64];
+    unsigned long long *ew = D->err_words ? D->err_words + (size_t)(D->iters_run & 1) * D->err_cap : nullptr;
+    vio_produce(img, ref, pos, slevel, errors, m, level_arg, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags, ew, s_res);
     if (blockIdx.x == 0) fl_stamp(flags, 2);
     if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();
 }
@@ -410,18 +449,24 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
     const bool begin = begin_residual >= 0.f;
     if (!force && !begin && D->stop) return;
     const unsigned epoch0 = *epoch_ptr;
+    unsigned long long *err_base = D->err_words;
+    const int err_cap = D->err_cap;
+    const int pass0 = begin ? 0 : D->iters_run;          // index of this launch's first pass within its pyramid level
 
     if (blockIdx.x == nprod) {
         __shared__ double s_fin[2 * NT];
         __shared__ double s_sums[FL_SUMS18];
         __shared__ FlSolveLds s_solve;
         __shared__ double s_cam[12];
+        __shared__ float s_ex[FL_EXACT_CHUNK];
         eskf18_prefetch(D, s_solve);
         if (begin) {
             __syncthreads();
             if (threadIdx.x < 24) D->xold[threadIdx.x] = s_solve.x[threadIdx.x];      // old_state = *state
             if (threadIdx.x == 32) {
                 s_solve.last_error = begin_residual; s_solve.iters_run = 0; s_solve.accepted = 0; s_solve.fragile = 0;
+                s_solve.last_exact = begin_residual; s_solve.last_exact_valid = 1; s_solve.acc_buf = 0; s_solve.acc_epoch = 0u;
+                D->last_exact = begin_residual; D->last_exact_valid = 1; D->err_acc_buf = 0; D->err_acc_epoch = 0u;
                 D->last_error = begin_residual; D->level = level; D->stop = 0; D->converged = 0; D->iters_run = 0; D->accepted = 0;
                 D->status = 0;
             }
@@ -431,7 +476,9 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
         for (int p = 0; p < count; p++) {
             const unsigned epoch = epoch0 + (unsigned)p;
             const int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
-            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, gst);
+            FlVioExact ex;
+            ex.words = err_base; ex.m = m; ex.cap = err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !force;
+            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, gst, nullptr, 0u, err_base ? &ex : nullptr);
             __syncthreads();
             vio_derive_pose(s_solve.xn, VC, D);
             // the same 12 threads publish what they just derived (D->Rcw / D->Pcw are their own stores)
@@ -460,6 +507,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
     __shared__ double s_red[2 * WPB * FL_SUMS18];
     __shared__ double s_pose[12];
     __shared__ int s_ctrl;
+    __shared__ float s_res[2 * WPB * 64];
     const FlVioConst vc = *VC;
     double Rcw[9], Pcw[3];
 #pragma unroll
@@ -479,7 +527,8 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
 #pragma unroll
             for (int i = 0; i < 3; i++) Pcw[i] = s_pose[9 + i];
         }
-        vio_produce(img, ref, pos, slevel, errors, m, level, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags);
+        vio_produce(img, ref, pos, slevel, errors, m, level, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags,
+                    err_base ? err_base + (size_t)((pass0 + ps) & 1) * err_cap : nullptr, s_res);
         __syncthreads();
     }
 }
@@ -490,6 +539,7 @@ __global__ void vio_level_begin_kernel(FlDev18 *__restrict__ D, int level, float
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     for (int i = 0; i < 24; i++) D->xold[i] = D->x[i];
     D->last_error = total_residual;
+    D->last_exact = total_residual; D->last_exact_valid = 1; D->err_acc_buf = 0; D->err_acc_epoch = 0u;
     D->level = level;
     D->stop = 0;
     D->converged = 0;

@@ -32,9 +32,10 @@ extern "C" {
 #define FL_NUM_NONFINITE 2    /* NaN/Inf in the state delta */
 #define FL_NUM_FEWPOINTS 4    /* no effective measurement */
 #define FL_NUM_TIMEOUT 8      /* a bounded in-kernel hand-off wait expired (the pass was abandoned) */
-#define FL_NUM_FRAGILE 16     /* VIO: an accept test `error <= last_error` (lidar_selection.cpp:859) was decided within 3e-5 relative,
-                                 i.e. inside the rounding noise of the reference's float running sum of res^2: the reference and this
-                                 library may legitimately take different branches there (they then differ by one sub-threshold step) */
+#define FL_NUM_FRAGILE 16     /* VIO: an accept test `error <= last_error` (lidar_selection.cpp:859) fell inside the rounding noise of the
+                                 reference's float running sum of res^2 and was decided by replaying that sum in the reference's own
+                                 arithmetic (informational). Only where the per-patch errors are not available -- the sharded
+                                 fl_vio_solve -- or under FL_ITER_FORCE it means "the reference may take the other branch here". */
 
 #define FL_DIM18 18           /* DIM_STATE, include/common_lib.h:34 */
 #define FL_DIM23 23           /* state_ikfom::DOF, include/use-ikfom.hpp:12-21 */

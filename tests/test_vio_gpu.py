@@ -142,14 +142,15 @@ def test_sharded_accumulate_then_solve_equals_fused(gpu_lib, scene):
     h.close()
 
 
-def test_accept_test_inside_rounding_noise_is_flagged(gpu_lib, oracle_lib):
+def test_accept_test_is_replayed_in_the_reference_arithmetic(gpu_lib, oracle_lib):
     """The reference decides `error <= last_error` on a FLOAT running sum of res^2 (lidar_selection.cpp:849-859): near convergence the
-    two errors agree to ~1e-6 and the outcome depends on the summation order, which a parallel reduction cannot reproduce. Contract:
-    whenever neither side reports such a decision (status bit 16 / oracle `fragile`) the final state agrees to 1e-9; when one does,
-    the two sides may differ by the one step in question, which is below the level's convergence threshold (1.7e-5 rad, 1e-5 m)."""
+    two errors agree to ~1e-6 and the outcome depends on the summation order. The device keeps every patch's float `patch_error`
+    exactly as the reference rounds it and, whenever its fast fp64 test is closer than 5e-4, replays the reference's running sum
+    (status bit 16 reports it): the accept/revert path and the final state then agree with the oracle on every frame -- also on
+    the ~1 in 10 where a tree-reduced sum takes the other branch -- and the per-patch errors are bit-identical."""
     capi, orc = gpu_lib, oracle_lib
     from fast_livo_amd import synth
-    seen_fragile = 0
+    replayed = 0
     for seed in range(1, 13):
         lio = synth.make_lio_frame(500, seed=synth.SEED + seed % 7)
         vf = synth.make_vio_frame(1000, lio, max_iterations=10, patch_seed=seed * 7919)
@@ -157,14 +158,14 @@ def test_accept_test_inside_rounding_noise_is_flagged(gpu_lib, oracle_lib):
         xg = capi.state18_from_frame(lio); xp = capi.state18_from_frame(lio)
         h.vio_set_frame(vf.img); h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
         infos = h.vio_compute_j(xg, xp)
+        eg = h.vio_get_errors(vf.m)
         xo = orc.state18_from_frame(lio)
         ro = orc.vio_compute_j(vf, xo, xo.copy())
-        fragile = any(i.status & 16 for i in infos) or any(o.fragile for o in ro["outs"])
-        seen_fragile += fragile
-        d = np.abs(xg.vec() - xo.vec()).max()
-        assert d <= (3e-5 if fragile else 1e-9), (seed, d, fragile)
-        same_path = all(infos[l].iterations == ro["outs"][l].iterations and infos[l].accepted == ro["outs"][l].accepted for l in range(3))
-        if same_path:
-            assert d <= 1e-9, (seed, d)
+        replayed += any(i.status & 16 for i in infos)
+        for l in range(3):
+            assert infos[l].iterations == ro["outs"][l].iterations and infos[l].accepted == ro["outs"][l].accepted, (seed, l)
+        assert np.abs(xg.vec() - xo.vec()).max() <= 1e-9, seed
+        assert np.abs(xg.cov_np() - xo.cov_np()).max() <= 1e-11, seed
+        assert np.array_equal(eg.view(np.uint32), ro["errors"].view(np.uint32)), seed
         h.close()
-    assert seen_fragile >= 1          # the situation does occur on ordinary frames
+    assert replayed >= 1          # the slow path is exercised by ordinary frames

@@ -26,8 +26,8 @@ for trial in range(T):
     e3 = np.abs(eg - ro["errors"]).max() / max(1.0, np.abs(ro["errors"]).max())
     its = [int(i.iterations) for i in ig]; ito = [int(o.iterations) for o in ro["outs"]]
     # an accept test decided inside the rounding noise of the reference's float running sum may go either way (status bit 16)
-    fragile = any(i.status & 16 for i in ig) or any(o.fragile for o in ro["outs"])
-    ok = (e1 <= (3e-5 if fragile else 1e-9)) and (e2 <= (1e-8 if fragile else 1e-11)) and (e3 <= (1e-2 if fragile else 1e-5)) and (fragile or its == ito)
+    fragile = any(i.status & 16 for i in ig)       # the exact replay of the reference's float error sum ran
+    ok = e1 <= 1e-9 and e2 <= 1e-11 and np.array_equal(eg.view(np.uint32), ro["errors"].view(np.uint32)) and its == ito
     # selection
     k = int(rng.choice([1, 3, 64, 500]))
     sf = synth.make_select_frame(k, seed=seed, n_keyframes=int(rng.integers(1, 4)))
