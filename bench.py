@@ -137,17 +137,32 @@ def main():
     if distributed:
         exchange = "torch.distributed.all_reduce"
         if os.environ.get("FL_BENCH_TORCH_EXCHANGE") != "1":
-            try:
-                for h_ in (hl, hv):
-                    uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-                    if rank == 0:
-                        uid.copy_(torch.frombuffer(bytearray(h_.comm_unique_id()), dtype=torch.uint8))
-                    dist.broadcast(uid, 0)
-                    torch.cuda.synchronize()
-                    h_.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, max(world, 1))
+            # every rank must take the same branch: the unique id carries rank 0's verdict in its last byte, and the outcome of
+            # comm_init is agreed on with a MIN all-reduce before anybody relies on the native communicator
+            ok = 1
+            for h_ in (hl, hv):
+                uid = torch.zeros(129, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    try:
+                        raw = bytearray(h_.comm_unique_id()) + bytearray([1])
+                        uid.copy_(torch.frombuffer(raw, dtype=torch.uint8))
+                    except Exception as e:   # noqa: BLE001
+                        print(f"[bench] native RCCL exchange unavailable ({e}); using torch.distributed", file=sys.stderr)
+                dist.broadcast(uid, 0)
+                torch.cuda.synchronize()
+                host = uid.cpu().numpy().tobytes()
+                if host[128] != 1:
+                    ok = 0
+                    break
+                try:
+                    h_.comm_init(bytes(host[:128]), rank, max(world, 1))
+                except Exception as e:   # noqa: BLE001
+                    print(f"[bench] rank {rank}: comm_init failed ({e})", file=sys.stderr)
+                    ok = 0                       # keep going: the other ranks are in the next broadcast
+            agree = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if int(agree.item()) == 1:
                 exchange = "ncclAllReduce on the pass stream (native)"
-            except Exception as e:   # noqa: BLE001
-                print(f"[bench] native RCCL exchange unavailable ({e}); using torch.distributed", file=sys.stderr)
     native = exchange.startswith("ncclAllReduce")
 
     # A frame of the reference runs its passes back to back (<= max_iteration + 1 LIO passes, <= max_iteration VIO passes per

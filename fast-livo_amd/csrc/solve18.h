@@ -155,7 +155,7 @@ __device__ __forceinline__ void fl_bcast_store(unsigned long long *bcast, int id
 }
 template <int KIND>
 __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, const double *s_sums, FlSolveLds &L, int gather_status,
-                                                   unsigned long long *bcast = nullptr, unsigned bepoch = 0u, const FlVioExact *ex = nullptr)
+                                                   unsigned long long *bcast = nullptr, unsigned bepoch = 0u, const FlVioExact ex = FlVioExact{})
 {
 #pragma clang fp contract(fast)
     const int tid = threadIdx.x;
@@ -172,6 +172,21 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
         // over those per-patch floats -- m dependent float additions by one lane, ~5 us, only on such passes -- for this pass and, if
         // not known yet, for the last accepted one, and decides on the reference's own float values (status bit 16 reports that the
         // slow path ran). Without the per-patch words (sharded solve kernel: `ex` == nullptr) bit 16 means "may differ".
+        const bool can_replay = ex.words != nullptr && ex.enabled;     // (by value: a nullable pointer to it kept the struct in scratch)
+        auto decide = [&](bool exact) {          // thread 0 only
+            const float error = exact ? L.exact_cur : (float)s_sums[FL_S_RES] / (float)s_sums[FL_S_NEFF];
+            const float last = exact ? L.last_exact : L.last_error;
+            const int acc = (error <= last) ? 1 : 0;
+            if (L.need_exact) L.fragile = 16;
+            L.accept = acc;
+            D->error = error;
+            if (acc) {
+                D->last_error = error; L.last_error = error;
+                L.acc_buf = L.iters_run & 1; L.acc_epoch = ex.epoch;
+                L.last_exact_valid = exact ? 1 : 0; L.last_exact = error;
+                D->err_acc_buf = L.acc_buf; D->err_acc_epoch = L.acc_epoch; D->last_exact_valid = L.last_exact_valid; D->last_exact = error;
+            }
+        };
         if (tid == 0) {
             const float n_meas = (float)s_sums[FL_S_NEFF];
             const float error = (float)s_sums[FL_S_RES] / n_meas;
@@ -180,36 +195,22 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
             // m additions of at most half an ulp each, plus the casts and the division
             const float thr = (n_meas * (1.0f / 64.0f) + 8.0f) * 5.9604645e-8f;
             L.need_exact = (last < 1e9f && fabsf(error - last) <= thr * fabsf(error)) ? 1 : 0;
-            L.exact_cur = error;
             L.exact_timeout = 0;
+            if (!(L.need_exact && can_replay)) decide(false);       // the common case: one barrier, as before
         }
         __syncthreads();
-        if (L.need_exact && ex && ex->enabled) {
+        if (L.need_exact && can_replay) {
             const int cur_buf = L.iters_run & 1;
-            const float fc = vio_exact_sum(ex->words + (size_t)cur_buf * ex->cap, ex->m, ex->epoch, ex->scratch, &L.exact_timeout);
-            if (tid == 0) L.exact_cur = fc / (float)(64 * ex->m);
+            const float fc = vio_exact_sum(ex.words + (size_t)cur_buf * ex.cap, ex.m, ex.epoch, ex.scratch, &L.exact_timeout);
+            if (tid == 0) L.exact_cur = fc / (float)(64 * ex.m);
             if (!L.last_exact_valid && L.acc_buf != cur_buf) {   // (same half: only when forced passes ran on after a rejection)
-                const float fl = vio_exact_sum(ex->words + (size_t)L.acc_buf * ex->cap, ex->m, L.acc_epoch, ex->scratch, &L.exact_timeout);
-                if (tid == 0) { L.last_exact = fl / (float)(64 * ex->m); L.last_exact_valid = 1; }
+                const float fl = vio_exact_sum(ex.words + (size_t)L.acc_buf * ex.cap, ex.m, L.acc_epoch, ex.scratch, &L.exact_timeout);
+                if (tid == 0) { L.last_exact = fl / (float)(64 * ex.m); L.last_exact_valid = 1; }
             }
             __syncthreads();
+            if (tid == 0) decide(!L.exact_timeout && L.last_exact_valid);
+            __syncthreads();
         }
-        if (tid == 0) {
-            const bool exact = L.need_exact && ex && ex->enabled && !L.exact_timeout && L.last_exact_valid;
-            const float error = (L.need_exact && !exact) ? (float)s_sums[FL_S_RES] / (float)s_sums[FL_S_NEFF] : L.exact_cur;
-            const float last = exact ? L.last_exact : L.last_error;
-            const int acc = (error <= last) ? 1 : 0;
-            if (L.need_exact) L.fragile = 16;
-            L.accept = acc;
-            D->error = error;
-            if (acc) {
-                D->last_error = error; L.last_error = error;
-                L.acc_buf = L.iters_run & 1; L.acc_epoch = ex ? ex->epoch : 0u;
-                L.last_exact_valid = exact ? 1 : 0; L.last_exact = error;
-                D->err_acc_buf = L.acc_buf; D->err_acc_epoch = L.acc_epoch; D->last_exact_valid = L.last_exact_valid; D->last_exact = error;
-            }
-        }
-        __syncthreads();
         if (!L.accept) {   // revert: state = old_state ; EKF_end (:888-892)
             if (tid < 24) {
                 const double xo = D->xold[tid];

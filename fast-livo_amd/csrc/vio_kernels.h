@@ -233,7 +233,11 @@ __device__ __forceinline__ void vio_patch_error(const float *r, int hl, bool act
         pe = (float)((double)pe + rd * rd);          // the product of two floats is exact in double: fused or not, same rounding
     }
     errors[i] = pe;
+#ifndef FL_AB_NO_ERRWORDS
     if (err_words)
+#else
+    if (false)
+#endif
         __hip_atomic_store(err_words + i, ((unsigned long long)__float_as_uint(pe) << 32) | (unsigned long long)epoch, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
             __shared__ float s_ex[FL_EXACT_CHUNK];
             FlVioExact ex;
             ex.words = D->err_words; ex.m = m; ex.cap = D->err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !(flags & FL_ITER_FORCE);
-            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, gst, nullptr, 0u, ex.words ? &ex : nullptr);
+            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, gst, nullptr, 0u, ex);
             __syncthreads();
             vio_derive_pose(s_solve.xn, VC, D);      // camera pose for the next pass's producers
         } else {
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
             const int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
             FlVioExact ex;
             ex.words = err_base; ex.m = m; ex.cap = err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !force;
-            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, gst, nullptr, 0u, err_base ? &ex : nullptr);
+            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, gst, nullptr, 0u, ex);
             __syncthreads();
             vio_derive_pose(s_solve.xn, VC, D);
             // the same 12 threads publish what they just derived (D->Rcw / D->Pcw are their own stores)
