@@ -201,6 +201,10 @@ SYMBOLS = {
     "fl_ikfom_accumulate": (C.c_int32, [_H, C.c_void_p, C.c_int32]),
     "fl_ikfom_solve": (C.c_int32, [_H, C.c_void_p, C.c_int32, C.POINTER(IterInfo)]),
     "fl_map_set_points": (C.c_int32, [_H, _fp, C.c_int32, C.c_float]),
+    "fl_map_clear": (C.c_int32, [_H, C.c_float]),
+    "fl_map_add_points": (C.c_int32, [_H, _fp, C.c_int32, C.c_float, C.c_void_p]),
+    "fl_map_delete_boxes": (C.c_int32, [_H, _fp, C.c_int32, C.c_void_p]),
+    "fl_map_get_points": (C.c_int32, [_H, _fp, C.c_int32, C.POINTER(C.c_int32)]),
     "fl_lio_search18": (C.c_int32, [_H, _fp, _u8p]),
     "fl_ikfom_search": (C.c_int32, [_H, _fp, _u8p]),
     "fl_lio_frame18_dev": (C.c_int32, [_H, C.POINTER(State18), _fp, C.c_int32, C.POINTER(IterInfo)]),
@@ -662,10 +666,43 @@ def state23_from_frame(fr):
 
 
 # ------------------------------------------------------------------------------------ device k-NN
+class MapInfo(C.Structure):
+    """fl_map_info"""
+    _fields_ = [("n_before", C.c_int32), ("n_after", C.c_int32), ("n_added", C.c_int32), ("n_removed", C.c_int32),
+                ("n_ambiguous", C.c_int32), ("status", C.c_int32)]
+
+
 def _knn_methods():
     def map_set_points(self, map_xyz, cell_size=0.5):
         m = np.ascontiguousarray(map_xyz, dtype=np.float32)
         self._chk(self.L.fl_map_set_points(self.h, _p(m, C.c_float), m.shape[0], cell_size), "fl_map_set_points")
+
+    def map_clear(self, cell_size=0.5):
+        self._chk(self.L.fl_map_clear(self.h, cell_size), "fl_map_clear")
+
+    def map_add_points(self, world_xyz, downsample_size):
+        """map_incremental on the device map; world_xyz None = the staged scan under the device's 18-state. Returns MapInfo."""
+        info = MapInfo()
+        if world_xyz is None:
+            self._chk(self.L.fl_map_add_points(self.h, None, 0, downsample_size, C.addressof(info)), "fl_map_add_points")
+        else:
+            w = np.ascontiguousarray(world_xyz, dtype=np.float32).reshape(-1, 3)
+            self._chk(self.L.fl_map_add_points(self.h, _p(w, C.c_float), w.shape[0], downsample_size, C.addressof(info)), "fl_map_add_points")
+        return info
+
+    def map_delete_boxes(self, boxes):
+        b = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
+        info = MapInfo()
+        self._chk(self.L.fl_map_delete_boxes(self.h, _p(b, C.c_float), b.shape[0], C.addressof(info)), "fl_map_delete_boxes")
+        return info
+
+    def map_get_points(self):
+        n = C.c_int32(0)
+        self._chk(self.L.fl_map_get_points(self.h, None, 0, C.byref(n)), "fl_map_get_points")
+        out = np.zeros((max(n.value, 1), 3), dtype=np.float32)
+        if n.value:
+            self._chk(self.L.fl_map_get_points(self.h, _p(out, C.c_float), n.value, C.byref(n)), "fl_map_get_points")
+        return out[:n.value]
 
     def lio_search18(self, n, want=True):
         nbr = np.zeros((n, 5, 3), dtype=np.float32)
@@ -700,7 +737,7 @@ def _knn_methods():
                                                       _p(limit, C.c_double), C.byref(info)), "fl_ikfom_update_iterated_dev")
         return info
 
-    for f in (map_set_points, lio_search18, ikfom_search, lio_frame18_dev, ikfom_update_iterated_dev):
+    for f in (map_set_points, map_clear, map_add_points, map_delete_boxes, map_get_points, lio_search18, ikfom_search, lio_frame18_dev, ikfom_update_iterated_dev):
         setattr(Handle, f.__name__, f)
 
 

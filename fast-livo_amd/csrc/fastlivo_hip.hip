@@ -10,6 +10,7 @@
 #include "ikfom_kernels.h"
 #include "knn_kernels.h"
 #include "voxel_kernels.h"
+#include "mapupd_kernels.h"
 #include "imu_kernels.h"
 #include "select_kernels.h"
 
@@ -37,6 +38,7 @@ struct fl_context {
     float4 *d_plane = nullptr, *d_normvec = nullptr;
     int cap_points = 0, n = 0;
     bool have_nbr = false;
+    bool begun18 = false;         // an 18-state is on the device (fl_lio_begin18 / fl_vio_begin / frame drivers)
     int num_cus = 0;              // compute units of the device: the multi-pass kernels need every workgroup resident (<= 1 per CU)
     bool normvec_valid = false;   // a pass with FL_ITER_KEEP_NORMVEC has run on the staged scan
     // 18-state block, reduction scratch
@@ -62,7 +64,16 @@ struct fl_context {
     FlDev23 *d_dev23 = nullptr;
     FlDev23 *h_dev23 = nullptr;
     // device map grid for the k-NN (knn_kernels.h)
-    float *d_map_raw = nullptr;
+    float *d_map_raw = nullptr, *d_map_raw2 = nullptr;   // the map array (original order) and its ping-pong partner (map updates)
+    // map maintenance on the device (mapupd_kernels.h)
+    float *d_mu_new = nullptr, *d_mu_boxes = nullptr;
+    int *d_mu_flags = nullptr, *d_mu_pos = nullptr, *d_mu_slot = nullptr;
+    struct FlBoxSlot *d_mu_tab = nullptr;
+    struct FlMapUpdInfo *d_mu_info = nullptr, *h_mu_info = nullptr;
+    void *d_mu_tmp = nullptr;
+    size_t mu_tmp_bytes = 0;
+    int mu_cap = 0, mu_new_cap = 0;
+    unsigned mu_tab_cap = 0;
     float4 *d_map_pts = nullptr;
     unsigned long long *d_map_keys = nullptr, *d_map_keys_tmp = nullptr;
     struct FlCellEntry *d_map_htab = nullptr;
@@ -225,6 +236,7 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
 }
 
 static void vox_free(fl_handle h);
+static void mapupd_free(fl_handle h);
 static void imu_free(fl_handle h);
 static void select_free(fl_handle h);
 extern "C" int32_t fl_comm_destroy(fl_handle h);
@@ -238,8 +250,9 @@ int32_t fl_destroy(fl_handle h)
     hipFree(h->d_plane); hipFree(h->d_normvec); hipFree(h->d_dev); hipFree(h->d_dev23); hipFree(h->d_records);
     hipFree(h->d_epoch); hipFree(h->d_sums_tmp); hipFree(h->d_bcast); hipFree(h->d_vc); hipFree(h->d_img); hipFree(h->d_ref);
     hipFree(h->d_errors); hipFree(h->d_err_words); hipFree(h->d_pos); hipFree(h->d_slevel); hipFree(h->d_vio_li);
-    hipFree(h->d_map_raw); hipFree(h->d_map_pts); hipFree(h->d_map_keys); hipFree(h->d_map_keys_tmp); hipFree(h->d_map_idx);
+    hipFree(h->d_map_raw); hipFree(h->d_map_raw2); hipFree(h->d_map_pts); hipFree(h->d_map_keys); hipFree(h->d_map_keys_tmp); hipFree(h->d_map_idx);
     hipFree(h->d_map_idx_tmp); hipFree(h->d_map_htab); hipFree(h->d_map_ckeys); hipFree(h->d_map_sort_tmp);
+    mapupd_free(h);
     vox_free(h);
     imu_free(h);
     select_free(h);
@@ -464,6 +477,7 @@ static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_sta
     HIPCHK(h, hipMemcpyAsync(h->d_dev, D, sizeof(FlDev18), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(eskf18_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev);
     HIPCHK(h, hipGetLastError());
+    h->begun18 = true;
     return FL_OK;
 }
 
@@ -625,6 +639,7 @@ int32_t fl_debug_get_wall(fl_handle h, long long *out2048)
 #include "api_vio.inc"
 #include "api_ikfom.inc"
 #include "api_knn.inc"
+#include "api_map.inc"
 #include "api_voxel.inc"
 #include "api_imu.inc"
 #include "api_select.inc"

@@ -1,5 +1,6 @@
 // demo_pipeline.cpp -- the LiDAR front of a frame through the host mirror, from plain C++ over the C ABI:
-// ImuProcessDev::UndistortPcl -> VoxelGridDev::filter_to_scan -> LioMode18Dev::update (map search on the device).
+// ImuProcessDev::UndistortPcl -> VoxelGridDev::filter_to_scan -> LioMode18Dev::update (map search on the device) ->
+// LocalMapDev::lasermap_fov_segment / map_incremental (the map stays on the device).
 // Input: little-endian binary written by tests/test_host_mirror_gpu.py; output: the updated StatesGroup as text.
 #include "fastlivo_shim.hpp"
 
@@ -56,6 +57,17 @@ int main(int argc, char **argv)
     printf("\n");
     for (int i = 0; i < 18; i++) printf("%.17g ", state.cov[i * 18 + i]);
     printf("\n%.17g %.17g\n", imu.proc.last_lidar_end_time, imu.proc.acc_s_last[2]);
+    // the frame's tail: window check at the new position, then the scan goes into the map (laserMapping.cpp:1395,1758)
+    LocalMapDev lm; lm.handle = h; lm.cube_len = 24.0; lm.DET_RANGE = 4.0f; lm.downsample_size = leaf;
+    V3D pos_lid = state.pos_end;
+    lm.lasermap_fov_segment(pos_lid);                 // first call: centres the window
+    pos_lid.v[0] += 8.0;                               // pretend the sensor moved: the window follows, one slab is cut off
+    const int cut = lm.lasermap_fov_segment(pos_lid);
+    const int removed = lm.kdtree_delete_counter;
+    lm.map_incremental();
+    if (lm.last_status < 0) { fprintf(stderr, "map: %s\n", fl_last_error_string(h)); return 1; }
+    printf("map %d boxes %d removed %d before %d after %d added %d\n", lm.last_status, cut, removed, lm.last.n_before, lm.last.n_after,
+           lm.last.n_added);
     fl_destroy(h);
     return 0;
 }

@@ -230,6 +230,77 @@ struct VoxelGridDev {
 };
 
 // ------------------------------------------------------------------------------------------------
+// The LiDAR map kept on the device: lasermap_fov_segment (laserMapping.cpp:363-417) + map_incremental (:692-706) +
+// the first frame's ikdtree.Build (:1411-1419). The window arithmetic is the reference's (floats of BoxPointType, doubles of
+// pos_LiD / cube_len); the point work is fl_map_delete_boxes / fl_map_add_points.
+// ------------------------------------------------------------------------------------------------
+struct LocalMapDev {
+    fl_handle handle = nullptr;
+    double cube_len = 200.0;                  // cube_side_length (:1118)
+    float DET_RANGE = 300.0f;                 // :83
+    float MOV_THRESHOLD = 1.5f;               // :90
+    float downsample_size = 0.5f;             // filter_size_map_min -> ikdtree.set_downsample_param (:1410)
+    float vertex_min[3] = {0, 0, 0}, vertex_max[3] = {0, 0, 0};      // LocalMap_Points
+    bool Localmap_Initialized = false;
+    int kdtree_delete_counter = 0;
+    fl_map_info last{};
+    int32_t last_status = 0;
+
+    // returns the number of boxes that were cut off (cub_needrm.size())
+    int lasermap_fov_segment(const V3D &pos_LiD)
+    {
+        kdtree_delete_counter = 0;
+        if (!Localmap_Initialized) {
+            for (int i = 0; i < 3; i++) {
+                vertex_min[i] = (float)(pos_LiD.v[i] - cube_len / 2.0);
+                vertex_max[i] = (float)(pos_LiD.v[i] + cube_len / 2.0);
+            }
+            Localmap_Initialized = true;
+            return 0;
+        }
+        float edge[3][2];
+        const float lim = MOV_THRESHOLD * DET_RANGE;
+        bool need_move = false;
+        for (int i = 0; i < 3; i++) {
+            edge[i][0] = (float)std::fabs(pos_LiD.v[i] - (double)vertex_min[i]);
+            edge[i][1] = (float)std::fabs(pos_LiD.v[i] - (double)vertex_max[i]);
+            if (edge[i][0] <= lim || edge[i][1] <= lim) need_move = true;
+        }
+        if (!need_move) return 0;
+        const double a = (cube_len - 2.0 * (double)MOV_THRESHOLD * (double)DET_RANGE) * 0.5 * 0.9;
+        const double b = (double)(DET_RANGE * (MOV_THRESHOLD - 1));
+        const float mov_dist = (float)(a > b ? a : b);
+        float nmin[3], nmax[3], boxes[18];
+        for (int i = 0; i < 3; i++) { nmin[i] = vertex_min[i]; nmax[i] = vertex_max[i]; }
+        int nb = 0;
+        for (int i = 0; i < 3; i++) {
+            float *bmin = boxes + nb * 6, *bmax = bmin + 3;
+            for (int k = 0; k < 3; k++) { bmin[k] = vertex_min[k]; bmax[k] = vertex_max[k]; }
+            if (edge[i][0] <= lim) {
+                nmax[i] -= mov_dist; nmin[i] -= mov_dist;
+                bmin[i] = vertex_max[i] - mov_dist;
+                nb++;
+            } else if (edge[i][1] <= lim) {
+                nmax[i] += mov_dist; nmin[i] += mov_dist;
+                bmax[i] = vertex_min[i] + mov_dist;
+                nb++;
+            }
+        }
+        for (int i = 0; i < 3; i++) { vertex_min[i] = nmin[i]; vertex_max[i] = nmax[i]; }
+        if (nb > 0) {
+            last_status = fl_map_delete_boxes(handle, boxes, nb, &last);
+            if (last_status >= 0) kdtree_delete_counter = last.n_removed;
+        }
+        return nb;
+    }
+    // feats_down_world of the scan staged on the device, under the state the LIO block left there
+    void map_incremental(bool first_frame_build = false)
+    {
+        last_status = fl_map_add_points(handle, nullptr, 0, first_frame_build ? 0.0f : downsample_size, &last);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
 // ImuProcess: the members UndistortPcl uses + the call, IMU_Processing.cpp:611-809 (Process2 :875)
 // ------------------------------------------------------------------------------------------------
 struct ImuProcessDev {

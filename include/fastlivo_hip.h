@@ -243,6 +243,35 @@ int32_t fl_ikfom_solve(fl_handle h, const double *d_sums, int32_t flags, fl_iter
  * (:692-706) with the current map points (k x 3 floats). cell_size (m) is the voxel edge of the device
  * grid (0.5 is a good default for filter_size_map 0.15-0.5). */
 int32_t fl_map_set_points(fl_handle h, const float *map_xyz, int32_t k, float cell_size);
+/* The map kept ON the device between frames (the map side of rows N1/N3): instead of re-staging the host map after every
+ * map_incremental, update the device copy in place. The array order is part of the contract (ties of the k-NN go to the lower
+ * index): surviving points keep their order, added points follow in input order.
+ *   fl_map_clear         an empty map with the given k-NN cell size (first frame, before ikdtree.Build's points arrive)
+ *   fl_map_add_points    map_incremental (src/laserMapping.cpp:692-706): KD_TREE::Add_Points(points, downsample_on = true)
+ *                        (include/ikd-Tree/ikd_Tree.cpp:382-457) with downsample_size = the tree's (filter_size_map_min,
+ *                        laserMapping.cpp:1410). Per down-sampling box [floor(p/ds)*ds, +ds) a new point falls into, the box ends
+ *                        with exactly one point: the old point closest to the box centre if strictly closer than every new point
+ *                        of the box, else the closest new point, the latest among equals (the sequential loop's outcome).
+ *                        downsample_size <= 0: every point is appended (Add_Points(.., false) / Build, :1411-1419).
+ *                        world_xyz == NULL: the scan staged on the device, body -> world under the 18-state the device holds
+ *                        (pointBodyToWorld, :695-698) -- after fl_lio_frame18_dev that is the updated state, as in the reference.
+ *   fl_map_delete_boxes  lasermap_fov_segment (:363-417): KD_TREE::Delete_Point_Boxes (ikd_Tree.cpp:501-520); boxes = nb x
+ *                        {min x,y,z, max x,y,z} floats (BoxPointType), a point goes iff min <= v && max > v on every axis (:650).
+ *   fl_map_get_points    read the map array back (parity checks, publishing); cap = 0 queries the size.
+ * Each update rebuilds the k-NN index of the whole map and costs one host synchronisation (the new size). */
+typedef struct fl_map_info {
+    int32_t n_before, n_after;
+    int32_t n_added;          /* new points that went in */
+    int32_t n_removed;        /* old points that left */
+    int32_t n_ambiguous;      /* points whose box membership depends on the rounding of floor(v/ds)*ds (the reference tests
+                                 coordinates against the box, this library partitions by floor(v/ds)): results may differ from the
+                                 sequential reference for these points only. 0 for power-of-two ds; ~1e-7 per coordinate otherwise */
+    int32_t status;           /* FL_NUM_NONFINITE: a coordinate outside +-2^20 boxes */
+} fl_map_info;
+int32_t fl_map_clear(fl_handle h, float cell_size);
+int32_t fl_map_add_points(fl_handle h, const float *world_xyz, int32_t n, float downsample_size, fl_map_info *info);
+int32_t fl_map_delete_boxes(fl_handle h, const float *boxes, int32_t nb, fl_map_info *info);
+int32_t fl_map_get_points(fl_handle h, float *xyz_out, int32_t cap, int32_t *n_out);
 /* One search pass at the current device state (after fl_lio_begin18 / fl_ikfom_begin): neighbours ->
  * planes -> selection flags, nothing leaves the device. nbr_xyz_out (n x 5 x 3) / valid_out (n) are
  * optional read-backs for parity checks. */

@@ -76,6 +76,15 @@ int orc_lio18_frame(orc_state18 *x, const float *body_xyz, int n, const double *
 int orc_knn5(const float *map_xyz, int k, const float *query_xyz, int n, float *nbr_xyz, float *sqdist, uint8_t *valid,
              int32_t *nbr_idx, int nthreads);
 
+/* Map maintenance as the reference drives the ikd-Tree (orc_map.c): KD_TREE::Add_Points(points, downsample) ikd_Tree.cpp:382-457,
+ * Delete_Point_Boxes :501-520, lasermap_fov_segment laserMapping.cpp:363-417 -- on a flat point array, sequentially. */
+typedef struct orc_map_info { int32_t n_before, n_after, n_added, n_removed, n_ambiguous; } orc_map_info;
+int orc_map_add_points(const float *map_xyz, int n_map, const float *new_xyz, int n_new, float downsample_size, float *out_xyz,
+                       orc_map_info *info);
+int orc_map_delete_boxes(const float *map_xyz, int n_map, const float *boxes, int nb, float *out_xyz, orc_map_info *info);
+int orc_fov_segment(float *win, int *initialized, const double *pos_lid, double cube_len, float det_range, float mov_threshold,
+                    float *boxes_out);
+
 /* pcl::VoxelGrid::applyFilter as used at laserMapping.cpp:1398-1399 / lidar_selection.cpp:352-353 (orc_voxel.c).
  * xyzi: n x 4 floats (x, y, z, intensity); out_xyzi has room for n points; centroids in ascending voxel index. */
 int orc_voxel_grid(const float *xyzi, int n, float leaf_x, float leaf_y, float leaf_z, float *out_xyzi, int32_t *out_n,

@@ -327,6 +327,55 @@ def knn5_bruteforce(map_xyz, query_xyz, nthreads=8):
     return nbr, sq, valid, idx
 
 
+class MapInfo(C.Structure):
+    _fields_ = [("n_before", C.c_int32), ("n_after", C.c_int32), ("n_added", C.c_int32), ("n_removed", C.c_int32),
+                ("n_ambiguous", C.c_int32)]
+
+
+def map_add_points(map_xyz, new_xyz, downsample_size):
+    """KD_TREE::Add_Points(new, downsample_on) on a flat array, sequentially (oracle/orc_map.c). Returns (map' (k,3), MapInfo)."""
+    map_xyz = np.ascontiguousarray(map_xyz, dtype=np.float32).reshape(-1, 3)
+    new_xyz = np.ascontiguousarray(new_xyz, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros((max(len(map_xyz) + len(new_xyz), 1), 3), dtype=np.float32)
+    info = MapInfo()
+    L = lib()
+    fp = C.POINTER(C.c_float)
+    L.orc_map_add_points.argtypes = [fp, C.c_int, fp, C.c_int, C.c_float, fp, C.POINTER(MapInfo)]
+    L.orc_map_add_points.restype = C.c_int
+    if L.orc_map_add_points(_p(map_xyz, C.c_float), len(map_xyz), _p(new_xyz, C.c_float), len(new_xyz), float(downsample_size),
+                            _p(out, C.c_float), C.byref(info)) != 0:
+        raise RuntimeError("orc_map_add_points failed")
+    return out[:info.n_after].copy(), info
+
+
+def map_delete_boxes(map_xyz, boxes):
+    """KD_TREE::Delete_Point_Boxes on a flat array (oracle/orc_map.c). boxes (nb,6) = min xyz, max xyz."""
+    map_xyz = np.ascontiguousarray(map_xyz, dtype=np.float32).reshape(-1, 3)
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
+    out = np.zeros((max(len(map_xyz), 1), 3), dtype=np.float32)
+    info = MapInfo()
+    L = lib()
+    fp = C.POINTER(C.c_float)
+    L.orc_map_delete_boxes.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.POINTER(MapInfo)]
+    L.orc_map_delete_boxes.restype = C.c_int
+    L.orc_map_delete_boxes(_p(map_xyz, C.c_float), len(map_xyz), _p(boxes, C.c_float), len(boxes), _p(out, C.c_float), C.byref(info))
+    return out[:info.n_after].copy(), info
+
+
+def fov_segment(win, initialized, pos_lid, cube_len, det_range=300.0, mov_threshold=1.5):
+    """lasermap_fov_segment's window logic (oracle/orc_map.c). win: float32[6] in/out. Returns (boxes (nb,6), initialized)."""
+    L = lib()
+    fp = C.POINTER(C.c_float)
+    L.orc_fov_segment.argtypes = [fp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_double, C.c_float, C.c_float, fp]
+    L.orc_fov_segment.restype = C.c_int
+    init = C.c_int(int(initialized))
+    pos = np.ascontiguousarray(pos_lid, dtype=np.float64)
+    boxes = np.zeros((3, 6), dtype=np.float32)
+    nb = L.orc_fov_segment(_p(win, C.c_float), C.byref(init), _p(pos, C.c_double), float(cube_len), float(det_range), float(mov_threshold),
+                           _p(boxes, C.c_float))
+    return boxes[:nb].copy(), bool(init.value)
+
+
 def voxel_grid(xyzi, leaf):
     """pcl::VoxelGrid restatement (oracle/orc_voxel.c): returns (centroids (m,4) float32, leaf_too_small)."""
     xyzi = np.ascontiguousarray(xyzi, dtype=np.float32)

@@ -58,7 +58,7 @@ def test_cpp_host_mirror_matches_ctypes_path(gpu_lib, scene, tmp_path):
     assert float(sur[8]) <= 1e-12 and float(sur[10]) <= 1e-9 * max(1.0, float(sur[12]))
 
 
-def test_cpp_device_pipeline_matches_ctypes_path(gpu_lib, tmp_path):
+def test_cpp_device_pipeline_matches_ctypes_path(gpu_lib, oracle_lib, tmp_path):
     """ImuProcessDev::UndistortPcl -> VoxelGridDev::filter_to_scan -> LioMode18Dev::update from plain C++ (demo_pipeline)
     vs the same three calls through ctypes: identical state."""
     capi = gpu_lib
@@ -79,6 +79,17 @@ def test_cpp_device_pipeline_matches_ctypes_path(gpu_lib, tmp_path):
     h.imu_undistort(pr, x, f.imu, f.pcl_beg_time, f.pcl_end_time, f.pts_xyzt, want=False)
     _, m, _ = h.scan_voxel_filter_resident(n, leaf)
     info = h.lio_frame18_dev(x, None)
+    # the frame's tail as demo_pipeline runs it: window check (oracle's lasermap_fov_segment), one slab cut off, map_incremental
+    orc = oracle_lib
+    win = np.zeros(6, dtype=np.float32)
+    pos = np.array(x.vec()[9:12])
+    _, init = orc.fov_segment(win, False, pos, cube_len=24.0, det_range=4.0, mov_threshold=1.5)
+    pos[0] += 8.0
+    boxes, init = orc.fov_segment(win, init, pos, 24.0, 4.0, 1.5)
+    assert len(boxes) == 1
+    di = h.map_delete_boxes(boxes)
+    ai = h.map_add_points(None, leaf)
+    map_after = h.map_get_points()
     h.close()
     fn = tmp_path / "pipe.bin"
     with open(fn, "wb") as fh:
@@ -100,3 +111,6 @@ def test_cpp_device_pipeline_matches_ctypes_path(gpu_lib, tmp_path):
     assert np.array_equal(diag, np.diag(x.cov_np()))
     tail = np.array(lines[3].split(), dtype=np.float64)
     assert tail[0] == pr.last_lidar_end_time and tail[1] == pr.acc_s_last[2]
+    mp = lines[4].split()
+    assert [int(mp[k]) for k in (1, 3, 5, 7, 9, 11)] == [0, 1, di.n_removed, ai.n_before, ai.n_after, ai.n_added]
+    assert di.n_removed > 0 and ai.n_added > 0 and ai.n_after == len(map_after)
