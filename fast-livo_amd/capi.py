@@ -669,7 +669,7 @@ def state23_from_frame(fr):
 class MapInfo(C.Structure):
     """fl_map_info"""
     _fields_ = [("n_before", C.c_int32), ("n_after", C.c_int32), ("n_added", C.c_int32), ("n_removed", C.c_int32),
-                ("n_ambiguous", C.c_int32), ("status", C.c_int32)]
+                ("n_ambiguous", C.c_int32), ("status", C.c_int32), ("cell_size", C.c_float)]
 
 
 def _knn_methods():

@@ -75,15 +75,18 @@ struct fl_context {
     int mu_cap = 0, mu_new_cap = 0;
     unsigned mu_tab_cap = 0;
     float4 *d_map_pts = nullptr;
-    unsigned long long *d_map_keys = nullptr, *d_map_keys_tmp = nullptr;
+    unsigned *d_map_slot = nullptr, *d_map_rank = nullptr, *d_map_first = nullptr;   // index build: cell slot / rank in cell per point, first point per slot
     struct FlCellEntry *d_map_htab = nullptr;
     unsigned long long *d_map_ckeys = nullptr;
-    unsigned *d_map_idx = nullptr, *d_map_idx_tmp = nullptr;
-    void *d_map_sort_tmp = nullptr;
-    size_t map_sort_bytes = 0;
+    void *d_map_scan_tmp = nullptr;
+    size_t map_scan_bytes = 0;
     int map_cap = 0, map_n = 0, map_max_ring = 0;
-    unsigned map_hcap = 0;
+    unsigned map_hcap = 0, map_hslots = 0;   // allocated / used slots of the cell table (power of two >= 2 x points)
     float map_cell = 0.f;
+    bool map_cell_auto = false;            // cell size follows the map's density (cell_size <= 0 at fl_map_set_points / fl_map_clear)
+    unsigned *d_map_occ = nullptr, *h_map_occ = nullptr;    // occupied slots among the sampled ones (device counter, pinned copy)
+    unsigned map_occ_sample = 0, map_occ_slots = 0;          // of the build the pinned copy belongs to
+    int map_occ_n = 0;
     // scan voxel filter (voxel_kernels.h)
     float4 *d_vox_in = nullptr, *d_vox_out = nullptr;
     unsigned *d_vox_keys = nullptr, *d_vox_keys_s = nullptr, *d_vox_vals = nullptr, *d_vox_vals_s = nullptr;
@@ -236,6 +239,7 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
 }
 
 static void vox_free(fl_handle h);
+static int32_t map_free(fl_handle h);
 static void mapupd_free(fl_handle h);
 static void imu_free(fl_handle h);
 static void select_free(fl_handle h);
@@ -250,8 +254,7 @@ int32_t fl_destroy(fl_handle h)
     hipFree(h->d_plane); hipFree(h->d_normvec); hipFree(h->d_dev); hipFree(h->d_dev23); hipFree(h->d_records);
     hipFree(h->d_epoch); hipFree(h->d_sums_tmp); hipFree(h->d_bcast); hipFree(h->d_vc); hipFree(h->d_img); hipFree(h->d_ref);
     hipFree(h->d_errors); hipFree(h->d_err_words); hipFree(h->d_pos); hipFree(h->d_slevel); hipFree(h->d_vio_li);
-    hipFree(h->d_map_raw); hipFree(h->d_map_raw2); hipFree(h->d_map_pts); hipFree(h->d_map_keys); hipFree(h->d_map_keys_tmp); hipFree(h->d_map_idx);
-    hipFree(h->d_map_idx_tmp); hipFree(h->d_map_htab); hipFree(h->d_map_ckeys); hipFree(h->d_map_sort_tmp);
+    map_free(h);
     mapupd_free(h);
     vox_free(h);
     imu_free(h);

@@ -241,12 +241,14 @@ int32_t fl_ikfom_solve(fl_handle h, const double *d_sums, int32_t flags, fl_iter
  * ---------------------------------------------------------------------------------------------- */
 /* Mirror of the host map on the device: call after ikdtree.Build (:1411-1419) and after map_incremental
  * (:692-706) with the current map points (k x 3 floats). cell_size (m) is the voxel edge of the device
- * grid (0.5 is a good default for filter_size_map 0.15-0.5). */
+ * grid: 2-3x the map's point spacing. cell_size <= 0: automatic -- the library keeps the points per occupied cell
+ * between 5 and 20 by moving the edge in steps of 1.5x whenever the map is (re)built; results do not depend on it
+ * (the search is exact for any cell), its cost does (a 0.5 m cell on a map thinned to 0.5 m spacing: 10x slower). */
 int32_t fl_map_set_points(fl_handle h, const float *map_xyz, int32_t k, float cell_size);
 /* The map kept ON the device between frames (the map side of rows N1/N3): instead of re-staging the host map after every
  * map_incremental, update the device copy in place. The array order is part of the contract (ties of the k-NN go to the lower
  * index): surviving points keep their order, added points follow in input order.
- *   fl_map_clear         an empty map with the given k-NN cell size (first frame, before ikdtree.Build's points arrive)
+ *   fl_map_clear         an empty map with the given k-NN cell size, <= 0: automatic (first frame, before ikdtree.Build's points arrive)
  *   fl_map_add_points    map_incremental (src/laserMapping.cpp:692-706): KD_TREE::Add_Points(points, downsample_on = true)
  *                        (include/ikd-Tree/ikd_Tree.cpp:382-457) with downsample_size = the tree's (filter_size_map_min,
  *                        laserMapping.cpp:1410). Per down-sampling box [floor(p/ds)*ds, +ds) a new point falls into, the box ends
@@ -267,6 +269,7 @@ typedef struct fl_map_info {
                                  coordinates against the box, this library partitions by floor(v/ds)): results may differ from the
                                  sequential reference for these points only. 0 for power-of-two ds; ~1e-7 per coordinate otherwise */
     int32_t status;           /* FL_NUM_NONFINITE: a coordinate outside +-2^20 boxes */
+    float cell_size;          /* k-NN cell edge the index was rebuilt with (moves only in automatic mode) */
 } fl_map_info;
 int32_t fl_map_clear(fl_handle h, float cell_size);
 int32_t fl_map_add_points(fl_handle h, const float *world_xyz, int32_t n, float downsample_size, fl_map_info *info);

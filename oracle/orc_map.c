@@ -9,8 +9,8 @@
  *                         calc_dist :1291-1295; caller map_incremental /root/reference/src/laserMapping.cpp:692-706
  *   orc_map_delete_boxes  KD_TREE::Delete_Point_Boxes :501-520 -> Delete_by_range point test :650; caller lasermap_fov_segment
  *                         laserMapping.cpp:363-417
- *   orc_fov_segment       lasermap_fov_segment's window logic itself (laserMapping.cpp:363-417; MOV_THRESHOLD 1.5f :61,
- *                         DET_RANGE, cube_len)
+ *   orc_fov_segment       lasermap_fov_segment's window logic itself (laserMapping.cpp:363-417; MOV_THRESHOLD 1.5f :90, DET_RANGE :83,
+ *                         cube_len :118,1118)
  * The tree's internals (balancing, lazy deletion, the rebuild thread) do not change WHICH points the map holds, only the order
  * Search_by_range reports them in; that order decides between old points of one box that are exactly equally far from its
  * centre. Not reproducible without the tree: the array order is used (lower index first), as in orc_knn.c. A point that wins

@@ -172,3 +172,40 @@ def test_growth_beyond_capacity_keeps_the_map(gpu_lib, oracle_lib, scene):
     got = h.map_get_points()
     assert np.array_equal(got[:60000], m0) and np.array_equal(got[60000:], new)
     h.close()
+
+
+def test_automatic_cell_size_follows_the_density_and_changes_no_result(gpu_lib, oracle_lib, scene):
+    """cell_size <= 0: the k-NN cell edge is chosen from the map's density and re-chosen when map_incremental thins the map.
+    The search is exact for any cell size: neighbour sets stay identical to brute force before and after."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    rng = np.random.default_rng(5)
+    fr = synth.make_lio_frame(3000, scene=scene)
+    h = _handle(capi, synth, fr)
+    x = capi.state18_from_frame(fr)
+    h.map_set_points(scene.map_xyz, 0.0)                      # automatic
+    h.lio_set_points(fr.body_xyz); h.lio_begin18(x, x)
+
+    def check(map_now):
+        nbr_g, valid_g = h.lio_search18(fr.n)
+        world = h.lio_get_world_points(fr.n)
+        nbr_o, _, valid_o, _ = orc.knn5_bruteforce(map_now, world)
+        assert np.array_equal(valid_g, valid_o)
+        ok = valid_o != 0
+        assert np.array_equal(nbr_g[ok], nbr_o[ok])
+    check(scene.map_xyz)
+    # thin the map to one point per 0.6 m box: every box of the scene is touched by a dense "scan" of the map's own points
+    dense = (scene.map_xyz + rng.normal(0, 0.01, scene.map_xyz.shape)).astype(np.float32)
+    i1 = h.map_add_points(dense, 0.6)
+    cur, oi = orc.map_add_points(scene.map_xyz, dense, 0.6)
+    assert oi.n_ambiguous == info_amb(i1) and np.array_equal(h.map_get_points(), cur)
+    i2 = h.map_add_points(dense[:10], 0.6)                    # the density of the thinned map is known by now: the cell grows
+    cur, _ = orc.map_add_points(cur, dense[:10], 0.6)
+    assert i2.cell_size > i1.cell_size >= 0.3
+    assert len(cur) < len(scene.map_xyz) // 3
+    check(cur)
+    h.close()
+
+
+def info_amb(i):
+    return i.n_ambiguous
