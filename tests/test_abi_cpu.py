@@ -33,6 +33,29 @@ def test_struct_sizes_match_header():
     assert C.sizeof(capi.Config) == 6 * 4 + 8 * (9 + 3 + 9 + 3 + 4 + 5 + 2)
 
 
+def test_struct_layouts_match_a_c_compiler(tmp_path):
+    """sizeof + offset of the last member of every struct of the header, as gcc lays them out, against the ctypes mirrors."""
+    import ctypes as C
+    import subprocess
+    pairs = {"fl_config": capi.Config, "fl_state18": capi.State18, "fl_state23": capi.State23, "fl_iter_info": capi.IterInfo,
+             "fl_map_info": capi.MapInfo, "fl_imu_sample": capi.ImuSample, "fl_pose6d": capi.Pose6d, "fl_imu_proc": capi.ImuProc,
+             "fl_patch_candidate": capi.PatchCandidate}
+    hdr = open(os.path.join(REPO_ROOT, "include", "fastlivo_hip.h")).read()
+    declared = set(re.findall(r"}\s*(fl_[a-z0-9_]+);", hdr))
+    assert declared == set(pairs), declared ^ set(pairs)
+    src = tmp_path / "sz.c"
+    body = "".join(f'printf("{n} %zu %zu\\n", sizeof({n}), offsetof({n}, {cls._fields_[-1][0]}));\n' for n, cls in pairs.items())
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "fastlivo_hip.h"\nint main(void){\n' + body + "return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(REPO_ROOT, "include"), "-o", str(exe), str(src)])
+    out = subprocess.check_output([str(exe)], text=True)
+    for line in out.strip().splitlines():
+        name, size, off = line.split()
+        cls = pairs[name]
+        assert C.sizeof(cls) == int(size), name
+        assert getattr(cls, cls._fields_[-1][0]).offset == int(off), name
+
+
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present")
 def test_create_fails_loudly_without_gpu():
     from fast_livo_amd import synth
