@@ -105,24 +105,28 @@ __device__ __forceinline__ void fl_imu_FC(const FlImuStep &S, const double *cg, 
     }
 }
 
+// The loop over the IMU intervals (:658-741) carries three chains of different weight: the per-interval quantities that depend
+// on the samples only (mean rates, dt, Exp(w, +-dt): two square roots, six divisions, two sine/cosine pairs), the state chain
+// (R <- R Exp, acc, pos, vel: ~100 flops per interval) and the covariance chain (two 18x18x18 products per interval). Run one after
+// the other by one lane, as a first version did, an interval cost 3.6 us (72 us per 20-sample frame, the longest kernel of the
+// LiDAR front). Here, per chunk of FL_IMU_CH intervals: (A) one lane per interval does the sample-only part, (B) one lane walks the
+// state chain, (C) one lane per interval forms the pieces of F_x / cov_w that need that interval's R, (D) the workgroup walks the
+// covariance chain, one element per lane. Every quantity is computed by the same expression as before, so the results are
+// bit-identical; only the schedule changed.
+#define FL_IMU_CH 64
 __global__ __launch_bounds__(FL_IMU_NT) void imu_forward_kernel(FlImuDev *__restrict__ D, const FlImuSample *__restrict__ v, int nv,
                                                                FlPose6 *__restrict__ poses)
 {
     __shared__ double sF[324], sP[324], sT[324], sC[324];
-    __shared__ FlImuStep sS;
+    __shared__ FlImuStep sS[FL_IMU_CH];
+    __shared__ double sExpF[FL_IMU_CH][9], sW[FL_IMU_CH][3], sA[FL_IMU_CH][3], sRb[FL_IMU_CH][9];
+    __shared__ int sGo[FL_IMU_CH];
+    __shared__ double sTail[FL_IMU_CH];        // tail.t of the interval (a global load inside the serial chain costs ~1 us)
     __shared__ double s_R[9], s_vel[3], s_pos[3], s_acc[3], s_w[3];
-    __shared__ int s_go, s_K;
-    __shared__ FlImuSample s_v[256];          // samples staged once: a global load per step costs ~1 us of latency
+    __shared__ int s_K;
     const int t = (int)threadIdx.x;
     const int ti = t / 18, tj = t % 18;
     if (t < 324) sP[t] = D->P[t];
-    const bool staged = nv <= 256;
-    if (staged) {
-        const double *src = reinterpret_cast<const double *>(v);
-        double *dst = reinterpret_cast<double *>(s_v);
-        for (int k = t; k < nv * 7; k += FL_IMU_NT) dst[k] = src[k];
-    }
-    const FlImuSample *vs = staged ? s_v : v;
     // per-frame constants in registers (every lane: the F/C construction below reads them)
     double bg[3], ba[3], grav[3], cg[3], ca[3], cbg[3], cba[3];
 #pragma unroll
@@ -142,10 +146,14 @@ __global__ __launch_bounds__(FL_IMU_NT) void imu_forward_kernel(FlImuDev *__rest
         s_K = 1;
     }
     __syncthreads();
-    for (int it = 0; it + 1 < nv; it++) {
-        if (t == 0) {
-            const FlImuSample head = vs[it], tail = vs[it + 1];
+    for (int c0 = 0; c0 + 1 < nv; c0 += FL_IMU_CH) {
+        const int ns = min(FL_IMU_CH, nv - 1 - c0);
+        // (A) sample-only part of interval c0 + t
+        if (t < ns) {
+            const FlImuSample head = v[c0 + t], tail = v[c0 + t + 1];
             const int go = !(tail.t < last_end);                                   // :666
+            sGo[t] = go;
+            sTail[t] = tail.t;
             if (go) {
                 double w[3], a[3];
                 for (int k = 0; k < 3; k++) {
@@ -157,42 +165,68 @@ __global__ __launch_bounds__(FL_IMU_NT) void imu_forward_kernel(FlImuDev *__rest
                     a[k] = a[k] * 9.81 / mean_acc_norm - ba[k];                    // :685
                 }
                 const double dt = (head.t < last_end) ? (tail.t - last_end) : (tail.t - head.t);   // :687-694
-                double Exp_f[9], Exp_m[9], RA[9], R[9];
-                for (int k = 0; k < 9; k++) R[k] = s_R[k];
+                double Exp_f[9], Exp_m[9];
                 fl_so3_exp_dt(w, dt, Exp_f);
                 fl_so3_exp_dt(w, -dt, Exp_m);                                      // :703
-                const double askew[9] = {0.0, -a[2], a[1], a[2], 0.0, -a[0], -a[1], a[0], 0.0};
-                fl_m3_mul(R, askew, RA);
-                for (int k = 0; k < 9; k++) { sS.Exp_m[k] = Exp_m[k]; sS.RAdt[k] = RA[k] * dt; sS.Rdt[k] = R[k] * dt; }   // :707-708
-                for (int i = 0; i < 3; i++)
-                    for (int j = 0; j < 3; j++) {                                  // :712
-                        double q = 0.0;
-                        for (int k = 0; k < 3; k++) q += R[i * 3 + k] * ca[k] * R[j * 3 + k];
-                        sS.Cacc[i * 3 + j] = q * dt * dt;
-                    }
-                sS.dt = dt;
-                fl_m3_mul(R, Exp_f, R);                                            // :719
-                double Ra[3], acc[3];
-                fl_m3_mv(R, a, Ra);
-                for (int k = 0; k < 3; k++) acc[k] = Ra[k] + grav[k];              // :722
-                for (int k = 0; k < 3; k++) s_pos[k] = s_pos[k] + s_vel[k] * dt + 0.5 * acc[k] * dt * dt;   // :725
-                for (int k = 0; k < 3; k++) s_vel[k] = s_vel[k] + acc[k] * dt;     // :728
-                for (int k = 0; k < 9; k++) s_R[k] = R[k];
-                for (int k = 0; k < 3; k++) { s_acc[k] = acc[k]; s_w[k] = w[k]; }   // :731-732
-                FlPose6 p;
-                p.offset_time = tail.t - beg;                                      // :733
-                for (int k = 0; k < 3; k++) { p.acc[k] = acc[k]; p.gyr[k] = w[k]; p.vel[k] = s_vel[k]; p.pos[k] = s_pos[k]; }
-                for (int k = 0; k < 9; k++) p.rot[k] = R[k];
-                poses[s_K] = p;
-                s_K = s_K + 1;
+                for (int k = 0; k < 9; k++) { sExpF[t][k] = Exp_f[k]; sS[t].Exp_m[k] = Exp_m[k]; }
+                for (int k = 0; k < 3; k++) { sW[t][k] = w[k]; sA[t][k] = a[k]; }
+                sS[t].dt = dt;
             }
-            s_go = go;
         }
         __syncthreads();
-        if (s_go) {                                                                // :716  cov = F cov F^T + cov_w
+        // (B) the state chain
+        if (t == 0) {
+            double R[9], vel[3], pos[3], acc[3] = {s_acc[0], s_acc[1], s_acc[2]}, wl[3] = {s_w[0], s_w[1], s_w[2]};
+            for (int k = 0; k < 9; k++) R[k] = s_R[k];
+            for (int k = 0; k < 3; k++) { vel[k] = s_vel[k]; pos[k] = s_pos[k]; }
+            int K = s_K;
+            for (int st = 0; st < ns; st++) {
+                if (!sGo[st]) continue;
+                const double dt = sS[st].dt;
+                double a[3], Exp_f[9];
+                for (int k = 0; k < 3; k++) { a[k] = sA[st][k]; wl[k] = sW[st][k]; }
+                for (int k = 0; k < 9; k++) { Exp_f[k] = sExpF[st][k]; sRb[st][k] = R[k]; }     // R before the step: F_x / cov_w use it (:707-712)
+                fl_m3_mul(R, Exp_f, R);                                            // :719
+                double Ra[3];
+                fl_m3_mv(R, a, Ra);
+                for (int k = 0; k < 3; k++) acc[k] = Ra[k] + grav[k];              // :722
+                for (int k = 0; k < 3; k++) pos[k] = pos[k] + vel[k] * dt + 0.5 * acc[k] * dt * dt;   // :725
+                for (int k = 0; k < 3; k++) vel[k] = vel[k] + acc[k] * dt;         // :728
+                FlPose6 p;
+                p.offset_time = sTail[st] - beg;                                   // :733
+                for (int k = 0; k < 3; k++) { p.acc[k] = acc[k]; p.gyr[k] = wl[k]; p.vel[k] = vel[k]; p.pos[k] = pos[k]; }
+                for (int k = 0; k < 9; k++) p.rot[k] = R[k];
+                poses[K] = p;
+                K++;
+            }
+            for (int k = 0; k < 9; k++) s_R[k] = R[k];
+            for (int k = 0; k < 3; k++) { s_vel[k] = vel[k]; s_pos[k] = pos[k]; s_acc[k] = acc[k]; s_w[k] = wl[k]; }   // :731-732
+            s_K = K;
+        }
+        __syncthreads();
+        // (C) the pieces of F_x and cov_w that need the interval's R
+        if (t < ns && sGo[t]) {
+            double R[9], RA[9];
+            for (int k = 0; k < 9; k++) R[k] = sRb[t][k];
+            const double a[3] = {sA[t][0], sA[t][1], sA[t][2]};
+            const double dt = sS[t].dt;
+            const double askew[9] = {0.0, -a[2], a[1], a[2], 0.0, -a[0], -a[1], a[0], 0.0};
+            fl_m3_mul(R, askew, RA);
+            for (int k = 0; k < 9; k++) { sS[t].RAdt[k] = RA[k] * dt; sS[t].Rdt[k] = R[k] * dt; }   // :707-708
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {                                      // :712
+                    double q = 0.0;
+                    for (int k = 0; k < 3; k++) q += R[i * 3 + k] * ca[k] * R[j * 3 + k];
+                    sS[t].Cacc[i * 3 + j] = q * dt * dt;
+                }
+        }
+        __syncthreads();
+        // (D) the covariance chain: cov = F cov F^T + cov_w (:716)
+        for (int st = 0; st < ns; st++) {
+            if (!sGo[st]) continue;                                                // uniform over the workgroup
             if (t < 324) {
                 double f, c;
-                fl_imu_FC(sS, cg, cbg, cba, ti, tj, f, c);
+                fl_imu_FC(sS[st], cg, cbg, cba, ti, tj, f, c);
                 sF[t] = f; sC[t] = c;
             }
             __syncthreads();
@@ -209,8 +243,8 @@ __global__ __launch_bounds__(FL_IMU_NT) void imu_forward_kernel(FlImuDev *__rest
                 for (int k = 0; k < 18; k++) q += sT[ti * 18 + k] * sF[tj * 18 + k];
                 sP[t] = q + sC[t];
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (t < 324) D->P[t] = sP[t];
     if (t == 0) {
