@@ -195,6 +195,20 @@ def make_lio_frame(n, seed=SEED, scene=None, t_LI=AVIA_T_LI, R_LI=AVIA_R_LI, sca
                     grav=np.array([-0.27, -0.40, -9.80]), cov18=cov18, cov23=cov23, scene=scene)
 
 
+def scan_from_pose(scene, R_true, p_true, n, seed, t_LI=AVIA_T_LI, R_LI=AVIA_R_LI, scan_noise=0.01, max_range=30.0):
+    """A LiDAR scan (body frame, float32) of the scene taken from the IMU pose (R_true, p_true): for trajectory tests."""
+    rng = np.random.default_rng(seed)
+    pts = np.zeros((0, 3))
+    while len(pts) < n:
+        cand = _sample_planes(rng, scene.planes, scene.areas, int((n - len(pts)) * 1.3) + 16, scan_noise)
+        rng_ = np.linalg.norm(cand - p_true, axis=1)
+        cand = cand[(rng_ > 1.0) & (rng_ < max_range)]
+        pts = np.concatenate([pts, cand])[:n]
+    p_imu = (pts - p_true) @ R_true
+    body = (p_imu - np.asarray(t_LI)) @ np.asarray(R_LI)
+    return np.ascontiguousarray(body.astype(np.float32))
+
+
 # ------------------------------------------------------------------------------------------ VIO
 @dataclasses.dataclass
 class VioFrame:
