@@ -84,6 +84,8 @@ def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FL_BENCH_SINGLE_DEVICE") == "1":     # test aid: all ranks on device 0 (1-GPU box), control plane over gloo
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -99,8 +101,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29617")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("FL_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
+    ctl = "cuda" if (not distributed or os.environ.get("FL_BENCH_BACKEND", "nccl") == "nccl") else "cpu"   # where control-plane tensors live
     import fastlivo  # noqa: F401
     from fast_livo_amd import capi, synth
 
@@ -120,13 +127,66 @@ def main():
     hl.set_stream(stream)
     hv.set_stream(stream)
     x0 = capi.state18_from_frame(fr)
-    hl.lio_set_points(fr.body_xyz)
-    hl.lio_begin18(x0, x0)
-    hl.lio_set_neighbours(nbr, valid)
-    hv.vio_set_frame(vf.img)
-    hv.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
-    hv.vio_begin(x0, x0)
     F = capi.FL_ITER_FORCE
+
+    def begin():
+        hl.lio_set_points(fr.body_xyz)
+        hl.lio_begin18(x0, x0)
+        hl.lio_set_neighbours(nbr, valid)
+        hv.vio_set_frame(vf.img)
+        hv.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+        hv.vio_begin(x0, x0)
+
+    # N > 1, first choice: the exchange INSIDE the pass kernels (api_p2p.inc): every rank maps the peers' exchange buffers (hipIpc),
+    # the solver workgroup of each pass trades the 32 sums peer to peer over xGMI, and a rank keeps enqueuing multi-pass launches
+    # exactly like the single-GPU path. It is verified before it is relied on (no time-out bit, all ranks bitwise equal after a few
+    # passes); every decision is agreed on by all ranks, otherwise they would wait for each other in different collectives.
+    p2p = False
+    if distributed and world >= 2 and os.environ.get("FL_BENCH_NO_P2P") != "1" and os.environ.get("FL_BENCH_TORCH_EXCHANGE") != "1":
+        def all_agree(flag):
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=ctl)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item()) == 1
+        gathered = []
+        exported = True
+        for h_ in (hl, hv):
+            mine = torch.zeros(65, dtype=torch.uint8, device=ctl)
+            try:
+                mine.copy_(torch.frombuffer(bytearray(h_.p2p_export(world)) + bytearray([1]), dtype=torch.uint8))
+            except Exception as e:   # noqa: BLE001
+                print(f"[bench] rank {rank}: p2p_export failed ({e})", file=sys.stderr)
+            allh = [torch.zeros(65, dtype=torch.uint8, device=ctl) for _ in range(world)]
+            dist.all_gather(allh, mine)
+            torch.cuda.synchronize()
+            raw = [t.cpu().numpy().tobytes() for t in allh]
+            exported = exported and all(r[64] == 1 for r in raw)
+            gathered.append([r[:64] for r in raw])
+        connected = exported
+        if exported:
+            try:
+                hl.p2p_connect(rank, world, gathered[0])
+                hv.p2p_connect(rank, world, gathered[1])
+            except Exception as e:   # noqa: BLE001
+                print(f"[bench] rank {rank}: p2p_connect failed ({e})", file=sys.stderr)
+                connected = False
+        connected = all_agree(connected)         # (also the barrier: nobody publishes before everybody has mapped everybody)
+        if connected:
+            begin()
+            i1 = hl.lio_iterate18(3, F)
+            i2 = hv.vio_iterate(VIO_LEVEL, 3, F)
+            sv = np.concatenate([hl.lio_get_state18().vec(), hv.vio_get_state18().vec()])
+            mine = torch.tensor(sv, dtype=torch.float64, device=ctl)
+            alls = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(alls, mine)
+            same = all(bool(torch.equal(a, alls[0])) for a in alls)
+            good = (i1.status & 8) == 0 and (i2.status & 8) == 0 and bool(np.isfinite(sv).all()) and same
+            p2p = all_agree(good)
+            if not p2p and rank == 0:
+                print(f"[bench] in-kernel peer exchange failed its self-test (status {i1.status}/{i2.status}, equal={same}); "
+                      "using RCCL", file=sys.stderr)
+        if not p2p:
+            hl.p2p_disconnect(); hv.p2p_disconnect()
+    begin()
     from fast_livo_amd.sharded import GpuLioBackend, GpuVioBackend, ShardedPass
     lio_pass = ShardedPass(GpuLioBackend(hl, F), dist)      # accumulate -> all_reduce(32 doubles) -> solve
     vio_pass = ShardedPass(GpuVioBackend(hv, VIO_LEVEL, F), dist)
@@ -134,14 +194,16 @@ def main():
     # N > 1: the exchange is done natively (ncclAllReduce on the handle's stream between accumulate and solve, api_comm.inc);
     # the unique ids travel over torch.distributed. If RCCL cannot be bound, fall back to torch.distributed.all_reduce.
     exchange = "none"
-    if distributed:
+    if p2p:
+        exchange = "in-kernel peer-to-peer exchange of the solver workgroups over xGMI (api_p2p.inc)"
+    elif distributed:
         exchange = "torch.distributed.all_reduce"
         if os.environ.get("FL_BENCH_TORCH_EXCHANGE") != "1":
             # every rank must take the same branch: the unique id carries rank 0's verdict in its last byte, and the outcome of
             # comm_init is agreed on with a MIN all-reduce before anybody relies on the native communicator
             ok = 1
             for h_ in (hl, hv):
-                uid = torch.zeros(129, dtype=torch.uint8, device="cuda")
+                uid = torch.zeros(129, dtype=torch.uint8, device=ctl)
                 if rank == 0:
                     try:
                         raw = bytearray(h_.comm_unique_id()) + bytearray([1])
@@ -159,7 +221,7 @@ def main():
                 except Exception as e:   # noqa: BLE001
                     print(f"[bench] rank {rank}: comm_init failed ({e})", file=sys.stderr)
                     ok = 0                       # keep going: the other ranks are in the next broadcast
-            agree = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            agree = torch.tensor([ok], dtype=torch.int32, device=ctl)
             dist.all_reduce(agree, op=dist.ReduceOp.MIN)
             if int(agree.item()) == 1:
                 exchange = "ncclAllReduce on the pass stream (native)"
@@ -170,7 +232,7 @@ def main():
     # from the solver to the producers inside the kernel); every pass still does the full work of a step.
     def steps(k):
         """k steps = k LIO passes + k VIO passes"""
-        if not distributed:
+        if not distributed or p2p:
             done = 0
             while done < k:
                 c = min(PASSES_PER_LAUNCH, k - done)
@@ -199,7 +261,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -210,7 +272,7 @@ def main():
 
     # ---- roofline of the dominant kernel (LIO pass), HIP events on the launch stream
     roof = None
-    if rank == 0:
+    if rank == 0 or p2p:       # with the in-kernel exchange a launch is a collective: every rank issues the same launches
         # the kernels of the timed region: one launch = PASSES_PER_LAUNCH passes (multi-pass kernels); average launch duration
         # from events on the launch stream around K back-to-back launches
         C = PASSES_PER_LAUNCH
@@ -232,6 +294,7 @@ def main():
         torch.cuda.synchronize()
         vio_launch_us = ev0.elapsed_time(ev1) * 1e3 / K
         lio_us, vio_us = lio_launch_us / C, vio_launch_us / C
+    if rank == 0:
         lio_bytes = LIO_BYTES_PER_POINT * args.points * C      # algorithmic bytes per launch = per pass x passes per launch
         vio_bytes = VIO_BYTES_PER_PATCH * args.patches * C
         dom = "lio18_multipass_kernel" if lio_us >= vio_us else "vio_multipass_kernel"
@@ -263,6 +326,9 @@ def main():
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline(fr, vf, nbr, valid, args.cpu_seconds)
 
+    if distributed:
+        torch.cuda.synchronize()
+        dist.barrier()          # nobody unmaps an exchange buffer a peer may still be using
     hl.close()
     hv.close()
     if rank == 0:
@@ -286,8 +352,9 @@ def main():
                        "points_per_gpu": args.points, "patches_per_gpu": args.patches,
                        "iteration_definition": "one LIO pass + one VIO pass, each = residuals + Jacobian rows + "
                                                "normal equations + gain solve + state update",
-                       "parallelism": f"point/patch-range shards x{world}, all-reduce of the 32-double normal-equation "
-                                      f"record per pass ({exchange})" if world > 1 else
+                       "parallelism": (f"point/patch-range shards x{world}, the 32-double normal-equation record summed over the "
+                                       f"ranks in every pass: {exchange}"
+                                       + (f"; {PASSES_PER_LAUNCH} consecutive passes per launch" if p2p else "")) if world > 1 else
                                       f"single GPU, fused multi-pass kernels ({PASSES_PER_LAUNCH} consecutive passes per launch, as in one frame)"},
             "frame_iterations_per_s": frame_it_s,
             "state_finite": finite,

@@ -201,6 +201,10 @@ SYMBOLS = {
     "fl_ikfom_accumulate": (C.c_int32, [_H, C.c_void_p, C.c_int32]),
     "fl_ikfom_solve": (C.c_int32, [_H, C.c_void_p, C.c_int32, C.POINTER(IterInfo)]),
     "fl_map_set_points": (C.c_int32, [_H, _fp, C.c_int32, C.c_float]),
+    "fl_p2p_export": (C.c_int32, [_H, C.c_int32, C.c_void_p]),
+    "fl_p2p_connect": (C.c_int32, [_H, C.c_int32, C.c_int32, C.c_void_p]),
+    "fl_p2p_connect_local": (C.c_int32, [_H, C.c_int32, C.c_int32, C.c_void_p]),
+    "fl_p2p_disconnect": (C.c_int32, [_H]),
     "fl_map_clear": (C.c_int32, [_H, C.c_float]),
     "fl_map_add_points": (C.c_int32, [_H, _fp, C.c_int32, C.c_float, C.c_void_p]),
     "fl_map_delete_boxes": (C.c_int32, [_H, _fp, C.c_int32, C.c_void_p]),
@@ -397,6 +401,20 @@ class Handle:
 
     def comm_destroy(self):
         self._chk(self.L.fl_comm_destroy(self.h), "fl_comm_destroy")
+
+    # ---- peer exchange inside the pass kernels (api_p2p.inc)
+    def p2p_export(self, world):
+        buf = (C.c_char * 64)()
+        self._chk(self.L.fl_p2p_export(self.h, world, buf), "fl_p2p_export")
+        return bytes(buf)
+
+    def p2p_connect(self, rank, world, handles):
+        """handles: list of `world` 64-byte strings (fl_p2p_export of every rank)"""
+        blob = (C.c_char * (64 * world)).from_buffer_copy(b"".join(handles))
+        self._chk(self.L.fl_p2p_connect(self.h, rank, world, blob), "fl_p2p_connect")
+
+    def p2p_disconnect(self):
+        self._chk(self.L.fl_p2p_disconnect(self.h), "fl_p2p_disconnect")
 
     def lio_iterate18_sharded(self, count=1, flags=0, want_info=True):
         info = IterInfo()
@@ -663,6 +681,14 @@ def state23_from_frame(fr):
     g = np.asarray(fr.grav, dtype=np.float64)
     s.grav[:] = g / np.linalg.norm(g) * 9.809
     return s
+
+
+def p2p_connect_local(handles):
+    """Connect Handle objects living in this process (rank = position in the list)."""
+    world = len(handles)
+    arr = (C.c_void_p * world)(*[C.cast(hh.h, C.c_void_p).value for hh in handles])
+    for r, hh in enumerate(handles):
+        hh._chk(hh.L.fl_p2p_connect_local(hh.h, r, world, arr), "fl_p2p_connect_local")
 
 
 # ------------------------------------------------------------------------------------ device k-NN

@@ -48,6 +48,12 @@ struct fl_context {
     unsigned *d_epoch = nullptr;    // launch epoch of the records, advanced on the device
     double *d_sums_tmp = nullptr;
     unsigned long long *d_bcast = nullptr;   // pose broadcast words of the multi-pass kernels (handoff.h)
+    // peer exchange of the sharded form (api_p2p.inc)
+    unsigned long long *d_xchg = nullptr;    // this rank's exchange buffer (fine-grained), [2][world][64] words
+    unsigned long long *xchg_peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool xchg_ipc_open[8] = {false, false, false, false, false, false, false, false};
+    unsigned *d_xepoch = nullptr;
+    int xchg_alloc_world = 0, xchg_world = 1, xchg_rank = 0;
     // VIO
     FlVioConst *d_vc = nullptr;
     FlVioConst h_vc;
@@ -244,6 +250,7 @@ static void mapupd_free(fl_handle h);
 static void imu_free(fl_handle h);
 static void select_free(fl_handle h);
 extern "C" int32_t fl_comm_destroy(fl_handle h);
+extern "C" int32_t fl_p2p_disconnect(fl_handle h);
 
 int32_t fl_destroy(fl_handle h)
 {
@@ -260,6 +267,7 @@ int32_t fl_destroy(fl_handle h)
     imu_free(h);
     select_free(h);
     fl_comm_destroy(h);
+    fl_p2p_disconnect(h);
     if (h->h_dev) hipHostFree(h->h_dev);
     if (h->h_dev23) hipHostFree(h->h_dev23);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -477,6 +485,10 @@ static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_sta
     D->last_exact_valid = 1;
     D->err_words = h->d_err_words;
     D->err_cap = h->cap_patches;
+    for (int r = 0; r < 8; r++) D->xchg_peer[r] = h->xchg_peer[r];
+    D->xchg_epoch = h->d_xepoch;
+    D->xchg_rank = h->xchg_rank;
+    D->xchg_world = h->xchg_world;
     HIPCHK(h, hipMemcpyAsync(h->d_dev, D, sizeof(FlDev18), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(eskf18_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev);
     HIPCHK(h, hipGetLastError());
@@ -647,5 +659,6 @@ int32_t fl_debug_get_wall(fl_handle h, long long *out2048)
 #include "api_imu.inc"
 #include "api_select.inc"
 #include "api_comm.inc"
+#include "api_p2p.inc"
 
 }  // extern "C"

@@ -66,6 +66,10 @@ struct FlDev18 {
     int32_t last_exact_valid;        // last_exact is the reference's float value of last_error (not the fp64-reduced one)
     float last_exact;
     int32_t pad_e;
+    // peer exchange of the sharded form (handoff.h peer_allreduce32): every rank's exchange buffer as this device addresses it
+    unsigned long long *xchg_peer[8];
+    unsigned *xchg_epoch;            // device word: epoch of the next exchange (same value on every rank)
+    int32_t xchg_rank, xchg_world;   // world <= 1: no exchange
 };
 
 // VIO constants (lidar_selection.cpp:35-59 + camera), computed on the host once per handle.

@@ -172,7 +172,8 @@ __device__ __forceinline__ void bcast_publish(unsigned long long *words, const d
 // Wave 0 of a producer workgroup polls (measured: letting all four waves poll with staggered phases costs more in extra
 // traffic than it gains in detection latency: 7.2-7.8 vs 7.1 us per pass). After the caller's __syncthreads
 // out12[0..11] = pose, *ctrl_out = control bits (bit 2 set on a timeout: bounded spin).
-__device__ __forceinline__ void bcast_wait(const unsigned long long *words, unsigned epoch, double *out12 /* LDS */, int *ctrl_out /* LDS */)
+__device__ __forceinline__ void bcast_wait(const unsigned long long *words, unsigned epoch, double *out12 /* LDS */, int *ctrl_out /* LDS */,
+                                           int spin_limit = FL_GATHER_SPIN_LIMIT)
 {
     const int tid = threadIdx.x;
     if (tid >= 64) return;
@@ -185,10 +186,84 @@ __device__ __forceinline__ void bcast_wait(const unsigned long long *words, unsi
             ok = ((unsigned)w == epoch);
         }
         if (__ballot(ok) == ~0ull) break;
-        if (spin > FL_GATHER_SPIN_LIMIT) { timeout = true; break; }
+        if (spin > spin_limit) { timeout = true; break; }
     }
     const unsigned payload = (unsigned)(w >> 32);
     const unsigned other = (unsigned)__shfl_xor((int)payload, 1, 64);
     if (tid < 24 && (tid & 1) == 0) out12[tid >> 1] = f64_make(payload, other);
     if (tid == 24) *ctrl_out = timeout ? 5 : (int)payload;
+}
+
+
+// ---- exchange between the ranks of the sharded form ("one-shot P2P all-gather: each rank writes its record into the
+// peers' mapped buffers + flag; fixed-order local sum"), INSIDE the pass kernel: the solver workgroup of every rank publishes the
+// 32 sums of its shard to every peer and adds up what the peers sent, in rank order -- so every rank holds bitwise the same
+// totals, solves redundantly and needs no broadcast, and a frame's passes stay one launch per rank (multi-pass kernels) instead of
+// accumulate -> ncclAllReduce -> solve per pass. Same "the data IS the flag" words as the pose broadcast: 2 words per double,
+// high half = payload, low half = exchange epoch, system-scope stores into fine-grained peer memory (over xGMI between GPUs), polled
+// with system-scope loads in the receiver's own memory. Layout of a rank's buffer: [epoch parity][sender rank][64 words]; two
+// parities suffice because a rank can be at most one exchange ahead of a peer (it needs the peer's words of exchange k to leave
+// exchange k). Ranks start their kernels at different times (separate processes): the wait is long (seconds) but bounded.
+#define FL_MAX_PEERS 8
+#define FL_XCHG_WORDS 64
+#define FL_XCHG_SPIN_LIMIT (1 << 22)
+struct FlPeerView {
+    unsigned long long *peer[FL_MAX_PEERS];
+    int rank, world;
+};
+__device__ __forceinline__ FlPeerView fl_peer_view(const FlDev18 *D)
+{
+    FlPeerView P;
+    P.rank = D->xchg_rank; P.world = D->xchg_world;
+#pragma unroll
+    for (int r = 0; r < FL_MAX_PEERS; r++) P.peer[r] = (r < P.world) ? D->xchg_peer[r] : nullptr;
+    return P;
+}
+// All threads of the (>= 256-thread) solver workgroup call it; sums = LDS[32], replaced by the total over the ranks;
+// tmp = LDS[FL_MAX_PEERS * 32]. Returns 0 or FL_NUM_TIMEOUT (all threads agree).
+__device__ __forceinline__ int peer_allreduce32(const FlPeerView &P, unsigned xe, double *sums, double *tmp)
+{
+    const int tid = threadIdx.x;
+    const size_t half = (size_t)(xe & 1u) * (size_t)P.world * FL_XCHG_WORDS;
+    if (tid < FL_XCHG_WORDS) {
+        const double v = sums[tid >> 1];
+        const unsigned payload = (tid & 1) ? f64_hi(v) : f64_lo(v);
+        const unsigned long long w = ((unsigned long long)payload << 32) | (unsigned long long)xe;
+#pragma unroll
+        for (int r = 0; r < FL_MAX_PEERS; r++)
+            if (r < P.world && r != P.rank)
+                __hip_atomic_store(P.peer[r] + half + (size_t)P.rank * FL_XCHG_WORDS + tid, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    int timeout = 0;
+    const int per_round = (int)blockDim.x / FL_XCHG_WORDS;           // senders polled at a time: one wave each
+    for (int s0 = 0; s0 < P.world; s0 += per_round) {
+        const int s = s0 + (tid >> 6), k = tid & 63;
+        const bool active = s < P.world && s != P.rank;
+        const unsigned long long *src = P.peer[P.rank] + half + (size_t)(active ? s : 0) * FL_XCHG_WORDS + k;
+        unsigned long long w = 0ull;
+        bool ok = !active;
+        for (int spin = 0; ; spin++) {
+            if (!ok) {
+                w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ok = ((unsigned)w == xe);
+            }
+            if (__ballot(ok) == ~0ull) break;
+            if (spin > FL_XCHG_SPIN_LIMIT) { timeout = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const unsigned payload = (unsigned)(w >> 32);
+        const unsigned other = (unsigned)__shfl_xor((int)payload, 1, 64);
+        if (active && (k & 1) == 0) tmp[s * 32 + (k >> 1)] = f64_make(payload, other);
+    }
+    __syncthreads();
+    double tot = 0.0;
+    if (tid < 32) {
+        for (int r = 0; r < P.world; r++) {
+            const double v = (r == P.rank) ? sums[tid] : tmp[r * 32 + tid];
+            tot = (r == 0) ? v : tot + v;
+        }
+    }
+    __syncthreads();
+    if (tid < 32) sums[tid] = tot;
+    return __syncthreads_or(timeout) ? FL_NUM_TIMEOUT : 0;
 }

@@ -126,9 +126,16 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_pass_kernel(const float *__re
         fl_stamp(flags, 8);
         if (MODE == 0) eskf18_prefetch_commit(pf_solver, s_solve);
         fl_stamp(flags, 9);
-        const int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
+        int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
         fl_stamp(flags, 10);
         if (threadIdx.x == 0) *epoch_ptr = epoch + 1u;
+        if (MODE == 0 && D->xchg_world > 1) {               // sharded form: totals over the ranks (handoff.h)
+            __shared__ double s_xchg[FL_MAX_PEERS * 32];
+            const FlPeerView PV = fl_peer_view(D);
+            const unsigned xe = *D->xchg_epoch;
+            gst |= peer_allreduce32(PV, xe, s_sums, s_xchg);
+            if (threadIdx.x == 0) *D->xchg_epoch = xe + 1u;
+        }
         if (MODE == 0) {
             eskf18_solve_block<FL_EPI_LIO>(D, s_sums, s_solve, gst);
         } else {
@@ -213,12 +220,16 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_multipass_kernel(const float 
         __shared__ double s_fin[2 * NT];
         __shared__ double s_sums[FL_SUMS18];
         __shared__ FlSolveLds s_solve;
+        __shared__ double s_xchg[FL_MAX_PEERS * 32];
         eskf18_prefetch(D, s_solve);
+        const FlPeerView PV = fl_peer_view(D);
+        const unsigned xe0 = PV.world > 1 ? *D->xchg_epoch : 0u;
         int done = 0;
         for (int p = 0; p < count; p++) {
             const unsigned epoch = epoch0 + (unsigned)p;
             if (p == 5) fl_stamp(flags, 16);
-            const int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
+            int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
+            if (PV.world > 1) gst |= peer_allreduce32(PV, xe0 + (unsigned)p, s_sums, s_xchg);      // sharded form: totals over the ranks
             if (p == 5) fl_stamp(flags, 17);
             eskf18_solve_block<FL_EPI_LIO>(D, s_sums, s_solve, gst, bcast, epoch + 1u);   // publishes pose + control word
             __syncthreads();
@@ -230,11 +241,15 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_multipass_kernel(const float 
             if (p + 1 < count) eskf18_restage(s_solve);
             __syncthreads();
         }
-        if (threadIdx.x == 0) *epoch_ptr = epoch0 + (unsigned)done;
+        if (threadIdx.x == 0) {
+            *epoch_ptr = epoch0 + (unsigned)done;
+            if (PV.world > 1) *D->xchg_epoch = xe0 + (unsigned)done;
+        }
         return;
     }
 
     // -------------------------------------------------------------------- producer workgroups
+    const int spin_limit = D->xchg_world > 1 ? FL_XCHG_SPIN_LIMIT : FL_GATHER_SPIN_LIMIT;   // the solver may be waiting for another process
     __shared__ double s_red[(NT / 64) * FL_SUMS18];
     __shared__ double s_pose[12];
     __shared__ int s_ctrl;
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_multipass_kernel(const float 
         }
         if (ps > 0) {
             if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 20 + 4 * (ps - 5));
-            bcast_wait(bcast, epoch, s_pose, &s_ctrl);
+            bcast_wait(bcast, epoch, s_pose, &s_ctrl, spin_limit);
             __syncthreads();
             if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 21 + 4 * (ps - 5));
             if (!force && (s_ctrl & 3)) break;

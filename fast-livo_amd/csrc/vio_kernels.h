@@ -392,13 +392,22 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
         fl_stamp(flags, 8);
         if (MODE == 0) eskf18_prefetch_commit(pf_solver, s_solve);
         fl_stamp(flags, 9);
-        const int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
+        int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
         fl_stamp(flags, 10);
         if (threadIdx.x == 0) *epoch_ptr = epoch + 1u;
+        const int world = (MODE == 0) ? D->xchg_world : 1;
+        if (world > 1) {                                    // sharded form: totals over the ranks (handoff.h)
+            __shared__ double s_xchg[FL_MAX_PEERS * 32];
+            const FlPeerView PV = fl_peer_view(D);
+            const unsigned xe = *D->xchg_epoch;
+            gst |= peer_allreduce32(PV, xe, s_sums, s_xchg);
+            if (threadIdx.x == 0) *D->xchg_epoch = xe + 1u;
+        }
         if (MODE == 0) {
             __shared__ float s_ex[FL_EXACT_CHUNK];
             FlVioExact ex;
-            ex.words = D->err_words; ex.m = m; ex.cap = D->err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !(flags & FL_ITER_FORCE);
+            // (the replay of the reference's float error sum needs every patch's error: not with the patches spread over ranks)
+            ex.words = D->err_words; ex.m = m; ex.cap = D->err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !(flags & FL_ITER_FORCE) && world <= 1;
             eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, gst, nullptr, 0u, ex);
             __syncthreads();
             vio_derive_pose(s_solve.xn, VC, D);      // camera pose for the next pass's producers
@@ -476,12 +485,16 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
             }
             __syncthreads();
         }
+        __shared__ double s_xchg[FL_MAX_PEERS * 32];
+        const FlPeerView PV = fl_peer_view(D);
+        const unsigned xe0 = PV.world > 1 ? *D->xchg_epoch : 0u;
         int done = 0;
         for (int p = 0; p < count; p++) {
             const unsigned epoch = epoch0 + (unsigned)p;
-            const int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
+            int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
+            if (PV.world > 1) gst |= peer_allreduce32(PV, xe0 + (unsigned)p, s_sums, s_xchg);      // sharded form: totals over the ranks
             FlVioExact ex;
-            ex.words = err_base; ex.m = m; ex.cap = err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !force;
+            ex.words = err_base; ex.m = m; ex.cap = err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !force && PV.world <= 1;
             eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, gst, nullptr, 0u, ex);
             __syncthreads();
             vio_derive_pose(s_solve.xn, VC, D);
@@ -496,7 +509,10 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
             if (p + 1 < count) eskf18_restage(s_solve);
             __syncthreads();
         }
-        if (threadIdx.x == 0) *epoch_ptr = epoch0 + (unsigned)done;
+        if (threadIdx.x == 0) {
+            *epoch_ptr = epoch0 + (unsigned)done;
+            if (PV.world > 1) *D->xchg_epoch = xe0 + (unsigned)done;
+        }
         if (level_info) {
             __syncthreads();
             if (threadIdx.x < 18) level_info->solution[threadIdx.x] = D->solution[threadIdx.x];
@@ -512,6 +528,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
     __shared__ double s_pose[12];
     __shared__ int s_ctrl;
     __shared__ float s_res[2 * WPB * 64];
+    const int spin_limit = D->xchg_world > 1 ? FL_XCHG_SPIN_LIMIT : FL_GATHER_SPIN_LIMIT;   // the solver may be waiting for another process
     const FlVioConst vc = *VC;
     double Rcw[9], Pcw[3];
 #pragma unroll
@@ -522,7 +539,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
         const unsigned epoch = epoch0 + (unsigned)ps;
         const FlVioFirst pf = vio_prefetch_first(ref, pos, slevel, m, level, nprod);
         if (ps > 0) {
-            bcast_wait(bcast, epoch, s_pose, &s_ctrl);
+            bcast_wait(bcast, epoch, s_pose, &s_ctrl, spin_limit);
             __syncthreads();
             if (!force && (s_ctrl & 3)) break;
             if (s_ctrl & 4) break;

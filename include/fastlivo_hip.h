@@ -381,6 +381,24 @@ int32_t fl_lio_iterate18_sharded(fl_handle h, int32_t count, int32_t flags, fl_i
 int32_t fl_vio_iterate_sharded(fl_handle h, int32_t level, int32_t count, int32_t flags, fl_iter_info *info);
 int32_t fl_ikfom_iterate_sharded(fl_handle h, int32_t count, int32_t flags, fl_iter_info *info);
 
+/* ------------------------------------------------------------------------------------------------
+ * Sharded form with the exchange INSIDE the pass kernels ("one-shot P2P all-gather ... each rank writes its
+ * record into the peers' mapped buffers + flag; fixed-order local sum"). After connecting, the ordinary Mode-18 / VIO entry
+ * points (fl_lio_iterate18, fl_lio_frame18_dev, fl_vio_iterate, fl_vio_compute_j, ...) run on this rank's range of the
+ * points / patches: the solver workgroup of every pass publishes its 32 sums into every peer's exchange buffer (fine-grained
+ * device memory, 8-byte self-validating words, over xGMI between GPUs) and adds up what the peers sent in rank order, so all
+ * ranks solve on bitwise-identical totals -- and the passes of a frame remain ONE launch per rank. Every rank must issue the
+ * same sequence of passes (it is a collective). State, covariance, configuration replicated; map / image replicated or sharded
+ * by the caller. The VIO accept test falls back to the fp64-reduced comparison (FL_NUM_FRAGILE = "may differ").
+ *   separate processes:  fl_p2p_export on every rank -> exchange the 64-byte handles (any transport) -> fl_p2p_connect
+ *   one process:         fl_p2p_connect_local(h, rank, world, all_handles) on every handle
+ * Connect before fl_*_begin of the frame. Waiting for a peer is bounded (seconds): FL_NUM_TIMEOUT in the status, no hang.
+ * ---------------------------------------------------------------------------------------------- */
+int32_t fl_p2p_export(fl_handle h, int32_t world /* 2..8 */, void *handle64_out /* 64 bytes */);
+int32_t fl_p2p_connect(fl_handle h, int32_t rank, int32_t world, const void *handles64 /* world x 64 bytes, own entry ignored */);
+int32_t fl_p2p_connect_local(fl_handle h, int32_t rank, int32_t world, const fl_handle *all /* world handles, all[rank] == h */);
+int32_t fl_p2p_disconnect(fl_handle h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,159 @@
+"""Sharded form with the exchange inside the pass kernels (api_p2p.inc / handoff.h peer_allreduce32): two ranks, each with half
+of the frame's points / patches, exchange their 32 sums peer to peer in the solver workgroup. On the 1-GPU test box both ranks
+live on device 0 -- in one process (fl_p2p_connect_local, one host thread per rank) and in two processes (hipIpc handles):
+the kernels, the protocol and the IPC plumbing are the ones a multi-GPU node uses, only the wire is not xGMI.
+Required: both ranks end bitwise equal; equal to the unsharded run within the re-association tolerance (1e-9)."""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_ranks(fns):
+    out, err = [None] * len(fns), [None] * len(fns)
+
+    def wrap(i):
+        try:
+            out[i] = fns[i]()
+        except Exception as e:   # noqa: BLE001
+            err[i] = e
+    th = [threading.Thread(target=wrap, args=(i,)) for i in range(len(fns))]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert not any(t.is_alive() for t in th), "a rank hangs"
+    for e in err:
+        if e:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_lio_passes_sharded_in_kernel(gpu_lib, oracle_lib, scene, world):
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    n, max_iter = 30000, 6
+    fr = synth.make_lio_frame(n, scene=scene)
+    nbr, valid = synth.knn5(scene, fr.world_at(fr.R_prior, fr.p_prior))
+    cfg = capi.config_from_frames(fr, max_iterations=max_iter)
+    ref = capi.Handle(cfg)
+    x0 = capi.state18_from_frame(fr)
+    ref.lio_set_points(fr.body_xyz); ref.lio_begin18(x0, x0); ref.lio_set_neighbours(nbr, valid)
+    iref = ref.lio_iterate18(max_iter + 1, 0)
+    xref = ref.lio_get_state18()
+    ref.close()
+    hs = [capi.Handle(cfg) for _ in range(world)]
+    capi.p2p_connect_local(hs)
+    cuts = np.linspace(0, n, world + 1).astype(int)
+
+    def rank(r):
+        def go():
+            h = hs[r]
+            sl = slice(cuts[r], cuts[r + 1])
+            h.lio_set_points(fr.body_xyz[sl]); h.lio_begin18(x0, x0); h.lio_set_neighbours(nbr[sl], valid[sl])
+            info = h.lio_iterate18(max_iter + 1, 0)
+            return info, h.lio_get_state18()
+        return go
+    res = _run_ranks([rank(r) for r in range(world)])
+    for info, x in res:
+        assert info.status == 0 and info.iterations == iref.iterations and info.effct_feat_num == iref.effct_feat_num
+        assert np.array_equal(x.vec(), res[0][1].vec())                 # ranks bitwise equal
+        assert np.abs(x.vec() - xref.vec()).max() <= 1e-9
+    # forced passes, one launch per pass (the non-multi-pass kernels exchange as well)
+    os.environ["FL_NO_MULTIPASS"] = "1"
+    try:
+        def rank1(r):
+            def go():
+                h = hs[r]
+                h.lio_begin18(x0, x0)
+                h.lio_set_neighbours(nbr[cuts[r]:cuts[r + 1]], valid[cuts[r]:cuts[r + 1]])
+                h.lio_iterate18(3, capi.FL_ITER_FORCE)
+                return h.lio_get_state18()
+            return go
+        res1 = _run_ranks([rank1(r) for r in range(world)])
+    finally:
+        del os.environ["FL_NO_MULTIPASS"]
+    assert all(np.array_equal(x.vec(), res1[0].vec()) for x in res1)
+    for h in hs:
+        h.close()
+
+
+def test_vio_levels_and_all_device_frame_sharded_in_kernel(gpu_lib, oracle_lib, scene):
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    n, m, max_iter = 20000, 900, 5
+    fr = synth.make_lio_frame(n, scene=scene)
+    vf = synth.make_vio_frame(m, fr)
+    cfg = capi.config_from_frames(fr, vf, max_iterations=max_iter)
+    x0 = capi.state18_from_frame(fr)
+    ref = capi.Handle(cfg)
+    ref.map_set_points(scene.map_xyz, 0.5)
+    xr = capi.state18_from_frame(fr)
+    ir = ref.lio_frame18_dev(xr, fr.body_xyz)
+    ref.vio_set_frame(vf.img); ref.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+    xv = capi.state18_from_frame(fr)
+    ref.vio_compute_j(xv, x0)
+    ref.close()
+    hs = [capi.Handle(cfg) for _ in range(2)]
+    capi.p2p_connect_local(hs)
+
+    def rank(r):
+        def go():
+            h = hs[r]
+            h.map_set_points(scene.map_xyz, 0.5)                         # map replicated, scan sharded
+            x = capi.state18_from_frame(fr)
+            info = h.lio_frame18_dev(x, fr.body_xyz[r * n // 2:(r + 1) * n // 2])
+            h.vio_set_frame(vf.img)
+            sl = slice(r * m // 2, (r + 1) * m // 2)
+            h.vio_set_patches(vf.ref_patch[sl], vf.pos[sl], vf.search_level[sl])
+            xvr = capi.state18_from_frame(fr)
+            h.vio_compute_j(xvr, x0)
+            return info, x, xvr
+        return go
+    res = _run_ranks([rank(0), rank(1)])
+    (i0, xa, va), (i1, xb, vb) = res
+    assert i0.status == 0 and i1.status == 0
+    assert i0.iterations == i1.iterations == ir.iterations and i0.effct_feat_num == i1.effct_feat_num == ir.effct_feat_num
+    assert np.array_equal(xa.vec(), xb.vec()) and np.array_equal(xa.cov_np(), xb.cov_np())
+    assert np.abs(xa.vec() - xr.vec()).max() <= 1e-9 and np.abs(xa.cov_np() - xr.cov_np()).max() <= 1e-11
+    assert np.array_equal(va.vec(), vb.vec())
+    assert np.abs(va.vec() - xv.vec()).max() <= 1e-6          # (the accept test of the sharded form is the fp64 one: DESIGN.md section 6)
+    for h in hs:
+        h.close()
+
+
+def test_two_processes_over_hip_ipc(gpu_lib, tmp_path):
+    """Each rank its own process (as under torch.distributed.run), handles exchanged through files, both on device 0."""
+    worker = os.path.join(ROOT, "tests", "p2p_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(o.strip().splitlines()[-1])
+    a, b = [np.array(o.split()[1:], dtype=np.float64) for o in outs]
+    assert outs[0].split()[0] == outs[1].split()[0] == "OK"
+    assert np.array_equal(a, b)
+
+
+def test_bench_n2_path_on_one_device(gpu_lib):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), with both ranks on device 0
+    and the control plane on gloo (FL_BENCH_SINGLE_DEVICE / FL_BENCH_BACKEND, test aids): handle exchange, connection, self-test,
+    timed region and the collective roofline launches of the in-kernel exchange path."""
+    import json
+    env = dict(os.environ, FL_BENCH_BACKEND="gloo", FL_BENCH_SINGLE_DEVICE="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "100", "--warmup", "20"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["state_finite"] and d["scaling"] == "weak"
+    assert "in-kernel peer-to-peer" in d["config"]["parallelism"]
+    assert d["roofline"]["lio_pass_us"] < 100 and d["roofline"]["vio_pass_us"] < 100      # no time-outs hidden in the launches
