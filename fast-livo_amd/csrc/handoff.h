@@ -208,15 +208,16 @@ __device__ __forceinline__ void bcast_wait(const unsigned long long *words, unsi
 #define FL_XCHG_WORDS 64
 #define FL_XCHG_SPIN_LIMIT (1 << 22)
 struct FlPeerView {
-    unsigned long long *peer[FL_MAX_PEERS];
+    unsigned long long *own;                   // this rank's buffer
+    unsigned long long *const *peer;           // D->xchg_peer (read with constant indices: a register array indexed at run time would live in scratch)
     int rank, world;
 };
 __device__ __forceinline__ FlPeerView fl_peer_view(const FlDev18 *D)
 {
     FlPeerView P;
     P.rank = D->xchg_rank; P.world = D->xchg_world;
-#pragma unroll
-    for (int r = 0; r < FL_MAX_PEERS; r++) P.peer[r] = (r < P.world) ? D->xchg_peer[r] : nullptr;
+    P.peer = D->xchg_peer;
+    P.own = (P.world > 1) ? D->xchg_peer[P.rank] : nullptr;
     return P;
 }
 // All threads of the (>= 256-thread) solver workgroup call it; sums = LDS[32], replaced by the total over the ranks;
@@ -239,7 +240,7 @@ __device__ __forceinline__ int peer_allreduce32(const FlPeerView &P, unsigned xe
     for (int s0 = 0; s0 < P.world; s0 += per_round) {
         const int s = s0 + (tid >> 6), k = tid & 63;
         const bool active = s < P.world && s != P.rank;
-        const unsigned long long *src = P.peer[P.rank] + half + (size_t)(active ? s : 0) * FL_XCHG_WORDS + k;
+        const unsigned long long *src = P.own + half + (size_t)(active ? s : 0) * FL_XCHG_WORDS + k;
         unsigned long long w = 0ull;
         bool ok = !active;
         for (int spin = 0; ; spin++) {
