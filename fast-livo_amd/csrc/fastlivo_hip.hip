@@ -45,6 +45,7 @@ struct fl_context {
     FlDev18 *d_dev = nullptr;
     FlDev18 *h_dev = nullptr;      // pinned mirror
     void *d_records = nullptr;      // tagged per-workgroup records (handoff.h)
+    size_t rec_fresh_bytes = 0;     // bytes of d_records the previous pass launch covered (records_for)
     unsigned *d_epoch = nullptr;    // launch epoch of the records, advanced on the device
     double *d_sums_tmp = nullptr;
     unsigned long long *d_bcast = nullptr;   // pose broadcast words of the multi-pass kernels (handoff.h)
@@ -374,6 +375,23 @@ static inline int lio_grid(int n)
     return b + 1;
 }
 
+// The records of a pass (handoff.h) validate themselves with a 6-bit tag of the launch epoch, so a record that the PREVIOUS launch
+// did not rewrite must not be looked at by the next one: LIO, VIO and Mode-23 passes of one handle share the buffer with different
+// grids and record sizes, and a stale tail could carry a matching tag once the epoch has advanced by a multiple of 63 in between.
+// Whatever lies beyond the bytes the previous launch covered is zeroed (tag 0 = "never written") before a larger launch reads it.
+static inline int vio_grid(int m);
+static inline int ik_grid(int n);
+static void *records_for(fl_handle h, size_t need_bytes)
+{
+    if (need_bytes > h->rec_fresh_bytes)
+        (void)hipMemsetAsync((char *)h->d_records + h->rec_fresh_bytes, 0, need_bytes - h->rec_fresh_bytes, h->stream);
+    h->rec_fresh_bytes = need_bytes;
+    return h->d_records;
+}
+static inline void *records_lio(fl_handle h) { return records_for(h, (size_t)lio_grid(h->n) * FL_SUMS18 * 8); }
+static inline void *records_vio(fl_handle h) { return records_for(h, (size_t)vio_grid(h->m) * FL_SUMS18 * 8); }
+static inline void *records_ik(fl_handle h) { return records_for(h, (size_t)ik_grid(h->n) * FL_SUMS23 * 8); }
+
 int32_t fl_lio_set_points(fl_handle h, const float *body_xyz, int32_t n)
 {
     if (!h || !body_xyz || n <= 0) return fail_arg(h, "fl_lio_set_points: bad argument");
@@ -538,12 +556,12 @@ static void launch_lio_passes(fl_handle h, int grid, int count, int flags)
     if (flags & FL_ITER_KEEP_NORMVEC) h->normvec_valid = true;
     if (count > 1 && grid <= h->num_cus && fl_multipass_enabled()) {
         hipLaunchKernelGGL(lio18_multipass_kernel, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_body, h->d_plane, h->d_sel, h->d_normvec,
-                           h->n, h->d_dev, h->d_records, h->d_epoch, h->d_bcast, (int)count, (int)flags);
+                           h->n, h->d_dev, records_lio(h), h->d_epoch, h->d_bcast, (int)count, (int)flags);
         return;
     }
     for (int i = 0; i < count; i++)
         hipLaunchKernelGGL(lio18_pass_kernel<0>, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_body, h->d_plane, h->d_sel,
-                           h->d_normvec, h->n, h->d_dev, h->d_records, h->d_epoch, (double *)nullptr, (int)flags);
+                           h->d_normvec, h->n, h->d_dev, records_lio(h), h->d_epoch, (double *)nullptr, (int)flags);
 }
 
 int32_t fl_lio_iterate18(fl_handle h, int32_t count, int32_t flags, fl_iter_info *info)
@@ -616,7 +634,7 @@ int32_t fl_lio_accumulate18(fl_handle h, double *d_sums, int32_t flags)
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(lio18_pass_kernel<1>, dim3(lio_grid(h->n)), dim3(FL_LIO_NT), 0, h->stream, h->d_body, h->d_plane,
-                       h->d_sel, h->d_normvec, h->n, h->d_dev, h->d_records, h->d_epoch, d_sums, (int)flags);
+                       h->d_sel, h->d_normvec, h->n, h->d_dev, records_lio(h), h->d_epoch, d_sums, (int)flags);
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipGetLastError());
     return FL_OK;
