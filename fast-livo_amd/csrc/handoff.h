@@ -14,7 +14,9 @@
 //             Cost: the partial sums keep 46 of 52 mantissa bits (relative 1.4e-14, two orders below
 //             the 1e-12 the parity tests allow for fp64 re-ordering; the inputs are float32).
 //             Stale words are always from the previous launch (every launch rewrites every record
-//             of its grid; the host zeroes the buffer whenever the grid size changes), i.e. tag-1.
+//             of its grid; the host zeroes the buffer whenever the grid size changes, and zeroes what
+//             the previous launch did not cover before a larger launch of another kernel reads it:
+//             records_for in fastlivo_hip.hip), i.e. tag-1 or 0.
 //   gather  : the solver workgroup re-reads the records with 16-byte sc1 buffer loads (L1-bypass, a
 //             whole sweep in flight together). A 16-lane row reads one 32-value group of a record, so
 //             one load instruction of a wave covers four records; each WAVE polls its own records

@@ -71,8 +71,20 @@ __device__ __forceinline__ float vio_exact_sum(const unsigned long long *w, int 
             scr[k] = __uint_as_float((unsigned)(v >> 32));
         }
         __syncthreads();
-        if (tid == 0)
-            for (int k = 0; k < cnt; k++) f = f + scr[k];
+        if (tid == 0) {
+            // one dependent float addition per patch; the operands come from LDS sixteen at a time so that the chain waits for
+            // the adder, not for LDS
+            int k = 0;
+            for (; k + 16 <= cnt; k += 16) {
+                const float4 a = *reinterpret_cast<const float4 *>(scr + k), b = *reinterpret_cast<const float4 *>(scr + k + 4);
+                const float4 c = *reinterpret_cast<const float4 *>(scr + k + 8), d = *reinterpret_cast<const float4 *>(scr + k + 12);
+                f = f + a.x; f = f + a.y; f = f + a.z; f = f + a.w;
+                f = f + b.x; f = f + b.y; f = f + b.z; f = f + b.w;
+                f = f + c.x; f = f + c.y; f = f + c.z; f = f + c.w;
+                f = f + d.x; f = f + d.y; f = f + d.z; f = f + d.w;
+            }
+            for (; k < cnt; k++) f = f + scr[k];
+        }
         __syncthreads();
     }
     return f;

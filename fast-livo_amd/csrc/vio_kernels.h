@@ -404,7 +404,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
             if (threadIdx.x == 0) *D->xchg_epoch = xe + 1u;
         }
         if (MODE == 0) {
-            __shared__ float s_ex[FL_EXACT_CHUNK];
+            __shared__ __attribute__((aligned(16))) float s_ex[FL_EXACT_CHUNK];
             FlVioExact ex;
             // (the replay of the reference's float error sum needs every patch's error: not with the patches spread over ranks)
             ex.words = D->err_words; ex.m = m; ex.cap = D->err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !(flags & FL_ITER_FORCE) && world <= 1;
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
         __shared__ double s_sums[FL_SUMS18];
         __shared__ FlSolveLds s_solve;
         __shared__ double s_cam[12];
-        __shared__ float s_ex[FL_EXACT_CHUNK];
+        __shared__ __attribute__((aligned(16))) float s_ex[FL_EXACT_CHUNK];
         eskf18_prefetch(D, s_solve);
         if (begin) {
             __syncthreads();
