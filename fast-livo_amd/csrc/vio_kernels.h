@@ -227,10 +227,19 @@ __device__ __forceinline__ void vio_patch_error(const float *r, int hl, bool act
     return;
 #endif
     float pe = 0.0f;
-#pragma unroll 8
-    for (int k = 0; k < 64; k++) {
-        const double rd = (double)r[k];
-        pe = (float)((double)pe + rd * rd);          // the product of two floats is exact in double: fused or not, same rounding
+#pragma unroll
+    for (int k = 0; k < 64; k += 16) {               // operands from LDS sixteen at a time: the chain waits for the adder only
+        float q[16];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float4 t = *reinterpret_cast<const float4 *>(r + k + 4 * j);
+            q[4 * j] = t.x; q[4 * j + 1] = t.y; q[4 * j + 2] = t.z; q[4 * j + 3] = t.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const double rd = (double)q[j];
+            pe = (float)((double)pe + rd * rd);      // the product of two floats is exact in double: fused or not, same rounding
+        }
     }
     errors[i] = pe;
 #ifndef FL_AB_NO_ERRWORDS
@@ -428,7 +437,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     for (int i = 0; i < 9; i++) Rcw[i] = D->Rcw[i];
 #pragma unroll
     for (int i = 0; i < 3; i++) Pcw[i] = D->Pcw[i];
-    __shared__ float s_res[2 * WPB * 64];
+    __shared__ __attribute__((aligned(16))) float s_res[2 * WPB * 64];
     unsigned long long *ew = D->err_words ? D->err_words + (size_t)(D->iters_run & 1) * D->err_cap : nullptr;
     vio_produce(img, ref, pos, slevel, errors, m, level_arg, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags, ew, s_res);
     if (blockIdx.x == 0) fl_stamp(flags, 2);
@@ -527,7 +536,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
     __shared__ double s_red[2 * WPB * FL_SUMS18];
     __shared__ double s_pose[12];
     __shared__ int s_ctrl;
-    __shared__ float s_res[2 * WPB * 64];
+    __shared__ __attribute__((aligned(16))) float s_res[2 * WPB * 64];
     const int spin_limit = D->xchg_world > 1 ? FL_XCHG_SPIN_LIMIT : FL_GATHER_SPIN_LIMIT;   // the solver may be waiting for another process
     const FlVioConst vc = *VC;
     double Rcw[9], Pcw[3];

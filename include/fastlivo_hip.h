@@ -393,6 +393,8 @@ int32_t fl_ikfom_iterate_sharded(fl_handle h, int32_t count, int32_t flags, fl_i
  *   separate processes:  fl_p2p_export on every rank -> exchange the 64-byte handles (any transport) -> fl_p2p_connect
  *   one process:         fl_p2p_connect_local(h, rank, world, all_handles) on every handle
  * Connect before fl_*_begin of the frame. Waiting for a peer is bounded (seconds): FL_NUM_TIMEOUT in the status, no hang.
+ * A replicated device map stays replicated only if every rank adds the WHOLE registered scan: fl_map_add_points(h, NULL, ..)
+ * adds this rank's range only -- pass the full world scan explicitly there.
  * ---------------------------------------------------------------------------------------------- */
 int32_t fl_p2p_export(fl_handle h, int32_t world /* 2..8 */, void *handle64_out /* 64 bytes */);
 int32_t fl_p2p_connect(fl_handle h, int32_t rank, int32_t world, const void *handles64 /* world x 64 bytes, own entry ignored */);
