@@ -116,6 +116,12 @@ def imu_samples(arr):
     return out
 
 
+class VmapObs(C.Structure):
+    """fl_vmap_obs"""
+    _fields_ = [("px", C.c_double * 2), ("f", C.c_double * 3), ("R", C.c_double * 9), ("t", C.c_double * 3), ("score", C.c_float),
+                ("level", C.c_int32), ("kf_id", C.c_int32), ("frame_id", C.c_int32)]
+
+
 class PatchCandidate(C.Structure):
     _fields_ = [("pos", C.c_double * 3), ("px_ref", C.c_double * 2), ("f_ref", C.c_double * 3), ("R_ref", C.c_double * 9),
                 ("t_ref", C.c_double * 3), ("keyframe_id", C.c_int32), ("level_ref", C.c_int32), ("grid_index", C.c_int32),
@@ -201,6 +207,12 @@ SYMBOLS = {
     "fl_ikfom_accumulate": (C.c_int32, [_H, C.c_void_p, C.c_int32]),
     "fl_ikfom_solve": (C.c_int32, [_H, C.c_void_p, C.c_int32, C.POINTER(IterInfo)]),
     "fl_map_set_points": (C.c_int32, [_H, _fp, C.c_int32, C.c_float]),
+    "fl_vmap_clear": (C.c_int32, [_H, C.c_int32]),
+    "fl_vmap_size": (C.c_int32, [_H, C.POINTER(C.c_int32)]),
+    "fl_vmap_get_point": (C.c_int32, [_H, C.c_int32, _dp, _fp, C.POINTER(C.c_int32), C.c_void_p]),
+    "fl_vmap_select": (C.c_int32, [_H, _dp, _dp, _fp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.POINTER(C.c_int32), _i32p, _fp, _i32p, _fp]),
+    "fl_vmap_add_sparse": (C.c_int32, [_H, _dp, _dp, _fp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    "fl_vmap_add_observation": (C.c_int32, [_H, _dp, _dp, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     "fl_p2p_export": (C.c_int32, [_H, C.c_int32, C.c_void_p]),
     "fl_p2p_connect": (C.c_int32, [_H, C.c_int32, C.c_int32, C.c_void_p]),
     "fl_p2p_connect_local": (C.c_int32, [_H, C.c_int32, C.c_int32, C.c_void_p]),
@@ -389,6 +401,51 @@ class Handle:
         k = na.value
         return dict(idx=idx[:k].copy(), errors=err[:k].copy(), levels=lvl[:k].copy(), reason=reason[:m].copy(),
                     patches=patches[:k].copy() if want_patches else None, depth=depth)
+
+    # ---- visual map on the device (api_vmap.inc)
+    def vmap_clear(self, grid_size):
+        self._chk(self.L.fl_vmap_clear(self.h, grid_size), "fl_vmap_clear")
+        self._vm_cells = (self.cfg.img_width // grid_size) * (self.cfg.img_height // grid_size)
+
+    def vmap_size(self):
+        n = C.c_int32(0)
+        self._chk(self.L.fl_vmap_size(self.h, C.byref(n)), "fl_vmap_size")
+        return n.value
+
+    def vmap_get_point(self, i):
+        pos = np.zeros(3, np.float64); val = C.c_float(0); nobs = C.c_int32(0)
+        obs = (VmapObs * 20)()
+        self._chk(self.L.fl_vmap_get_point(self.h, i, pos.ctypes.data_as(_dp), C.byref(val), C.byref(nobs), obs), "fl_vmap_get_point")
+        return pos, val.value, [obs[k] for k in range(nobs.value)]
+
+    def vmap_select(self, Rcw, Pcw, scan_down_world, ncc_en=False, ncc_thre=0.0, outlier_threshold=300.0, want_patches=True):
+        Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(9); Pcw = np.ascontiguousarray(Pcw, np.float64)
+        scan = np.ascontiguousarray(scan_down_world, np.float32).reshape(-1, 3)
+        m = self._vm_cells
+        sel = np.zeros(m, np.int32); err = np.zeros(m, np.float32); lvl = np.zeros(m, np.int32)
+        patches = np.zeros((m, 192), np.float32) if want_patches else None
+        ns = C.c_int32(0)
+        self._chk(self.L.fl_vmap_select(self.h, Rcw.ctypes.data_as(_dp), Pcw.ctypes.data_as(_dp), scan.ctypes.data_as(_fp) if len(scan) else None,
+                                        len(scan), 1 if ncc_en else 0, ncc_thre, outlier_threshold, C.byref(ns), sel.ctypes.data_as(_i32p),
+                                        err.ctypes.data_as(_fp), lvl.ctypes.data_as(_i32p),
+                                        patches.ctypes.data_as(_fp) if want_patches else None), "fl_vmap_select")
+        k = ns.value
+        return dict(points=sel[:k].copy(), errors=err[:k].copy(), levels=lvl[:k].copy(), patches=patches[:k].copy() if want_patches else None)
+
+    def vmap_add_sparse(self, Rcw, Pcw, scan_world, keyframe_id, frame_id):
+        Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(9); Pcw = np.ascontiguousarray(Pcw, np.float64)
+        scan = np.ascontiguousarray(scan_world, np.float32).reshape(-1, 3)
+        na = C.c_int32(0)
+        self._chk(self.L.fl_vmap_add_sparse(self.h, Rcw.ctypes.data_as(_dp), Pcw.ctypes.data_as(_dp), scan.ctypes.data_as(_fp), len(scan),
+                                            keyframe_id, frame_id, C.byref(na)), "fl_vmap_add_sparse")
+        return na.value
+
+    def vmap_add_observation(self, Rcw, Pcw, keyframe_id, frame_id):
+        Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(9); Pcw = np.ascontiguousarray(Pcw, np.float64)
+        na = C.c_int32(0)
+        self._chk(self.L.fl_vmap_add_observation(self.h, Rcw.ctypes.data_as(_dp), Pcw.ctypes.data_as(_dp), keyframe_id, frame_id, C.byref(na)),
+                  "fl_vmap_add_observation")
+        return na.value
 
     def comm_unique_id(self):
         buf = (C.c_char * 128)()

@@ -11,6 +11,7 @@
 #include "knn_kernels.h"
 #include "voxel_kernels.h"
 #include "mapupd_kernels.h"
+#include "vmap_kernels.h"
 #include "imu_kernels.h"
 #include "select_kernels.h"
 
@@ -49,6 +50,16 @@ struct fl_context {
     unsigned *d_epoch = nullptr;    // launch epoch of the records, advanced on the device
     double *d_sums_tmp = nullptr;
     unsigned long long *d_bcast = nullptr;   // pose broadcast words of the multi-pass kernels (handoff.h)
+    // visual map on the device (vmap_kernels.h)
+    struct FlVPoint *d_vm_pts = nullptr;
+    unsigned long long *d_vm_key = nullptr, *d_vm_best = nullptr, *d_vm_set = nullptr;
+    int *d_vm_val = nullptr;
+    int32_t *d_vm_num = nullptr, *d_vm_sel = nullptr;
+    struct FlVmapParams *d_vm_prm = nullptr;
+    struct FlVmapCount *d_vm_cnt = nullptr;
+    float *d_vm_scan = nullptr;
+    int vm_n = 0, vm_cap = 0, vm_length = 0, vm_grid = 0, vm_scan_cap = 0, vm_nsel = 0;
+    unsigned vm_set_cap = 0;
     // peer exchange of the sharded form (api_p2p.inc)
     unsigned long long *d_xchg = nullptr;    // this rank's exchange buffer (fine-grained), [2][world][64] words
     unsigned long long *xchg_peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -250,6 +261,7 @@ static int32_t map_free(fl_handle h);
 static void mapupd_free(fl_handle h);
 static void imu_free(fl_handle h);
 static void select_free(fl_handle h);
+static void vmap_free(fl_handle h);
 extern "C" int32_t fl_comm_destroy(fl_handle h);
 extern "C" int32_t fl_p2p_disconnect(fl_handle h);
 
@@ -267,6 +279,7 @@ int32_t fl_destroy(fl_handle h)
     vox_free(h);
     imu_free(h);
     select_free(h);
+    vmap_free(h);
     fl_comm_destroy(h);
     fl_p2p_disconnect(h);
     if (h->h_dev) hipHostFree(h->h_dev);
@@ -676,6 +689,7 @@ int32_t fl_debug_get_wall(fl_handle h, long long *out2048)
 #include "api_voxel.inc"
 #include "api_imu.inc"
 #include "api_select.inc"
+#include "api_vmap.inc"
 #include "api_comm.inc"
 #include "api_p2p.inc"
 

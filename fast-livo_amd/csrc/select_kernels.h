@@ -268,7 +268,7 @@ __global__ __launch_bounds__(FL_BLOCK) void vio_grid_kernel(const double *__rest
     const double o0 = G->fpos[0] - p[0], o1 = G->fpos[1] - p[1], o2 = G->fpos[2] - p[2];
     const float cur_dist = (float)sqrt(o0 * o0 + o1 * o1 + o2 * o2);
     if (cur_dist <= 10000.f)
-        atomicMin(&key[index], ((unsigned long long)__float_as_uint(cur_dist) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)j));
+        atomicMin(&key[index], ((unsigned long long)__float_as_uint(cur_dist) << 32) | (unsigned long long)(0xFFFFFFFEu - (unsigned)j));   // 0xFFFFFFFF = no point yet
     const float cv = value[j];
     if (cv >= 0.f) atomicMax(&val[index], __float_as_int(cv));
 }

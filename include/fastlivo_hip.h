@@ -367,6 +367,36 @@ int32_t fl_vio_select_patches(fl_handle h, const double *Rcw, const double *Pcw,
                               float *patches_out, float *depth_out);
 
 /* ------------------------------------------------------------------------------------------------
+ * The visual map on the device: the caller's side of addFromSparseMap, so that no per-point visual-map data crosses PCIe.
+ * A map point = position, Shi-Tomasi score and up to 20 observations {px, f, T_f_w, score, level, keyframe id, frame id} in the
+ * order of the reference's list (front = newest). Per frame, in the order of LidarSelector::detect (:1050-1064), with the
+ * current image staged by fl_vio_set_frame and registered once with fl_vio_add_keyframe (its id is what new observations refer to):
+ *   fl_vmap_select           addFromSparseMap (src/lidar_selection.cpp:346-587), whole: scan_down_world_xyz = the scan after
+ *                            downSizeFilter (:352-353, fl_scan_voxel_filter); voxels the scan touches (:383-391), depth image,
+ *                            the map points of those voxels projected + grid competition (:412-466), Point::getCloseViewObs
+ *                            (src/point.cpp:141-178) per winning cell, then warp / NCC / outlier gates as fl_vio_select_patches.
+ *                            The accepted patches are the staged VIO patch set (fl_vio_compute_j can follow); sel_point (nullable,
+ *                            room for (W/grid)*(H/grid)) = their map indices (sub_sparse_map->voxel_points), errors / search_levels
+ *                            alike, patches_out n_selected x 192 floats. Rcw/Pcw = new_frame_->T_f_w_ at that moment (LIO posterior).
+ *   fl_vmap_add_sparse       addSparseMap (:142-197) + AddPoint (:199-230): scan_world_xyz = the scan `pg` itself; a scan point founds
+ *                            a map point where its score beats every map point that projected into its grid cell during
+ *                            fl_vmap_select (map_value is not reset in between, :81-90).
+ *   fl_vmap_add_observation  addObservation (:913-965) for the points selected by the last fl_vmap_select, with the pose AFTER
+ *                            fl_vio_compute_j.
+ * fl_vmap_clear(grid_size) creates the (empty) map; grid_size as LidarSelector::grid_size. Only the distortion-free camera.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fl_vmap_obs { double px[2], f[3], R[9], t[3]; float score; int32_t level, kf_id, frame_id; } fl_vmap_obs;
+int32_t fl_vmap_clear(fl_handle h, int32_t grid_size);
+int32_t fl_vmap_size(fl_handle h, int32_t *n);
+int32_t fl_vmap_get_point(fl_handle h, int32_t i, double *pos, float *value, int32_t *n_obs, fl_vmap_obs *obs /* room for 20 */);
+int32_t fl_vmap_select(fl_handle h, const double *Rcw, const double *Pcw, const float *scan_down_world_xyz, int32_t n, int32_t ncc_en,
+                       double ncc_thre, double outlier_threshold, int32_t *n_selected, int32_t *sel_point, float *errors, int32_t *search_levels,
+                       float *patches_out);
+int32_t fl_vmap_add_sparse(fl_handle h, const double *Rcw, const double *Pcw, const float *scan_world_xyz, int32_t n, int32_t keyframe_id,
+                           int32_t frame_id, int32_t *n_added);
+int32_t fl_vmap_add_observation(fl_handle h, const double *Rcw, const double *Pcw, int32_t keyframe_id, int32_t frame_id, int32_t *n_added);
+
+/* ------------------------------------------------------------------------------------------------
  * Sharded form with the exchange done natively: each rank stages its contiguous range of the scan
  * points / patches; a pass = accumulate (this rank's range) -> ncclAllReduce of the 32-double (Mode-23: 96) record
  * on the handle's stream (RCCL over xGMI) -> solve, replicated on bitwise-identical inputs. Three enqueues, no host

@@ -169,6 +169,25 @@ int orc_vio_select(const orc_vio_config *cfg, const double *Rcw, const double *P
 int orc_vio_grid_select(const orc_vio_config *cfg, const double *Rcw, const double *Pcw, const double *pos, const float *value, int k,
                         int grid_size, int32_t *winner, float *map_dist, float *map_value, int32_t *grid_num);
 
+/* The visual map and its three per-frame steps (orc_vmap.c): addSparseMap :142-230, addFromSparseMap :346-587 (whole),
+ * addObservation :913-965, Point::getCloseViewObs / getFurthestViewObs (point.cpp). Opaque handle. */
+#define ORC_VMAP_MAX_OBS 20
+typedef struct orc_vmap orc_vmap;
+typedef struct orc_vmap_obs { double px[2], f[3], R[9], t[3]; float score; int32_t level, kf_id, frame_id; } orc_vmap_obs;
+orc_vmap *orc_vmap_create(const orc_vio_config *cfg, int grid_size);
+void orc_vmap_destroy(orc_vmap *m);
+int orc_vmap_size(const orc_vmap *m);
+int orc_vmap_get_point(const orc_vmap *m, int i, double *pos, float *value, int32_t *n_obs, orc_vmap_obs *obs);
+void orc_vmap_get_grid(const orc_vmap *m, float *map_value, int32_t *grid_num);
+float orc_shi_tomasi(const uint8_t *img, int width, int height, int u, int v);
+int orc_vmap_add_sparse(orc_vmap *m, const double *Rcw, const double *Pcw, const uint8_t *img, const float *scan_world_xyz, int n,
+                        int kf_id, int frame_id);
+int orc_vmap_select(orc_vmap *m, const double *Rcw, const double *Pcw, const uint8_t *cur_img, const uint8_t *const *keyframes,
+                    const float *scan_down_world_xyz, int n, int ncc_en, double ncc_thre, double outlier_threshold,
+                    int32_t *sel_point, float *errors, int32_t *search_levels, float *patches, int32_t *n_selected);
+int orc_vmap_add_observation(orc_vmap *m, const double *Rcw, const double *Pcw, const uint8_t *img, const int32_t *sel_point,
+                             const int32_t *search_levels, int n_sel, int kf_id, int frame_id);
+
 /* vk::PinholeCamera::world2cam (rpg_vikit, unpinned master; restated from memory). */
 void orc_world2cam(const orc_vio_config *cfg, const double *xyz_c, double *px);
 

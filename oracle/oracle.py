@@ -449,6 +449,74 @@ def vio_select(cfg, Rcw, Pcw, cur_img, keyframes, depth, cand, ncc_en=False, ncc
     return dict(idx=idx[:k].copy(), errors=err[:k].copy(), levels=lvl[:k].copy(), reason=reason[:m].copy(), patches=patches[:k].copy())
 
 
+class VmapObs(C.Structure):
+    _fields_ = [("px", C.c_double * 2), ("f", C.c_double * 3), ("R", C.c_double * 9), ("t", C.c_double * 3), ("score", C.c_float),
+                ("level", C.c_int32), ("kf_id", C.c_int32), ("frame_id", C.c_int32)]
+
+
+class VMap:
+    """The visual map of LidarSelector on flat arrays (oracle/orc_vmap.c)."""
+
+    def __init__(self, cfg, grid_size):
+        L = lib()
+        L.orc_vmap_create.restype = C.c_void_p
+        L.orc_vmap_create.argtypes = [C.POINTER(VioConfig), C.c_int]
+        L.orc_vmap_destroy.argtypes = [C.c_void_p]
+        L.orc_vmap_size.argtypes = [C.c_void_p]
+        L.orc_vmap_get_point.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p]
+        dp, fp, u8, i32 = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+        L.orc_vmap_add_sparse.argtypes = [C.c_void_p, dp, dp, u8, fp, C.c_int, C.c_int, C.c_int]
+        L.orc_vmap_select.argtypes = [C.c_void_p, dp, dp, u8, C.POINTER(u8), fp, C.c_int, C.c_int, C.c_double, C.c_double, i32, fp, i32, fp, i32]
+        L.orc_vmap_add_observation.argtypes = [C.c_void_p, dp, dp, u8, i32, i32, C.c_int, C.c_int, C.c_int]
+        self.L, self.cfg = L, cfg
+        self.cells = (cfg.width // grid_size) * (cfg.height // grid_size)
+        self.m = L.orc_vmap_create(C.byref(cfg), grid_size)
+
+    def close(self):
+        if self.m:
+            self.L.orc_vmap_destroy(self.m)
+            self.m = None
+
+    def size(self):
+        return self.L.orc_vmap_size(self.m)
+
+    def get_point(self, i):
+        pos = np.zeros(3, np.float64); val = C.c_float(0); nobs = C.c_int32(0)
+        obs = (VmapObs * 20)()
+        assert self.L.orc_vmap_get_point(self.m, i, _p(pos, C.c_double), C.byref(val), C.byref(nobs), obs) == 0
+        return pos, val.value, [obs[k] for k in range(nobs.value)]
+
+    def add_sparse(self, Rcw, Pcw, img, scan_world, kf_id, frame_id):
+        Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(9); Pcw = np.ascontiguousarray(Pcw, np.float64)
+        img = np.ascontiguousarray(img, np.uint8); scan = np.ascontiguousarray(scan_world, np.float32).reshape(-1, 3)
+        return self.L.orc_vmap_add_sparse(self.m, _p(Rcw, C.c_double), _p(Pcw, C.c_double), _p(img, C.c_uint8), _p(scan, C.c_float), len(scan),
+                                          kf_id, frame_id)
+
+    def select(self, Rcw, Pcw, cur_img, keyframes, scan_down_world, ncc_en=False, ncc_thre=0.0, outlier_threshold=300.0):
+        Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(9); Pcw = np.ascontiguousarray(Pcw, np.float64)
+        cur = np.ascontiguousarray(cur_img, np.uint8)
+        kfs = [np.ascontiguousarray(k, np.uint8) for k in keyframes]
+        ptrs = (C.POINTER(C.c_uint8) * max(len(kfs), 1))(*[k.ctypes.data_as(C.POINTER(C.c_uint8)) for k in kfs])
+        scan = np.ascontiguousarray(scan_down_world, np.float32).reshape(-1, 3)
+        m = self.cells
+        sel = np.zeros(m, np.int32); err = np.zeros(m, np.float32); lvl = np.zeros(m, np.int32); patches = np.zeros((m, 192), np.float32)
+        ns = C.c_int32(0)
+        rc = self.L.orc_vmap_select(self.m, _p(Rcw, C.c_double), _p(Pcw, C.c_double), _p(cur, C.c_uint8), ptrs, _p(scan, C.c_float), len(scan),
+                                    1 if ncc_en else 0, ncc_thre, outlier_threshold, _p(sel, C.c_int32), _p(err, C.c_float), _p(lvl, C.c_int32),
+                                    _p(patches, C.c_float), C.byref(ns))
+        if rc != 0:
+            raise RuntimeError("orc_vmap_select failed: %d" % rc)
+        k = ns.value
+        return dict(points=sel[:k].copy(), errors=err[:k].copy(), levels=lvl[:k].copy(), patches=patches[:k].copy())
+
+    def add_observation(self, Rcw, Pcw, img, sel_points, levels, kf_id, frame_id):
+        Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(9); Pcw = np.ascontiguousarray(Pcw, np.float64)
+        img = np.ascontiguousarray(img, np.uint8)
+        sp = np.ascontiguousarray(sel_points, np.int32); lv = np.ascontiguousarray(levels, np.int32)
+        return self.L.orc_vmap_add_observation(self.m, _p(Rcw, C.c_double), _p(Pcw, C.c_double), _p(img, C.c_uint8), _p(sp, C.c_int32),
+                                               _p(lv, C.c_int32), len(sp), kf_id, frame_id)
+
+
 def vio_grid_select(cfg, Rcw, Pcw, pos, value, grid_size):
     Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(9); Pcw = np.ascontiguousarray(Pcw, np.float64)
     pos = np.ascontiguousarray(pos, np.float64); value = np.ascontiguousarray(value, np.float32)

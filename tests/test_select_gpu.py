@@ -130,3 +130,8 @@ def test_grid_competition_matches_oracle(gpu_lib, k, grid_size):
         assert np.array_equal(dev[key].view(np.uint32), ref[key].view(np.uint32)), key
     if k >= 500:
         assert (ref["winner"] >= 0).sum() > 3
+    # the FIRST point of the list alone in the image: it must be reported as the winner of its cell (index 0 is not "none")
+    centre = (np.array([[0.0, 0.0, 6.0]]) - sf.Pcw) @ sf.Rcw
+    ref1 = orc.vio_grid_select(orc.vio_config(sf.vio), sf.Rcw, sf.Pcw, centre, np.array([5.0], np.float32), grid_size)
+    dev1 = h.vio_grid_select(sf.Rcw, sf.Pcw, centre, np.array([5.0], np.float32), grid_size)
+    assert (ref1["winner"] == 0).sum() == 1 and np.array_equal(dev1["winner"], ref1["winner"])

@@ -1,0 +1,85 @@
+"""The visual map on the device (api_vmap.inc) against oracle/orc_vmap.c over a sequence of frames: per frame, in the order of
+LidarSelector::detect, addFromSparseMap (whole) -> addSparseMap -> [pose update] -> addObservation. Everything the three steps
+produce is compared bit for bit: the selected map points, their patches / errors / search levels, the number of points founded,
+and at the end every map point with its full observation list (the >= 20 observations branch included)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_obs(a, b):
+    for f in ("px", "f", "R", "t"):
+        if not np.array_equal(np.array(getattr(a, f)), np.array(getattr(b, f))):
+            return False
+    return a.score == b.score and a.level == b.level and a.kf_id == b.kf_id and a.frame_id == b.frame_id
+
+
+def _run(capi, orc, synth, scene, frames, step, thr, n_scan=5000, grid=40, seed=11):
+    rng = np.random.default_rng(seed)
+    lio = synth.make_lio_frame(n_scan, scene=scene)
+    vf = synth.make_vio_frame(16, lio)
+    h = capi.Handle(capi.config_from_frames(lio, vf, max_iterations=3))
+    ocfg = orc.vio_config(vf)
+    vm = orc.VMap(ocfg, grid)
+    h.vmap_clear(grid)
+    base = vf.img
+    scan_all = lio.world_at(lio.R_true, lio.p_true).astype(np.float32)
+    kf_imgs = []
+    stats = dict(selected=0, added=0, obs=0, max_obs=0)
+    R_wi, p_wi = lio.R_true.copy(), lio.p_true.copy()
+    for k in range(frames):
+        R_wi = R_wi @ synth.exp_so3(np.array([0.0, 0.0, 0.004]))
+        p_wi = p_wi + step
+        Rcw, Pcw = synth.cam_pose(vf.Rcl, vf.Pcl, lio.R_LI, lio.t_LI, R_wi, p_wi)
+        img = np.ascontiguousarray(np.roll(base, (k % 5, -(k % 7)), axis=(0, 1)))
+        scan = scan_all[rng.permutation(len(scan_all))[: n_scan - 200 * (k % 3)]]
+        down, _ = orc.voxel_grid(np.concatenate([scan, np.zeros((len(scan), 1), np.float32)], axis=1), 0.2)     # downSizeFilter (:352-353)
+        down = np.ascontiguousarray(down[:, :3])
+        h.vio_set_frame(img)
+        kf = h.vio_add_keyframe(img)
+        kf_imgs.append(img)
+        assert kf == k
+        # addFromSparseMap
+        g = h.vmap_select(Rcw, Pcw, down, outlier_threshold=thr)
+        o = vm.select(Rcw, Pcw, img, kf_imgs, down, outlier_threshold=thr)
+        assert np.array_equal(g["points"], o["points"]), f"frame {k}"
+        assert np.array_equal(g["levels"], o["levels"]) and np.array_equal(g["errors"], o["errors"]), f"frame {k}"
+        assert np.array_equal(g["patches"], o["patches"]), f"frame {k}"
+        stats["selected"] += len(o["points"])
+        # addSparseMap
+        ag = h.vmap_add_sparse(Rcw, Pcw, scan, kf, k)
+        ao = vm.add_sparse(Rcw, Pcw, img, scan, kf, k)
+        assert ag == ao and h.vmap_size() == vm.size(), f"frame {k}: {ag} vs {ao}"
+        stats["added"] += ao
+        # (ComputeJ moves the pose a little) -> addObservation
+        R2 = synth.exp_so3(rng.normal(0, 2e-4, 3)) @ Rcw
+        P2 = Pcw + rng.normal(0, 2e-3, 3)
+        og = h.vmap_add_observation(R2, P2, kf, k)
+        oo = vm.add_observation(R2, P2, img, o["points"], o["levels"], kf, k)
+        assert og == oo, f"frame {k}: {og} vs {oo}"
+        stats["obs"] += oo
+    n = vm.size()
+    assert h.vmap_size() == n and n > 0
+    for i in range(n):
+        pg, vg, obg = h.vmap_get_point(i)
+        po, vo, obo = vm.get_point(i)
+        assert np.array_equal(pg, po) and vg == vo and len(obg) == len(obo), f"point {i}"
+        assert all(_same_obs(a, b) for a, b in zip(obg, obo)), f"point {i}"
+        stats["max_obs"] = max(stats["max_obs"], len(obo))
+    vm.close(); h.close()
+    return stats
+
+
+def test_sequence_with_the_standard_gates(gpu_lib, oracle_lib, scene):
+    from fast_livo_amd import synth
+    st = _run(gpu_lib, oracle_lib, synth, scene, frames=8, step=np.array([0.04, 0.02, 0.0]), thr=300.0)
+    assert st["added"] > 100 and st["selected"] > 0
+
+
+def test_long_sequence_fills_the_observation_lists(gpu_lib, oracle_lib, scene):
+    """gate wide open so that every winning map point is tracked; the camera moves 0.12 m per frame, so from the fifth frame on
+    every tracked point gains an observation per frame and the oldest map points run into the 20-observation limit."""
+    from fast_livo_amd import synth
+    st = _run(gpu_lib, oracle_lib, synth, scene, frames=30, step=np.array([0.10, 0.06, 0.0]), thr=1e12, n_scan=3000)
+    assert st["obs"] > 500 and st["max_obs"] == 20
