@@ -23,7 +23,7 @@ import make_golden_lib as mg  # noqa: E402
 
 scene = synth.make_scene()
 out = {}
-for name in ("lio18_iter", "vio_level", "ikfom_update", "knn5", "voxel_grid", "imu_undistort", "vio_select"):
+for name in ("lio18_iter", "vio_level", "ikfom_update", "knn5", "voxel_grid", "imu_undistort", "vio_select", "map_update", "vmap_sequence"):
     out[name] = getattr(mg, "run_" + name)(orc, scene)
 
 # cross-check LIO against numpy

@@ -79,3 +79,60 @@ def run_vio_select(orc, scene):
     return {"reason": r["reason"].tolist(), "idx": r["idx"].tolist(), "levels": r["levels"].tolist(), "errors": r["errors"].tolist(),
             "depth_nonzero": [int((depth > 0).sum())], "depth_sum": [float(depth.astype(np.float64).sum())],
             "patch0": r["patches"][0].tolist() if len(r["idx"]) else [], "patches_checksum": _ck(r["patches"])}
+
+
+def map_case(scene):
+    rng = np.random.default_rng(808)
+    m0 = scene.map_xyz[rng.choice(len(scene.map_xyz), 4000, replace=False)]
+    new = (scene.map_xyz[rng.choice(len(scene.map_xyz), 1500, replace=False)] + rng.normal(0, 0.02, (1500, 3))).astype(np.float32)
+    lo = m0.min(0)
+    box = np.array([[lo[0], lo[1], lo[2], lo[0] + 4.0, lo[1] + 30.0, lo[2] + 10.0]], dtype=np.float32)
+    return m0, new, box
+
+
+def run_map_update(orc, scene):
+    m0, new, box = map_case(scene)
+    a, ia = orc.map_add_points(m0, new, 0.25)
+    b, ib = orc.map_delete_boxes(a, box)
+    return {"after_add": [ia.n_after, ia.n_added, ia.n_removed, ia.n_ambiguous], "after_delete": [ib.n_after, ib.n_removed],
+            "add_checksum": _ck(a), "delete_checksum": _ck(b), "tail": a[-3:].reshape(-1).tolist()}
+
+
+def vmap_case(scene):
+    from fast_livo_amd import synth
+    lio = synth.make_lio_frame(2500, scene=scene)
+    vf = synth.make_vio_frame(8, lio)
+    scan = lio.world_at(lio.R_true, lio.p_true).astype(np.float32)
+    poses, imgs = [], []
+    R_wi, p_wi = lio.R_true.copy(), lio.p_true.copy()
+    for k in range(4):
+        R_wi = R_wi @ synth.exp_so3(np.array([0.0, 0.0, 0.005]))
+        p_wi = p_wi + np.array([0.2, 0.1, 0.0])
+        poses.append(synth.cam_pose(vf.Rcl, vf.Pcl, lio.R_LI, lio.t_LI, R_wi, p_wi))
+        imgs.append(np.ascontiguousarray(np.roll(vf.img, (k, -2 * k), axis=(0, 1))))
+    return lio, vf, scan, poses, imgs
+
+
+def vmap_summary(sel_counts, added, obs, points):
+    """points: list of (pos, value, obs list) -- folded into checksums"""
+    pos = np.array([p[0] for p in points], np.float64)
+    val = np.array([p[1] for p in points], np.float32)
+    nob = np.array([len(p[2]) for p in points], np.int32)
+    px = np.array([[o.px[0], o.px[1]] for p in points for o in p[2]], np.float64)
+    fr = np.array([o.frame_id for p in points for o in p[2]], np.int32)
+    return {"selected": sel_counts, "added": added, "obs_added": obs, "n_points": [len(points)], "pos_checksum": _ck(pos),
+            "value_checksum": _ck(val), "n_obs_checksum": _ck(nob), "px_checksum": _ck(px), "frame_checksum": _ck(fr)}
+
+
+def run_vmap_sequence(orc, scene):
+    lio, vf, scan, poses, imgs = vmap_case(scene)
+    vm = orc.VMap(orc.vio_config(vf), 40)
+    sel_counts, added, obs = [], [], []
+    for k, ((Rcw, Pcw), img) in enumerate(zip(poses, imgs)):
+        s = vm.select(Rcw, Pcw, img, imgs[:k + 1], scan, outlier_threshold=1e12)
+        sel_counts.append(len(s["points"]))
+        added.append(vm.add_sparse(Rcw, Pcw, img, scan, k, k))
+        obs.append(vm.add_observation(Rcw, Pcw, img, s["points"], s["levels"], k, k))
+    pts = [vm.get_point(i) for i in range(vm.size())]
+    vm.close()
+    return vmap_summary(sel_counts, added, obs, pts)
