@@ -244,6 +244,47 @@ def make_image(width, height, seed=SEED):
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
+def world_texture(p, seed=SEED):
+    """A brightness field attached to the WORLD (sum of spatial sinusoids, wavelengths 0.2-0.9 m): what a Lambertian scene looks
+    like from any pose. p (...,3) -> float (...)"""
+    rng = np.random.default_rng(seed + 77)
+    out = np.zeros(p.shape[:-1])
+    for _ in range(24):
+        k = rng.normal(size=3)
+        k *= rng.uniform(7.0, 30.0) / np.linalg.norm(k)
+        out += rng.uniform(0.4, 1.0) * np.sin(p @ k + rng.uniform(0, 2 * np.pi))
+    return out
+
+
+def render_image(scene, cam, Rcw, Pcw, seed=SEED, noise=1.0):
+    """The scene as the pinhole camera (Rcw, Pcw: camera <- world) sees it: every pixel's ray is intersected with the scene's
+    rectangles and takes the world texture at the nearest hit. Consistent across poses, so photometric alignment is meaningful."""
+    W, H = cam["width"], cam["height"]
+    vv, uu = np.mgrid[0:H, 0:W].astype(np.float64)
+    d_c = np.stack([(uu - cam["cx"]) / cam["fx"], (vv - cam["cy"]) / cam["fy"], np.ones_like(uu)], -1).reshape(-1, 3)
+    c = -Rcw.T @ Pcw
+    d_w = d_c @ Rcw                                   # Rcw^T d per row
+    best_t = np.full(len(d_w), np.inf)
+    for (O, e1, e2) in scene.planes:
+        n = np.cross(e1, e2)
+        den = d_w @ n
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = ((O - c) @ n) / den
+        hit = c + t[:, None] * d_w - O
+        G = np.array([[e1 @ e1, e1 @ e2], [e1 @ e2, e2 @ e2]])
+        ab = np.linalg.solve(G, np.stack([hit @ e1, hit @ e2]))
+        ok = (t > 0.05) & (ab[0] >= 0) & (ab[0] <= 1) & (ab[1] >= 0) & (ab[1] <= 1) & np.isfinite(t)
+        best_t = np.where(ok & (t < best_t), t, best_t)
+    seen = np.isfinite(best_t)
+    pts = c + np.where(seen, best_t, 1.0)[:, None] * d_w
+    tex = world_texture(pts, seed)
+    img = 128.0 + 11.0 * tex
+    img[~seen] = 128.0
+    rng = np.random.default_rng(seed + 1234 + int(abs(Pcw[0]) * 1e6) % 100000)
+    img = img + rng.normal(0, noise, img.shape)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8).reshape(H, W)
+
+
 def world2cam(cam, xyz_c):
     """vk::PinholeCamera::world2cam as restated in oracle/orc_vio.c (from memory of rpg_vikit)."""
     u = xyz_c[..., 0] / xyz_c[..., 2]
