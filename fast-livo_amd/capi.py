@@ -372,9 +372,14 @@ class Handle:
                                             mv.ctypes.data_as(_fp), gn.ctypes.data_as(_i32p), C.byref(ln)), "fl_vio_grid_select")
         return dict(winner=win, map_dist=md, map_value=mv, grid_num=gn)
 
-    def vio_add_keyframe(self, img):
-        img = np.ascontiguousarray(img, np.uint8)
+    def vio_add_keyframe(self, img=None):
+        """img None: the image staged by vio_set_frame becomes the keyframe (no second upload)"""
         kid = C.c_int32(-1)
+        if img is None:
+            self._chk(self.L.fl_vio_add_keyframe(self.h, None, self.cfg.img_width, self.cfg.img_height, self.cfg.img_width, C.byref(kid)),
+                      "fl_vio_add_keyframe")
+            return kid.value
+        img = np.ascontiguousarray(img, np.uint8)
         self._chk(self.L.fl_vio_add_keyframe(self.h, img.ctypes.data_as(_u8p), img.shape[1], img.shape[0], img.shape[1], C.byref(kid)),
                   "fl_vio_add_keyframe")
         return kid.value

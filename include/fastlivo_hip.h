@@ -359,6 +359,7 @@ typedef struct fl_patch_candidate {
  * the closest one, the later one on equal float distances; -1: none), map_dist, map_value, grid_num (1 TYPE_MAP, 3 TYPE_UNKNOWN). */
 int32_t fl_vio_grid_select(fl_handle h, const double *Rcw, const double *Pcw, const double *pos, const float *value, int32_t k,
                            int32_t grid_size, int32_t *winner, float *map_dist, float *map_value, int32_t *grid_num, int32_t *length_out);
+/* gray == NULL: the current image staged by fl_vio_set_frame becomes the keyframe (device-to-device copy, no second upload) */
 int32_t fl_vio_add_keyframe(fl_handle h, const uint8_t *gray, int32_t width, int32_t height, int32_t stride, int32_t *keyframe_id);
 int32_t fl_vio_drop_keyframe(fl_handle h, int32_t keyframe_id);
 int32_t fl_vio_select_patches(fl_handle h, const double *Rcw, const double *Pcw, const float *scan_world_xyz, int32_t n_scan,

@@ -61,7 +61,7 @@ def test_livo_frames_on_one_handle(gpu_lib, oracle_lib, scene):
         down = np.ascontiguousarray(down[:, :3])
         Rcw, Pcw = synth.cam_pose(vf0.Rcl, vf0.Pcl, fr0.R_LI, fr0.t_LI, np.array(xo.rot).reshape(3, 3), np.array(xo.pos[:]))
         h.vio_set_frame(img)
-        kf = h.vio_add_keyframe(img)
+        kf = h.vio_add_keyframe()             # the staged image becomes the keyframe
         kf_imgs.append(img)
         g = h.vmap_select(Rcw, Pcw, down, outlier_threshold=3000.0)
         o = vm.select(Rcw, Pcw, img, kf_imgs, down, outlier_threshold=3000.0)
