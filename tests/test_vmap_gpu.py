@@ -83,3 +83,33 @@ def test_long_sequence_fills_the_observation_lists(gpu_lib, oracle_lib, scene):
     from fast_livo_amd import synth
     st = _run(gpu_lib, oracle_lib, synth, scene, frames=30, step=np.array([0.10, 0.06, 0.0]), thr=1e12, n_scan=3000)
     assert st["obs"] > 500 and st["max_obs"] == 20
+
+
+def test_map_growth_across_a_reallocation(gpu_lib, oracle_lib, scene):
+    """addSparseMap from 70 different view points: the map outgrows its first allocation (4096 points) and keeps its contents."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    lio = synth.make_lio_frame(6000, scene=scene)
+    vf = synth.make_vio_frame(8, lio)
+    h = capi.Handle(capi.config_from_frames(lio, vf))
+    vm = orc.VMap(orc.vio_config(vf), 40)
+    h.vmap_clear(40)
+    scan = lio.world_at(lio.R_true, lio.p_true).astype(np.float32)
+    h.vio_set_frame(vf.img)
+    kf = h.vio_add_keyframe()
+    for k in range(70):
+        R_wi = lio.R_true @ synth.exp_so3(np.array([0.0, 0.0, 0.09 * k]))
+        Rcw, Pcw = synth.cam_pose(vf.Rcl, vf.Pcl, lio.R_LI, lio.t_LI, R_wi, lio.p_true)
+        # a fresh selection step would reset map_value; without it only better-scoring points found new map points -- same on both sides
+        assert h.vmap_add_sparse(Rcw, Pcw, scan, kf, k) == vm.add_sparse(Rcw, Pcw, vf.img, scan, kf, k)
+        if True:                # as a frame would: the selection resets the cells' map_value
+            g = h.vmap_select(Rcw, Pcw, scan[:2000], outlier_threshold=1e12, want_patches=False)
+            o = vm.select(Rcw, Pcw, vf.img, [vf.img], scan[:2000], outlier_threshold=1e12)
+            assert np.array_equal(g["points"], o["points"])
+    n = vm.size()
+    assert h.vmap_size() == n and n > 4096, n
+    for i in list(range(0, n, 97)) + [n - 1]:
+        pg, vg, obg = h.vmap_get_point(i)
+        po, vo, obo = vm.get_point(i)
+        assert np.array_equal(pg, po) and vg == vo and len(obg) == len(obo) and all(_same_obs(a, b) for a, b in zip(obg, obo))
+    vm.close(); h.close()
