@@ -46,10 +46,29 @@ __global__ __launch_bounds__(FL_BLOCK) void vio_depth_kernel(const float *__rest
     atomicMax(&depth64[(size_t)W * v + u], key);
 }
 
+// vk::PinholeCamera::cam2world; with distortion = cv::undistortPoints' five fixed-point sweeps on a float pixel (oracle/orc_vio.c)
 __device__ __forceinline__ void fl_cam2world(const FlVioConst &c, double u, double v, double *f)
 {
-    const double x = (u - c.cx) / c.fx, y = (v - c.cy) / c.fy, z = 1.0;
-    const double n = sqrt(x * x + y * y + z * z);
+    double x, y;
+    if (!c.distort) {
+        x = (u - c.cx) / c.fx; y = (v - c.cy) / c.fy;
+    } else {
+        const double ifx = 1. / c.fx, ify = 1. / c.fy;
+        x = (double)(float)u; y = (double)(float)v;
+        x = (x - c.cx) * ifx; y = (y - c.cy) * ify;
+        const double x0 = x, y0 = y;
+        const double k1 = c.d[0], k2 = c.d[1], p1 = c.d[2], p2 = c.d[3], k3 = c.d[4];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+            const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+            const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+            x = (x0 - deltaX) * icdist; y = (y0 - deltaY) * icdist;
+        }
+        x = (double)(float)x; y = (double)(float)y;
+    }
+    const double z = 1.0, n = sqrt(x * x + y * y + z * z);
     f[0] = x / n; f[1] = y / n; f[2] = z / n;
 }
 __device__ __forceinline__ void fl_se3_apply(const double *R, const double *t, const double *x, double *o)

@@ -451,10 +451,29 @@ class SelectFrame:
     outlier_threshold: float = 300.0
 
 
-def make_select_frame(m, seed=SEED, n_keyframes=3, discont_frac=0.1, lio=None):
+def cam2world(cam, px):
+    """Bearing of a pixel (vk::PinholeCamera::cam2world): pinhole inverse, or cv::undistortPoints' five sweeps with distortion."""
+    d = cam["d"]
+    if not abs(d[0]) > 1e-7:
+        b = np.array([(px[0] - cam["cx"]) / cam["fx"], (px[1] - cam["cy"]) / cam["fy"], 1.0])
+        return b / np.linalg.norm(b)
+    x = (float(np.float32(px[0])) - cam["cx"]) / cam["fx"]
+    y = (float(np.float32(px[1])) - cam["cy"]) / cam["fy"]
+    x0, y0 = x, y
+    for _ in range(5):
+        r2 = x * x + y * y
+        ic = 1.0 / (1 + ((d[4] * r2 + d[1]) * r2 + d[0]) * r2)
+        dx = 2 * d[2] * x * y + d[3] * (r2 + 2 * x * x)
+        dy = d[2] * (r2 + 2 * y * y) + 2 * d[3] * x * y
+        x, y = (x0 - dx) * ic, (y0 - dy) * ic
+    b = np.array([float(np.float32(x)), float(np.float32(y)), 1.0])
+    return b / np.linalg.norm(b)
+
+
+def make_select_frame(m, seed=SEED, n_keyframes=3, discont_frac=0.1, lio=None, distortion=False):
     rng = np.random.default_rng(seed + 501)
     lio = lio if lio is not None else make_lio_frame(2000, seed=seed)
-    vf = make_vio_frame(m, lio, seed=seed)
+    vf = make_vio_frame(m, lio, seed=seed, distortion=distortion)
     cam = vf.cam
     Rcw, Pcw = cam_pose(vf.Rcl, vf.Pcl, lio.R_LI, lio.t_LI, lio.R_true, lio.p_true)
     kfs, kR, kt = [vf.img], [Rcw.copy()], [Pcw.copy()]
@@ -476,8 +495,7 @@ def make_select_frame(m, seed=SEED, n_keyframes=3, discont_frac=0.1, lio=None):
                 ckf[i] = attempt
                 break
         cpx[i] = px
-        b = np.array([(px[0] - cam["cx"]) / cam["fx"], (px[1] - cam["cy"]) / cam["fy"], 1.0])
-        cf[i] = b / np.linalg.norm(b)
+        cf[i] = cam2world(cam, px)
     # scan: around every candidate a few returns at (almost) its depth; for some a return 3 m behind inside the 9x9 window
     pf = pos @ Rcw.T + Pcw
     scan_c = []

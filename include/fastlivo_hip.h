@@ -341,7 +341,8 @@ int32_t fl_imu_undistort(fl_handle h, fl_imu_proc *proc_io, fl_state18 *state_io
  * fl_vio_set_patches(ref = warped patches, pos = pt->pos_, search_level): fl_vio_compute_j can follow directly and
  * the 768-byte patches never visit the host. Outputs (all nullable except n_accepted): accepted_idx / errors /
  * search_levels (room for m), reason (m: 0 accepted, 1 depth discontinuity, 3 NCC, 4 outlier), patches_out
- * (m x 192 floats, parity checks), depth_out (width x height floats). Only the distortion-free camera is supported.
+ * (m x 192 floats, parity checks), depth_out (width x height floats). With distortion coefficients in fl_config, cam2world is
+ * cv::undistortPoints as vikit calls it (five fixed-point sweeps on the float pixel).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct fl_patch_candidate {
     double pos[3];             /* pt->pos_ */
@@ -384,7 +385,7 @@ int32_t fl_vio_select_patches(fl_handle h, const double *Rcw, const double *Pcw,
  *                            fl_vmap_select (map_value is not reset in between, :81-90).
  *   fl_vmap_add_observation  addObservation (:913-965) for the points selected by the last fl_vmap_select, with the pose AFTER
  *                            fl_vio_compute_j.
- * fl_vmap_clear(grid_size) creates the (empty) map; grid_size as LidarSelector::grid_size. Only the distortion-free camera.
+ * fl_vmap_clear(grid_size) creates the (empty) map; grid_size as LidarSelector::grid_size.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct fl_vmap_obs { double px[2], f[3], R[9], t[3]; float score; int32_t level, kf_id, frame_id; } fl_vmap_obs;
 int32_t fl_vmap_clear(fl_handle h, int32_t grid_size);

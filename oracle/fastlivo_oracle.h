@@ -190,6 +190,8 @@ int orc_vmap_add_observation(orc_vmap *m, const double *Rcw, const double *Pcw, 
 
 /* vk::PinholeCamera::world2cam (rpg_vikit, unpinned master; restated from memory). */
 void orc_world2cam(const orc_vio_config *cfg, const double *xyz_c, double *px);
+/* vk::PinholeCamera::cam2world; with distortion = cv::undistortPoints (five sweeps), restated in orc_vio.c */
+void orc_cam2world(const orc_vio_config *cfg, double u, double v, double *f);
 
 /* ------------------------------------------------------------- Mode-23 (IKFoM, dormant path) */
 typedef struct orc_state23 {

@@ -17,8 +17,8 @@
  * and the reference observation handed in here as a candidate.
  * Third-party arithmetic not under /root/reference, restated from the published sources (unpinned; PARITY UNPINNED):
  *   vk::interpolateMat_8u (rpg_vikit vision.h): w00=(1-sx)(1-sy), w01=(1-sx)sy, w10=sx(1-sy), w11=1-w00-w01-w10, floats;
- *   vk::PinholeCamera::cam2world: ((u-cx)/fx, (v-cy)/fy, 1).normalized() -- only the distortion-free model is
- *   restated (with distortion vikit calls cv::undistortPoints); world2cam as in orc_vio.c;
+ *   vk::PinholeCamera::cam2world: ((u-cx)/fx, (v-cy)/fy, 1).normalized(); with distortion vikit calls cv::undistortPoints,
+ *   restated as its five fixed-point sweeps (orc_cam2world in orc_vio.c); world2cam as in orc_vio.c;
  *   vk::AbstractCamera::isInFrame(obs, boundary): boundary <= obs < size - boundary;
  *   Sophus::SE3 (T*p, inverse, product) stated with rotation matrices (Sophus a621ff keeps a quaternion: results
  *   agree to rounding, not bitwise); Eigen 2x2 inverse = adjugate * (1/det).
@@ -36,12 +36,7 @@ static void s_mv(const double *A, const double *x, double *o)
 }
 static int in_frame(int u, int v, int boundary, int w, int h) { return u >= boundary && u < w - boundary && v >= boundary && v < h - boundary; }
 
-static void cam2world(const orc_vio_config *c, double u, double v, double *f)
-{
-    double x = (u - c->cx) / c->fx, y = (v - c->cy) / c->fy, z = 1.0;
-    const double n = sqrt(x * x + y * y + z * z);
-    f[0] = x / n; f[1] = y / n; f[2] = z / n;
-}
+static void cam2world(const orc_vio_config *c, double u, double v, double *f) { orc_cam2world(c, u, v, f); }
 
 static float interpolate_8u(const uint8_t *img, int stride, float u, float v)
 {
@@ -78,7 +73,6 @@ int orc_vio_select(const orc_vio_config *cfg, const double *Rcw, const double *P
 {
     const int W = cfg->width, H = cfg->height, ps = cfg->patch_size, half = ps / 2, pst = ps * ps;
     int na = 0;
-    if (fabs(cfg->d[0]) > 0.0000001) return -2;          /* cam2world with distortion is not restated */
     for (int ci = 0; ci < m; ci++) {
         const orc_patch_candidate *c = &cand[ci];
         if (reason) reason[ci] = 0;

@@ -43,6 +43,34 @@ void orc_world2cam(const orc_vio_config *cfg, const double *xyz_c, double *px)
     }
 }
 
+/* vk::PinholeCamera::cam2world (rpg_vikit pinhole_camera.cpp; unpinned, restated): without distortion the bearing of the pixel;
+ * with distortion vikit packs (u, v) into a cv::Point2f, calls cv::undistortPoints(src, dst, K, D) and normalises (px.x, px.y, 1).
+ * cv::undistortPoints (OpenCV 3.x/4.x imgproc/undistort.cpp, the 4-argument overload: TermCriteria(MAX_ITER, 5, 0.01) = five
+ * fixed-point sweeps, no tolerance test), restated for the 5-coefficient model k1,k2,p1,p2,k3: float in, doubles inside, float out. */
+void orc_cam2world(const orc_vio_config *c, double u, double v, double *f)
+{
+    double x, y;
+    if (!(fabs(c->d[0]) > 0.0000001)) {
+        x = (u - c->cx) / c->fx; y = (v - c->cy) / c->fy;
+    } else {
+        const double ifx = 1. / c->fx, ify = 1. / c->fy;
+        x = (double)(float)u; y = (double)(float)v;
+        x = (x - c->cx) * ifx; y = (y - c->cy) * ify;
+        const double x0 = x, y0 = y;
+        const double k1 = c->d[0], k2 = c->d[1], p1 = c->d[2], p2 = c->d[3], k3 = c->d[4];
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+            const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+            const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+            x = (x0 - deltaX) * icdist; y = (y0 - deltaY) * icdist;
+        }
+        x = (double)(float)x; y = (double)(float)y;
+    }
+    const double z = 1.0, n = sqrt(x * x + y * y + z * z);
+    f[0] = x / n; f[1] = y / n; f[2] = z / n;
+}
+
 typedef struct vio_extr {
     double Rci[9], Pci[3], Jdphi_dR[9], Jdp_dR[9];
     double fx, fy;

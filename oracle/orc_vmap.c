@@ -45,12 +45,7 @@ static void mv(const double *A, const double *x, double *o)
     memcpy(o, t, sizeof t);
 }
 static void w2f(const double *R, const double *t, const double *p, double *o) { mv(R, p, o); o[0] += t[0]; o[1] += t[1]; o[2] += t[2]; }
-static void cam2world(const orc_vio_config *c, double u, double v, double *f)
-{
-    double x = (u - c->cx) / c->fx, y = (v - c->cy) / c->fy, z = 1.0;
-    const double n = sqrt(x * x + y * y + z * z);
-    f[0] = x / n; f[1] = y / n; f[2] = z / n;
-}
+static void cam2world(const orc_vio_config *c, double u, double v, double *f) { orc_cam2world(c, u, v, f); }
 /* T_f_w.inverse().translation() = -R^T t */
 static void frame_pos(const double *R, const double *t, double *o)
 {

@@ -33,9 +33,11 @@ def _same(dev, ref):
     assert np.array_equal(dev["patches"].view(np.uint32), ref["patches"].view(np.uint32))
 
 
-@pytest.mark.parametrize("m", [1, 37, 600, 2000])
-def test_selection_matches_oracle(gpu_lib, m):
-    capi, synth, sf, h, ids = _setup(m)
+@pytest.mark.parametrize("m,distortion", [(1, False), (37, False), (600, False), (2000, False), (600, True)])
+def test_selection_matches_oracle(gpu_lib, m, distortion):
+    """distortion=True: the shipped camera files carry radtan coefficients; world2cam applies them, cam2world is
+    cv::undistortPoints' five sweeps (restated on both sides)"""
+    capi, synth, sf, h, ids = _setup(m, distortion=distortion)
     depth, ref = _oracle(sf, orc.patch_candidates(sf), outlier_threshold=sf.outlier_threshold)
     dev = h.vio_select_patches(sf.Rcw, sf.Pcw, sf.scan_world, capi.patch_candidates(sf, ids), outlier_threshold=sf.outlier_threshold,
                                want_depth=True)

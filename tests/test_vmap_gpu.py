@@ -15,10 +15,10 @@ def _same_obs(a, b):
     return a.score == b.score and a.level == b.level and a.kf_id == b.kf_id and a.frame_id == b.frame_id
 
 
-def _run(capi, orc, synth, scene, frames, step, thr, n_scan=5000, grid=40, seed=11):
+def _run(capi, orc, synth, scene, frames, step, thr, n_scan=5000, grid=40, seed=11, distortion=False):
     rng = np.random.default_rng(seed)
     lio = synth.make_lio_frame(n_scan, scene=scene)
-    vf = synth.make_vio_frame(16, lio)
+    vf = synth.make_vio_frame(16, lio, distortion=distortion)
     h = capi.Handle(capi.config_from_frames(lio, vf, max_iterations=3))
     ocfg = orc.vio_config(vf)
     vm = orc.VMap(ocfg, grid)
@@ -75,6 +75,13 @@ def test_sequence_with_the_standard_gates(gpu_lib, oracle_lib, scene):
     from fast_livo_amd import synth
     st = _run(gpu_lib, oracle_lib, synth, scene, frames=8, step=np.array([0.04, 0.02, 0.0]), thr=300.0)
     assert st["added"] > 100 and st["selected"] > 0
+
+
+def test_sequence_with_a_distorted_camera(gpu_lib, oracle_lib, scene):
+    """radtan coefficients of the shipped camera file: projections through the distortion model, bearings through undistortPoints"""
+    from fast_livo_amd import synth
+    st = _run(gpu_lib, oracle_lib, synth, scene, frames=6, step=np.array([0.12, 0.05, 0.0]), thr=1e12, distortion=True)
+    assert st["added"] > 100 and st["selected"] > 50 and st["obs"] > 0
 
 
 def test_long_sequence_fills_the_observation_lists(gpu_lib, oracle_lib, scene):
