@@ -36,6 +36,11 @@ int main(int argc, char **argv)
     rd(f, samples.data(), samples.size());
     std::vector<float> pts((size_t)n * 4), map((size_t)k_map * 3);
     rd(f, pts.data(), pts.size()); rd(f, map.data(), map.size());
+    // optional: camera extrinsics of the state frame (Rci, Pci) and a 640 x 512 grey image
+    double Rci[9], Pci[3];
+    std::vector<uint8_t> image((size_t)cfg.img_width * cfg.img_height);
+    const bool have_cam = fread(Rci, sizeof(double), 9, f) == 9;
+    if (have_cam) { rd(f, Pci, 3); rd(f, image.data(), image.size()); }
     fclose(f);
 
     fl_handle h = nullptr;
@@ -68,6 +73,27 @@ int main(int argc, char **argv)
     if (lm.last_status < 0) { fprintf(stderr, "map: %s\n", fl_last_error_string(h)); return 1; }
     printf("map %d boxes %d removed %d before %d after %d added %d\n", lm.last_status, cut, removed, lm.last.n_before, lm.last.n_after,
            lm.last.n_added);
+    // optional camera half (LidarSelectorDev::detect), two frames on the same image: the first founds map points, the second tracks them
+    if (have_cam) {
+        std::vector<float> pg((size_t)feats_down_size * 3), pg_down((size_t)feats_down_size * 4);
+        if (fl_lio_get_world_points(h, pg.data())) { fprintf(stderr, "world points: %s\n", fl_last_error_string(h)); return 1; }
+        std::vector<float> pg4((size_t)feats_down_size * 4, 0.0f);
+        for (int i = 0; i < feats_down_size; i++) for (int k = 0; k < 3; k++) pg4[(size_t)i * 4 + k] = pg[(size_t)i * 3 + k];
+        int32_t n_down = 0, small = 0;
+        if (fl_scan_voxel_filter(h, pg4.data(), feats_down_size, 0.2f, 0.2f, 0.2f, 0, pg_down.data(), &n_down, &small) < 0) return 1;   // downSizeFilter (:352-353)
+        std::vector<float> down3((size_t)n_down * 3);
+        for (int i = 0; i < n_down; i++) for (int k = 0; k < 3; k++) down3[(size_t)i * 3 + k] = pg_down[(size_t)i * 4 + k];
+        LidarSelectorDev sel; sel.handle = h; sel.grid_size = 40; sel.outlier_threshold = 1e12;
+        if (sel.init() < 0) { fprintf(stderr, "vmap: %s\n", fl_last_error_string(h)); return 1; }
+        for (int f2 = 0; f2 < 2; f2++) {
+            sel.detect(image.data(), cfg.img_width, cfg.img_height, cfg.img_width, pg.data(), feats_down_size, down3.data(), n_down, Rci, Pci, state);
+            if (sel.last_status < 0) { fprintf(stderr, "detect: %s\n", fl_last_error_string(h)); return 1; }
+            printf("cam %d selected %d founded %d observed %d\n", f2, sel.n_selected, sel.n_founded, sel.n_observed);
+        }
+        for (int i = 0; i < 9; i++) printf("%.17g ", state.rot_end.m[i]);
+        for (int i = 0; i < 3; i++) printf("%.17g ", state.pos_end.v[i]);
+        printf("\n");
+    }
     fl_destroy(h);
     return 0;
 }

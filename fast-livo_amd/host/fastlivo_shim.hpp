@@ -354,4 +354,66 @@ struct VioUpdater {
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// LidarSelector::detect(cv::Mat img, PointCloudXYZI::Ptr pg), lidar_selection.cpp:1027-1075, with the visual map on the device:
+// addFromSparseMap -> addSparseMap -> ComputeJ -> addObservation become one call each
+// ------------------------------------------------------------------------------------------------
+struct LidarSelectorDev {
+    fl_handle handle = nullptr;
+    int grid_size = 40;
+    bool ncc_en = false;
+    double ncc_thre = 0.0, outlier_threshold = 300.0;
+    int32_t frame_id = 0;
+    int32_t last_status = 0;
+    int n_selected = 0, n_founded = 0, n_observed = 0;
+
+    int32_t init() { return last_status = fl_vmap_clear(handle, grid_size); }            // LidarSelector::init (:61-79)
+
+    // T_f_w of the frame from the state, as updateFrameState does (:904-911): Rcw = Rci * R^T, Pcw = -Rci * R^T * p + Pci
+    static void frame_pose(const double *Rci, const double *Pci, const StatesGroup &s, double *Rcw, double *Pcw)
+    {
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double a = 0.0;
+                for (int k = 0; k < 3; k++) a += Rci[i * 3 + k] * s.rot_end.m[j * 3 + k];
+                Rcw[i * 3 + j] = a;
+            }
+        for (int i = 0; i < 3; i++) {
+            double a = 0.0;
+            for (int k = 0; k < 3; k++) a += Rcw[i * 3 + k] * s.pos_end.v[k];
+            Pcw[i] = -a + Pci[i];
+        }
+    }
+
+    // img: grey image of the frame; pg / pg_down: the registered scan and its 0.2 m down-sampled form (world frame, xyz floats)
+    void detect(const uint8_t *img, int width, int height, int stride, const float *pg, int n_pg, const float *pg_down, int n_down,
+                const double *Rci, const double *Pci, StatesGroup &state)
+    {
+        int32_t kf = -1;
+        last_status = fl_vio_set_frame(handle, img, width, height, stride);
+        if (last_status >= 0) last_status = fl_vio_add_keyframe(handle, nullptr, width, height, width, &kf);   // the staged image
+        if (last_status < 0) return;
+        double Rcw[9], Pcw[3];
+        frame_pose(Rci, Pci, state, Rcw, Pcw);
+        int32_t ns = 0, na = 0, no = 0;
+        last_status = fl_vmap_select(handle, Rcw, Pcw, pg_down, n_down, ncc_en ? 1 : 0, ncc_thre, outlier_threshold, &ns, nullptr, nullptr,
+                                     nullptr, nullptr);                                             // addFromSparseMap (:1050)
+        if (last_status < 0) return;
+        last_status = fl_vmap_add_sparse(handle, Rcw, Pcw, pg, n_pg, kf, frame_id, &na);           // addSparseMap (:1054)
+        if (last_status < 0) return;
+        if (ns > 0) {                                                                               // ComputeJ (:1060)
+            fl_state18 st, sp;
+            to_abi(state, st);
+            sp = st;
+            last_status = fl_vio_compute_j(handle, &st, &sp, nullptr);
+            if (last_status < 0) return;
+            from_abi(st, state);
+            frame_pose(Rci, Pci, state, Rcw, Pcw);
+        }
+        last_status = fl_vmap_add_observation(handle, Rcw, Pcw, kf, frame_id, &no);                 // addObservation (:1064)
+        n_selected = ns; n_founded = na; n_observed = no;
+        frame_id++;
+    }
+};
+
 }  // namespace fastlivo_host

@@ -72,7 +72,9 @@ def test_cpp_device_pipeline_matches_ctypes_path(gpu_lib, oracle_lib, tmp_path):
     lio = synth.make_lio_frame(n)
     f = synth.make_imu_frame(n, n_imu=20, lio=lio, quiet=True)
     f.pts_xyzt[:, :3] = lio.body_xyz
-    h = capi.Handle(capi.config_from_frames(lio, max_iterations=max_iter))
+    # the configuration demo_pipeline builds: identity camera extrinsic, fx = fy = 400, principal point (320, 256)
+    cam = dict(width=640, height=512, fx=400.0, fy=400.0, cx=320.0, cy=256.0, d=(0.0,) * 5)
+    h = capi.Handle(capi.make_config(lio.R_LI, lio.t_LI, np.eye(3), np.zeros(3), cam, max_iterations=max_iter))
     h.map_set_points(lio.scene.map_xyz, cell)
     x = capi.state18_from_frame(lio); pr = capi.imu_proc_from_frame(f)
     pr0 = capi.imu_proc_from_frame(f)
@@ -90,6 +92,34 @@ def test_cpp_device_pipeline_matches_ctypes_path(gpu_lib, oracle_lib, tmp_path):
     di = h.map_delete_boxes(boxes)
     ai = h.map_add_points(None, leaf)
     map_after = h.map_get_points()
+    x_lio = x.copy()
+    # the camera half as LidarSelectorDev::detect runs it, twice on the same image
+    img = synth.make_image(640, 512, seed=3)
+    Rci = np.eye(3) @ lio.R_LI.T
+    Pci = np.eye(3) @ (-lio.R_LI.T @ lio.t_LI)
+    world = h.lio_get_world_points(m)
+    down, nd, _ = h.scan_voxel_filter(np.ascontiguousarray(np.concatenate([world, np.zeros((m, 1), np.float32)], axis=1)), 0.2)
+    down = np.ascontiguousarray(down[:nd, :3])
+    h.vmap_clear(40)
+    cam_counts = []
+    for f2 in range(2):
+        h.vio_set_frame(img)
+        kf = h.vio_add_keyframe()
+
+        def pose(st):
+            R = np.array(st.rot).reshape(3, 3)
+            Rcw = Rci @ R.T
+            return Rcw, -(Rcw @ np.array(st.pos[:])) + Pci
+        Rcw, Pcw = pose(x)
+        g = h.vmap_select(Rcw, Pcw, down, outlier_threshold=1e12, want_patches=False)
+        na = h.vmap_add_sparse(Rcw, Pcw, world, kf, f2)
+        if len(g["points"]):
+            xp = x.copy()
+            h.vio_compute_j(x, xp)
+            Rcw, Pcw = pose(x)
+        no = h.vmap_add_observation(Rcw, Pcw, kf, f2)
+        cam_counts.append((len(g["points"]), na, no))
+    assert cam_counts[0][1] > 20 and cam_counts[1][0] > 10
     h.close()
     fn = tmp_path / "pipe.bin"
     with open(fn, "wb") as fh:
@@ -100,17 +130,23 @@ def test_cpp_device_pipeline_matches_ctypes_path(gpu_lib, oracle_lib, tmp_path):
         fh.write(bytes(pr0))
         fh.write(np.ascontiguousarray(f.imu, dtype="<f8").tobytes())
         fh.write(f.pts_xyzt.astype("<f4").tobytes()); fh.write(lio.scene.map_xyz.astype("<f4").tobytes())
+        fh.write(np.asarray(Rci, dtype="<f8").tobytes()); fh.write(np.asarray(Pci, dtype="<f8").tobytes()); fh.write(img.tobytes())
     out = subprocess.run([demo, str(fn)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().splitlines()
     head = lines[0].split()
     assert int(head[1]) == 0 and int(head[5]) == info.effct_feat_num and int(head[7]) == m
     vals = np.array(lines[1].split(), dtype=np.float64)
-    assert np.array_equal(vals, x.vec()[:15])                 # rot, pos, vel: bit-identical (%.17g round-trips)
+    assert np.array_equal(vals, x_lio.vec()[:15])             # rot, pos, vel: bit-identical (%.17g round-trips)
     diag = np.array(lines[2].split(), dtype=np.float64)
-    assert np.array_equal(diag, np.diag(x.cov_np()))
+    assert np.array_equal(diag, np.diag(x_lio.cov_np()))
     tail = np.array(lines[3].split(), dtype=np.float64)
     assert tail[0] == pr.last_lidar_end_time and tail[1] == pr.acc_s_last[2]
     mp = lines[4].split()
     assert [int(mp[k]) for k in (1, 3, 5, 7, 9, 11)] == [0, 1, di.n_removed, ai.n_before, ai.n_after, ai.n_added]
     assert di.n_removed > 0 and ai.n_added > 0 and ai.n_after == len(map_after)
+    for f2 in range(2):
+        cl = lines[5 + f2].split()
+        assert (int(cl[3]), int(cl[5]), int(cl[7])) == cam_counts[f2], (cl, cam_counts)
+    cam_state = np.array(lines[7].split(), dtype=np.float64)
+    assert np.array_equal(cam_state, x.vec()[:12])               # state after the second frame's ComputeJ: bit-identical
