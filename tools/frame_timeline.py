@@ -1,5 +1,7 @@
 """Print the kernel timeline of one all-device frame from a rocprofv3 --kernel-trace csv (arg: trace dir)."""
 import csv, glob, sys
+if len(sys.argv) < 2:
+    raise SystemExit("usage: frame_timeline.py <rocprofv3 output directory with a *kernel_trace.csv>")
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
