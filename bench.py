@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 N_POINTS = 50000
 N_PATCHES = 2000
 PASSES_PER_LAUNCH = 10   # avia.yaml max_iteration
+AT_SCALE_POINTS = 8000000  # roofline.at_scale: the LIO pass where the traffic, not the hand-off latency, is the time
 VIO_LEVEL = 0
 # algorithmic HBM bytes per unit and launch
 LIO_BYTES_PER_POINT = 12 + 16 + 1      # body xyz + cached plane (n,d) + selection flag
@@ -45,6 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle sample")
     ap.add_argument("--sweep", action="store_true", help="also print a kernel-only size sweep to stderr")
+    ap.add_argument("--no-at-scale", action="store_true", help="skip the 8 M-point pass of roofline.at_scale")
     return ap.parse_args()
 
 
@@ -319,6 +321,12 @@ def main():
                 "passes_per_launch": C, "lio_pass_us": lio_us, "vio_pass_us": vio_us,
                 "note": "latency-bound at BASELINE sizes: a pass moves 1.45 MB (LIO) / 0.82 MB (VIO) = 0.2 us at 8 TB/s, against "
                         "two cross-workgroup hand-offs of ~2 us each per pass (SURVEY.md fact 5); see the DESIGN.md size sweep"}
+        if world == 1 and not args.no_at_scale:
+            # the same pass kernel where it is bandwidth-bound: at BASELINE sizes a pass is 0.2 us of traffic
+            # behind ~6 us of hand-off latency, at 8 M points the traffic is the time
+            us8, gb8 = lio_pass_at(capi, synth, scene, cfg, x0, AT_SCALE_POINTS)
+            roof["at_scale"] = {"kernel": "lio18_pass_kernel", "points": AT_SCALE_POINTS, "pass_us": us8, "achieved": gb8, "unit": "GB/s",
+                                "frac": gb8 / HBM_PEAK_GBS, "algorithmic_bytes": LIO_BYTES_PER_POINT * AT_SCALE_POINTS}
         if args.sweep:
             sweep(capi, synth, scene, cfg, x0, sys.stderr)
 
@@ -374,37 +382,43 @@ def main():
         print(json.dumps(out), flush=True)
 
 
+def lio_pass_at(capi, synth, scene, cfg, x0, n):
+    """Average duration (us) and effective bandwidth (GB/s) of one forced LIO pass over n points, HIP events on the launch stream."""
+    import torch
+    fr = synth.make_lio_frame(min(n, 200000), scene=scene)
+    reps = (n + fr.n - 1) // fr.n
+    body = np.tile(fr.body_xyz, (reps, 1))[:n]
+    w = fr.world_at(fr.R_prior, fr.p_prior)
+    nbr, valid = synth.knn5(scene, w)
+    nbr = np.tile(nbr, (reps, 1, 1))[:n]
+    valid = np.tile(valid, reps)[:n]
+    h = capi.Handle(cfg)
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    h.lio_set_points(body)
+    h.lio_begin18(x0, x0)
+    h.lio_set_neighbours(nbr, valid)
+    K = 100 if n <= 1000000 else 20
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(5):
+        h.lio_iterate18(1, capi.FL_ITER_FORCE, want_info=False)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(K):
+        h.lio_iterate18(1, capi.FL_ITER_FORCE, want_info=False)
+    ev1.record()
+    torch.cuda.synchronize()
+    us = ev0.elapsed_time(ev1) * 1e3 / K
+    gbs = LIO_BYTES_PER_POINT * n / (us * 1e-6) / 1e9
+    h.close()
+    return us, gbs
+
+
 def sweep(capi, synth, scene, cfg, x0, fh):
     """Kernel-only effective bandwidth of the LIO pass over a size sweep."""
-    import torch
     for n in (50000, 200000, 1000000, 4000000, 8000000):
-        fr = synth.make_lio_frame(min(n, 200000), scene=scene)
-        reps = (n + fr.n - 1) // fr.n
-        body = np.tile(fr.body_xyz, (reps, 1))[:n]
-        w = fr.world_at(fr.R_prior, fr.p_prior)
-        nbr, valid = synth.knn5(scene, w)
-        nbr = np.tile(nbr, (reps, 1, 1))[:n]
-        valid = np.tile(valid, reps)[:n]
-        h = capi.Handle(cfg)
-        h.set_stream(torch.cuda.current_stream().cuda_stream)
-        h.lio_set_points(body)
-        h.lio_begin18(x0, x0)
-        h.lio_set_neighbours(nbr, valid)
-        K = 100 if n <= 1000000 else 20
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(5):
-            h.lio_iterate18(1, capi.FL_ITER_FORCE, want_info=False)
-        torch.cuda.synchronize()
-        ev0.record()
-        for _ in range(K):
-            h.lio_iterate18(1, capi.FL_ITER_FORCE, want_info=False)
-        ev1.record()
-        torch.cuda.synchronize()
-        us = ev0.elapsed_time(ev1) * 1e3 / K
-        gbs = LIO_BYTES_PER_POINT * n / (us * 1e-6) / 1e9
+        us, gbs = lio_pass_at(capi, synth, scene, cfg, x0, n)
         print(json.dumps({"sweep_points": n, "lio_pass_us": us, "effective_GBps": gbs, "frac_of_8TBps": gbs / HBM_PEAK_GBS}),
               file=fh)
-        h.close()
 
 
 if __name__ == "__main__":
