@@ -335,3 +335,14 @@ __global__ __launch_bounds__(FL_BLOCK) void vmap_addobs_kernel(FlVPoint *__restr
     const unsigned long long b = __ballot(added != 0);
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(&cnt->obs_added, (int)__popcll(b));
 }
+
+// how many observations of the map refer to keyframe `kf` (fl_vio_drop_keyframe refuses while any does: the reference keeps such an
+// image alive through the Feature's cv::Mat)
+__global__ __launch_bounds__(FL_BLOCK) void vmap_kfrefs_kernel(const FlVPoint *__restrict__ pts, int n, int kf, int *__restrict__ count)
+{
+    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
+    int c = 0;
+    if (i < n)
+        for (int k = 0; k < pts[i].n_obs; k++) c += pts[i].obs[k].kf_id == kf;
+    if (c) atomicAdd(count, c);
+}

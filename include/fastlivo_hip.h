@@ -362,6 +362,7 @@ int32_t fl_vio_grid_select(fl_handle h, const double *Rcw, const double *Pcw, co
                            int32_t grid_size, int32_t *winner, float *map_dist, float *map_value, int32_t *grid_num, int32_t *length_out);
 /* gray == NULL: the current image staged by fl_vio_set_frame becomes the keyframe (device-to-device copy, no second upload) */
 int32_t fl_vio_add_keyframe(fl_handle h, const uint8_t *gray, int32_t width, int32_t height, int32_t stride, int32_t *keyframe_id);
+/* refused (FL_ERR_ARG) while observations of the device visual map (fl_vmap_*) still refer to the keyframe */
 int32_t fl_vio_drop_keyframe(fl_handle h, int32_t keyframe_id);
 int32_t fl_vio_select_patches(fl_handle h, const double *Rcw, const double *Pcw, const float *scan_world_xyz, int32_t n_scan,
                               const fl_patch_candidate *cand, int32_t m, int32_t ncc_en, double ncc_thre, double outlier_threshold,

@@ -115,6 +115,8 @@ def test_map_growth_across_a_reallocation(gpu_lib, oracle_lib, scene):
             assert np.array_equal(g["points"], o["points"])
     n = vm.size()
     assert h.vmap_size() == n and n > 4096, n
+    with pytest.raises(capi.FlError, match="still refer to keyframe"):       # every observation was made on keyframe `kf`
+        h.vio_drop_keyframe(kf)
     for i in list(range(0, n, 97)) + [n - 1]:
         pg, vg, obg = h.vmap_get_point(i)
         po, vo, obo = vm.get_point(i)
