@@ -213,6 +213,7 @@ SYMBOLS = {
     "fl_vmap_select": (C.c_int32, [_H, _dp, _dp, _fp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.POINTER(C.c_int32), _i32p, _fp, _i32p, _fp]),
     "fl_vmap_add_sparse": (C.c_int32, [_H, _dp, _dp, _fp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     "fl_vmap_add_observation": (C.c_int32, [_H, _dp, _dp, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    "fl_vmap_release_keyframes": (C.c_int32, [_H, C.POINTER(C.c_int32)]),
     "fl_p2p_export": (C.c_int32, [_H, C.c_int32, C.c_void_p]),
     "fl_p2p_connect": (C.c_int32, [_H, C.c_int32, C.c_int32, C.c_void_p]),
     "fl_p2p_connect_local": (C.c_int32, [_H, C.c_int32, C.c_int32, C.c_void_p]),
@@ -451,6 +452,11 @@ class Handle:
         self._chk(self.L.fl_vmap_add_observation(self.h, Rcw.ctypes.data_as(_dp), Pcw.ctypes.data_as(_dp), keyframe_id, frame_id, C.byref(na)),
                   "fl_vmap_add_observation")
         return na.value
+
+    def vmap_release_keyframes(self):
+        n = C.c_int32(0)
+        self._chk(self.L.fl_vmap_release_keyframes(self.h, C.byref(n)), "fl_vmap_release_keyframes")
+        return n.value
 
     def comm_unique_id(self):
         buf = (C.c_char * 128)()

@@ -346,3 +346,14 @@ __global__ __launch_bounds__(FL_BLOCK) void vmap_kfrefs_kernel(const FlVPoint *_
         for (int k = 0; k < pts[i].n_obs; k++) c += pts[i].obs[k].kf_id == kf;
     if (c) atomicAdd(count, c);
 }
+
+// references per keyframe over the whole map (fl_vmap_release_keyframes)
+__global__ __launch_bounds__(FL_BLOCK) void vmap_kfhist_kernel(const FlVPoint *__restrict__ pts, int n, int n_kf, int *__restrict__ hist)
+{
+    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < pts[i].n_obs; k++) {
+        const int kf = pts[i].obs[k].kf_id;
+        if (kf >= 0 && kf < n_kf) atomicAdd(&hist[kf], 1);
+    }
+}

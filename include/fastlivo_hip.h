@@ -398,6 +398,9 @@ int32_t fl_vmap_select(fl_handle h, const double *Rcw, const double *Pcw, const 
 int32_t fl_vmap_add_sparse(fl_handle h, const double *Rcw, const double *Pcw, const float *scan_world_xyz, int32_t n, int32_t keyframe_id,
                            int32_t frame_id, int32_t *n_added);
 int32_t fl_vmap_add_observation(fl_handle h, const double *Rcw, const double *Pcw, int32_t keyframe_id, int32_t frame_id, int32_t *n_added);
+/* Frees the keyframe images (fl_vio_add_keyframe) that no observation of the map refers to any more -- what the reference's
+ * reference counting of Feature::img does; call now and then on long runs (one image per frame is 0.3 MB). */
+int32_t fl_vmap_release_keyframes(fl_handle h, int32_t *n_released);
 
 /* ------------------------------------------------------------------------------------------------
  * Sharded form with the exchange done natively: each rank stages its contiguous range of the scan

@@ -117,6 +117,12 @@ def test_map_growth_across_a_reallocation(gpu_lib, oracle_lib, scene):
     assert h.vmap_size() == n and n > 4096, n
     with pytest.raises(capi.FlError, match="still refer to keyframe"):       # every observation was made on keyframe `kf`
         h.vio_drop_keyframe(kf)
+    spare = [h.vio_add_keyframe() for _ in range(3)]                          # images nothing refers to
+    assert h.vmap_release_keyframes() == 3                                    # ... go; the one in use stays
+    with pytest.raises(capi.FlError):
+        h.vio_drop_keyframe(spare[0])
+    g = h.vmap_select(Rcw, Pcw, scan[:2000], outlier_threshold=1e12, want_patches=False)      # still warps out of `kf`
+    assert len(g["points"]) > 0
     for i in list(range(0, n, 97)) + [n - 1]:
         pg, vg, obg = h.vmap_get_point(i)
         po, vo, obo = vm.get_point(i)
