@@ -429,6 +429,9 @@ int32_t fl_ikfom_iterate_sharded(fl_handle h, int32_t count, int32_t flags, fl_i
  *   separate processes:  fl_p2p_export on every rank -> exchange the 64-byte handles (any transport) -> fl_p2p_connect
  *   one process:         fl_p2p_connect_local(h, rank, world, all_handles) on every handle
  * Connect before fl_*_begin of the frame. Waiting for a peer is bounded (seconds): FL_NUM_TIMEOUT in the status, no hang.
+ * A pass kernel waits for its peers' kernels, so every rank must issue its passes in the same order and nothing a rank's kernel
+ * waits for may be queued BEHIND it: give all connected handles of a process one stream (fl_set_stream; bench.py does), and when
+ * several ranks share one device (tests) one stream per rank -- HIP multiplexes streams onto a few hardware queues.
  * A replicated device map stays replicated only if every rank adds the WHOLE registered scan: fl_map_add_points(h, NULL, ..)
  * adds this rank's range only -- pass the full world scan explicitly there.
  * ---------------------------------------------------------------------------------------------- */
