@@ -40,6 +40,7 @@ struct fl_context {
     int cap_points = 0, n = 0;
     bool have_nbr = false;
     bool begun18 = false;         // an 18-state is on the device (fl_lio_begin18 / fl_vio_begin / frame drivers)
+    int last_state_mode = 0;      // 18 / 23: which filter state was staged last (fl_map_add_points(NULL) registers the scan under it)
     int num_cus = 0;              // compute units of the device: the multi-pass kernels need every workgroup resident (<= 1 per CU)
     bool normvec_valid = false;   // a pass with FL_ITER_KEEP_NORMVEC has run on the staged scan
     // 18-state block, reduction scratch
@@ -524,6 +525,7 @@ static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_sta
     hipLaunchKernelGGL(eskf18_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev);
     HIPCHK(h, hipGetLastError());
     h->begun18 = true;
+    h->last_state_mode = 18;
     return FL_OK;
 }
 

@@ -255,8 +255,9 @@ int32_t fl_map_set_points(fl_handle h, const float *map_xyz, int32_t k, float ce
  *                        with exactly one point: the old point closest to the box centre if strictly closer than every new point
  *                        of the box, else the closest new point, the latest among equals (the sequential loop's outcome).
  *                        downsample_size <= 0: every point is appended (Add_Points(.., false) / Build, :1411-1419).
- *                        world_xyz == NULL: the scan staged on the device, body -> world under the 18-state the device holds
- *                        (pointBodyToWorld, :695-698) -- after fl_lio_frame18_dev that is the updated state, as in the reference.
+ *                        world_xyz == NULL: the scan staged on the device, body -> world under the filter state the device holds
+ *                        (pointBodyToWorld, :695-698; the 18-state or, after fl_ikfom_*, the state_ikfom) -- after
+ *                        fl_lio_frame18_dev / fl_ikfom_update_iterated_dev that is the updated state, as in the reference.
  *   fl_map_delete_boxes  lasermap_fov_segment (:363-417): KD_TREE::Delete_Point_Boxes (ikd_Tree.cpp:501-520); boxes = nb x
  *                        {min x,y,z, max x,y,z} floats (BoxPointType), a point goes iff min <= v && max > v on every axis (:650).
  *   fl_map_get_points    read the map array back (parity checks, publishing); cap = 0 queries the size.

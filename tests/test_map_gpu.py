@@ -209,3 +209,22 @@ def test_automatic_cell_size_follows_the_density_and_changes_no_result(gpu_lib, 
 
 def info_amb(i):
     return i.n_ambiguous
+
+
+def test_resident_scan_under_the_ikfom_state(gpu_lib, oracle_lib, scene):
+    """Mode-23: after fl_ikfom_update_iterated_dev, fl_map_add_points(NULL) registers the scan under the updated state_ikfom."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    fr = synth.make_lio_frame(5000, scene=scene)
+    h = _handle(capi, synth, fr, 3)
+    h.map_set_points(scene.map_xyz, 0.5)
+    x = capi.state23_from_frame(fr)
+    P = fr.cov23.copy()
+    h.ikfom_update_iterated_dev(x, P, fr.body_xyz, 0.001)
+    world = h.ikfom_world_points(x, fr.n)                    # pointBodyToWorld under the updated state (the same kernel the search uses)
+    info = h.map_add_points(None, 0.25)
+    want, oi = orc.map_add_points(scene.map_xyz, world, 0.25)
+    assert info.n_after == oi.n_after
+    if oi.n_ambiguous == 0:
+        assert np.array_equal(h.map_get_points(), want)
+    h.close()
