@@ -142,3 +142,34 @@ def test_sharded_pass_gloo_world2(oracle_lib, emul_lib):
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "RANK0 OK" in out.stdout and "RANK1 OK" in out.stdout, out.stdout[-2000:]
+
+
+def test_cpp_local_map_window_follows_the_oracle(tmp_path):
+    """LocalMapDev::lasermap_fov_segment (C++ host mirror) against oracle/orc_map.c::orc_fov_segment along a random walk: the same
+    boxes are cut off and the window is the same float for float. Runs without a device (the deletion call fails on a null handle)."""
+    import subprocess
+    from oracle import oracle as orc
+    from fast_livo_amd import LIB_PATH, capi
+    capi.build()
+    src = os.path.join(os.path.dirname(__file__), "host_emul", "fov_walk.cpp")
+    exe = tmp_path / "fov_walk"
+    libdir = os.path.dirname(LIB_PATH)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", str(exe), src, "-L" + libdir, "-lfastlivo_hip", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    rng = np.random.default_rng(12)
+    steps = np.cumsum(rng.normal(0, 6.0, (300, 3)) + np.array([4.0, -2.0, 0.5]), axis=0)
+    cube, det, mov = 120.0, 20.0, 1.5
+    inp = f"{len(steps)} {cube} {det} {mov}\n" + "\n".join(" ".join(repr(float(v)) for v in p) for p in steps) + "\n"
+    out = subprocess.run([str(exe)], input=inp, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    win = np.zeros(6, dtype=np.float32)
+    init = False
+    moved = 0
+    for p, ln in zip(steps, lines):
+        boxes, init = orc.fov_segment(win, init, p, cube, det, mov)
+        vals = ln.split()
+        assert int(vals[0]) == len(boxes)
+        assert np.array_equal(np.array(vals[1:], dtype=np.float32), win), ln
+        moved += len(boxes) > 0
+    assert moved > 10
