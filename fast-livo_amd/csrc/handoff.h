@@ -222,6 +222,18 @@ __device__ __forceinline__ FlPeerView fl_peer_view(const FlDev18 *D)
     P.own = (P.world > 1) ? D->xchg_peer[P.rank] : nullptr;
     return P;
 }
+// The same with the peers' addresses staged in LDS once per launch (multi-pass kernels: the state block is rewritten by the solver
+// every pass, so the compiler would re-load the eight pointers from memory in every exchange). All threads call it; ends with a barrier.
+__device__ __forceinline__ FlPeerView fl_peer_view_lds(const FlDev18 *D, unsigned long long **lds8)
+{
+    if (threadIdx.x < FL_MAX_PEERS) lds8[threadIdx.x] = D->xchg_peer[threadIdx.x];
+    FlPeerView P;
+    P.rank = D->xchg_rank; P.world = D->xchg_world;
+    P.own = (P.world > 1) ? D->xchg_peer[P.rank] : nullptr;
+    __syncthreads();
+    P.peer = lds8;
+    return P;
+}
 // All threads of the (>= 256-thread) solver workgroup call it; sums = LDS[32], replaced by the total over the ranks;
 // tmp = LDS[FL_MAX_PEERS * 32]. Returns 0 or FL_NUM_TIMEOUT (all threads agree).
 __device__ __forceinline__ int peer_allreduce32(const FlPeerView &P, unsigned xe, double *sums, double *tmp)

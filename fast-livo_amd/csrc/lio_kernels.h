@@ -222,7 +222,8 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_multipass_kernel(const float 
         __shared__ FlSolveLds s_solve;
         __shared__ double s_xchg[FL_MAX_PEERS * 32];
         eskf18_prefetch(D, s_solve);
-        const FlPeerView PV = fl_peer_view(D);
+        __shared__ unsigned long long *s_peers[FL_MAX_PEERS];
+        const FlPeerView PV = fl_peer_view_lds(D, s_peers);
         const unsigned xe0 = PV.world > 1 ? *D->xchg_epoch : 0u;
         int done = 0;
         for (int p = 0; p < count; p++) {

@@ -495,7 +495,8 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
             __syncthreads();
         }
         __shared__ double s_xchg[FL_MAX_PEERS * 32];
-        const FlPeerView PV = fl_peer_view(D);
+        __shared__ unsigned long long *s_peers[FL_MAX_PEERS];
+        const FlPeerView PV = fl_peer_view_lds(D, s_peers);
         const unsigned xe0 = PV.world > 1 ? *D->xchg_epoch : 0u;
         int done = 0;
         for (int p = 0; p < count; p++) {
