@@ -124,6 +124,7 @@ struct fl_context {
     // VIO patch selection (select_kernels.h)
     std::vector<uint8_t *> kf_ptrs;            // device copies of the reference images (Feature::img), by keyframe id
     uint8_t **d_kf_table = nullptr;
+    int *d_sel_owner = nullptr;             // Warp_map: first depth-passing candidate per reference keyframe (select_kernels.h)
     int kf_table_cap = 0;
     bool kf_table_dirty = true;
     unsigned long long *d_depth64 = nullptr;

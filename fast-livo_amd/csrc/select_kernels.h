@@ -89,11 +89,47 @@ __device__ __forceinline__ float fl_interpolate_8u(const uint8_t *__restrict__ i
 }
 
 #define FL_SEL_NT 256
+// depth-continuity test of a candidate (:484-506), all 64 lanes of its wavefront; true = discontinuous
+__device__ __forceinline__ bool fl_depth_discontinuous(const FlVioConst &VC, const unsigned long long *__restrict__ depth64, const double *pt_cam,
+                                                       const double *pc, int lane)
+{
+    const int W = VC.width, H = VC.height, half = 4;
+    const int pu = min(max((int)pc[0], half), W - 1 - half), pv = min(max((int)pc[1], half), H - 1 - half);   // clamp: the reference reads unchecked
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int k = lane + 64 * r;
+        if (k < 81 && k != 40) {
+            const int u = k / 9 - half, v = k % 9 - half;
+            const float d = __uint_as_float((unsigned)depth64[(size_t)W * (v + pv) + u + pu]);
+            if (d != 0.f && fabs(pt_cam[2] - (double)d) > 1.5) bad = true;
+        }
+    }
+    return __any(bad) != 0;
+}
+// Warp_map of addFromSparseMap (:530-546): the affine warp and the search level are computed for the FIRST candidate of a reference
+// frame that passes the depth test and reused for every later candidate observed in the same frame (one image per frame: the
+// keyframe id is the key). owner_of_kf[kf] = that first candidate, by atomicMin over the candidate index.
+__global__ __launch_bounds__(FL_SEL_NT) void vio_select_owner_kernel(const FlPatchCandidate *__restrict__ cand, const FlSelectParams *__restrict__ S,
+                                                                    const FlVioConst *__restrict__ VCp,
+                                                                    const unsigned long long *__restrict__ depth64, int *__restrict__ owner_of_kf)
+{
+    const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+    const int ci = blockIdx.x * (FL_SEL_NT / 64) + wv;
+    if (ci >= S->m) return;
+    const FlPatchCandidate &c = cand[ci];
+    double pt_cam[3], pc[2];
+    fl_se3_apply(S->Rcw, S->Pcw, c.pos, pt_cam);
+    fl_world2cam(*VCp, pt_cam, pc);
+    if (fl_depth_discontinuous(*VCp, depth64, pt_cam, pc, lane)) return;
+    if (lane == 0) atomicMin(&owner_of_kf[c.keyframe_id], ci);
+}
 // reason: 0 accepted, 1 depth discontinuity, 3 NCC gate, 4 outlier gate
 __global__ __launch_bounds__(FL_SEL_NT) void vio_select_kernel(const FlPatchCandidate *__restrict__ cand, const FlSelectParams *__restrict__ S,
                                                               const FlVioConst *__restrict__ VCp, const uint8_t *__restrict__ cur_img,
                                                               const uint8_t *const *__restrict__ keyframes,
-                                                              const unsigned long long *__restrict__ depth64, float *__restrict__ patches /* m x 192 */,
+                                                              const unsigned long long *__restrict__ depth64, const int *__restrict__ owner_of_kf,
+                                                              float *__restrict__ patches /* m x 192 */,
                                                               float *__restrict__ errors, int32_t *__restrict__ slevel, int32_t *__restrict__ reason)
 {
     __shared__ float s_d2[FL_SEL_NT / 64][64];
@@ -106,38 +142,27 @@ __global__ __launch_bounds__(FL_SEL_NT) void vio_select_kernel(const FlPatchCand
     double pt_cam[3], pc[2];
     fl_se3_apply(S->Rcw, S->Pcw, c.pos, pt_cam);
     fl_world2cam(VC, pt_cam, pc);                                                                        // :480-481
-    // depth continuity :484-506 -- 80 neighbours of the 9x9 window, two per lane
-    const int pu = min(max((int)pc[0], half), W - 1 - half), pv = min(max((int)pc[1], half), H - 1 - half);   // clamp: the reference reads unchecked
-    bool bad = false;
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int k = lane + 64 * r;
-        if (k < 81 && k != 40) {
-            const int u = k / 9 - half, v = k % 9 - half;
-            const float d = __uint_as_float((unsigned)depth64[(size_t)W * (v + pv) + u + pu]);
-            if (d != 0.f && fabs(pt_cam[2] - (double)d) > 1.5) bad = true;
-        }
-    }
-    if (__any(bad)) { if (lane == 0) reason[ci] = 1; return; }
+    if (fl_depth_discontinuous(VC, depth64, pt_cam, pc, lane)) { if (lane == 0) reason[ci] = 1; return; }      // :484-506
+    const FlPatchCandidate &w = cand[owner_of_kf[c.keyframe_id]];      // Warp_map: whose warp this reference frame uses (vio_select_owner_kernel)
     // getWarpMatrixAffine :232-256 (every lane, same values)
     double Rt[9], ref_pos[3], T_R[9], T_t[3];
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int j = 0; j < 3; j++) Rt[i * 3 + j] = c.R_ref[j * 3 + i];
+        for (int j = 0; j < 3; j++) Rt[i * 3 + j] = w.R_ref[j * 3 + i];
 #pragma unroll
-    for (int i = 0; i < 3; i++) ref_pos[i] = -(Rt[i * 3] * c.t_ref[0] + Rt[i * 3 + 1] * c.t_ref[1] + Rt[i * 3 + 2] * c.t_ref[2]);   // Feature::pos()
-    const double dv0 = ref_pos[0] - c.pos[0], dv1 = ref_pos[1] - c.pos[1], dv2 = ref_pos[2] - c.pos[2];
+    for (int i = 0; i < 3; i++) ref_pos[i] = -(Rt[i * 3] * w.t_ref[0] + Rt[i * 3 + 1] * w.t_ref[1] + Rt[i * 3 + 2] * w.t_ref[2]);   // Feature::pos()
+    const double dv0 = ref_pos[0] - w.pos[0], dv1 = ref_pos[1] - w.pos[1], dv2 = ref_pos[2] - w.pos[2];
     const double depth_ref = sqrt(dv0 * dv0 + dv1 * dv1 + dv2 * dv2);
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) T_R[i * 3 + j] = S->Rcw[i * 3] * Rt[j] + S->Rcw[i * 3 + 1] * Rt[3 + j] + S->Rcw[i * 3 + 2] * Rt[6 + j];
     fl_se3_apply(S->Rcw, S->Pcw, ref_pos, T_t);
-    const double xyz_ref[3] = {c.f_ref[0] * depth_ref, c.f_ref[1] * depth_ref, c.f_ref[2] * depth_ref};
+    const double xyz_ref[3] = {w.f_ref[0] * depth_ref, w.f_ref[1] * depth_ref, w.f_ref[2] * depth_ref};
     double du[3], dw[3];
-    fl_cam2world(VC, c.px_ref[0] + (double)half, c.px_ref[1], du);
-    fl_cam2world(VC, c.px_ref[0], c.px_ref[1] + (double)half, dw);
+    fl_cam2world(VC, w.px_ref[0] + (double)half, w.px_ref[1], du);
+    fl_cam2world(VC, w.px_ref[0], w.px_ref[1] + (double)half, dw);
     const double su = xyz_ref[2] / du[2], sw = xyz_ref[2] / dw[2];
 #pragma unroll
     for (int k = 0; k < 3; k++) { du[k] *= su; dw[k] *= sw; }

@@ -350,7 +350,8 @@ typedef struct fl_patch_candidate {
     double px_ref[2];          /* ref_ftr->px */
     double f_ref[3];           /* ref_ftr->f */
     double R_ref[9], t_ref[3]; /* ref_ftr->T_f_w_ */
-    int32_t keyframe_id;       /* id of ref_ftr->img from fl_vio_add_keyframe */
+    int32_t keyframe_id;       /* id of ref_ftr->img from fl_vio_add_keyframe; also the key of the reference's Warp_map (ref_ftr->id_:
+                                  one image per frame), i.e. candidates of one keyframe share the warp of the first of them (:530-546) */
     int32_t level_ref;         /* ref_ftr->level (not read by warpAffine) */
     int32_t grid_index;        /* caller's bookkeeping */
     int32_t reserved;

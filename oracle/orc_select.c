@@ -5,7 +5,8 @@
  *   depth image of the scan                          :376-410   (orc_vio_depth_image)
  *   per grid winner (the loop at :470-583):
  *     depth-continuity test                          :484-506
- *     getWarpMatrixAffine                            :232-256  (call :531-532, level_ref = pyramid_level = 0)
+ *     Warp_map: warp + search level per reference frame :530-546 (first candidate of a frame computes them, the rest reuse them)
+ *     getWarpMatrixAffine                            :232-256  (call :537-538, level_ref = pyramid_level = 0)
  *     getBestSearchLevel                             :315-329  (call :534, max_level 2)
  *     warpAffine for pyramid levels 0..2             :258-296  (call :545-548)
  *     getpatch of the current image, level 0         :119-140  (call :557)
@@ -26,6 +27,7 @@
 #include "fastlivo_oracle.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 static void s_mv(const double *A, const double *x, double *o)
@@ -72,7 +74,8 @@ int orc_vio_select(const orc_vio_config *cfg, const double *Rcw, const double *P
                    float *errors, int32_t *search_levels, int32_t *n_accepted, int32_t *reason)
 {
     const int W = cfg->width, H = cfg->height, ps = cfg->patch_size, half = ps / 2, pst = ps * ps;
-    int na = 0;
+    int na = 0, n_warp = 0;
+    int32_t *warp_kf = (int32_t *)malloc(sizeof(int32_t) * (size_t)(m > 0 ? m : 1)), *warp_owner = (int32_t *)malloc(sizeof(int32_t) * (size_t)(m > 0 ? m : 1));
     for (int ci = 0; ci < m; ci++) {
         const orc_patch_candidate *c = &cand[ci];
         if (reason) reason[ci] = 0;
@@ -89,22 +92,30 @@ int orc_vio_select(const orc_vio_config *cfg, const double *Rcw, const double *P
                 if (fabs(pt_cam[2] - (double)d) > 1.5) { discont = 1; break; }
             }
         if (discont) { if (reason) reason[ci] = 1; continue; }
+        /* Warp_map (:530-546): the affine warp and the search level are computed for the FIRST candidate of a reference frame that
+         * gets this far and REUSED for every later candidate observed in the same frame (key ref_ftr->id_; one image per frame, so the
+         * keyframe id stands for it) -- with that first candidate's pixel, bearing, depth and pose, not the current one's */
+        int owner = -1;
+        for (int k = 0; k < n_warp; k++)
+            if (warp_kf[k] == c->keyframe_id) { owner = warp_owner[k]; break; }
+        if (owner < 0) { owner = ci; warp_kf[n_warp] = c->keyframe_id; warp_owner[n_warp] = ci; n_warp++; }
+        const orc_patch_candidate *w = &cand[owner];
         /* getWarpMatrixAffine :232-256 */
         double Rt[9], ref_pos[3], T_R[9], T_t[3];
         for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) Rt[i * 3 + j] = c->R_ref[j * 3 + i];
-        s_mv(Rt, c->t_ref, ref_pos);
+            for (int j = 0; j < 3; j++) Rt[i * 3 + j] = w->R_ref[j * 3 + i];
+        s_mv(Rt, w->t_ref, ref_pos);
         for (int k = 0; k < 3; k++) ref_pos[k] = -ref_pos[k];                                          /* Feature::pos() */
-        const double dv[3] = {ref_pos[0] - c->pos[0], ref_pos[1] - c->pos[1], ref_pos[2] - c->pos[2]};
+        const double dv[3] = {ref_pos[0] - w->pos[0], ref_pos[1] - w->pos[1], ref_pos[2] - w->pos[2]};
         const double depth_ref = sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
         for (int i = 0; i < 3; i++)                                                                    /* T_cur_ref = T_cur * T_ref^-1 */
             for (int j = 0; j < 3; j++) T_R[i * 3 + j] = Rcw[i * 3] * Rt[j] + Rcw[i * 3 + 1] * Rt[3 + j] + Rcw[i * 3 + 2] * Rt[6 + j];
         s_mv(Rcw, ref_pos, T_t);
         for (int k = 0; k < 3; k++) T_t[k] += Pcw[k];
-        const double xyz_ref[3] = {c->f_ref[0] * depth_ref, c->f_ref[1] * depth_ref, c->f_ref[2] * depth_ref};
+        const double xyz_ref[3] = {w->f_ref[0] * depth_ref, w->f_ref[1] * depth_ref, w->f_ref[2] * depth_ref};
         double du[3], dw[3];
-        cam2world(cfg, c->px_ref[0] + (double)half, c->px_ref[1], du);
-        cam2world(cfg, c->px_ref[0], c->px_ref[1] + (double)half, dw);
+        cam2world(cfg, w->px_ref[0] + (double)half, w->px_ref[1], du);
+        cam2world(cfg, w->px_ref[0], w->px_ref[1] + (double)half, dw);
         const double su = xyz_ref[2] / du[2], sw = xyz_ref[2] / dw[2];
         for (int k = 0; k < 3; k++) { du[k] *= su; dw[k] *= sw; }
         double q[3], px_cur[2], px_du[2], px_dv[2];
@@ -175,6 +186,7 @@ int orc_vio_select(const orc_vio_config *cfg, const double *Rcw, const double *P
         na++;
     }
     *n_accepted = na;
+    free(warp_kf); free(warp_owner);
     return 0;
 }
 
