@@ -1,6 +1,8 @@
 /*
  * include/fastlivo_hip.h -- C ABI of libfastlivo_hip.so, the MI355X (gfx950) implementation of
- * FAST-LIVO's per-frame residual/Jacobian assembly + iterated error-state Kalman update.
+ * FAST-LIVO's per-frame residual/Jacobian assembly + iterated error-state Kalman update (Mode-18 LIO, VIO, Mode-23) and, section
+ * by section below, of the steps either side of it: the map's 5-NN search and its updates, scan undistortion and down-sampling,
+ * the VIO patch selection and the visual map, and the sharded forms for several GPUs.
  *
  * Drop-in boundary.  Every entry point names the reference code whose body
  * it replaces (paths relative to the reference tree, snapshot 2024-11-08).  The reference-side
@@ -35,7 +37,8 @@ extern "C" {
 #define FL_NUM_FRAGILE 16     /* VIO: an accept test `error <= last_error` (lidar_selection.cpp:859) fell inside the rounding noise of the
                                  reference's float running sum of res^2 and was decided by replaying that sum in the reference's own
                                  arithmetic (informational). Only where the per-patch errors are not available -- the sharded
-                                 fl_vio_solve -- or under FL_ITER_FORCE it means "the reference may take the other branch here". */
+                                 forms (fl_vio_solve, fl_p2p_*) -- or under FL_ITER_FORCE it means "the reference may take the other
+                                 branch here". */
 
 #define FL_DIM18 18           /* DIM_STATE, include/common_lib.h:34 */
 #define FL_DIM23 23           /* state_ikfom::DOF, include/use-ikfom.hpp:12-21 */
