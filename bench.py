@@ -174,8 +174,9 @@ def main():
         connected = all_agree(connected)         # (also the barrier: nobody publishes before everybody has mapped everybody)
         if connected:
             begin()
-            i1 = hl.lio_iterate18(3, F)
-            i2 = hv.vio_iterate(VIO_LEVEL, 3, F)
+            for _ in range(3):           # the launches of the timed region: multi-pass kernels, both epoch parities several times
+                i1 = hl.lio_iterate18(PASSES_PER_LAUNCH, F)
+                i2 = hv.vio_iterate(VIO_LEVEL, PASSES_PER_LAUNCH, F)
             sv = np.concatenate([hl.lio_get_state18().vec(), hv.vio_get_state18().vec()])
             mine = torch.tensor(sv, dtype=torch.float64, device=ctl)
             alls = [torch.zeros_like(mine) for _ in range(world)]
