@@ -138,6 +138,15 @@ inline void h_share_model(state_ikfom &s, esekfom::dyn_share_datastruct<double> 
     }
 }
 
+// The callback with the reference's exact signature -- `typedef void measurementModel_dyn_share(state &,
+// dyn_share_datastruct<scalar_type> &)` (esekfom.hpp:129) -- as laserMapping.cpp defines it (:961) and registers it
+// (`kf.init_dyn_share(get_f, df_dx, df_dw, h_share_model, NUM_MAX_ITERATIONS, epsi)`, :1233-1235).  The reference's body reads
+// file-scope globals (feats_down_body, ikdtree, Nearest_Points, point_selected_surf, ...); this one reads the file-scope context
+// below, which the frame loop fills where the reference fills those globals (handle + kNN provider once, n per frame after
+// fl_lio_set_points).
+inline HShareContext g_hshare;
+inline void h_share_model(state_ikfom &s, esekfom::dyn_share_datastruct<double> &ekfom_data) { h_share_model(s, ekfom_data, g_hshare); }
+
 // ------------------------------------------------------------------------------------------------
 // Mode-18 LIO block of main(): `if(lidar_en){ for(iterCount=-1; ...) {...} }`, laserMapping.cpp:1504-1733
 // ------------------------------------------------------------------------------------------------

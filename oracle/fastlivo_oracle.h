@@ -229,6 +229,14 @@ int orc_ikfom_update_iterated(orc_state23 *x, double *P, const float *body_xyz, 
                               void *knn_ctx, int nthreads, uint8_t *sel_out, float *normvec_out,
                               orc_ikfom_out *out);
 
+/* The same update around ANY measurement callback of the reference's shape -- measurementModel_dyn_share, esekfom.hpp:129:
+ * `void (state &, dyn_share_datastruct<scalar_type> &)`, registered by init_dyn_share (:238-254), invoked at :1636.  The callback
+ * receives the state and the in/out flags valid (true on entry) / converge, and returns h_x (rows x 12 row-major) and h (rows).
+ * Used by tests to run a replacement h_share_model through the unmodified updater. */
+typedef void (*orc_h_dyn_share_fn)(void *ctx, orc_state23 *x, int *valid, int *converge, int *rows, const double **h_x, const double **h);
+int orc_ikfom_update_dyn_share(orc_state23 *x, double *P, double R, int maximum_iter, const double *limit /*23*/,
+                               orc_h_dyn_share_fn h_dyn_share, void *h_ctx, orc_ikfom_out *out);
+
 /* state_ikfom boxplus / boxminus (build_manifold.hpp:192-200) exposed for unit tests. */
 void orc_state23_boxplus(orc_state23 *x, const double *dx /*23*/);
 void orc_state23_boxminus(const orc_state23 *x, const orc_state23 *other, double *dx /*23*/);

@@ -313,6 +313,35 @@ def ikfom_update(x, P, body, R, max_iter, scene_knn, limit=None, nthreads=4):
     return dict(status=st, out=out, sel=sel, normvec=normvec)
 
 
+H_DYN_SHARE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(State23), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                             C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.POINTER(C.c_double)))
+
+
+def ikfom_update_dyn_share(x, P, R, max_iter, h_dyn_share, limit=None):
+    """update_iterated_dyn_share_modified (esekfom.hpp:1619-1928) around a Python measurement callback of the reference's shape:
+    h_dyn_share(state: State23, valid: bool, converge: bool) -> (valid, h_x (rows,12) float64, h (rows,) float64)."""
+    limit = np.full(23, 0.001) if limit is None else np.ascontiguousarray(limit, dtype=np.float64)
+    out = IkfomOut()
+    keep = []
+
+    def cb(ctx, xs, valid, converge, rows, hx_out, h_out):
+        v, hx, hv = h_dyn_share(xs.contents, bool(valid[0]), bool(converge[0]))
+        hx = np.ascontiguousarray(hx, dtype=np.float64).reshape(-1, 12)
+        hv = np.ascontiguousarray(hv, dtype=np.float64).reshape(-1)
+        keep[:] = [hx, hv]
+        valid[0] = 1 if v else 0
+        rows[0] = hx.shape[0]
+        hx_out[0] = _p(hx, C.c_double) if hx.size else None
+        h_out[0] = _p(hv, C.c_double) if hv.size else None
+    L = lib()
+    L.orc_ikfom_update_dyn_share.restype = C.c_int
+    L.orc_ikfom_update_dyn_share.argtypes = [C.POINTER(State23), C.POINTER(C.c_double), C.c_double, C.c_int, C.POINTER(C.c_double),
+                                             H_DYN_SHARE_FN, C.c_void_p, C.POINTER(IkfomOut)]
+    st = L.orc_ikfom_update_dyn_share(C.byref(x), _p(P, C.c_double), R, max_iter, _p(limit, C.c_double), H_DYN_SHARE_FN(cb), None,
+                                      C.byref(out))
+    return dict(status=st, out=out)
+
+
 def knn5_bruteforce(map_xyz, query_xyz, nthreads=8):
     """Exact float-distance 5-NN (oracle/orc_knn.c): nbr (n,5,3), sqdist (n,5), valid (n,), idx (n,5)."""
     map_xyz = np.ascontiguousarray(map_xyz, dtype=np.float32)

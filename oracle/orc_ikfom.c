@@ -337,23 +337,18 @@ static void cols_apply(double *P, int n, int idx, int k, const double *J /* righ
     }
 }
 
-int orc_ikfom_update_iterated(orc_state23 *x_, double *P_, const float *body_xyz, int n, double R,
-                              int maximum_iter, const double *limit, orc_knn_fn knn, void *knn_ctx,
-                              int nthreads, uint8_t *sel_out, float *normvec_out, orc_ikfom_out *out)
+/* ---- update_iterated_dyn_share_modified (esekfom.hpp:1619-1928) around a measurement callback of the reference's shape:
+ * `typedef void measurementModel_dyn_share(state &, dyn_share_datastruct<scalar_type> &)` (esekfom.hpp:129), registered by
+ * init_dyn_share (:238-254) and invoked once per iteration at :1636.  The callback sees the state and the in/out flags `valid`
+ * (reset to true before every call, :1635) and `converge`, and hands back h_x (rows x 12, row-major) and h (rows) -- the members
+ * of dyn_share_datastruct the updater reads (:1641,:1712,:1781,:1801,:1806).  `valid == false` skips the iteration (:1649-1652). */
+int orc_ikfom_update_dyn_share(orc_state23 *x_, double *P_, double R, int maximum_iter, const double *limit,
+                               orc_h_dyn_share_fn h_dyn_share, void *h_ctx, orc_ikfom_out *out)
 {
-    const size_t nn = (size_t)(n > 0 ? n : 1);
-    float *world = (float *)malloc(sizeof(float) * 3 * nn);
-    float *nbr = (float *)calloc(15 * nn, sizeof(float));
-    uint8_t *valid = (uint8_t *)calloc(nn, 1);
-    uint8_t *sel = (uint8_t *)calloc(nn, 1);
-    float *normvec = (float *)calloc(4 * nn, sizeof(float));
-    double *res_last = (double *)calloc(nn, sizeof(double));
-    double *h_x = (double *)malloc(sizeof(double) * 12 * nn);
-    double *h = (double *)malloc(sizeof(double) * nn);
     static const int SO3_idx[2] = {3, 6};
     const int S2_idx = 21;
 
-    int converge = 1, t = 0, status = 0, iters = 0, searches = 0, neff = 0;
+    int converge = 1, valid = 1, t = 0, status = 0, iters = 0, neff = 0;
     orc_state23 x_propagated = *x_;
     double P_propagated[N23 * N23], L_[N23 * N23];
     memcpy(P_propagated, P_, sizeof P_propagated);
@@ -363,20 +358,15 @@ int orc_ikfom_update_iterated(orc_state23 *x_, double *P_, const float *body_xyz
     int finished = 0;
 
     for (int i = -1; i < maximum_iter && !finished; i++) {
-        /* h_dyn_share(x_, dyn_share) */
-        if (converge) {
-            for (int k = 0; k < n; k++) world_point23(x_, body_xyz + (size_t)k * 3, world + (size_t)k * 3);
-            knn(knn_ctx, world, n, nbr, valid);
-            memcpy(sel, valid, nn);
-            searches++;
-        }
-        double tr;
-        neff = orc_h_share_model(x_, body_xyz, nbr, sel, n, nthreads, NULL, normvec, res_last, h_x, h, &tr);
+        const double *h_x = NULL, *h = NULL;
+        valid = 1;
+        h_dyn_share(h_ctx, x_, &valid, &converge, &neff, &h_x, &h);
         iters++;
         const int dof_Measurement = neff;
         double dx[N23];
         orc_state23_boxminus(x_, &x_propagated, dx);
         memcpy(dx_new, dx, sizeof dx);
+        if (!valid) continue;                                  /* esekfom.hpp:1649-1652 */
         memcpy(P_, P_propagated, sizeof P_propagated);
 
         for (int b = 0; b < 2; b++) {
@@ -541,17 +531,62 @@ int orc_ikfom_update_iterated(orc_state23 *x_, double *P_, const float *body_xyz
     }
     for (int k = 0; k < N23; k++)
         if (!isfinite(dx_[k])) status |= 2;
-    if (sel_out) memcpy(sel_out, sel, nn);
-    if (normvec_out) memcpy(normvec_out, normvec, sizeof(float) * 4 * nn);
     if (out) {
         memcpy(out->HTH, HTH, sizeof HTH);
         memcpy(out->HTh, HTh, sizeof HTh);
         memcpy(out->dx, dx_, sizeof dx_);
         out->iterations = iters;
-        out->searches = searches;
+        out->searches = 0;
         out->effct_feat_num = neff;
         out->status = status;
     }
-    free(world); free(nbr); free(valid); free(sel); free(normvec); free(res_last); free(h_x); free(h);
+    return status;
+}
+
+/* ---- the reference's own callback, h_share_model (laserMapping.cpp:961-1093), as the h_dyn_share of the update above */
+typedef struct {
+    const float *body_xyz;
+    int n, nthreads, searches;
+    orc_knn_fn knn;
+    void *knn_ctx;
+    float *world, *nbr, *normvec;
+    uint8_t *valid, *sel;
+    double *res_last, *h_x, *h;
+} hshare_ctx;
+static void hshare_cb(void *vctx, orc_state23 *x, int *valid, int *converge, int *rows, const double **h_x, const double **h)
+{
+    hshare_ctx *c = (hshare_ctx *)vctx;
+    (void)valid;
+    if (*converge) {                                            /* laserMapping.cpp:994-1013 */
+        for (int k = 0; k < c->n; k++) world_point23(x, c->body_xyz + (size_t)k * 3, c->world + (size_t)k * 3);
+        c->knn(c->knn_ctx, c->world, c->n, c->nbr, c->valid);
+        memcpy(c->sel, c->valid, (size_t)(c->n > 0 ? c->n : 1));
+        c->searches++;
+    }
+    double tr;
+    *rows = orc_h_share_model(x, c->body_xyz, c->nbr, c->sel, c->n, c->nthreads, NULL, c->normvec, c->res_last, c->h_x, c->h, &tr);
+    *h_x = c->h_x; *h = c->h;
+}
+
+int orc_ikfom_update_iterated(orc_state23 *x_, double *P_, const float *body_xyz, int n, double R,
+                              int maximum_iter, const double *limit, orc_knn_fn knn, void *knn_ctx,
+                              int nthreads, uint8_t *sel_out, float *normvec_out, orc_ikfom_out *out)
+{
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    hshare_ctx c;
+    c.body_xyz = body_xyz; c.n = n; c.nthreads = nthreads; c.searches = 0; c.knn = knn; c.knn_ctx = knn_ctx;
+    c.world = (float *)malloc(sizeof(float) * 3 * nn);
+    c.nbr = (float *)calloc(15 * nn, sizeof(float));
+    c.valid = (uint8_t *)calloc(nn, 1);
+    c.sel = (uint8_t *)calloc(nn, 1);
+    c.normvec = (float *)calloc(4 * nn, sizeof(float));
+    c.res_last = (double *)calloc(nn, sizeof(double));
+    c.h_x = (double *)malloc(sizeof(double) * 12 * nn);
+    c.h = (double *)malloc(sizeof(double) * nn);
+    const int status = orc_ikfom_update_dyn_share(x_, P_, R, maximum_iter, limit, hshare_cb, &c, out);
+    if (out) out->searches = c.searches;
+    if (sel_out) memcpy(sel_out, c.sel, nn);
+    if (normvec_out) memcpy(normvec_out, c.normvec, sizeof(float) * 4 * nn);
+    free(c.world); free(c.nbr); free(c.valid); free(c.sel); free(c.normvec); free(c.res_last); free(c.h_x); free(c.h);
     return status;
 }
