@@ -175,6 +175,8 @@ SYMBOLS = {
     "fl_set_timing": (C.c_int32, [_H, C.c_int32]),
     "fl_get_last_kernel_ms": (C.c_int32, [_H, _fp]),
     "fl_debug_get_stamps": (C.c_int32, [_H, C.POINTER(C.c_longlong)]),
+    "fl_debug_hog": (C.c_int32, [_H, C.c_int32, C.c_int32, C.c_int32]),
+    "fl_debug_counters": (C.c_int32, [_H, _i32p]),
     "fl_lio_set_points": (C.c_int32, [_H, _fp, C.c_int32]),
     "fl_lio_set_neighbours": (C.c_int32, [_H, _fp, _u8p, C.c_int32]),
     "fl_lio_get_selection": (C.c_int32, [_H, _u8p, _fp]),
@@ -260,6 +262,8 @@ def lib():
             pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
+            if name.startswith("fl_debug_") and os.environ.get("FL_LIB_PATH") and not hasattr(L, name):
+                continue               # an older A/B build (tools/) may lack a debug aid
             fn = getattr(L, name)      # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
@@ -812,6 +816,16 @@ def _knn_methods():
                   "fl_ikfom_search")
         return nbr, valid
 
+    def debug_hog(self, blocks, lds_bytes, usec):
+        self._chk(self.L.fl_debug_hog(self.h, int(blocks), int(lds_bytes), int(usec)), "fl_debug_hog")
+
+    def debug_counters(self):
+        """dict(fallbacks, resumes, capacity, cus): multi-pass launches refused by the admission check, frames resumed after an
+        abandoned pass, workgroups of a multi-pass kernel the device holds at once, compute units."""
+        a = np.zeros(4, dtype=np.int32)
+        self._chk(self.L.fl_debug_counters(self.h, a.ctypes.data_as(_i32p)), "fl_debug_counters")
+        return dict(fallbacks=int(a[0]), resumes=int(a[1]), capacity=int(a[2]), cus=int(a[3]))
+
     def lio_frame18_dev(self, state, body):
         """body None: use the scan already staged on the device (lio_set_points / scan_voxel_filter)."""
         info = IterInfo()
@@ -831,7 +845,8 @@ def _knn_methods():
                                                       _p(limit, C.c_double), C.byref(info)), "fl_ikfom_update_iterated_dev")
         return info
 
-    for f in (map_set_points, map_clear, map_add_points, map_delete_boxes, map_get_points, lio_search18, ikfom_search, lio_frame18_dev, ikfom_update_iterated_dev):
+    for f in (map_set_points, map_clear, map_add_points, map_delete_boxes, map_get_points, lio_search18, ikfom_search, lio_frame18_dev, ikfom_update_iterated_dev,
+              debug_hog, debug_counters):
         setattr(Handle, f.__name__, f)
 
 

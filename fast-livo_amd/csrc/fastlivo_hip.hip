@@ -23,6 +23,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -35,6 +36,8 @@ struct fl_context {
     hipEvent_t aux_event = nullptr;
     // LIO
     float *d_body = nullptr, *d_nbr = nullptr, *d_world = nullptr;
+    float4 *d_gate = nullptr;     // staged scan as (x, y, z, T), T = per-point selection threshold (fl_math.h: fl_gate_threshold); valid when gate_valid
+    bool gate_valid = false;
     uint8_t *d_valid = nullptr, *d_sel = nullptr;
     float4 *d_plane = nullptr, *d_normvec = nullptr;
     int cap_points = 0, n = 0;
@@ -42,6 +45,12 @@ struct fl_context {
     bool begun18 = false;         // an 18-state is on the device (fl_lio_begin18 / fl_vio_begin / frame drivers)
     int last_state_mode = 0;      // 18 / 23: which filter state was staged last (fl_map_add_points(NULL) registers the scan under it)
     int num_cus = 0;              // compute units of the device: the multi-pass kernels need every workgroup resident (<= 1 per CU)
+    int mp_capacity = 0;          // workgroups of a multi-pass kernel the device can hold at once (occupancy x CUs)
+    unsigned *h_mp_done = nullptr;   // pinned host word the solver workgroup of a multi-pass launch writes its sequence number to when it ends
+    unsigned *d_mp_done = nullptr;   // ... as the device addresses it
+    unsigned mp_seq = 0;             // sequence number of this handle's last multi-pass launch
+    int mp_last_grid = 0;
+    int mp_fallbacks = 0, mp_resumes = 0;   // diagnostics: launches sent down the per-pass path by the admission check / frames resumed
     bool normvec_valid = false;   // a pass with FL_ITER_KEEP_NORMVEC has run on the staged scan
     // 18-state block, reduction scratch
     FlDev18 *d_dev = nullptr;
@@ -209,6 +218,48 @@ static void build_vio_const(const fl_config &c, FlVioConst &v)
     v.distort = (fabs(c.d[0]) > 0.0000001) ? 1 : 0;
 }
 
+// ---- co-residency of the multi-pass kernels, made explicit --------------------------------------------------------------
+// A multi-pass kernel waits for its own other workgroups (handoff.h), so ALL of them must be resident. What the device can
+// hold is occupancy x CUs workgroups (hipOccupancyMaxActiveBlocksPerMultiprocessor, queried per handle); what is already
+// on it are the multi-pass launches of OTHER streams of this process that have not completed (launches of one stream run
+// one after the other and do not compete). Every multi-pass launch ends by writing its sequence number to a pinned host
+// word of its handle; a launch is admitted only while in-flight workgroups + its own fit, otherwise the passes go down the one-launch-per-pass path, whose
+// kernels never wait for anything that is not already running. Other processes / foreign kernels are invisible to this
+// check: for them the bounded waits end in an ABANDONED pass (solve18.h) and the drivers resume the frame per pass
+// (resume_after_timeout below) -- the caller sees neither.
+static std::mutex g_mp_mu;
+static std::vector<fl_context *> g_mp_handles;      // live handles of this process
+// in flight = launched and its completion word not written yet (one store by the launch's last action; no events, no
+// extra commands in the stream -- an event per launch cost ~0.5 us per pass of GPU time)
+static bool mp_admit(fl_handle h, int grid)
+{
+    std::lock_guard<std::mutex> lk(g_mp_mu);
+    int busy = 0;
+    for (fl_context *o : g_mp_handles) {
+        if (o == h || o->cfg.device != h->cfg.device || o->stream == h->stream) continue;
+        if (o->mp_seq != __atomic_load_n(o->h_mp_done, __ATOMIC_RELAXED)) busy += o->mp_last_grid;
+    }
+    if (busy + grid > h->mp_capacity) { h->mp_fallbacks++; return false; }
+    h->mp_seq++;                    // the launch that follows carries this number
+    h->mp_last_grid = grid;
+    return true;
+}
+// FL_NUM_TIMEOUT handling: clears the abandoned mark so that the enqueued per-pass chain runs (solve18.h, fl_pass_skipped)
+__global__ void eskf18_resume_kernel(FlDev18 *__restrict__ D)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { D->status &= ~FL_NUM_TIMEOUT; D->resume_count = 0; }
+}
+// debug / test aid: occupies `blocks` workgroup slots for ~`usec` microseconds (tests/test_coresidency_gpu.py)
+__global__ __launch_bounds__(256) void fl_hog_kernel(long long ticks, int *sink)
+{
+    extern __shared__ int s_hog[];                 // dynamic LDS: what keeps other workgroups off the CU
+    const long long t0 = (long long)wall_clock64();
+    int v = 0;
+    s_hog[threadIdx.x] = 0;
+    while ((long long)wall_clock64() - t0 < ticks) { v++; __builtin_amdgcn_s_sleep(8); }
+    if (v == -1) *sink = s_hog[0];
+}
+
 extern "C" {
 
 int32_t fl_create(const fl_config *cfg, fl_handle *out)
@@ -239,8 +290,8 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
         h->num_cus = prop.multiProcessorCount;
     }
     HIPCHK(h, hipMalloc(&h->d_sums_tmp, sizeof(double) * FL_SUMS23));
-    HIPCHK(h, hipMalloc(&h->d_bcast, sizeof(unsigned long long) * 64));
-    HIPCHK(h, hipMemset(h->d_bcast, 0, sizeof(unsigned long long) * 64));
+    HIPCHK(h, hipMalloc(&h->d_bcast, sizeof(unsigned long long) * FL_BCAST_STRIDE * 16));     // up to 16 copies of the words (handoff.h)
+    HIPCHK(h, hipMemset(h->d_bcast, 0, sizeof(unsigned long long) * FL_BCAST_STRIDE * 16));
     HIPCHK(h, hipMalloc(&h->d_vc, sizeof(FlVioConst)));
     HIPCHK(h, hipMemset(h->d_records, 0, (size_t)16 * FL_MAX_BLOCKS * FL_SUMS23));
     {
@@ -254,6 +305,20 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
     HIPCHK(h, hipMemcpy(h->d_vc, &h->h_vc, sizeof(FlVioConst), hipMemcpyHostToDevice));
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_mp_done, 64, hipHostMallocMapped));
+    *h->h_mp_done = 0u;
+    HIPCHK(h, hipHostGetDevicePointer((void **)&h->d_mp_done, h->h_mp_done, 0));
+    {
+        int b_lio = 0, b_vio = 0, b_ik = 0;
+        HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_lio, lio18_multipass_kernel, FL_LIO_NT, 0));
+        HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_vio, vio_multipass_kernel, FL_VIO_NT, 0));
+        b_ik = b_lio;
+        int b = b_lio < b_vio ? b_lio : b_vio;
+        if (b_ik < b) b = b_ik;
+        h->mp_capacity = b * h->num_cus;
+        if (const char *e = getenv("FL_MP_CAPACITY")) h->mp_capacity = atoi(e);     // test aid
+    }
+    { std::lock_guard<std::mutex> lk(g_mp_mu); g_mp_handles.push_back(h); }
     *out = h;
     return FL_OK;
 }
@@ -272,7 +337,7 @@ int32_t fl_destroy(fl_handle h)
     if (!h) return FL_OK;
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
-    hipFree(h->d_body); hipFree(h->d_nbr); hipFree(h->d_world); hipFree(h->d_valid); hipFree(h->d_sel);
+    hipFree(h->d_body); hipFree(h->d_nbr); hipFree(h->d_world); hipFree(h->d_valid); hipFree(h->d_sel); hipFree(h->d_gate);
     hipFree(h->d_plane); hipFree(h->d_normvec); hipFree(h->d_dev); hipFree(h->d_dev23); hipFree(h->d_records);
     hipFree(h->d_epoch); hipFree(h->d_sums_tmp); hipFree(h->d_bcast); hipFree(h->d_vc); hipFree(h->d_img); hipFree(h->d_ref);
     hipFree(h->d_errors); hipFree(h->d_err_words); hipFree(h->d_pos); hipFree(h->d_slevel); hipFree(h->d_vio_li);
@@ -286,6 +351,12 @@ int32_t fl_destroy(fl_handle h)
     fl_p2p_disconnect(h);
     if (h->h_dev) hipHostFree(h->h_dev);
     if (h->h_dev23) hipHostFree(h->h_dev23);
+    {
+        std::lock_guard<std::mutex> lk(g_mp_mu);
+        for (size_t i = 0; i < g_mp_handles.size(); i++)
+            if (g_mp_handles[i] == h) { g_mp_handles[i] = g_mp_handles.back(); g_mp_handles.pop_back(); break; }
+    }
+    if (h->h_mp_done) hipHostFree(h->h_mp_done);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->aux_event) hipEventDestroy(h->aux_event);
@@ -351,14 +422,15 @@ static int32_t ensure_points(fl_handle h, int n)
     while (cap < n) cap *= 2;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     hipFree(h->d_body); hipFree(h->d_nbr); hipFree(h->d_world); hipFree(h->d_valid); hipFree(h->d_sel);
-    hipFree(h->d_plane); hipFree(h->d_normvec);
-    h->d_body = h->d_nbr = h->d_world = nullptr; h->d_valid = h->d_sel = nullptr; h->d_plane = h->d_normvec = nullptr;
-    h->cap_points = 0;
+    hipFree(h->d_plane); hipFree(h->d_normvec); hipFree(h->d_gate);
+    h->d_body = h->d_nbr = h->d_world = nullptr; h->d_valid = h->d_sel = nullptr; h->d_plane = h->d_normvec = nullptr; h->d_gate = nullptr;
+    h->cap_points = 0; h->gate_valid = false;
     HIPCHK(h, hipMalloc(&h->d_body, sizeof(float) * 3 * (size_t)cap));
     HIPCHK(h, hipMalloc(&h->d_nbr, sizeof(float) * 15 * (size_t)cap));
     HIPCHK(h, hipMalloc(&h->d_world, sizeof(float) * 3 * (size_t)cap));
     HIPCHK(h, hipMalloc(&h->d_valid, (size_t)cap));
     HIPCHK(h, hipMalloc(&h->d_sel, (size_t)cap));
+    HIPCHK(h, hipMalloc(&h->d_gate, sizeof(float4) * (size_t)cap));
     HIPCHK(h, hipMalloc(&h->d_plane, sizeof(float4) * (size_t)cap));
     HIPCHK(h, hipMalloc(&h->d_normvec, sizeof(float4) * (size_t)cap));
     h->cap_points = cap;
@@ -418,6 +490,7 @@ int32_t fl_lio_set_points(fl_handle h, const float *body_xyz, int32_t n)
     h->n = n;
     h->have_nbr = false;
     h->normvec_valid = false;
+    h->gate_valid = false;
     HIPCHK(h, hipMemcpyAsync(h->d_body, body_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_sel, 0, (size_t)n, h->stream));
     return FL_OK;
@@ -567,18 +640,47 @@ static bool fl_multipass_enabled()
     if (v < 0) v = getenv("FL_NO_MULTIPASS") ? 0 : 1;
     return v == 1;
 }
-static void launch_lio_passes(fl_handle h, int grid, int count, int flags)
+// per-point gate thresholds of the staged scan (fl_math.h: fl_gate_threshold): once per scan, before its first pass
+static void ensure_gates(fl_handle h)
+{
+    if (h->gate_valid || h->n <= 0) return;
+    hipLaunchKernelGGL(lio_gate_kernel, dim3((h->n + FL_BLOCK - 1) / FL_BLOCK), dim3(FL_BLOCK), 0, h->stream, h->d_body, h->d_gate, h->n);
+    h->gate_valid = true;
+}
+// may this handle use the multi-pass form for a grid of `grid` workgroups right now?
+static bool multipass_ok(fl_handle h, int grid) { return grid <= h->num_cus && fl_multipass_enabled() && mp_admit(h, grid); }
+static void launch_lio_passes(fl_handle h, int grid, int count, int flags, bool allow_multi = true)
 {
     if (flags & FL_ITER_KEEP_NORMVEC) h->normvec_valid = true;
-    if (count > 1 && grid <= h->num_cus && fl_multipass_enabled()) {
-        hipLaunchKernelGGL(lio18_multipass_kernel, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_body, h->d_plane, h->d_sel, h->d_normvec,
-                           h->n, h->d_dev, records_lio(h), h->d_epoch, h->d_bcast, (int)count, (int)flags);
+    ensure_gates(h);
+    if (allow_multi && count > 1 && multipass_ok(h, grid)) {
+        hipLaunchKernelGGL(lio18_multipass_kernel, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_gate, h->d_plane, h->d_sel, h->d_normvec,
+                           h->n, h->d_dev, records_lio(h), h->d_epoch, h->d_bcast, (int)count, (int)flags, h->d_mp_done, h->mp_seq);
         return;
     }
     for (int i = 0; i < count; i++)
-        hipLaunchKernelGGL(lio18_pass_kernel<0>, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_body, h->d_plane, h->d_sel,
+        hipLaunchKernelGGL(lio18_pass_kernel<0>, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_gate, h->d_plane, h->d_sel,
                            h->d_normvec, h->n, h->d_dev, records_lio(h), h->d_epoch, (double *)nullptr, (int)flags);
 }
+// A pass of the enqueued chain was abandoned after a hand-off time-out (status bit FL_NUM_TIMEOUT, state untouched, everything
+// behind it skipped): clear the mark and run what is left with one launch per pass. `enqueue(remaining)` re-enqueues the tail
+// of the caller's chain; up to three attempts, then the bit is surfaced. Not in the sharded form: there the ranks may have
+// parted ways (one completed the pass, the other did not) and only the caller can restart them together (fl_p2p_connect).
+extern "C++" {
+template <class F>
+static int32_t resume_after_timeout(fl_handle h, fl_iter_info *li, F enqueue)
+{
+    for (int attempt = 0; attempt < 3 && (li->status & FL_NUM_TIMEOUT) && h->xchg_world <= 1; attempt++) {
+        h->mp_resumes++;
+        const int remaining = h->h_dev->resume_count;
+        hipLaunchKernelGGL(eskf18_resume_kernel, dim3(1), dim3(1), 0, h->stream, h->d_dev);
+        int32_t st = enqueue(remaining);
+        if (st) return st;
+        if ((st = read_info18(h, li))) return st;
+    }
+    return FL_OK;
+}
+}  // extern "C++"
 
 int32_t fl_lio_iterate18(fl_handle h, int32_t count, int32_t flags, fl_iter_info *info)
 {
@@ -591,8 +693,14 @@ int32_t fl_lio_iterate18(fl_handle h, int32_t count, int32_t flags, fl_iter_info
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipGetLastError());
     h->last_launches = count;
-    if (info) return read_info18(h, info);
-    return FL_OK;
+    if (!info) return FL_OK;          // enqueue only: a time-out stays visible in the status of a later read-back
+    int32_t st = read_info18(h, info);
+    if (st) return st;
+    return resume_after_timeout(h, info, [&](int remaining) -> int32_t {
+        launch_lio_passes(h, grid, remaining < count ? remaining : count, flags, false);
+        HIPCHK(h, hipGetLastError());
+        return FL_OK;
+    });
 }
 
 int32_t fl_lio_get_state18(fl_handle h, fl_state18 *out)
@@ -649,7 +757,8 @@ int32_t fl_lio_accumulate18(fl_handle h, double *d_sums, int32_t flags)
     if (h->n <= 0 || !h->have_nbr) return fail_arg(h, "fl_lio_accumulate18: points/neighbours not staged");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(lio18_pass_kernel<1>, dim3(lio_grid(h->n)), dim3(FL_LIO_NT), 0, h->stream, h->d_body, h->d_plane,
+    ensure_gates(h);
+    hipLaunchKernelGGL(lio18_pass_kernel<1>, dim3(lio_grid(h->n)), dim3(FL_LIO_NT), 0, h->stream, h->d_gate, h->d_plane,
                        h->d_sel, h->d_normvec, h->n, h->d_dev, records_lio(h), h->d_epoch, d_sums, (int)flags);
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipGetLastError());
@@ -663,6 +772,28 @@ int32_t fl_lio_solve18(fl_handle h, const double *d_sums, int32_t flags, fl_iter
     hipLaunchKernelGGL(eskf18_solve_kernel, dim3(1), dim3(FL_BLOCK), 0, h->stream, h->d_dev, d_sums, 0, (int)flags, (const FlVioConst *)h->d_vc);
     HIPCHK(h, hipGetLastError());
     if (info) return read_info18(h, info);
+    return FL_OK;
+}
+
+// Debug / test aid: a foreign kernel that occupies `blocks` workgroup slots (256 threads, lds_bytes of LDS each) for ~usec
+// microseconds on a stream of its own -- what another process on the same GPU looks like to the multi-pass kernels.
+int32_t fl_debug_hog(fl_handle h, int32_t blocks, int32_t lds_bytes, int32_t usec)
+{
+    if (!h || blocks <= 0 || lds_bytes < 1024 || usec <= 0) return fail_arg(h, "fl_debug_hog: bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (!h->aux_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+    HIPCHK(h, hipFuncSetAttribute((const void *)fl_hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(fl_hog_kernel, dim3(blocks), dim3(256), (size_t)lds_bytes, h->aux_stream, (long long)usec * 100ll /* 100 MHz */,
+                       (int *)h->d_epoch + 8);
+    HIPCHK(h, hipGetLastError());
+    return FL_OK;
+}
+// out[0] multi-pass launches refused by the admission check (sent down the per-pass path), out[1] frames resumed after an
+// abandoned pass, out[2] workgroups of a multi-pass kernel the device holds at once, out[3] compute units
+int32_t fl_debug_counters(fl_handle h, int32_t *out4)
+{
+    if (!h || !out4) return fail_arg(h, "fl_debug_counters: null argument");
+    out4[0] = h->mp_fallbacks; out4[1] = h->mp_resumes; out4[2] = h->mp_capacity; out4[3] = h->num_cus;
     return FL_OK;
 }
 

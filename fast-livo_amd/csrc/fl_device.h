@@ -65,7 +65,7 @@ struct FlDev18 {
     uint32_t err_acc_epoch;          // ... and the epoch they are tagged with
     int32_t last_exact_valid;        // last_exact is the reference's float value of last_error (not the fp64-reduced one)
     float last_exact;
-    int32_t pad_e;
+    int32_t resume_count;            // passes an abandoned launch chain left undone (FL_NUM_TIMEOUT; solve18.h, fl_pass_skipped)
     // peer exchange of the sharded form (handoff.h peer_allreduce32): every rank's exchange buffer as this device addresses it
     unsigned long long *xchg_peer[8];
     unsigned *xchg_epoch;            // device word: epoch of the next exchange (same value on every rank)

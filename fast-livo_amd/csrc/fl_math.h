@@ -224,6 +224,68 @@ FL_HD int fl_point_gates(const float *pb, const float *pl /*plane n,d*/, const d
     return sel;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The selection gate as a per-point threshold.  `s > 0.9` with s = (float)(1 - 0.9*|pd2| / sqrt(|p_b|))
+// (laserMapping.cpp:1574-1576) costs two fp64 square roots and an fp64 division per point and pass, although sqrt(|p_b|)
+// depends on the body point only and the expression is monotone in |pd2|: 0.9*a rounds monotonically, so do the division
+// by a positive number, 1 - x, and the cast to float.  Hence {a >= 0 : gate(a)} is a down-set [0, T] of floats, and
+//     gate(|pd2|)  <=>  |pd2| <= T          (NaN fails both; T = -1 when even a = 0 fails: |p_b| = 0 or non-finite)
+// with T found ONCE per point (per frame) by evaluating the reference's own expression: bracket around q/9 and bisection on
+// the float's bit pattern.  The per-pass test is one float compare -- bit-identical selections by construction
+// (tests/test_lio18_gpu.py: 0 flips), ~40 fp64 instructions fewer per point and pass.
+// ------------------------------------------------------------------------------------------------
+FL_HD int fl_gate_expr(float a, double q)     // the reference's expression, verbatim
+{
+    const float s = (float)(1 - 0.9 * fabs((double)a) / q);
+    return ((double)s > 0.9) ? 1 : 0;
+}
+FL_HD float fl_bits_float(unsigned u) { union { unsigned u; float f; } c; c.u = u; return c.f; }
+FL_HD unsigned fl_float_bits(float f) { union { unsigned u; float f; } c; c.f = f; return c.u; }
+FL_HD float fl_gate_threshold(const float *pb)
+{
+    const double b0 = (double)pb[0], b1 = (double)pb[1], b2 = (double)pb[2];
+    const double pbn = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
+    const double q = sqrt(pbn);
+    if (!fl_gate_expr(0.0f, q)) return -1.0f;
+    const unsigned top = 0x7F7FFFFFu;                       // FLT_MAX
+    if (fl_gate_expr(fl_bits_float(top), q)) return fl_bits_float(top);
+    unsigned lo = 0u, hi = top;                             // gate(lo) true, gate(hi) false
+    {   // narrow the bracket around the analytic crossing a ~ q / 9 (a few ulps off at most)
+        const float est = (float)(q * (1.0 / 9.0));
+        const unsigned e = fl_float_bits(est);
+        if (e > 64u && e < top - 64u) {
+            if (fl_gate_expr(fl_bits_float(e - 64u), q)) lo = e - 64u;
+            if (!fl_gate_expr(fl_bits_float(e + 64u), q)) hi = e + 64u;
+        }
+    }
+    while (hi - lo > 1u) {
+        const unsigned mid = lo + (hi - lo) / 2u;
+        if (fl_gate_expr(fl_bits_float(mid), q)) lo = mid; else hi = mid;
+    }
+    return fl_bits_float(lo);
+}
+// fl_point_gates with the gate as a threshold (gate_T = fl_gate_threshold(pb)): same outputs, bit for bit.
+FL_HD int fl_point_gates_T(const float *pb, float gate_T, const float *pl /*plane n,d*/, const double *R /*9*/, const double *p /*3*/,
+                           const double *R_LI, const double *t_LI, double *p_i /*3 out*/, float *pw /*3 out*/, float *pd2_out, int *eff)
+{
+    const double b0 = (double)pb[0], b1 = (double)pb[1], b2 = (double)pb[2];
+    p_i[0] = (R_LI[0] * b0 + R_LI[1] * b1 + R_LI[2] * b2) + t_LI[0];
+    p_i[1] = (R_LI[3] * b0 + R_LI[4] * b1 + R_LI[5] * b2) + t_LI[1];
+    p_i[2] = (R_LI[6] * b0 + R_LI[7] * b1 + R_LI[8] * b2) + t_LI[2];
+    const double g0 = R[0] * p_i[0] + R[1] * p_i[1] + R[2] * p_i[2];
+    const double g1 = R[3] * p_i[0] + R[4] * p_i[1] + R[5] * p_i[2];
+    const double g2 = R[6] * p_i[0] + R[7] * p_i[1] + R[8] * p_i[2];
+    pw[0] = (float)(g0 + p[0]);
+    pw[1] = (float)(g1 + p[1]);
+    pw[2] = (float)(g2 + p[2]);
+    const float pd2 = pl[0] * pw[0] + pl[1] * pw[1] + pl[2] * pw[2] + pl[3];
+    *pd2_out = pd2;
+    const float a = fabsf(pd2);
+    const int sel = (a <= gate_T) ? 1 : 0;
+    *eff = (sel && (a <= 2.0f)) ? 1 : 0;
+    return sel;
+}
+
 // Mode-18 Jacobian row (src/laserMapping.cpp:1611-1629): row = [ [p_i]x R^T n , n ], z = -pd2.
 FL_HD void fl_row18(const double *p_i, const float *pl, float pd2, const double *R, double *row /*6*/, double *z)
 {

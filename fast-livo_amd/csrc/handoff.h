@@ -157,6 +157,15 @@ __device__ __forceinline__ int gather_records(const void *records, int nprod, un
 // is single-copy atomic and written through (sc1); a reader that sees the expected epoch in a word has that word's
 // payload -- no fence, no flag ordering (Guideline 16 "the data IS the flag"), and the doubles arrive bit-exact.
 #define FL_BCAST_WORDS 25
+// The words exist in FL_BCAST_REPL copies, FL_BCAST_STRIDE words apart (different memory channels): ~200 producer workgroups
+// polling ONE 200-byte region made that region's channel the hot spot of the whole hand-off; workgroup b polls copy b % REPL.
+#ifndef FL_BCAST_REPL
+#define FL_BCAST_REPL 4
+#endif
+#define FL_BCAST_STRIDE 544                 /* 4352 bytes */
+#ifndef FL_BCAST_PHASES
+#define FL_BCAST_PHASES 2
+#endif
 __device__ __forceinline__ void bcast_publish(unsigned long long *words, const double *x12 /* LDS */, int ctrl, unsigned epoch)
 {
     const int tid = threadIdx.x;
@@ -168,7 +177,10 @@ __device__ __forceinline__ void bcast_publish(unsigned long long *words, const d
         } else {
             payload = (unsigned)ctrl;
         }
-        __hip_atomic_store(words + tid, ((unsigned long long)payload << 32) | (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int r = 0; r < FL_BCAST_REPL; r++)
+            __hip_atomic_store(words + (size_t)r * FL_BCAST_STRIDE + tid, ((unsigned long long)payload << 32) | (unsigned long long)epoch, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 // Wave 0 of a producer workgroup polls (measured: letting all four waves poll with staggered phases costs more in extra
@@ -179,17 +191,34 @@ __device__ __forceinline__ void bcast_wait(const unsigned long long *words, unsi
 {
     const int tid = threadIdx.x;
     if (tid >= 64) return;
+    words += (size_t)(blockIdx.x % FL_BCAST_REPL) * FL_BCAST_STRIDE;
+    const bool mine = tid < FL_BCAST_WORDS;
+    const unsigned long long *src = words + (mine ? tid : 0);
     unsigned long long w = 0ull;
-    bool ok = tid >= FL_BCAST_WORDS;
     bool timeout = false;
+#if FL_BCAST_PHASES == 2
+    // two polls in flight, half a round trip apart: a poll answers one memory round trip (~0.6 us) after it was issued, so a
+    // single poll loop notices the words up to one round trip late; two interleaved loops halve that
+    unsigned long long wa = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_sleep(10);
+    for (int spin = 0; ; spin++) {
+        unsigned long long wb = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__ballot(!mine || (unsigned)wa == epoch) == ~0ull) { w = wa; break; }
+        wa = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__ballot(!mine || (unsigned)wb == epoch) == ~0ull) { w = wb; break; }
+        if (spin > spin_limit) { timeout = true; break; }
+    }
+#else
+    bool ok = !mine;
     for (int spin = 0; ; spin++) {
         if (!ok) {
-            w = __hip_atomic_load(words + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok = ((unsigned)w == epoch);
         }
         if (__ballot(ok) == ~0ull) break;
         if (spin > spin_limit) { timeout = true; break; }
     }
+#endif
     const unsigned payload = (unsigned)(w >> 32);
     const unsigned other = (unsigned)__shfl_xor((int)payload, 1, 64);
     if (tid < 24 && (tid & 1) == 0) out12[tid >> 1] = f64_make(payload, other);

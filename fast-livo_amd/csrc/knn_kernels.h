@@ -261,7 +261,7 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
                                                                   float *__restrict__ nbr_out /* nullable n x 15 */,
                                                                   uint8_t *__restrict__ valid_out /* nullable */, int cond)
 {
-    if ((cond & 1) && (!D->need_search || D->stop)) return;
+    if ((cond & 1) && (!D->need_search || D->stop || (D->status & 8 /* FL_NUM_TIMEOUT: abandoned chain */))) return;
     const bool stamp = (cond & 2) && threadIdx.x == 0 && blockIdx.x < 512;
     if (stamp) g_fl_wall[blockIdx.x] = (long long)wall_clock64();
     __shared__ int s_at[FL_KNN_QPB][5];
@@ -428,8 +428,9 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
     }
     float pl[4];
     const int ok = fl_esti_plane(nb, pl);
-    plane[iq] = make_float4(pl[0], pl[1], pl[2], pl[3]);
-    sel[iq] = (uint8_t)(valid && ok);
+    const bool keep = valid && ok && (pl[0] == pl[0]);
+    plane[iq] = keep ? make_float4(pl[0], pl[1], pl[2], pl[3]) : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);   // see lio_fit_planes_kernel
+    sel[iq] = (uint8_t)keep;
     if (nbr_out) {
 #pragma unroll
         for (int k = 0; k < 15; k++) nbr_out[(size_t)iq * 15 + k] = nb[k];

@@ -44,8 +44,21 @@ __global__ __launch_bounds__(FL_BLOCK) void lio_fit_planes_kernel(const float *_
     for (int k = 0; k < 15; k++) nb[k] = s_nb[threadIdx.x * 15 + k];   // stride 15 dwords: conflict-free
     float pl[4];
     const int ok = fl_esti_plane(nb, pl);
-    plane[i] = make_float4(pl[0], pl[1], pl[2], pl[3]);
-    sel[i] = (uint8_t)((valid[i] != 0) && ok);
+    const bool keep = (valid[i] != 0) && ok && (pl[0] == pl[0]);   // (a NaN normal from degenerate neighbours fails every gate of the first pass anyway)
+    // a point that is not selected carries a NaN normal: the pass kernels then need no separate read of the selection byte
+    // (n.x = NaN -> pd2 = NaN -> fails every gate), 32 instead of 33 bytes per point and pass
+    plane[i] = keep ? make_float4(pl[0], pl[1], pl[2], pl[3]) : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
+    sel[i] = (uint8_t)keep;
+}
+
+// Per-frame, per-point gate threshold (fl_math.h: fl_gate_threshold): depends on the body point only.
+// Written as (x, y, z, T): a pass then fetches a point with ONE 16-byte load instead of three 4-byte loads at stride 12.
+__global__ __launch_bounds__(FL_BLOCK) void lio_gate_kernel(const float *__restrict__ body, float4 *__restrict__ body4, int n)
+{
+    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float pb[3] = {body[i * 3], body[i * 3 + 1], body[i * 3 + 2]};
+    body4[i] = make_float4(pb[0], pb[1], pb[2], fl_gate_threshold(pb));
 }
 
 // Per-frame prepare: Q and T of fl_math.h (depends on P and the measurement covariance only). One workgroup of
@@ -88,10 +101,30 @@ __global__ __launch_bounds__(128) void eskf18_prepare_kernel(FlDev18 *__restrict
     if (t == 0) D->status = s_st[0] | s_st[1] | s_st[2] | s_st[3] | s_st[4] | s_st[5];
 }
 
+// A multi-pass launch tells the host that its workgroups are gone (admission check of fastlivo_hip.hip): one system-scope
+// store of the launch's sequence number into a pinned host word, by the solver workgroup as its last action.
+__device__ __forceinline__ void fl_mp_done(unsigned *done_word, unsigned seq, bool solver_wg)
+{
+    if (solver_wg && threadIdx.x == 0 && done_word) __hip_atomic_store(done_word, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Is this launch a no-op?  (a) an earlier pass of the enqueued chain was ABANDONED (hand-off time-out, solve18.h): nothing runs
+// until the host has resumed the frame, and the launch adds the passes it would have run to D->resume_count so that the host
+// knows how much is left; (b) the filter stopped or waits for a search (not under FL_ITER_FORCE). Uniform over the grid.
+__device__ __forceinline__ bool fl_pass_skipped(FlDev18 *__restrict__ D, int flags, int passes, bool counter_thread)
+{
+    if (D->status & FL_NUM_TIMEOUT) {
+        if (counter_thread) D->resume_count += passes;
+        return true;
+    }
+    return !(flags & FL_ITER_FORCE) && (D->stop || (D->need_search && D->searched_at != D->iters_run));
+}
+
 // -------------------------------------------------------------------------------------------- K1
 // grid = producers + 1 ; MODE 0: fused pass ; MODE 1: accumulate only (sums -> sums_out)
 template <int MODE>
-__global__ __launch_bounds__(FL_LIO_NT) void lio18_pass_kernel(const float *__restrict__ body, const float4 *__restrict__ plane,
+__global__ __launch_bounds__(FL_LIO_NT) void lio18_pass_kernel(const float4 *__restrict__ body4,
+                                                              float4 *__restrict__ plane,
                                                               uint8_t *__restrict__ sel, float4 *__restrict__ normvec, int n,
                                                               FlDev18 *__restrict__ D, void *__restrict__ records,
                                                               unsigned *__restrict__ epoch_ptr, double *__restrict__ sums_out,
@@ -105,17 +138,15 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_pass_kernel(const float *__re
     // round trip instead of two on the producers' critical path (harmless if the pass is a no-op).
     const int i_first = blockIdx.x * NT + threadIdx.x;
     const bool have_first = (blockIdx.x != nprod) && (i_first < n);
-    uint8_t pf_sel = 0;
-    float pf_b0 = 0.f, pf_b1 = 0.f, pf_b2 = 0.f;
+    float4 pf_b = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 pf_pl = make_float4(0.f, 0.f, 0.f, 0.f);
     if (have_first) {
-        pf_sel = sel[i_first];
-        pf_b0 = body[i_first * 3 + 0]; pf_b1 = body[i_first * 3 + 1]; pf_b2 = body[i_first * 3 + 2];
+        pf_b = body4[i_first];
         pf_pl = plane[i_first];
     }
     double pf_solver = 0.0;
     if (MODE == 0 && blockIdx.x == nprod) pf_solver = eskf18_prefetch_issue(D);
-    if (!(flags & FL_ITER_FORCE) && (D->stop || (D->need_search && D->searched_at != D->iters_run))) return;
+    if (fl_pass_skipped(D, flags, 1, blockIdx.x == 0 && threadIdx.x == 0)) return;
     const unsigned epoch = *epoch_ptr;
 
     if (blockIdx.x == nprod) {
@@ -124,7 +155,8 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_pass_kernel(const float *__re
         __shared__ double s_sums[FL_SUMS18];
         __shared__ FlSolveLds s_solve;
         fl_stamp(flags, 8);
-        if (MODE == 0) eskf18_prefetch_commit(pf_solver, s_solve);
+        FlSolveRegs G;
+        if (MODE == 0) { eskf18_prefetch_commit(pf_solver, s_solve); eskf18_load_regs(s_solve, G); }
         fl_stamp(flags, 9);
         int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
         fl_stamp(flags, 10);
@@ -137,7 +169,7 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_pass_kernel(const float *__re
             if (threadIdx.x == 0) *D->xchg_epoch = xe + 1u;
         }
         if (MODE == 0) {
-            eskf18_solve_block<FL_EPI_LIO>(D, s_sums, s_solve, gst);
+            eskf18_solve_block<FL_EPI_LIO>(D, s_sums, s_solve, G, gst);
         } else {
             if (threadIdx.x < FL_SUMS18) sums_out[threadIdx.x] = s_sums[threadIdx.x];
         }
@@ -162,22 +194,21 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_pass_kernel(const float *__re
     // point's ~150 fp64 instructions, so that with several points per lane (n > 65 k) the loop is bound by issue/HBM, not by
     // one memory round trip per point
     for (int i = i_first; i < n; i += nprod * NT) {
-        const uint8_t c_sel = pf_sel;
-        const float pb[3] = {pf_b0, pf_b1, pf_b2};
+        const float pb[3] = {pf_b.x, pf_b.y, pf_b.z};
+        const float c_gate = pf_b.w;
         const float4 plq = pf_pl;
         const int inext = i + nprod * NT;
         if (inext < n) {
-            pf_sel = sel[inext];
-            pf_b0 = body[inext * 3 + 0]; pf_b1 = body[inext * 3 + 1]; pf_b2 = body[inext * 3 + 2];
+            pf_b = body4[inext];
             pf_pl = plane[inext];
         }
-        if (!c_sel) continue;
+        if (!(plq.x == plq.x)) continue;          // not selected (NaN normal, see lio_fit_planes_kernel)
         const float pl[4] = {plq.x, plq.y, plq.z, plq.w};
         double p_i[3];
         float pw[3], pd2;
         int eff;
-        const int s = fl_point_gates(pb, pl, R, p, RLI, tLI, p_i, pw, &pd2, &eff);
-        if (!s) sel[i] = 0;
+        const int s = fl_point_gates_T(pb, c_gate, pl, R, p, RLI, tLI, p_i, pw, &pd2, &eff);
+        if (!s) { sel[i] = 0; plane[i].x = __builtin_nanf(""); }
         if ((flags & FL_ITER_KEEP_NORMVEC) && s) normvec[i] = make_float4(pl[0], pl[1], pl[2], pd2);
         if (eff) {
             double row[6], z;
@@ -203,16 +234,20 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_pass_kernel(const float *__re
 // pose and are issued before the wait. Requires every workgroup co-resident: the host uses it only for grids <= 256
 // workgroups (<= 1 per CU) and falls back to one launch per pass otherwise; every spin is bounded.
 // Arithmetic per pass is that of lio18_pass_kernel<0>: states are bit-identical.
-__global__ __launch_bounds__(FL_LIO_NT) void lio18_multipass_kernel(const float *__restrict__ body, const float4 *__restrict__ plane,
+__global__ __launch_bounds__(FL_LIO_NT, 2) void lio18_multipass_kernel(const float4 *__restrict__ body4,
+                                                                   float4 *__restrict__ plane,
                                                                    uint8_t *__restrict__ sel, float4 *__restrict__ normvec, int n,
                                                                    FlDev18 *__restrict__ D, void *__restrict__ records,
                                                                    unsigned *__restrict__ epoch_ptr, unsigned long long *__restrict__ bcast,
-                                                                   int count, int flags)
+                                                                   int count, int flags, unsigned *__restrict__ done_word, unsigned done_seq)
 {
     constexpr int NT = FL_LIO_NT;
     const int nprod = gridDim.x - 1;
     const bool force = (flags & FL_ITER_FORCE) != 0;
-    if (!force && (D->stop || (D->need_search && D->searched_at != D->iters_run))) return;
+    if (fl_pass_skipped(D, flags, count, blockIdx.x == 0 && threadIdx.x == 0)) {
+        fl_mp_done(done_word, done_seq, blockIdx.x == nprod);
+        return;
+    }
     const unsigned epoch0 = *epoch_ptr;
 
     if (blockIdx.x == nprod) {
@@ -228,24 +263,30 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_multipass_kernel(const float 
         int done = 0;
         for (int p = 0; p < count; p++) {
             const unsigned epoch = epoch0 + (unsigned)p;
+            FlSolveRegs G;
+            eskf18_load_regs(s_solve, G);                        // solve operands into wave 0's registers while the producers work
             if (p == 5) fl_stamp(flags, 16);
             int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
             if (PV.world > 1) gst |= peer_allreduce32(PV, xe0 + (unsigned)p, s_sums, s_xchg);      // sharded form: totals over the ranks
             if (p == 5) fl_stamp(flags, 17);
-            eskf18_solve_block<FL_EPI_LIO>(D, s_sums, s_solve, gst, bcast, epoch + 1u);   // publishes pose + control word
+            eskf18_solve_block<FL_EPI_LIO>(D, s_sums, s_solve, G, gst, bcast, epoch + 1u, FlVioExact{}, nullptr, (p == 5) ? (flags & FL_ITER_STAMP) : 0);   // wave 0 publishes pose + control word
+            if (p == 5) fl_stamp(flags, 35);
             __syncthreads();
             if (p == 5) fl_stamp(flags, 18);
             done = p + 1;
-            const int ctrl = s_solve.ctrl;                       // bit 2: a gather timeout ends the launch
+            const int ctrl = s_solve.ctrl;                       // bit 2: a hand-off time-out abandoned the pass and ends the launch
+            if (ctrl & 4) {
+                if (threadIdx.x == 0) D->resume_count = count - p;      // this pass and the ones behind it are still to do
+                break;
+            }
             if (!force && (ctrl & 3)) break;
-            if (ctrl & 4) break;
             if (p + 1 < count) eskf18_restage(s_solve);
-            __syncthreads();
         }
         if (threadIdx.x == 0) {
             *epoch_ptr = epoch0 + (unsigned)done;
             if (PV.world > 1) *D->xchg_epoch = xe0 + (unsigned)done;
         }
+        fl_mp_done(done_word, done_seq, true);     // the solver leaves last: every producer has left its last wait by now
         return;
     }
 
@@ -264,12 +305,10 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_multipass_kernel(const float 
     for (int ps = 0; ps < count; ps++) {
         const unsigned epoch = epoch0 + (unsigned)ps;
         // this pass's first point: loads issued before the wait for the pose
-        uint8_t pf_sel = 0;
-        float pf_b0 = 0.f, pf_b1 = 0.f, pf_b2 = 0.f;
+            float4 pf_b = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 pf_pl = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i_first < n) {
-            pf_sel = sel[i_first];
-            pf_b0 = body[i_first * 3 + 0]; pf_b1 = body[i_first * 3 + 1]; pf_b2 = body[i_first * 3 + 2];
+                pf_b = body4[i_first];
             pf_pl = plane[i_first];
         }
         if (ps > 0) {
@@ -289,22 +328,21 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_multipass_kernel(const float 
         for (int k = 0; k < FL_SUMS18; k++) v[k] = 0.0;
         // rolling software prefetch as in lio18_pass_kernel
         for (int i = i_first; i < n; i += nprod * NT) {
-            const uint8_t c_sel = pf_sel;
-            const float pb[3] = {pf_b0, pf_b1, pf_b2};
+                const float pb[3] = {pf_b.x, pf_b.y, pf_b.z};
+            const float c_gate = pf_b.w;
             const float4 plq = pf_pl;
             const int inext = i + nprod * NT;
             if (inext < n) {
-                pf_sel = sel[inext];
-                pf_b0 = body[inext * 3 + 0]; pf_b1 = body[inext * 3 + 1]; pf_b2 = body[inext * 3 + 2];
+                    pf_b = body4[inext];
                 pf_pl = plane[inext];
             }
-            if (!c_sel) continue;
+            if (!(plq.x == plq.x)) continue;          // not selected (NaN normal, see lio_fit_planes_kernel)
             const float pl[4] = {plq.x, plq.y, plq.z, plq.w};
             double p_i[3];
             float pw[3], pd2;
             int eff;
-            const int s = fl_point_gates(pb, pl, R, p, RLI, tLI, p_i, pw, &pd2, &eff);
-            if (!s) sel[i] = 0;
+            const int s = fl_point_gates_T(pb, c_gate, pl, R, p, RLI, tLI, p_i, pw, &pd2, &eff);
+            if (!s) { sel[i] = 0; plane[i].x = __builtin_nanf(""); }
             if ((flags & FL_ITER_KEEP_NORMVEC) && s) normvec[i] = make_float4(pl[0], pl[1], pl[2], pd2);
             if (eff) {
                 double row[6], z;
@@ -325,24 +363,19 @@ __global__ __launch_bounds__(FL_LIO_NT) void lio18_multipass_kernel(const float 
 
 // -------------------------------------------------------------------------------------------- K3
 // Solve from an externally reduced record (sharded form). vio != 0 selects the VIO epilogue.
-struct FlVioConst;
-__device__ __forceinline__ void vio_derive_pose(const double *xn, const FlVioConst *__restrict__ VC, FlDev18 *__restrict__ D);
 __global__ __launch_bounds__(FL_BLOCK) void eskf18_solve_kernel(FlDev18 *__restrict__ D, const double *__restrict__ sums_in,
                                                                int vio, int flags, const FlVioConst *__restrict__ VC)
 {
+    if (D->status & FL_NUM_TIMEOUT) return;
     if (!(flags & FL_ITER_FORCE) && (D->stop || (!vio && D->need_search && D->searched_at != D->iters_run))) return;
     __shared__ double s_sums[FL_SUMS18];
     __shared__ FlSolveLds s_solve;
     if (threadIdx.x < FL_SUMS18) s_sums[threadIdx.x] = sums_in[threadIdx.x];
     eskf18_prefetch(D, s_solve);
-    __syncthreads();
-    if (vio) {
-        eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, 0);
-        __syncthreads();
-        vio_derive_pose(s_solve.xn, VC, D);
-    } else {
-        eskf18_solve_block<FL_EPI_LIO>(D, s_sums, s_solve, 0);
-    }
+    FlSolveRegs G;
+    eskf18_load_regs(s_solve, G, vio ? VC : nullptr);
+    if (vio) eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, 0, nullptr, 0u, FlVioExact{}, VC);   // incl. the derived camera pose
+    else eskf18_solve_block<FL_EPI_LIO>(D, s_sums, s_solve, G, 0);
 }
 
 // -------------------------------------------------------------------------------------------- K4
@@ -352,6 +385,7 @@ __global__ __launch_bounds__(384) void eskf18_cov_update_kernel(FlDev18 *__restr
     __shared__ double sP[324];
     __shared__ double sG[108];
     const int t = threadIdx.x;
+    if (D->status & FL_NUM_TIMEOUT) return;          // abandoned frame: the host resumes it and enqueues this kernel again
     if (t < 324) sP[t] = D->P[t];
     if (t == 0) {
         double G6[108];

@@ -4,14 +4,21 @@
 // Math (fl_math.h, fast form):  C = Q + S (SPD 6x6),  z = C^-1 (sign*HTz - S vec6),
 //       delta = T z + vec,  x (+)= delta, then the rematch/stop judgement (LIO,
 //       laserMapping.cpp:1688-1728) or the accept/revert bookkeeping (VIO, lidar_selection.cpp:857-899).
-// Latency is what matters (one workgroup on the critical path of every pass), so
-//   * everything that depends only on the incoming state is done BEFORE the records arrive, while
-//     the producers are still working: Q, T, x, x_prop staged in LDS, vec = x_prop (-) x including
-//     the SO(3) Log;
-//   * after the gather the independent chains run on different wavefronts:
-//       wave 0: LDL^T of C in registers, rhs, triangular solves; lanes 0..17: delta_r = vec_r + T_r.z
-//       then wave 0 lanes 0..8: one element each of R*Exp(delta_rot) || wave 1: additive states ||
-//       wave 2: judgement.
+// Latency is what matters (one workgroup on the critical path of every pass). Round-2 form:
+//   * everything that depends only on the incoming state is done BEFORE the records arrive, while the producers are
+//     still working: Q, T, x, x_prop staged in LDS, vec = x_prop (-) x including the SO(3) Log, and then -- new --
+//     the per-lane operands of the solve are pulled into the REGISTERS of wavefront 0 (FlSolveRegs: row r of T / vec_r /
+//     x_r in lane r);
+//   * after the gather, wavefront 0 alone runs the whole chain without a single workgroup barrier: C = Q + S and the
+//     right-hand side as a 7th row, right-looking LDL^T with reciprocal + two Newton steps instead of six IEEE
+//     divisions (the forward substitution falls out of the same elimination), back substitution, delta_r in lane r,
+//     rotation update R * Exp(delta) from the power series of sin(t)/t and (1-cos t)/t^2 in t^2 (no sqrt, no division,
+//     no sin/cos), additive states, judgement, the pose words of the multi-pass broadcast -- every lane that forms a
+//     result stores/publishes it itself. The other wavefronts only write side outputs (sums). The previous form spent
+//     ~2 us here (three barriers, 6 divisions, sqrt + sin + cos, LDS round trips): DESIGN.md section 4.1.
+//   * a pass whose hand-off timed out (gather or peer exchange) is ABANDONED: the state does not move, FL_NUM_TIMEOUT
+//     becomes sticky in D->status, every later kernel of the enqueued chain sees it and does nothing, and the host re-runs the remaining passes
+//     (fastlivo_hip.hip: resume_after_timeout). Status bits are sticky on the device between fl_*_begin and the read-back.
 #pragma once
 
 #include "fl_device.h"
@@ -27,8 +34,10 @@ struct FlSolveLds {
     double delta[18];
     double xn[12];      // rotation (9) and position (3) after the pass: input of the VIO derived pose
     double xadd[15];    // the additive states (pos, vel, bg, ba, grav) after the pass (multi-pass kernels restage from LDS)
-    int ctrl;           // multi-pass kernels: bit0 stop, bit1 search wanted (written by the judging lane)
+    double cam[12];     // VIO: derived camera pose (Rcw, Pcw) of the state after the pass
+    int ctrl;           // bit0 stop, bit1 search wanted, bit2 abandoned (written by wavefront 0)
     int fragile;        // VIO: sticky FL_NUM_FRAGILE (16) once an accept test was decided within float-rounding distance
+    int sticky;         // status bits accumulated since fl_*_begin (mirror of D->status)
     // VIO exact accept test (see eskf18_solve_block): mirrors of the FlDev18 fields, kept across the passes of a multi-pass launch
     int need_exact, acc_buf, last_exact_valid, exact_timeout;
     unsigned acc_epoch;
@@ -90,6 +99,28 @@ __device__ __forceinline__ float vio_exact_sum(const unsigned long long *w, int 
     return f;
 }
 
+// vec = x_prop (-) x: additive part by wave 1, Log(R^T R_prop) (common_lib.h:354-358, so3_math.h:75-81) by one lane of wave 2.
+__device__ __forceinline__ void eskf18_form_vec(FlSolveLds &L)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    if (wave == 1) {
+        if (lane < 15) L.vec[3 + lane] = L.xp[9 + lane] - L.x[9 + lane];
+    } else if (wave == 2 && lane == 0) {
+        double rd[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) rd[i * 3 + j] = L.x[0 * 3 + i] * L.xp[0 * 3 + j] + L.x[1 * 3 + i] * L.xp[1 * 3 + j] + L.x[2 * 3 + i] * L.xp[2 * 3 + j];
+        const double tr = rd[0] + rd[4] + rd[8];
+        const double theta = (tr > 3.0 - 1e-6) ? 0.0 : acos(0.5 * (tr - 1));
+        const double fk = (fabs(theta) < 0.001) ? 0.5 : (0.5 * theta / sin(theta));
+        L.vec[0] = fk * (rd[7] - rd[5]);
+        L.vec[1] = fk * (rd[2] - rd[6]);
+        L.vec[2] = fk * (rd[3] - rd[1]);
+    }
+}
+
 // Stage 0 (before the gather): stage the solve inputs in LDS and form vec = x_prop (-) x.
 // Split in two so that the loads can be issued before the kernel's control-word round trip.
 __device__ __forceinline__ double eskf18_prefetch_issue(const FlDev18 *__restrict__ D)
@@ -106,7 +137,7 @@ __device__ __forceinline__ double eskf18_prefetch_issue(const FlDev18 *__restric
     else if (tid == 195) v = (double)D->max_iter;
     else if (tid == 196) v = (double)D->iters_run;
     else if (tid == 197) v = (double)D->accepted;
-    else if (tid == 198) v = (double)(D->status & 16);
+    else if (tid == 198) v = (double)D->status;
     else if (tid == 199) v = (double)D->err_acc_buf;
     else if (tid == 200) v = (double)D->err_acc_epoch;
     else if (tid == 201) v = (double)D->last_exact_valid;
@@ -126,54 +157,149 @@ __device__ __forceinline__ void eskf18_prefetch_commit(double v, FlSolveLds &L)
     else if (tid == 195) L.max_iter = (int)v;
     else if (tid == 196) L.iters_run = (int)v;
     else if (tid == 197) L.accepted = (int)v;
-    else if (tid == 198) L.fragile = (int)v;
+    else if (tid == 198) { L.sticky = (int)v; L.fragile = (int)v & 16; }
     else if (tid == 199) L.acc_buf = (int)v;
     else if (tid == 200) L.acc_epoch = (unsigned)v;
     else if (tid == 201) L.last_exact_valid = (int)v;
     else if (tid == 202) L.last_exact = (float)v;
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
-    if (wave == 1) {
-        if (lane < 15) L.vec[3 + lane] = L.xp[9 + lane] - L.x[9 + lane];
-    } else if (wave == 2 && lane == 0) {
-        // Log(R^T R_prop), common_lib.h:354-358, so3_math.h:75-81
-        double rd[9];
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) rd[i * 3 + j] = L.x[0 * 3 + i] * L.xp[0 * 3 + j] + L.x[1 * 3 + i] * L.xp[1 * 3 + j] + L.x[2 * 3 + i] * L.xp[2 * 3 + j];
-        const double tr = rd[0] + rd[4] + rd[8];
-        const double theta = (tr > 3.0 - 1e-6) ? 0.0 : acos(0.5 * (tr - 1));
-        const double fk = (fabs(theta) < 0.001) ? 0.5 : (0.5 * theta / sin(theta));
-        L.vec[0] = fk * (rd[7] - rd[5]);
-        L.vec[1] = fk * (rd[2] - rd[6]);
-        L.vec[2] = fk * (rd[3] - rd[1]);
-    }
-    // visibility of L.vec to wave 0 is ensured by the __syncthreads inside the gather / before the solve
+    eskf18_form_vec(L);
+    __syncthreads();
 }
 __device__ __forceinline__ void eskf18_prefetch(const FlDev18 *__restrict__ D, FlSolveLds &L)
 {
     eskf18_prefetch_commit(eskf18_prefetch_issue(D), L);
 }
 
-// Solve + state update + judgement. All threads of the workgroup call it (NT >= 256); s_sums in LDS.
-// FMA contraction is allowed here (compared to the oracle by tolerance, never bitwise).
-// bcast != nullptr (multi-pass kernels): the lanes that form the new pose publish it themselves the moment it exists
-// (self-validating words of handoff.h, tagged bepoch), the judging lane publishes the control word.
+// Operands of the solve in the registers of wavefront 0 (other wavefronts load them too -- cheap -- and never use them).
+// Loaded after eskf18_prefetch_commit / eskf18_restage, i.e. BEFORE the gather, and live across it.
+struct FlSolveRegs {
+    double trow[6];     // lane r < 18: row r of T
+    double vecr;        // lane r < 18: vec[r]
+    double xl;          // lane l < 24: x[l]
+    double rrow[3];     // lane l < 9 : row (l / 3) of R
+    float last_error;   // VIO: last_error as it stands BEFORE this pass
+    double rci[3], pci; // VIO, lane t < 12: the row of Rci (and the element of Pci) its camera-pose element needs (vio_cam_element)
+};
+__device__ __forceinline__ constexpr int fl_tri(int i, int j) { return i * (i + 1) / 2 + j; }   // j <= i
+__device__ __forceinline__ void eskf18_load_regs(const FlSolveLds &L, FlSolveRegs &G, const FlVioConst *__restrict__ VC = nullptr)
+{
+    const int lane = threadIdx.x & 63;
+    G.rci[0] = G.rci[1] = G.rci[2] = 0.0; G.pci = 0.0;
+    if (VC) {
+        const int t = lane < 12 ? lane : 0;
+        const int i = t < 9 ? t / 3 : t - 9;
+#pragma unroll
+        for (int k = 0; k < 3; k++) G.rci[k] = VC->Rci[i * 3 + k];
+        G.pci = VC->Pci[i];
+    }
+    const int r = lane < 18 ? lane : 0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) G.trow[c] = L.T[r * 6 + c];
+    G.vecr = L.vec[r];
+    G.xl = L.x[lane < 24 ? lane : 0];
+    const int ri = lane < 9 ? lane / 3 : 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) G.rrow[k] = L.x[ri * 3 + k];
+    G.last_error = L.last_error;
+}
+
 __device__ __forceinline__ void fl_bcast_store(unsigned long long *bcast, int idx, double v, unsigned bepoch)
 {
-    __hip_atomic_store(bcast + 2 * idx, ((unsigned long long)f64_lo(v) << 32) | (unsigned long long)bepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(bcast + 2 * idx + 1, ((unsigned long long)f64_hi(v) << 32) | (unsigned long long)bepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long lo = ((unsigned long long)f64_lo(v) << 32) | (unsigned long long)bepoch;
+    const unsigned long long hi = ((unsigned long long)f64_hi(v) << 32) | (unsigned long long)bepoch;
+#pragma unroll
+    for (int r = 0; r < FL_BCAST_REPL; r++) {          // every copy (handoff.h): workgroup b polls copy b % FL_BCAST_REPL
+        __hip_atomic_store(bcast + (size_t)r * FL_BCAST_STRIDE + 2 * idx, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(bcast + (size_t)r * FL_BCAST_STRIDE + 2 * idx + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
-template <int KIND>
-__device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, const double *s_sums, FlSolveLds &L, int gather_status,
-                                                   unsigned long long *bcast = nullptr, unsigned bepoch = 0u, const FlVioExact ex = FlVioExact{})
+__device__ __forceinline__ void fl_bcast_ctrl(unsigned long long *bcast, int ctrl, unsigned bepoch)
+{
+#pragma unroll
+    for (int r = 0; r < FL_BCAST_REPL; r++)
+        __hip_atomic_store(bcast + (size_t)r * FL_BCAST_STRIDE + 24, ((unsigned long long)(unsigned)ctrl << 32) | (unsigned long long)bepoch, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Reciprocal for the pivots: v_rcp_f64 + two Newton steps (relative error ~1e-16; the solve is compared by tolerance).
+__device__ __forceinline__ double fl_rcp_nr(double d)
 {
 #pragma clang fp contract(fast)
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    return r;
+}
+// value of a wave-0 lane in every lane
+__device__ __forceinline__ double fl_lane_bcast(double v, int src)
+{
+    const unsigned lo = __builtin_amdgcn_readlane(f64_lo(v), src);
+    const unsigned hi = __builtin_amdgcn_readlane(f64_hi(v), src);
+    return f64_make(lo, hi);
+}
+// `sqrt(t2) * k < thr` decided on t2 (no sqrt) unless t2 is within rounding distance of the boundary, where the exact expression runs
+#define FL_NORM_BELOW(t2, k, thr) fl_norm_below_impl((t2), (k), (thr), ((thr) / (k)) * ((thr) / (k)), 1e-12 * (((thr) / (k)) * ((thr) / (k))))
+__device__ __forceinline__ bool fl_norm_below_impl(double t2, double k, double thr, const double b /* compile-time */, const double band)
+{
+#pragma clang fp contract(off)
+    if (fabs(t2 - b) > band) return t2 < b;
+    asm volatile("" : "+v"(t2));          // keeps the compiler from speculating the (long) sqrt expansion into the common path
+    return sqrt(t2) * k < thr;
+}
+
+// camera pose element `t` (0..8: Rcw, 9..11: Pcw) of the state xn = {rot(9), pos(3)}: Rcw = Rci Rwi^T, Pcw = -Rci Rwi^T Pwi + Pci
+// (lidar_selection.cpp:780-784) in exactly the reference's operation order (it feeds the float sub-pixel weights).
+__device__ __forceinline__ double vio_cam_element(int t, const double *xn, const double (&rci)[3], double pci)
+{
+#pragma clang fp contract(off)
+    if (t < 9) {
+        const int j = t % 3;              // Rcw[i][j] = sum_k Rci[i][k] * Rwi[j][k]
+        return rci[0] * xn[j * 3 + 0] + rci[1] * xn[j * 3 + 1] + rci[2] * xn[j * 3 + 2];
+    }
+    double T[3];                          // T = (-Rci) Rwi^T ; Pcw = T Pwi + Pci
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        T[j] = (-rci[0]) * xn[j * 3 + 0] + (-rci[1]) * xn[j * 3 + 1] + (-rci[2]) * xn[j * 3 + 2];
+    return (T[0] * xn[9] + T[1] * xn[10] + T[2] * xn[11]) + pci;
+}
+
+// Solve + state update + judgement. All threads of the workgroup call it (NT >= 256); s_sums in LDS (complete: the gather
+// ends with a barrier). G: eskf18_load_regs of THIS pass. FMA contraction is allowed in the solve (compared to the oracle by
+// tolerance, never bitwise). bcast != nullptr (multi-pass kernels): wavefront 0 publishes the pose for the producers' next pass
+// (LIO: R, p; VIO: the derived Rcw, Pcw) and the control word as self-validating words tagged bepoch.
+// On return (after the CALLER's __syncthreads) L.ctrl, L.xn, L.xadd, L.cam are valid for everybody.
+template <int KIND>
+__device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, const double *s_sums, FlSolveLds &L, const FlSolveRegs &G,
+                                                   int gather_status, unsigned long long *bcast = nullptr, unsigned bepoch = 0u,
+                                                   const FlVioExact ex = FlVioExact{}, const FlVioConst *__restrict__ VC = nullptr, int dbg = 0)
+{
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const double sign = (KIND == FL_EPI_VIO) ? -1.0 : 1.0;
 
+    // ---- a hand-off timed out: abandon the pass. Nothing of the state moves; the launch chain ends (stop), the host resumes.
+    if (gather_status) {
+        if (wave == 0) {
+            if (lane < 12) {
+                L.xn[lane] = L.x[lane];
+                if (bcast) fl_bcast_store(bcast, lane, (KIND == FL_EPI_VIO) ? ((lane < 9) ? D->Rcw[lane] : D->Pcw[lane - 9]) : L.x[lane], bepoch);
+            }
+            if (lane >= 9 && lane < 24) L.xadd[lane - 9] = L.x[lane];
+            if (lane == 0) {
+                L.sticky |= FL_NUM_TIMEOUT;
+                D->status = L.sticky;                 // every kernel of the chain checks this bit first: nothing else runs (D->stop stays as it is)
+                L.ctrl = 1 | 4;
+                if (bcast) fl_bcast_ctrl(bcast, 1 | 4, bepoch);
+            }
+        }
+        return;
+    }
+
+    if (wave == 3 && lane < FL_SUMS18) D->sums[lane] = s_sums[lane];
+
+    bool slow = false, need_exact = false;
     if (KIND == FL_EPI_VIO) {
         // error = sum(res^2) / n_meas ; accept iff error <= last_error (lidar_selection.cpp:857-861).
         // The reference forms `error` as a FLOAT running sum: per patch `patch_error += res*res` over its 64 pixels, then
@@ -184,34 +310,20 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
         // over those per-patch floats -- m dependent float additions by one lane, ~5 us, only on such passes -- for this pass and, if
         // not known yet, for the last accepted one, and decides on the reference's own float values (status bit 16 reports that the
         // slow path ran). Without the per-patch words (sharded solve kernel: `ex` == nullptr) bit 16 means "may differ".
+        // Every thread evaluates the trigger itself from pass-invariant inputs (G.last_error was read before the gather), so the
+        // common case needs no barrier.
         const bool can_replay = ex.words != nullptr && ex.enabled;     // (by value: a nullable pointer to it kept the struct in scratch)
-        auto decide = [&](bool exact) {          // thread 0 only
-            const float error = exact ? L.exact_cur : (float)s_sums[FL_S_RES] / (float)s_sums[FL_S_NEFF];
-            const float last = exact ? L.last_exact : L.last_error;
-            const int acc = (error <= last) ? 1 : 0;
-            if (L.need_exact) L.fragile = 16;
-            L.accept = acc;
-            D->error = error;
-            if (acc) {
-                D->last_error = error; L.last_error = error;
-                L.acc_buf = L.iters_run & 1; L.acc_epoch = ex.epoch;
-                L.last_exact_valid = exact ? 1 : 0; L.last_exact = error;
-                D->err_acc_buf = L.acc_buf; D->err_acc_epoch = L.acc_epoch; D->last_exact_valid = L.last_exact_valid; D->last_exact = error;
-            }
-        };
-        if (tid == 0) {
-            const float n_meas = (float)s_sums[FL_S_NEFF];
-            const float error = (float)s_sums[FL_S_RES] / n_meas;
-            const float last = L.last_error;
-            // worst-case distance between this fp64-reduced value and the reference's float running sum, for both operands:
-            // m additions of at most half an ulp each, plus the casts and the division
-            const float thr = (n_meas * (1.0f / 64.0f) + 8.0f) * 5.9604645e-8f;
-            L.need_exact = (last < 1e9f && fabsf(error - last) <= thr * fabsf(error)) ? 1 : 0;
-            L.exact_timeout = 0;
-            if (!(L.need_exact && can_replay)) decide(false);       // the common case: one barrier, as before
-        }
-        __syncthreads();
-        if (L.need_exact && can_replay) {
+        const float n_meas = (float)s_sums[FL_S_NEFF];
+        const float error = (float)s_sums[FL_S_RES] / n_meas;
+        const float last = G.last_error;
+        // worst-case distance between this fp64-reduced value and the reference's float running sum, for both operands:
+        // m additions of at most half an ulp each, plus the casts and the division
+        const float thr = (n_meas * (1.0f / 64.0f) + 8.0f) * 5.9604645e-8f;
+        need_exact = (last < 1e9f && fabsf(error - last) <= thr * fabsf(error));
+        slow = need_exact && can_replay;
+        if (slow && tid == 0) L.exact_timeout = 0;
+        if (slow) {      // uniform over the workgroup
+            __syncthreads();
             const int cur_buf = L.iters_run & 1;
             const float fc = vio_exact_sum(ex.words + (size_t)cur_buf * ex.cap, ex.m, ex.epoch, ex.scratch, &L.exact_timeout);
             if (tid == 0) L.exact_cur = fc / (float)(64 * ex.m);
@@ -220,181 +332,265 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
                 if (tid == 0) { L.last_exact = fl / (float)(64 * ex.m); L.last_exact_valid = 1; }
             }
             __syncthreads();
-            if (tid == 0) decide(!L.exact_timeout && L.last_exact_valid);
-            __syncthreads();
         }
-        if (!L.accept) {   // revert: state = old_state ; EKF_end (:888-892)
-            if (tid < 24) {
-                const double xo = D->xold[tid];
-                D->x[tid] = xo;
-                if (tid < 12) L.xn[tid] = xo;
-                if (tid >= 9) L.xadd[tid - 9] = xo;
+    }
+    if (wave != 0) return;
+
+    // =========================================================================== wavefront 0 from here on, no workgroup barrier
+    int accept = 1;
+    if (KIND == FL_EPI_VIO) {
+        const float n_meas = (float)s_sums[FL_S_NEFF];
+        const float e_fast = (float)s_sums[FL_S_RES] / n_meas;
+        const bool exact = slow && !L.exact_timeout && L.last_exact_valid;
+        const float error = exact ? L.exact_cur : e_fast;
+        const float last = exact ? L.last_exact : G.last_error;
+        accept = (error <= last) ? 1 : 0;
+        __builtin_amdgcn_wave_barrier();           // every lane has read the fields lane 0 rewrites below
+        if (lane == 0) {
+            if (need_exact) L.fragile = 16;
+            L.accept = accept;
+            D->error = error;
+            if (accept) {
+                D->last_error = error; L.last_error = error;
+                L.acc_buf = L.iters_run & 1; L.acc_epoch = ex.epoch;
+                L.last_exact_valid = exact ? 1 : 0; L.last_exact = error;
+                D->err_acc_buf = L.acc_buf; D->err_acc_epoch = L.acc_epoch; D->last_exact_valid = L.last_exact_valid; D->last_exact = error;
             }
-            if (tid == 64) {
-                L.iters_run = L.iters_run + 1;
-                D->iters_run = L.iters_run;
+        }
+        if (!accept) {   // revert: state = old_state ; EKF_end (:888-892)
+            double xo = 0.0;
+            if (lane < 24) {
+                xo = D->xold[lane];
+                D->x[lane] = xo;
+                if (lane < 12) L.xn[lane] = xo;
+                if (lane >= 9) L.xadd[lane - 9] = xo;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (VC && lane < 12) {
+                const double ce = vio_cam_element(lane, L.xn, G.rci, G.pci);
+                if (lane < 9) D->Rcw[lane] = ce; else D->Pcw[lane - 9] = ce;
+                L.cam[lane] = ce;
+                if (bcast) fl_bcast_store(bcast, lane, ce, bepoch);
+            }
+            if (lane == 0) {
+                const int it = L.iters_run + 1;
+                L.iters_run = it;
+                D->iters_run = it;
                 D->stop = 1;
                 L.ctrl = 1;
                 D->converged = 1;
                 D->neff = (int)s_sums[FL_S_NEFF];
-                D->total_residual = (double)L.last_error;
-                D->status = gather_status | L.fragile;
+                D->total_residual = (double)G.last_error;
+                L.sticky |= L.fragile;
+                D->status = L.sticky;
+                if (bcast) fl_bcast_ctrl(bcast, 1, bepoch);
             }
-            if (wave == 3 && lane < FL_SUMS18) D->sums[lane] = s_sums[lane];
             return;
         }
     }
 
-    // ---- wave 0: factorise, solve, delta.  Other waves: side outputs.
-    if (wave == 0) {
-        FlLdl6 f;
-        double S[6][6], C[6][6], z[6];
-        fl_unpack_S(s_sums, S);
+    double dl, z[6];
+    int bad = 0;
+    fl_stamp(dbg, 30);
+    {
+#pragma clang fp contract(fast)
+        const double sign = (KIND == FL_EPI_VIO) ? -1.0 : 1.0;
+        double s[27];
 #pragma unroll
-        for (int i = 0; i < 6; i++)
-#pragma unroll
-            for (int j = 0; j < 6; j++) C[i][j] = L.Q[i * 6 + j] + S[i][j];
-        const int bad = fl_ldl6(C, f);
+        for (int k = 0; k < 27; k++) s[k] = s_sums[k];             // LDS broadcast reads
+        // S(i,j), i <= j, row-major upper triangle: index i*6 - i*(i-1)/2 + (j-i)
+#define FL_SIDX(i, j) ((i) <= (j) ? ((i) * 6 - (i) * ((i) - 1) / 2 + ((j) - (i))) : ((j) * 6 - (j) * ((j) - 1) / 2 + ((i) - (j))))
+        double c[6][6];        // lower triangle of C = Q + S
+        double w[6];           // right-hand side, eliminated along with C as a 7th row
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            double b = sign * s_sums[FL_S_HTZ + i];
 #pragma unroll
-            for (int k = 0; k < 6; k++) b -= S[i][k] * L.vec[k];
-            z[i] = b;
+            for (int j = 0; j <= i; j++) c[i][j] = L.Q[i * 6 + j] + s[FL_SIDX(i, j)];      // (Q, vec6: LDS broadcast reads too --
+            double b = sign * s[FL_S_HTZ + i];                                              //  held in registers across the gather they
+#pragma unroll                                                                              //  cost the kernel half its occupancy)
+            for (int k = 0; k < 6; k++) b = fma(-s[FL_SIDX(i, k)], L.vec[k], b);
+            w[i] = b;
         }
-        fl_ldl6_solve(f, z);
-        if (lane < 18) {
-            double dl = L.vec[lane];
+#undef FL_SIDX
+        if (dbg) { double keep = w[5] + c[5][0]; asm volatile("" ::"v"(keep)); fl_stamp(dbg, 31); }
+        // right-looking LDL^T on the augmented lower triangle: after column j, c[i][j] = L_ij and w carries D^-1 L^-1 b
 #pragma unroll
-            for (int c = 0; c < 6; c++) dl += L.T[lane * 6 + c] * z[c];
-            L.delta[lane] = dl;
-            D->solution[lane] = dl;
+        for (int j = 0; j < 6; j++) {
+            const double dj = c[j][j];
+            if (!(dj > 0.0)) bad = 1;
+            const double inv = fl_rcp_nr(dj);
+            double u[6];
+#pragma unroll
+            for (int i = j + 1; i < 6; i++) { u[i] = c[i][j]; c[i][j] = u[i] * inv; }
+            const double wj = w[j] * inv;
+            w[j] = wj;
+#pragma unroll
+            for (int i = j + 1; i < 6; i++) {
+#pragma unroll
+                for (int k = j + 1; k < 6; k++)
+                    if (k <= i) c[i][k] = fma(-c[i][j], u[k], c[i][k]);
+                w[i] = fma(-wj, u[i], w[i]);
+            }
         }
-        if (lane == 0) L.st = bad | gather_status;
-    } else if (wave == 3) {
-        if (lane < FL_SUMS18) {
-            const double sv = s_sums[lane];
-            D->sums[lane] = sv;
-            D->sums_acc[lane] = sv;   // LIO: last executed pass ; VIO: last accepted pass (accept path)
+        if (dbg) { double keep = w[5] + c[5][4]; asm volatile("" ::"v"(keep)); fl_stamp(dbg, 32); }
+        // back substitution L^T z = w
+#pragma unroll
+        for (int i = 5; i >= 0; i--) {
+            double zi = w[i];
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                if (k > i) zi = fma(-c[k][i], z[k], zi);
+            z[i] = zi;
         }
-    } else if (KIND == FL_EPI_VIO && wave == 1) {
-        if (lane < 24) D->xold[lane] = L.x[lane];   // old_state = *state (:863)
+        dl = G.vecr;
+#pragma unroll
+        for (int cc = 0; cc < 6; cc++) dl = fma(G.trow[cc], z[cc], dl);
     }
-    __syncthreads();
+    if (dbg) { asm volatile("" ::"v"(dl)); fl_stamp(dbg, 33); }
+    if (lane < 18) D->solution[lane] = dl;
+    int st = bad;
+    if (__ballot(lane < 18 && !(fabs(dl) <= DBL_MAX)) != 0ull) st |= 2;
 
-    // ---- state update and judgement on separate waves
-    if (wave == 0) {
+    // ---- state update: lane l < 9 forms R(l/3, l%3) of R * Exp(d0,d1,d2) (so3_math.h:54-72, common_lib.h:345), lanes 9..23 add
+    const double d0 = fl_lane_bcast(dl, 0), d1 = fl_lane_bcast(dl, 1), d2 = fl_lane_bcast(dl, 2);
+    const double d3 = fl_lane_bcast(dl, 3), d4 = fl_lane_bcast(dl, 4), d5 = fl_lane_bcast(dl, 5);
+    const double t2 = d0 * d0 + d1 * d1 + d2 * d2;
+    const double p2 = d3 * d3 + d4 * d4 + d5 * d5;
+    double xnew = G.xl;
+    {
+#pragma clang fp contract(fast)
+        // the reference leaves R alone unless |d| > 1e-5
+        bool rotate;
+        if (fabs(t2 - 1e-10) > 1e-22) rotate = t2 > 1e-10;
+        else { double tt = t2; asm volatile("" : "+v"(tt)); rotate = sqrt(tt) > 0.00001; }   // (asm: no speculation of the sqrt)
         if (lane < 9) {
-            // R <- R * Exp(d0,d1,d2): lane (i,j) forms its element (so3_math.h:54-72, common_lib.h:345)
-            const int i = lane / 3, j = lane % 3;
-            const double d0 = L.delta[0], d1 = L.delta[1], d2 = L.delta[2];
-            const double nrm = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-            if (nrm > 0.00001) {
-                const double r0 = d0 / nrm, r1 = d1 / nrm, r2 = d2 / nrm;
-                const double K[9] = {0.0, -r2, r1, r2, 0.0, -r0, -r1, r0, 0.0};
-                double s, c;
-                fl_sin_omc(nrm, &s, &c);
-                double acc = 0.0;
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    double e[3];   // row k of E = I + s K + c K K
-#pragma unroll
-                    for (int q = 0; q < 3; q++) {
-                        const double kk = K[k * 3 + 0] * K[0 * 3 + q] + K[k * 3 + 1] * K[1 * 3 + q] + K[k * 3 + 2] * K[2 * 3 + q];
-                        e[q] = ((k == q) ? 1.0 : 0.0) + s * K[k * 3 + q] + c * kk;
-                    }
-                    const double ekj = (j == 0) ? e[0] : ((j == 1) ? e[1] : e[2]);
-                    acc += L.x[i * 3 + k] * ekj;
+            if (rotate) {
+                double a, b;       // a = sin(t)/t, b = (1 - cos t)/t^2
+                if (t2 <= 0.25) {
+                    double pa = 1.0 / 1307674368000.0;
+                    pa = fma(pa, -t2, 1.0 / 6227020800.0);
+                    pa = fma(pa, -t2, 1.0 / 39916800.0);
+                    pa = fma(pa, -t2, 1.0 / 362880.0);
+                    pa = fma(pa, -t2, 1.0 / 5040.0);
+                    pa = fma(pa, -t2, 1.0 / 120.0);
+                    pa = fma(pa, -t2, 1.0 / 6.0);
+                    a = fma(pa, -t2, 1.0);
+                    double pb = 1.0 / 20922789888000.0;
+                    pb = fma(pb, -t2, 1.0 / 87178291200.0);
+                    pb = fma(pb, -t2, 1.0 / 479001600.0);
+                    pb = fma(pb, -t2, 1.0 / 3628800.0);
+                    pb = fma(pb, -t2, 1.0 / 40320.0);
+                    pb = fma(pb, -t2, 1.0 / 720.0);
+                    pb = fma(pb, -t2, 1.0 / 24.0);
+                    b = fma(pb, -t2, 0.5);
+                } else {
+                    const double t = sqrt(t2);
+                    a = sin(t) / t;
+                    b = (1.0 - cos(t)) / t2;
                 }
-                D->x[lane] = acc;
-                L.xn[lane] = acc;
-                if (KIND == FL_EPI_LIO && bcast) fl_bcast_store(bcast, lane, acc, bepoch);
-            } else {
-                L.xn[lane] = L.x[lane];
-                if (KIND == FL_EPI_LIO && bcast) fl_bcast_store(bcast, lane, L.x[lane], bepoch);
+                // E = I + a K + b K^2, K = skew(d): K^2 = d d^T - t2 I.  Lane (i, j): sum_k R(i,k) E(k,j)
+                const int j = lane % 3;
+                const double dj = (j == 0) ? d0 : ((j == 1) ? d1 : d2);
+                const double diag = 1.0 - b * t2;
+                // column j of E
+                double e0 = b * d0 * dj, e1 = b * d1 * dj, e2 = b * d2 * dj;
+                if (j == 0) { e0 += diag; e1 += a * d2; e2 -= a * d1; }
+                else if (j == 1) { e0 -= a * d2; e1 += diag; e2 += a * d0; }
+                else { e0 += a * d1; e1 -= a * d0; e2 += diag; }
+                xnew = G.rrow[0] * e0 + G.rrow[1] * e1 + G.rrow[2] * e2;
             }
         }
-    } else if (wave == 1) {
-        if (lane < 15) {
-            const double nv = L.x[9 + lane] + L.delta[3 + lane];
-            D->x[9 + lane] = nv;
-            L.xadd[lane] = nv;
-            if (lane < 3) {
-                L.xn[9 + lane] = nv;
-                if (KIND == FL_EPI_LIO && bcast) fl_bcast_store(bcast, 9 + lane, nv, bepoch);
-            }
+    }
+    // additive states: lane 9 + k adds delta[3 + k]; delta lives in lane 3 + k, six lanes further down
+    {
+        const double dsh = __shfl(dl, (lane >= 6) ? lane - 6 : 0, FL_WAVE);
+        if (lane >= 9 && lane < 24) xnew = G.xl + dsh;
+    }
+    if (dbg) { asm volatile("" ::"v"(xnew)); fl_stamp(dbg, 34); }
+    if (lane < 24) {
+        D->x[lane] = xnew;
+        if (lane < 12) {
+            L.xn[lane] = xnew;
+            if (KIND == FL_EPI_LIO && bcast) fl_bcast_store(bcast, lane, xnew, bepoch);
         }
-    } else if (wave == 2) {
+        if (lane >= 9) L.xadd[lane - 9] = xnew;
+    }
+    if (lane < 18) L.delta[lane] = dl;
+    if (lane < FL_SUMS18) D->sums_acc[lane] = s_sums[lane];   // LIO: last executed pass ; VIO: last accepted pass
+    if (KIND == FL_EPI_VIO && lane < 24) D->xold[lane] = G.xl;   // old_state = *state (:863)
+
+    fl_stamp(dbg, 36);
+    // ---- judgement (uniform arithmetic; lane 0 writes)
+    if (KIND == FL_EPI_LIO) {
+        // laserMapping.cpp:1688-1728
+        const int converged = (FL_NORM_BELOW(t2, 57.3, 0.01) && FL_NORM_BELOW(p2, 100.0, 0.015)) ? 1 : 0;
+        int rematch = L.rematch, need_search = 0, stop = 0;
+        const int it = L.iterCount, iters = L.iters_run + 1;
+        if (converged || ((rematch == 0) && (it == (L.max_iter - 2)))) { need_search = 1; rematch++; }
+        if (rematch >= 2 || (it == L.max_iter - 1)) stop = 1;
+        const int ctrl = (stop ? 1 : 0) | (need_search ? 2 : 0);
+        const int neff_lt1 = (s_sums[FL_S_NEFF] < 1.0) ? 4 : 0;
+        __builtin_amdgcn_wave_barrier();
+        if (dbg) { asm volatile("" ::"v"(ctrl + neff_lt1)); fl_stamp(dbg, 37); }
         if (lane == 0) {
-            const double rn = sqrt(L.delta[0] * L.delta[0] + L.delta[1] * L.delta[1] + L.delta[2] * L.delta[2]);
-            const double tn = sqrt(L.delta[3] * L.delta[3] + L.delta[4] * L.delta[4] + L.delta[5] * L.delta[5]);
-            int st = L.st;
-#pragma unroll
-            for (int r = 0; r < 18; r++)
-                if (!(fabs(L.delta[r]) <= DBL_MAX)) st |= 2;
-            if (KIND == FL_EPI_LIO) {
-                // laserMapping.cpp:1688-1728
-                const int converged = (rn * 57.3 < 0.01) && (tn * 100 < 0.015);
-                int rematch = L.rematch, need_search = 0, stop = 0;
-                const int it = L.iterCount;
-                if (converged || ((rematch == 0) && (it == (L.max_iter - 2)))) { need_search = 1; rematch++; }
-                if (rematch >= 2 || (it == L.max_iter - 1)) stop = 1;
-                L.rematch = rematch; L.iterCount = it + 1; L.iters_run = L.iters_run + 1;
-                D->converged = converged;
-                D->rematch_num = rematch;
-                D->need_search = need_search;
-                D->stop = stop;
-                D->iterCount = it + 1;
-                D->iters_run = L.iters_run;
-                D->neff = (int)s_sums[FL_S_NEFF];
-                D->total_residual = s_sums[FL_S_RES];
-                D->status = st | ((s_sums[FL_S_NEFF] < 1.0) ? 4 : 0);
-                L.ctrl = (stop ? 1 : 0) | (need_search ? 2 : 0) | (gather_status ? 4 : 0);
-                if (bcast)
-                    __hip_atomic_store(bcast + 24, ((unsigned long long)(unsigned)L.ctrl << 32) | (unsigned long long)bepoch, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                // lidar_selection.cpp:883-899
-                int stop = ((rn * 57.3f < 0.001f) && (tn * 100.0f < 0.001f)) ? 1 : 0;
-                D->converged = stop;
-                L.accepted = L.accepted + 1;
-                D->accepted = L.accepted;
-                const int it = L.iters_run + 1;
-                L.iters_run = it;
-                D->iters_run = it;
-                if (it >= L.max_iter) stop = 1;
-                D->stop = stop;
-                D->neff = (int)s_sums[FL_S_NEFF];
-                D->total_residual = (double)L.last_error;
-                D->status = st | L.fragile;
-                L.ctrl = stop ? 1 : 0;
-            }
+            L.rematch = rematch; L.iterCount = it + 1; L.iters_run = iters;
+            L.ctrl = ctrl;
+            if (bcast) fl_bcast_ctrl(bcast, ctrl, bepoch);
+            D->converged = converged;
+            D->rematch_num = rematch;
+            D->need_search = need_search;
+            D->stop = stop;
+            D->iterCount = it + 1;
+            D->iters_run = iters;
+            D->neff = (int)s_sums[FL_S_NEFF];
+            D->total_residual = s_sums[FL_S_RES];
+            L.sticky |= st | neff_lt1;
+            D->status = L.sticky;
+        }
+    } else {
+        // lidar_selection.cpp:883-899 ; the derived camera pose of the new state for the next pass's producers
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (VC && lane < 12) {
+            const double ce = vio_cam_element(lane, L.xn, G.rci, G.pci);
+            if (lane < 9) D->Rcw[lane] = ce; else D->Pcw[lane - 9] = ce;
+            L.cam[lane] = ce;
+            if (bcast) fl_bcast_store(bcast, lane, ce, bepoch);
+        }
+        int stop = (FL_NORM_BELOW(t2, (double)57.3f, (double)0.001f) && FL_NORM_BELOW(p2, (double)100.0f, (double)0.001f)) ? 1 : 0;
+        const int converged = stop;
+        const int it = L.iters_run + 1;
+        if (it >= L.max_iter) stop = 1;
+        const int accepted = L.accepted + 1;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            L.accepted = accepted; L.iters_run = it;
+            L.ctrl = stop ? 1 : 0;
+            if (bcast) fl_bcast_ctrl(bcast, stop ? 1 : 0, bepoch);
+            D->converged = converged;
+            D->accepted = accepted;
+            D->iters_run = it;
+            D->stop = stop;
+            D->neff = (int)s_sums[FL_S_NEFF];
+            D->total_residual = (double)L.last_error;
+            L.sticky |= st | L.fragile;
+            D->status = L.sticky;
         }
     }
 }
 
 // Multi-pass kernels: after eskf18_solve_block (and a __syncthreads) make the new state the solve input of the next
 // pass without a global round trip: x <- x (+) delta from LDS, vec = x_prop (-) x as in eskf18_prefetch_commit.
+// All threads; ends with a barrier (the registers of the next pass are loaded right after).
 __device__ __forceinline__ void eskf18_restage(FlSolveLds &L)
 {
     const int tid = threadIdx.x;
     if (tid < 9) L.x[tid] = L.xn[tid];
     else if (tid < 24) L.x[tid] = L.xadd[tid - 9];
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
-    if (wave == 1) {
-        if (lane < 15) L.vec[3 + lane] = L.xp[9 + lane] - L.x[9 + lane];
-    } else if (wave == 2 && lane == 0) {
-        double rd[9];
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) rd[i * 3 + j] = L.x[0 * 3 + i] * L.xp[0 * 3 + j] + L.x[1 * 3 + i] * L.xp[1 * 3 + j] + L.x[2 * 3 + i] * L.xp[2 * 3 + j];
-        const double tr = rd[0] + rd[4] + rd[8];
-        const double theta = (tr > 3.0 - 1e-6) ? 0.0 : acos(0.5 * (tr - 1));
-        const double fk = (fabs(theta) < 0.001) ? 0.5 : (0.5 * theta / sin(theta));
-        L.vec[0] = fk * (rd[7] - rd[5]);
-        L.vec[1] = fk * (rd[2] - rd[6]);
-        L.vec[2] = fk * (rd[3] - rd[1]);
-    }
+    eskf18_form_vec(L);
+    __syncthreads();
 }

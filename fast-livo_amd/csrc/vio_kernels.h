@@ -390,6 +390,10 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     const FlVioFirst pf = vio_prefetch_first(ref, pos, slevel, m, level_arg, nprod);
     double pf_solver = 0.0;
     if (MODE == 0 && blockIdx.x == nprod) pf_solver = eskf18_prefetch_issue(D);
+    if (D->status & FL_NUM_TIMEOUT) {             // an earlier pass of the chain was abandoned (solve18.h): the host resumes
+        if (blockIdx.x == 0 && threadIdx.x == 0) D->resume_count += 1;
+        return;
+    }
     if (!(flags & FL_ITER_FORCE) && D->stop) return;
     const unsigned epoch = *epoch_ptr;
 
@@ -399,7 +403,8 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
         __shared__ double s_sums[FL_SUMS18];
         __shared__ FlSolveLds s_solve;
         fl_stamp(flags, 8);
-        if (MODE == 0) eskf18_prefetch_commit(pf_solver, s_solve);
+        FlSolveRegs G;
+        if (MODE == 0) { eskf18_prefetch_commit(pf_solver, s_solve); eskf18_load_regs(s_solve, G, VC); }
         fl_stamp(flags, 9);
         int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
         fl_stamp(flags, 10);
@@ -417,9 +422,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
             FlVioExact ex;
             // (the replay of the reference's float error sum needs every patch's error: not with the patches spread over ranks)
             ex.words = D->err_words; ex.m = m; ex.cap = D->err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !(flags & FL_ITER_FORCE) && world <= 1;
-            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, gst, nullptr, 0u, ex);
-            __syncthreads();
-            vio_derive_pose(s_solve.xn, VC, D);      // camera pose for the next pass's producers
+            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, gst, nullptr, 0u, ex, VC);   // incl. the camera pose for the next pass's producers
         } else {
             if (threadIdx.x < FL_SUMS18) sums_out[threadIdx.x] = s_sums[threadIdx.x];
         }
@@ -453,13 +456,14 @@ struct FlVioLevelInfo {
 // Up to `count` passes of one pyramid level in ONE launch (see lio18_multipass_kernel): the solver broadcasts the derived camera
 // pose (Rcw, Pcw: what the producers consume) and the stop bit; a rejected solve (error went up, lidar_selection.cpp:888-892)
 // reverts and stops like the reference. Bit-identical to `count` launches of vio_pass_kernel<0>.
-__global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t *__restrict__ img, const float *__restrict__ ref,
+__global__ __launch_bounds__(FL_VIO_NT, 2) void vio_multipass_kernel(const uint8_t *__restrict__ img, const float *__restrict__ ref,
                                                                  const double *__restrict__ pos, const int32_t *__restrict__ slevel,
                                                                  float *__restrict__ errors, int m, int level,
                                                                  const FlVioConst *__restrict__ VC, FlDev18 *__restrict__ D,
                                                                  void *__restrict__ records, unsigned *__restrict__ epoch_ptr,
                                                                  unsigned long long *__restrict__ bcast, int count, int flags,
-                                                                 float begin_residual, FlVioLevelInfo *__restrict__ level_info)
+                                                                 float begin_residual, FlVioLevelInfo *__restrict__ level_info,
+                                                                 unsigned *__restrict__ done_word, unsigned done_seq)
 {
     // begin_residual >= 0: the launch starts a pyramid level, i.e. it first does what vio_level_begin_kernel does (UpdateState
     // prologue, lidar_selection.cpp:747,756); level_info != nullptr: it ends with what vio_level_end_kernel does. ComputeJ then
@@ -469,7 +473,12 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
     const int nprod = gridDim.x - 1;
     const bool force = (flags & FL_ITER_FORCE) != 0;
     const bool begin = begin_residual >= 0.f;
-    if (!force && !begin && D->stop) return;
+    if (D->status & FL_NUM_TIMEOUT) {             // an earlier pass of the chain was abandoned: nothing runs until the host has resumed
+        if (blockIdx.x == 0 && threadIdx.x == 0) D->resume_count += count;
+        fl_mp_done(done_word, done_seq, blockIdx.x == gridDim.x - 1);
+        return;
+    }
+    if (!force && !begin && D->stop) { fl_mp_done(done_word, done_seq, blockIdx.x == gridDim.x - 1); return; }
     const unsigned epoch0 = *epoch_ptr;
     unsigned long long *err_base = D->err_words;
     const int err_cap = D->err_cap;
@@ -479,14 +488,13 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
         __shared__ double s_fin[2 * NT];
         __shared__ double s_sums[FL_SUMS18];
         __shared__ FlSolveLds s_solve;
-        __shared__ double s_cam[12];
         __shared__ __attribute__((aligned(16))) float s_ex[FL_EXACT_CHUNK];
         eskf18_prefetch(D, s_solve);
         if (begin) {
             __syncthreads();
             if (threadIdx.x < 24) D->xold[threadIdx.x] = s_solve.x[threadIdx.x];      // old_state = *state
             if (threadIdx.x == 32) {
-                s_solve.last_error = begin_residual; s_solve.iters_run = 0; s_solve.accepted = 0; s_solve.fragile = 0;
+                s_solve.last_error = begin_residual; s_solve.iters_run = 0; s_solve.accepted = 0; s_solve.fragile = 0; s_solve.sticky = 0;
                 s_solve.last_exact = begin_residual; s_solve.last_exact_valid = 1; s_solve.acc_buf = 0; s_solve.acc_epoch = 0u;
                 D->last_exact = begin_residual; D->last_exact_valid = 1; D->err_acc_buf = 0; D->err_acc_epoch = 0u;
                 D->last_error = begin_residual; D->level = level; D->stop = 0; D->converged = 0; D->iters_run = 0; D->accepted = 0;
@@ -501,23 +509,23 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
         int done = 0;
         for (int p = 0; p < count; p++) {
             const unsigned epoch = epoch0 + (unsigned)p;
+            FlSolveRegs G;
+            eskf18_load_regs(s_solve, G, VC);                    // solve operands into wave 0's registers while the producers work
             int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
             if (PV.world > 1) gst |= peer_allreduce32(PV, xe0 + (unsigned)p, s_sums, s_xchg);      // sharded form: totals over the ranks
             FlVioExact ex;
             ex.words = err_base; ex.m = m; ex.cap = err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !force && PV.world <= 1;
-            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, gst, nullptr, 0u, ex);
-            __syncthreads();
-            vio_derive_pose(s_solve.xn, VC, D);
-            // the same 12 threads publish what they just derived (D->Rcw / D->Pcw are their own stores)
-            if (threadIdx.x < 12) s_cam[threadIdx.x] = (threadIdx.x < 9) ? D->Rcw[threadIdx.x] : D->Pcw[threadIdx.x - 9];
+            // wave 0 solves, derives the camera pose of the new state and publishes it (+ the control word) for the producers
+            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, gst, bcast, epoch + 1u, ex, VC);
             __syncthreads();
             done = p + 1;
-            const int ctrl = s_solve.ctrl | (gst ? 4 : 0);
-            bcast_publish(bcast, s_cam, ctrl, epoch + 1u);
+            const int ctrl = s_solve.ctrl;
+            if (ctrl & 4) {                                      // abandoned (hand-off time-out): this pass and the rest are still to do
+                if (threadIdx.x == 0) D->resume_count = count - p;
+                break;
+            }
             if (!force && (ctrl & 3)) break;
-            if (ctrl & 4) break;
             if (p + 1 < count) eskf18_restage(s_solve);
-            __syncthreads();
         }
         if (threadIdx.x == 0) {
             *epoch_ptr = epoch0 + (unsigned)done;
@@ -531,6 +539,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
                 level_info->accepted = D->accepted; level_info->status = D->status; level_info->converged = D->converged;
             }
         }
+        fl_mp_done(done_word, done_seq, true);
         return;
     }
 
@@ -568,6 +577,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_multipass_kernel(const uint8_t 
 __global__ void vio_level_begin_kernel(FlDev18 *__restrict__ D, int level, float total_residual)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (D->status & FL_NUM_TIMEOUT) return;       // abandoned chain (solve18.h): the host resumes, nothing is reset behind its back
     for (int i = 0; i < 24; i++) D->xold[i] = D->x[i];
     D->last_error = total_residual;
     D->last_exact = total_residual; D->last_exact_valid = 1; D->err_acc_buf = 0; D->err_acc_epoch = 0u;
@@ -598,6 +608,7 @@ __global__ __launch_bounds__(384) void vio_cov_update_kernel(FlDev18 *__restrict
     __shared__ double sG[108];
     const int t = threadIdx.x;
     const bool apply = D->last_error < 1e10f;
+    if (D->status & FL_NUM_TIMEOUT) return;       // abandoned frame: enqueued again after the resume
     if (t < 324) sP[t] = D->P[t];
     if (t == 0) {   // G[:,0:6] of the last ACCEPTED iteration (G is only rewritten on acceptance, :877)
         double G6[108];

@@ -127,6 +127,12 @@ int32_t fl_debug_get_wall(fl_handle h, long long *out2048);
 /* Times the last fl_lio_iterate18 / fl_vio_iterate batch with HIP events on the handle's stream. */
 int32_t fl_set_timing(fl_handle h, int32_t enable);
 int32_t fl_get_last_kernel_ms(fl_handle h, float *ms);
+/* Debug / test aids for the resident-grid assumption of the multi-pass kernels: a foreign kernel that
+ * occupies `blocks` workgroup slots (256 threads + lds_bytes of LDS each) for ~usec microseconds on a stream of its own, and the
+ * counters {multi-pass launches the admission check sent down the per-pass path, frames resumed after an abandoned pass,
+ * workgroups of a multi-pass kernel the device can hold, compute units}. */
+int32_t fl_debug_hog(fl_handle h, int32_t blocks, int32_t lds_bytes, int32_t usec);
+int32_t fl_debug_counters(fl_handle h, int32_t *out4);
 /* Debug: shader-clock phase stamps of the last pass launched with flag FL_ITER_STAMP (64 slots). */
 #define FL_ITER_STAMP 4
 int32_t fl_debug_get_stamps(fl_handle h, long long *out64);

@@ -1,0 +1,105 @@
+"""The resident-grid assumption of the multi-pass kernels made explicit: they wait for their own other
+workgroups, so every workgroup must be on the device at once.
+  * inside one process the library keeps count (occupancy x CUs against the multi-pass launches of its other streams that have
+    not completed) and sends launches that would not fit down the one-launch-per-pass path;
+  * against what it cannot see (another process, a foreign kernel) the bounded waits end in an ABANDONED pass -- state untouched,
+    FL_NUM_TIMEOUT sticky, the rest of the enqueued chain skipped -- and the drivers re-run the remaining passes per pass.
+Either way the caller gets the same bits as from an undisturbed run and no status bit."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(capi, fr, scene, max_iter=10):
+    h = capi.Handle(capi.config_from_frames(fr, max_iterations=max_iter))
+    h.map_set_points(scene.map_xyz, 0.5)
+    return h
+
+
+def test_six_concurrent_filters_and_a_foreign_kernel(gpu_lib, scene):
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    n, frames = 50000, 6
+    fr = synth.make_lio_frame(n, scene=scene)
+    vf = synth.make_vio_frame(2000, fr)
+    # undisturbed reference run
+    h0 = capi.Handle(capi.config_from_frames(fr, vf, max_iterations=10))
+    h0.map_set_points(scene.map_xyz, 0.5)
+    x_ref = capi.state18_from_frame(fr)
+    i_ref = h0.lio_frame18_dev(x_ref, fr.body_xyz)
+    h0.vio_set_frame(vf.img); h0.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+    xv_ref = capi.state18_from_frame(fr)
+    h0.vio_compute_j(xv_ref, capi.state18_from_frame(fr))
+    assert i_ref.status == 0
+    cap = h0.debug_counters()
+    h0.close()
+
+    # ---- six filters at once, each on its own handle/stream/thread; a foreign kernel takes most of the chip meanwhile
+    hs = []
+    for k in range(6):
+        h = capi.Handle(capi.config_from_frames(fr, vf, max_iterations=10))
+        h.map_set_points(scene.map_xyz, 0.5)
+        h.vio_set_frame(vf.img); h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+        hs.append(h)
+    results = [None] * 6
+    errors = []
+
+    def work(k):
+        try:
+            out = []
+            for f in range(frames):
+                x = capi.state18_from_frame(fr)
+                info = hs[k].lio_frame18_dev(x, fr.body_xyz)
+                xv = capi.state18_from_frame(fr)
+                hs[k].vio_compute_j(xv, capi.state18_from_frame(fr))
+                out.append((x.vec().copy(), x.cov_np().copy(), info.status, info.iterations, xv.vec().copy()))
+            results[k] = out
+        except Exception as e:      # noqa: BLE001
+            errors.append((k, repr(e)))
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    # the foreign kernel: 3/4 of the CUs, nearly all of their LDS, for 150 ms
+    hs[0].debug_hog(int(cap["cus"] * 3 // 4), 150 * 1024, 150000)
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for k in range(6):
+        for (xv_, cov_, st, it, xvio) in results[k]:
+            assert st == 0                                   # no time-out bit surfaced
+            assert it == i_ref.iterations
+            assert np.array_equal(xv_, x_ref.vec()) and np.array_equal(cov_, x_ref.cov_np())
+            assert np.array_equal(xvio, xv_ref.vec())
+    tot = dict(fallbacks=0, resumes=0)
+    for h in hs:
+        c = h.debug_counters()
+        tot["fallbacks"] += c["fallbacks"]; tot["resumes"] += c["resumes"]
+        h.close()
+    print(f"\n[co-residency] capacity {cap['capacity']} workgroups on {cap['cus']} CUs; 6 filters x {frames} frames: "
+          f"{tot['fallbacks']} launches sent down the per-pass path by the admission check, {tot['resumes']} frames resumed after an abandoned pass")
+    assert tot["fallbacks"] + tot["resumes"] > 0            # the machinery was exercised
+
+
+def test_abandoned_pass_is_resumed_with_identical_result(gpu_lib, scene):
+    """One filter, the chip taken away under it: the multi-pass launch cannot become resident, its waits expire, the pass is
+    abandoned and the frame driver finishes the frame per pass -- same state, status 0."""
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    fr = synth.make_lio_frame(50000, scene=scene)
+    h = _frame(capi, fr, scene)
+    x_ref = capi.state18_from_frame(fr)
+    i_ref = h.lio_frame18_dev(x_ref, fr.body_xyz)
+    c = h.debug_counters()
+    h.debug_hog(c["cus"], 150 * 1024, 120000)               # every CU's LDS taken for 120 ms
+    import time
+    time.sleep(0.02)                                        # (the foreign kernel is on the device before the frame is enqueued)
+    x = capi.state18_from_frame(fr)
+    info = h.lio_frame18_dev(x, fr.body_xyz)
+    c2 = h.debug_counters()
+    assert info.status == 0 and info.iterations == i_ref.iterations
+    assert np.array_equal(x.vec(), x_ref.vec()) and np.array_equal(x.cov_np(), x_ref.cov_np())
+    print(f"\n[co-residency] resumes {c2['resumes'] - c['resumes']}, admission fallbacks {c2['fallbacks'] - c['fallbacks']}")
+    h.close()

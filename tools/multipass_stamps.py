@@ -19,5 +19,5 @@ for rep in range(4):
     t0 = st[20]
     names = {20: "prod0 p5 wait_start", 21: "prod0 p5 pose_seen", 22: "prod0 p5 compute_done", 23: "prod0 p5 published", 16: "solver p5 gather_start",
              17: "solver p5 gather_done", 18: "solver p5 solve_done+sync", 24: "prod0 p6 wait_start", 25: "prod0 p6 pose_seen", 26: "prod0 p6 compute_done",
-             27: "prod0 p6 published"}
+             27: "prod0 p6 published", 30: "solve: start", 31: "solve: C,rhs formed", 32: "solve: eliminated", 33: "solve: delta", 34: "solve: state", 35: "solve: returned", 36: "solve: stores issued", 37: "solve: judged"}
     print(json.dumps({names[k]: int(st[k] - t0) * 10 for k in sorted(names, key=lambda k: st[k])}))
