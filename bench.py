@@ -6,11 +6,22 @@ One *step* = one LIVO ESKF iteration over one synthetic frame already resident i
                     -> H^T H / H^T z reduction -> 18-state gain solve -> state (+)= delta
   * one VIO pass  : 2 000 8x8 photometric patches (pyramid level 0) -> same reduction/solve
 (BASELINE config 3, "LIVO: 50k pts + 2k 8x8 patches"; kNN excluded on both sides, neighbours
-pre-staged -- SURVEY.md section 8d).  With --gpus N (launched by torch.distributed.run, one rank
-per GPU) every rank holds its own 50k-point / 2k-patch shard of an N-times larger frame (weak
-scaling), reduces its partial normal equations on the device, all-reduces the 32-double record
-over RCCL and runs the gain solve redundantly.  `value` = shard-iterations/s summed over ranks
-(= N x frame-iterations/s); `frame_iterations_per_s` is reported next to it.
+pre-staged -- SURVEY.md section 8d).
+
+`value` is always FRAME iterations/s: how many ESKF iterations of ONE frame the job completes per second.
+With --gpus N (launched by torch.distributed.run, one rank per GPU) the frame is sharded by point/patch range:
+  --scaling strong (default): the frame of the metric (50 k points + 2 k patches; `--points 200000` = BASELINE config 4) is
+                   split over the ranks, every rank holds 1/N of it;
+  --scaling weak : every rank holds its own 50 k + 2 k shard of an N-times larger frame (`shard_iterations_per_s` =
+                   N x value is reported next to `value` as a secondary key).
+Every pass the ranks sum their 32-double normal-equation records (in-kernel peer exchange, else RCCL) and solve redundantly.
+
+The same JSON line carries, at N = 1: `roofline` (dominant kernel + `at_scale` for the LIO pass at 8 M / 32 M points and
+`at_scale_vio` for the VIO pass at 2 k -> 1 M patches), `frame` (whole all-device LIO frame incl. plane fits and searches +
+ComputeJ), `restage` (the iteration with one H2D neighbour restage per pass), `mode23` (BASELINE config 2 with the 23-state
+IKFoM filter), `pass_mix` (how many of the timed forced passes did a full solve) and the CPU baselines (`cpu_baseline`: the
+reference's own threading; `cpu_baseline_all_cores`: best over thread counts, VIO patch loop threaded too).
+`--only SECTION` runs one of {at_scale, vio_sweep, mode23, frame, restage} alone (the rocprofv3 runs behind profiles/).
 
 Prints ONE JSON line on rank 0.
 """
@@ -20,6 +31,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # CPU baselines: idle OpenMP threads must not spin against the working ones
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,12 +41,14 @@ sys.path.insert(0, ROOT)
 N_POINTS = 50000
 N_PATCHES = 2000
 PASSES_PER_LAUNCH = 10   # avia.yaml max_iteration
-AT_SCALE_POINTS = 8000000  # roofline.at_scale: the LIO pass where the traffic, not the hand-off latency, is the time
+AT_SCALE_POINTS = (8000000, 32000000)   # roofline.at_scale: the LIO pass where the traffic, not the hand-off latency, is the time
+VIO_SWEEP = (2000, 200000, 1000000)
 VIO_LEVEL = 0
 # algorithmic HBM bytes per unit and launch
-LIO_BYTES_PER_POINT = 12 + 16 + 1      # body xyz + cached plane (n,d) + selection flag
+LIO_BYTES_PER_POINT = 12 + 16 + 1      # body xyz + cached plane (n,d) + selection flag (the kernel itself reads 16 + 16: DESIGN.md 4.2)
 VIO_BYTES_PER_PATCH = 405 + 4          # 256 ref + 121 image footprint + 24 pos + 4 level, + 4 written
 HBM_PEAK_GBS = 8000.0                  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SECTIONS = ("at_scale", "vio_sweep", "mode23", "frame", "restage")
 
 
 def parse():
@@ -41,39 +56,48 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--points", type=int, default=N_POINTS)
+    ap.add_argument("--points", type=int, default=N_POINTS, help="points of the frame (strong scaling: of the whole frame; weak: per rank)")
     ap.add_argument("--patches", type=int, default=N_PATCHES)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle sample")
-    ap.add_argument("--sweep", action="store_true", help="also print a kernel-only size sweep to stderr")
-    ap.add_argument("--no-at-scale", action="store_true", help="skip the 8 M-point pass of roofline.at_scale")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU-oracle sample")
+    ap.add_argument("--sweep", action="store_true", help="also print a kernel-only LIO size sweep to stderr")
+    ap.add_argument("--no-extras", action="store_true", help="skip at_scale / vio sweep / mode23 / frame / restage")
+    ap.add_argument("--only", choices=SECTIONS, default=None, help="run ONE extra section alone and print it (rocprofv3 runs)")
     return ap.parse_args()
 
 
-def cpu_baseline(fr, vf, nbr, valid, budget_s):
-    """The CPU oracle (a port of the reference loop bodies; the reference itself cannot be built
-    here) timed on this box's host cores: LIO pass with the reference's OpenMP width (4 threads,
-    CMakeLists.txt:23-26), VIO pass single-threaded as in the reference."""
-    from oracle import oracle as orc
-    threads = min(4, os.cpu_count() or 1)
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def _time_livo_iteration(orc, fr, vf, nbr, valid, lio_threads, vio_threads, budget_s, max_reps=200):
     x0 = orc.state18_from_frame(fr)
-    vf1 = vf
-    old_max = vf1.max_iterations
-    vf1.max_iterations = 1
+    orc.lib().orc_vio_set_threads(vio_threads)
+    old_max = vf.max_iterations
+    vf.max_iterations = 1
     times = []
     t_end = time.perf_counter() + budget_s
     reps = 0
-    while reps < 3 or (time.perf_counter() < t_end and reps < 200):
+    while reps < 3 or (time.perf_counter() < t_end and reps < max_reps):
         x = x0.copy()
         sel = valid.copy()
         t0 = time.perf_counter()
-        orc.lio18_iterate(x, x0, fr.body_xyz, nbr, sel, fr.R_LI, fr.t_LI, fr.laser_point_cov, nthreads=threads)
+        orc.lio18_iterate(x, x0, fr.body_xyz, nbr, sel, fr.R_LI, fr.t_LI, fr.laser_point_cov, nthreads=lio_threads)
         xv = x0.copy()
-        orc.vio_update_state(vf1, xv, x0, 1e10, VIO_LEVEL)
+        orc.vio_update_state(vf, xv, x0, 1e10, VIO_LEVEL)
         times.append(time.perf_counter() - t0)
         reps += 1
-    vf1.max_iterations = old_max
+    vf.max_iterations = old_max
+    orc.lib().orc_vio_set_threads(1)
     t = np.array(times[1:]) if len(times) > 1 else np.array(times)
+    return t
+
+
+def cpu_baseline(fr, vf, nbr, valid, budget_s):
+    """The CPU oracle (a port of the reference loop bodies; the Eigen/PCL/ROS parts of the reference cannot be built here)
+    timed on this box's host cores: LIO pass with the reference's OpenMP width (4 threads, CMakeLists.txt:23-26), VIO pass
+    single-threaded as in the reference."""
+    from oracle import oracle as orc
+    threads = min(4, os.cpu_count() or 1)
+    t = _time_livo_iteration(orc, fr, vf, nbr, valid, threads, 1, budget_s)
     med = float(np.median(t))
     return {"value": 1.0 / med, "unit": "iterations/s", "cores": threads, "kind": "port",
             "host_cores_available": os.cpu_count(),
@@ -82,11 +106,210 @@ def cpu_baseline(fr, vf, nbr, valid, budget_s):
                       f"p90 {np.percentile(t, 90) * 1e3:.2f}"}
 
 
+def cpu_baseline_all_cores(fr, vf, nbr, valid, budget_s):
+    """What a well-threaded host does (SURVEY 8d "all cores" + "generous baseline"): the same oracle with the LIO point loop AND
+    the VIO patch loop / column sums on t threads (bit-identical results for any t, oracle/orc_vio.c), t swept up to all cores;
+    the best median is the value."""
+    from oracle import oracle as orc
+    ncpu = os.cpu_count() or 1
+    cands = sorted({t for t in (4, 8, 16, 32, 64, 128, ncpu) if t <= ncpu})
+    table = {}
+    per = max(1.5, budget_s / max(1, len(cands)))
+    for t in cands:
+        ts = _time_livo_iteration(orc, fr, vf, nbr, valid, t, t, per, max_reps=60)
+        table[str(t)] = float(np.median(ts)) * 1e3
+    best = min(table, key=lambda k: table[k])
+    return {"value": 1e3 / table[best], "unit": "iterations/s", "cores": int(best), "kind": "port",
+            "host_cores_available": ncpu, "ms_by_threads": table,
+            "sample": f"median LIVO iteration ({fr.n} pts + {vf.m} patches, level {VIO_LEVEL}) per thread count, LIO point loop and "
+                      f"VIO patch loop both on t OpenMP threads (the reference threads only the LIO loop, with 4); best at t = {best}"}
+
+
+# ------------------------------------------------------------------------------------------------ extra sections (N = 1)
+def _events(torch):
+    return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+
+def lio_pass_at(capi, synth, scene, cfg, x0, n):
+    """Average duration (us) and effective bandwidth (GB/s) of one forced LIO pass over n points, HIP events on the launch stream."""
+    import torch
+    fr = synth.make_lio_frame(min(n, 200000), scene=scene)
+    reps = (n + fr.n - 1) // fr.n
+    body = np.tile(fr.body_xyz, (reps, 1))[:n]
+    w = fr.world_at(fr.R_prior, fr.p_prior)
+    nbr, valid = synth.knn5(scene, w)
+    nbr = np.tile(nbr, (reps, 1, 1))[:n]
+    valid = np.tile(valid, reps)[:n]
+    h = capi.Handle(cfg)
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    h.lio_set_points(body)
+    h.lio_begin18(x0, x0)
+    h.lio_set_neighbours(nbr, valid)
+    del nbr, body
+    K = 100 if n <= 1000000 else 20
+    ev0, ev1 = _events(torch)
+    for _ in range(5):
+        h.lio_iterate18(1, capi.FL_ITER_FORCE, want_info=False)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(K):
+        h.lio_iterate18(1, capi.FL_ITER_FORCE, want_info=False)
+    ev1.record()
+    torch.cuda.synchronize()
+    us = ev0.elapsed_time(ev1) * 1e3 / K
+    gbs = LIO_BYTES_PER_POINT * n / (us * 1e-6) / 1e9
+    h.close()
+    return us, gbs
+
+
+def section_at_scale(capi, synth, scene, cfg, x0):
+    out = []
+    for n in AT_SCALE_POINTS:
+        us, gbs = lio_pass_at(capi, synth, scene, cfg, x0, n)
+        out.append({"kernel": "lio18_pass_kernel", "points": n, "pass_us": us, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                    "algorithmic_bytes": LIO_BYTES_PER_POINT * n,
+                    "note": "8 M points x 32 B read = 256 MB = the size of the Infinity Cache: part of it stays on chip between the passes of a "
+                            "frame; 32 M points stream from HBM" if n == AT_SCALE_POINTS[0] else "streams from HBM (1 GB per pass)"})
+    return out
+
+
+def section_vio_sweep(capi, synth, fr, vf, cfg, x0):
+    """One forced VIO pass (level 0, one launch per pass) over m patches: m = 2 k (BASELINE), 200 k, 1 M (the 2 k patch set tiled)."""
+    import torch
+    out = []
+    for m in VIO_SWEEP:
+        reps = (m + vf.m - 1) // vf.m
+        ref = np.tile(vf.ref_patch, (reps, 1, 1))[:m]
+        pos = np.tile(vf.pos, (reps, 1))[:m]
+        sl = np.tile(vf.search_level, reps)[:m]
+        h = capi.Handle(cfg)
+        h.set_stream(torch.cuda.current_stream().cuda_stream)
+        h.vio_set_frame(vf.img)
+        h.vio_set_patches(ref, pos, sl)
+        h.vio_begin(x0, x0)
+        K = 100 if m <= 200000 else 20
+        ev0, ev1 = _events(torch)
+        for _ in range(5):
+            h.vio_iterate(VIO_LEVEL, 1, capi.FL_ITER_FORCE, want_info=False)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(K):
+            h.vio_iterate(VIO_LEVEL, 1, capi.FL_ITER_FORCE, want_info=False)
+        ev1.record()
+        torch.cuda.synchronize()
+        us = ev0.elapsed_time(ev1) * 1e3 / K
+        gbs = VIO_BYTES_PER_PATCH * m / (us * 1e-6) / 1e9
+        out.append({"kernel": "vio_pass_kernel", "patches": m, "pass_us": us, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                    "algorithmic_bytes": VIO_BYTES_PER_PATCH * m, "ns_per_patch": us * 1e3 / m})
+        h.close()
+    return out
+
+
+def section_mode23(capi, synth, scene, fr, cfg, nbr, valid):
+    """BASELINE config 2 with the 23-state IKFoM filter (esekfom.hpp:1619-1928): 50 k points, forced passes, neighbours pre-staged."""
+    import torch
+    h = capi.Handle(cfg)
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    x23 = capi.state23_from_frame(fr)
+    h.lio_set_points(fr.body_xyz)
+    h.ikfom_begin(x23, fr.cov23.copy())
+    h.lio_set_neighbours(nbr, valid)
+    C = PASSES_PER_LAUNCH
+    F = capi.FL_ITER_FORCE
+    for _ in range(10):
+        h.ikfom_iterate(C, F, want_info=False)
+    torch.cuda.synchronize()
+    K = 100
+    ev0, ev1 = _events(torch)
+    ev0.record()
+    for _ in range(K):
+        h.ikfom_iterate(C, F, want_info=False)
+    ev1.record()
+    torch.cuda.synchronize()
+    us = ev0.elapsed_time(ev1) * 1e3 / (K * C)
+    ev0.record()
+    for _ in range(K):
+        h.ikfom_iterate(1, F, want_info=False)
+    ev1.record()
+    torch.cuda.synchronize()
+    us1 = ev0.elapsed_time(ev1) * 1e3 / K
+    info = h.ikfom_iterate(1, F)
+    h.close()
+    return {"workload": f"BASELINE config 2: {fr.n} pts point-to-plane, 23-state IKFoM update (state_ikfom), neighbours/planes resident",
+            "pass_us": us, "pass_us_one_launch_per_pass": us1, "iterations_per_s": 1e6 / us, "passes_per_launch": C,
+            "status": int(info.status), "effct_feat_num": int(info.effct_feat_num)}
+
+
+def section_frame(capi, synth, scene, fr, vf, cfg):
+    """The whole frame as a running system does it, everything on the device: fl_lio_frame18_dev = scan H2D + [k-NN search + plane fit when
+    asked, passes until converged] + covariance update + read-back, then fl_vio_compute_j = 3 pyramid levels until the reference's stop
+    rule + covariance update + read-back. Host wall time (median), nothing excluded."""
+    h = capi.Handle(cfg)
+    h.map_set_points(scene.map_xyz, 0.5)
+    h.vio_set_frame(vf.img)
+    h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+    tl, tv, its, acc = [], [], 0, 0
+    for rep in range(40):
+        x = capi.state18_from_frame(fr)
+        t0 = time.perf_counter()
+        info = h.lio_frame18_dev(x, fr.body_xyz)
+        t1 = time.perf_counter()
+        xv = capi.state18_from_frame(fr)
+        infos = h.vio_compute_j(xv, capi.state18_from_frame(fr))
+        t2 = time.perf_counter()
+        if rep >= 5:
+            tl.append(t1 - t0); tv.append(t2 - t1)
+        its = int(info.iterations)
+        acc = int(sum(i.iterations for i in infos))
+    h.close()
+    lio_ms, vio_ms = float(np.median(tl)) * 1e3, float(np.median(tv)) * 1e3
+    return {"lio_frame_ms": lio_ms, "vio_computej_ms": vio_ms, "frame_ms": lio_ms + vio_ms, "lio_passes": its, "vio_passes_3_levels": acc,
+            "frame_iterations_per_s": (its + acc) / ((lio_ms + vio_ms) * 1e-3),
+            "what": f"fl_lio_frame18_dev ({fr.n} pts, {len(scene.map_xyz)} map points: H2D, searches + plane fits, passes, covariance) + "
+                    f"fl_vio_compute_j ({vf.m} patches, levels 2-1-0); host wall time incl. every synchronisation"}
+
+
+def section_restage(capi, synth, fr, cfg, x0, nbr, valid):
+    """The host-kNN integration's worst case (SURVEY 8d second figure): EVERY pass preceded by a restage of the neighbours from the host
+    (3.05 MB H2D) + plane fit, then one pass."""
+    import torch
+    h = capi.Handle(cfg)
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    h.lio_set_points(fr.body_xyz)
+    h.lio_begin18(x0, x0)
+    F = capi.FL_ITER_FORCE
+    pin_n = h.host_alloc(nbr.shape, np.float32)
+    pin_n[:] = nbr
+    for _ in range(5):
+        h.lio_set_neighbours(pin_n, valid); h.lio_iterate18(1, F, want_info=False)
+    torch.cuda.synchronize()
+    K = 200
+    t0 = time.perf_counter()
+    for _ in range(K):
+        h.lio_set_neighbours(pin_n, valid)
+        h.lio_iterate18(1, F, want_info=False)
+    torch.cuda.synchronize()
+    us_pinned = (time.perf_counter() - t0) / K * 1e6
+    t0 = time.perf_counter()
+    for _ in range(K):
+        h.lio_set_neighbours(nbr, valid)
+        h.lio_iterate18(1, F, want_info=False)
+    torch.cuda.synchronize()
+    us_pageable = (time.perf_counter() - t0) / K * 1e6
+    h.host_free(pin_n)
+    h.close()
+    return {"lio_iteration_us_pinned_host_memory": us_pinned, "lio_iteration_us_pageable_host_memory": us_pageable,
+            "bytes_restaged_per_iteration": int(nbr.nbytes + valid.nbytes),
+            "what": "one LIO iteration = H2D of the 5-NN (n x 15 floats + n bytes) + lio_fit_planes_kernel + one pass, host wall time"}
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("FL_BENCH_SINGLE_DEVICE") == "1":     # test aid: all ranks on device 0 (1-GPU box), control plane over gloo
+    single_device = os.environ.get("FL_BENCH_SINGLE_DEVICE") == "1"
+    if single_device:     # test aid: all ranks on device 0 (1-GPU box), control plane over gloo
         local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
@@ -98,52 +321,82 @@ def main():
         raise SystemExit("bench.py needs a GPU: the ESKF hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     distributed = world > 1 or os.environ.get("FL_BENCH_FORCE_SHARDED") == "1"   # the env var exercises the N>1 code path on one GPU
+    backend = os.environ.get("FL_BENCH_BACKEND", "nccl")
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29617")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        backend = os.environ.get("FL_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
 
-    ctl = "cuda" if (not distributed or os.environ.get("FL_BENCH_BACKEND", "nccl") == "nccl") else "cpu"   # where control-plane tensors live
+    ctl = "cuda" if (not distributed or backend == "nccl") else "cpu"   # where control-plane tensors live
     import fastlivo  # noqa: F401
     from fast_livo_amd import capi, synth
+    from fast_livo_amd.sharded import shard_range
 
-    # ---- synthetic frame: this rank's shard of an (world x points)-point scan
+    # ---- synthetic frame and this rank's shard of it
     scene = synth.make_scene()
-    fr = synth.make_lio_frame(args.points, scene=scene, point_seed=synth.SEED + 101 + 17 * rank)
-    vf = synth.make_vio_frame(args.patches, fr, patch_seed=synth.SEED + 103 + 17 * rank)
-    world_pts = fr.world_at(fr.R_prior, fr.p_prior)
+    if args.scaling == "strong" or world == 1:
+        # ONE frame of --points / --patches, the same on every rank (same seeds); rank r keeps the range [r n/N, (r+1) n/N)
+        fr_full = synth.make_lio_frame(args.points, scene=scene, point_seed=synth.SEED + 101)
+        vf_full = synth.make_vio_frame(args.patches, fr_full, patch_seed=synth.SEED + 103)
+        lo, hi = shard_range(fr_full.n, rank, world)
+        plo, phi = shard_range(vf_full.m, rank, world)
+        fr, vf = fr_full, vf_full
+        body = np.ascontiguousarray(fr_full.body_xyz[lo:hi])
+        world_pts = fr_full.world_at(fr_full.R_prior, fr_full.p_prior)[lo:hi]
+        ref_patch = np.ascontiguousarray(vf_full.ref_patch[plo:phi])
+        ppos = np.ascontiguousarray(vf_full.pos[plo:phi])
+        pslv = np.ascontiguousarray(vf_full.search_level[plo:phi])
+        frame_points, frame_patches = fr_full.n, vf_full.m
+    else:
+        fr = synth.make_lio_frame(args.points, scene=scene, point_seed=synth.SEED + 101 + 17 * rank)
+        vf = synth.make_vio_frame(args.patches, fr, patch_seed=synth.SEED + 103 + 17 * rank)
+        body = fr.body_xyz
+        world_pts = fr.world_at(fr.R_prior, fr.p_prior)
+        ref_patch, ppos, pslv = vf.ref_patch, vf.pos, vf.search_level
+        frame_points, frame_patches = fr.n * world, vf.m * world
     nbr, valid = synth.knn5(scene, world_pts)
+    n_rank, m_rank = int(body.shape[0]), int(ref_patch.shape[0])
 
     cfg = capi.config_from_frames(fr, vf, max_iterations=10, device=local_rank)
-    hl = capi.Handle(cfg)   # LIO filter
-    hv = capi.Handle(cfg)   # VIO filter
+    x0 = capi.state18_from_frame(fr)
+    F = capi.FL_ITER_FORCE
     side = torch.cuda.Stream()            # everything (kernels, RCCL ordering, events) on one non-default stream
     torch.cuda.set_stream(side)
     stream = torch.cuda.current_stream().cuda_stream
+
+    if args.only:           # one extra section alone (N = 1): what the rocprofv3 runs behind profiles/ execute
+        sec = {"at_scale": lambda: section_at_scale(capi, synth, scene, cfg, x0),
+               "vio_sweep": lambda: section_vio_sweep(capi, synth, fr, vf, cfg, x0),
+               "mode23": lambda: section_mode23(capi, synth, scene, fr, cfg, nbr, valid),
+               "frame": lambda: section_frame(capi, synth, scene, fr, vf, cfg),
+               "restage": lambda: section_restage(capi, synth, fr, cfg, x0, nbr, valid)}[args.only]()
+        print(json.dumps({"section": args.only, "result": sec}), flush=True)
+        return
+
+    hl = capi.Handle(cfg)   # LIO filter
+    hv = capi.Handle(cfg)   # VIO filter
     hl.set_stream(stream)
     hv.set_stream(stream)
-    x0 = capi.state18_from_frame(fr)
-    F = capi.FL_ITER_FORCE
 
     def begin():
-        hl.lio_set_points(fr.body_xyz)
+        hl.lio_set_points(body)
         hl.lio_begin18(x0, x0)
         hl.lio_set_neighbours(nbr, valid)
         hv.vio_set_frame(vf.img)
-        hv.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+        hv.vio_set_patches(ref_patch, ppos, pslv)
         hv.vio_begin(x0, x0)
 
     # N > 1, first choice: the exchange INSIDE the pass kernels (api_p2p.inc): every rank maps the peers' exchange buffers (hipIpc),
-    # the solver workgroup of each pass trades the 32 sums peer to peer over xGMI, and a rank keeps enqueuing multi-pass launches
+    # the solver workgroup of each pass trades the 32 sums peer to peer, and a rank keeps enqueuing multi-pass launches
     # exactly like the single-GPU path. It is verified before it is relied on (no time-out bit, all ranks bitwise equal after a few
     # passes); every decision is agreed on by all ranks, otherwise they would wait for each other in different collectives.
     p2p = False
+    selftest = None
     if distributed and world >= 2 and os.environ.get("FL_BENCH_NO_P2P") != "1" and os.environ.get("FL_BENCH_TORCH_EXCHANGE") != "1":
         def all_agree(flag):
             t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=ctl)
@@ -172,6 +425,7 @@ def main():
                 print(f"[bench] rank {rank}: p2p_connect failed ({e})", file=sys.stderr)
                 connected = False
         connected = all_agree(connected)         # (also the barrier: nobody publishes before everybody has mapped everybody)
+        selftest = "not connected (export / hipIpc mapping failed on some rank)"
         if connected:
             begin()
             for _ in range(3):           # the launches of the timed region: multi-pass kernels, both epoch parities several times
@@ -184,6 +438,7 @@ def main():
             same = all(bool(torch.equal(a, alls[0])) for a in alls)
             good = (i1.status & 8) == 0 and (i2.status & 8) == 0 and bool(np.isfinite(sv).all()) and same
             p2p = all_agree(good)
+            selftest = "passed" if p2p else f"failed (status {i1.status}/{i2.status}, ranks bitwise equal: {same})"
             if not p2p and rank == 0:
                 print(f"[bench] in-kernel peer exchange failed its self-test (status {i1.status}/{i2.status}, equal={same}); "
                       "using RCCL", file=sys.stderr)
@@ -196,11 +451,12 @@ def main():
 
     # N > 1: the exchange is done natively (ncclAllReduce on the handle's stream between accumulate and solve, api_comm.inc);
     # the unique ids travel over torch.distributed. If RCCL cannot be bound, fall back to torch.distributed.all_reduce.
+    wire = ("xGMI between the GPUs" if not single_device else "all ranks on ONE device (test aid: no xGMI involved)")
     exchange = "none"
     if p2p:
-        exchange = "in-kernel peer-to-peer exchange of the solver workgroups over xGMI (api_p2p.inc)"
+        exchange = f"in-kernel peer-to-peer exchange of the solver workgroups (api_p2p.inc), {wire}"
     elif distributed:
-        exchange = "torch.distributed.all_reduce"
+        exchange = f"torch.distributed.all_reduce ({backend})"
         if os.environ.get("FL_BENCH_TORCH_EXCHANGE") != "1":
             # every rank must take the same branch: the unique id carries rank 0's verdict in its last byte, and the outcome of
             # comm_init is agreed on with a MIN all-reduce before anybody relies on the native communicator
@@ -227,7 +483,7 @@ def main():
             agree = torch.tensor([ok], dtype=torch.int32, device=ctl)
             dist.all_reduce(agree, op=dist.ReduceOp.MIN)
             if int(agree.item()) == 1:
-                exchange = "ncclAllReduce on the pass stream (native)"
+                exchange = f"ncclAllReduce on the pass stream (native RCCL), {wire}"
     native = exchange.startswith("ncclAllReduce")
 
     # A frame of the reference runs its passes back to back (<= max_iteration + 1 LIO passes, <= max_iteration VIO passes per
@@ -259,6 +515,7 @@ def main():
 
     steps(args.warmup)
     fence()
+    acc0 = hv.vio_iterate(VIO_LEVEL, 0, F) if not distributed else None     # counters before the timed region (N = 1)
     t0 = time.perf_counter()
     steps(args.steps)
     fence()
@@ -268,19 +525,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # what the forced passes of the timed region did: a VIO pass whose error went up reverts before the gain solve
+    # (lidar_selection.cpp:888-892) and is cheaper; LIO passes always solve, over the points still selected
+    pass_mix = None
+    if not distributed:
+        acc1 = hv.vio_iterate(VIO_LEVEL, 0, F)
+        li = hl.lio_iterate18(0, F)
+        pass_mix = {"vio_passes": int(acc1.iterations - acc0.iterations), "vio_passes_with_full_solve": int(acc1.accepted - acc0.accepted),
+                    "lio_effective_points_last_pass": int(li.effct_feat_num), "lio_points": n_rank,
+                    "note": "FL_ITER_FORCE passes: every LIO pass does residuals + reduction + solve; a VIO pass that is rejected "
+                            "(error went up) skips the gain solve, as in the reference"}
+
     # sanity: the filters must have produced finite states
     xs = hl.lio_get_state18().vec()
     xv = hv.vio_get_state18().vec()
     finite = bool(np.isfinite(xs).all() and np.isfinite(xv).all())
 
-    # ---- roofline of the dominant kernel (LIO pass), HIP events on the launch stream
+    # ---- roofline of the dominant kernel, HIP events on the launch stream
     roof = None
     if rank == 0 or p2p:       # with the in-kernel exchange a launch is a collective: every rank issues the same launches
         # the kernels of the timed region: one launch = PASSES_PER_LAUNCH passes (multi-pass kernels); average launch duration
         # from events on the launch stream around K back-to-back launches
         C = PASSES_PER_LAUNCH
         K = max(50, min(args.steps // C, 300))
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0, ev1 = _events(torch)
         for _ in range(10):
             hl.lio_iterate18(C, F, want_info=False)
         torch.cuda.synchronize()
@@ -298,8 +566,8 @@ def main():
         vio_launch_us = ev0.elapsed_time(ev1) * 1e3 / K
         lio_us, vio_us = lio_launch_us / C, vio_launch_us / C
     if rank == 0:
-        lio_bytes = LIO_BYTES_PER_POINT * args.points * C      # algorithmic bytes per launch = per pass x passes per launch
-        vio_bytes = VIO_BYTES_PER_PATCH * args.patches * C
+        lio_bytes = LIO_BYTES_PER_POINT * n_rank * C      # algorithmic bytes per launch = per pass x passes per launch
+        vio_bytes = VIO_BYTES_PER_PATCH * m_rank * C
         dom = "lio18_multipass_kernel" if lio_us >= vio_us else "vio_multipass_kernel"
         dom_bytes, dom_us = (lio_bytes, lio_launch_us) if lio_us >= vio_us else (vio_bytes, vio_launch_us)
         ach = dom_bytes / (dom_us * 1e-6) / 1e9
@@ -321,19 +589,23 @@ def main():
                           "inter-kernel boundary)",
                 "passes_per_launch": C, "lio_pass_us": lio_us, "vio_pass_us": vio_us,
                 "note": "latency-bound at BASELINE sizes: a pass moves 1.45 MB (LIO) / 0.82 MB (VIO) = 0.2 us at 8 TB/s, against "
-                        "two cross-workgroup hand-offs of ~2 us each per pass (SURVEY.md fact 5); see the DESIGN.md size sweep"}
-        if world == 1 and not args.no_at_scale:
-            # the same pass kernel where it is bandwidth-bound: at BASELINE sizes a pass is 0.2 us of traffic
-            # behind ~6 us of hand-off latency, at 8 M points the traffic is the time
-            us8, gb8 = lio_pass_at(capi, synth, scene, cfg, x0, AT_SCALE_POINTS)
-            roof["at_scale"] = {"kernel": "lio18_pass_kernel", "points": AT_SCALE_POINTS, "pass_us": us8, "achieved": gb8, "unit": "GB/s",
-                                "frac": gb8 / HBM_PEAK_GBS, "algorithmic_bytes": LIO_BYTES_PER_POINT * AT_SCALE_POINTS}
+                        "two cross-workgroup hand-offs per pass (SURVEY.md fact 5); at_scale / at_scale_vio: the same kernels where "
+                        "the traffic is the time"}
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        hl.close(); hv.close()
+        roof["at_scale"] = section_at_scale(capi, synth, scene, cfg, x0)
+        roof["at_scale_vio"] = section_vio_sweep(capi, synth, fr, vf, cfg, x0)
+        extras["mode23"] = section_mode23(capi, synth, scene, fr, cfg, nbr, valid)
+        extras["frame"] = section_frame(capi, synth, scene, fr, vf, cfg)
+        extras["restage"] = section_restage(capi, synth, fr, cfg, x0, nbr, valid)
         if args.sweep:
             sweep(capi, synth, scene, cfg, x0, sys.stderr)
 
-    cpu = None
+    cpu = cpu_all = None
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline(fr, vf, nbr, valid, args.cpu_seconds)
+        cpu_all = cpu_baseline_all_cores(fr, vf, nbr, valid, args.cpu_seconds)
 
     if distributed:
         torch.cuda.synchronize()
@@ -342,36 +614,52 @@ def main():
     hv.close()
     if rank == 0:
         frame_it_s = args.steps / elapsed
+        if world > 1:
+            par = (f"{args.scaling} scaling: one frame of {frame_points} points + {frame_patches} patches in point/patch-range shards x{world} "
+                   f"({n_rank} + {m_rank} per rank), the 32-double normal-equation record summed over the ranks in every pass: {exchange}"
+                   + (f"; {PASSES_PER_LAUNCH} consecutive passes per launch" if p2p else ""))
+        else:
+            par = f"single GPU, fused multi-pass kernels ({PASSES_PER_LAUNCH} consecutive passes per launch, as in one frame)"
         out = {
             "metric": "ESKF iterations/sec (50k LiDAR pts + 2k 8x8 patches)",
-            "value": frame_it_s * world,
+            "value": frame_it_s,
             "unit": "iterations/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32 point/pixel math + f64 Jacobian rows, reduction and solve",
             "data": "synthetic",
-            "config": {"workload": f"LIVO (BASELINE config 3): {args.points} pts point-to-plane LIO pass + {args.patches} "
-                                   f"8x8 patches VIO pass (level {VIO_LEVEL}) per GPU, 18-state (StatesGroup) ESKF, "
-                                   "neighbours/planes/image resident in HBM",
-                       "points_per_gpu": args.points, "patches_per_gpu": args.patches,
-                       "iteration_definition": "one LIO pass + one VIO pass, each = residuals + Jacobian rows + "
+            "config": {"workload": f"LIVO (BASELINE config {'3' if frame_points == N_POINTS else '4' if frame_points == 200000 else '3-like'}): "
+                                   f"one frame of {frame_points} pts (point-to-plane LIO pass) + {frame_patches} 8x8 patches (VIO pass, level "
+                                   f"{VIO_LEVEL}), 18-state (StatesGroup) ESKF, neighbours/planes/image resident in HBM",
+                       "frame_points": frame_points, "frame_patches": frame_patches,
+                       "points_per_gpu": n_rank, "patches_per_gpu": m_rank,
+                       "iteration_definition": "one LIO pass + one VIO pass over the WHOLE frame, each = residuals + Jacobian rows + "
                                                "normal equations + gain solve + state update",
-                       "parallelism": (f"point/patch-range shards x{world}, the 32-double normal-equation record summed over the "
-                                       f"ranks in every pass: {exchange}"
-                                       + (f"; {PASSES_PER_LAUNCH} consecutive passes per launch" if p2p else "")) if world > 1 else
-                                      f"single GPU, fused multi-pass kernels ({PASSES_PER_LAUNCH} consecutive passes per launch, as in one frame)"},
+                       "parallelism": par},
             "frame_iterations_per_s": frame_it_s,
             "state_finite": finite,
             "roofline": roof,
             "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": cpu_all,
         }
+        if world > 1:
+            out["exchange"] = {"used": "in-kernel p2p" if p2p else ("native RCCL" if native else "torch.distributed"),
+                               "p2p_selftest": selftest, "rccl_ranks": world if backend == "nccl" else 0,
+                               "ranks_on_distinct_devices": not single_device}
+            if args.scaling == "weak":
+                out["shard_iterations_per_s"] = frame_it_s * world     # secondary: (50 k + 2 k)-unit iterations per second over all ranks
+        if pass_mix:
+            out["pass_mix"] = pass_mix
+        out.update(extras)
         if cpu:
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
+        if cpu_all:
+            out["speedup_vs_cpu_baseline_all_cores"] = out["value"] / cpu_all["value"]
     if distributed:
         dist.destroy_process_group()       # (the handles' own communicators went with hl.close() / hv.close())
     if rank == 0:
@@ -381,37 +669,6 @@ def main():
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
-
-
-def lio_pass_at(capi, synth, scene, cfg, x0, n):
-    """Average duration (us) and effective bandwidth (GB/s) of one forced LIO pass over n points, HIP events on the launch stream."""
-    import torch
-    fr = synth.make_lio_frame(min(n, 200000), scene=scene)
-    reps = (n + fr.n - 1) // fr.n
-    body = np.tile(fr.body_xyz, (reps, 1))[:n]
-    w = fr.world_at(fr.R_prior, fr.p_prior)
-    nbr, valid = synth.knn5(scene, w)
-    nbr = np.tile(nbr, (reps, 1, 1))[:n]
-    valid = np.tile(valid, reps)[:n]
-    h = capi.Handle(cfg)
-    h.set_stream(torch.cuda.current_stream().cuda_stream)
-    h.lio_set_points(body)
-    h.lio_begin18(x0, x0)
-    h.lio_set_neighbours(nbr, valid)
-    K = 100 if n <= 1000000 else 20
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(5):
-        h.lio_iterate18(1, capi.FL_ITER_FORCE, want_info=False)
-    torch.cuda.synchronize()
-    ev0.record()
-    for _ in range(K):
-        h.lio_iterate18(1, capi.FL_ITER_FORCE, want_info=False)
-    ev1.record()
-    torch.cuda.synchronize()
-    us = ev0.elapsed_time(ev1) * 1e3 / K
-    gbs = LIO_BYTES_PER_POINT * n / (us * 1e-6) / 1e9
-    h.close()
-    return us, gbs
 
 
 def sweep(capi, synth, scene, cfg, x0, fh):

@@ -511,13 +511,17 @@ __global__ __launch_bounds__(FL_VIO_NT, 2) void vio_multipass_kernel(const uint8
             const unsigned epoch = epoch0 + (unsigned)p;
             FlSolveRegs G;
             eskf18_load_regs(s_solve, G, VC);                    // solve operands into wave 0's registers while the producers work
+            if (p == 5) fl_stamp(flags, 16);
             int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
             if (PV.world > 1) gst |= peer_allreduce32(PV, xe0 + (unsigned)p, s_sums, s_xchg);      // sharded form: totals over the ranks
+            if (p == 5) fl_stamp(flags, 17);
             FlVioExact ex;
             ex.words = err_base; ex.m = m; ex.cap = err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !force && PV.world <= 1;
             // wave 0 solves, derives the camera pose of the new state and publishes it (+ the control word) for the producers
-            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, gst, bcast, epoch + 1u, ex, VC);
+            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, gst, bcast, epoch + 1u, ex, VC, (p == 5) ? (flags & FL_ITER_STAMP) : 0);
+            if (p == 5) fl_stamp(flags, 35);
             __syncthreads();
+            if (p == 5) fl_stamp(flags, 18);
             done = p + 1;
             const int ctrl = s_solve.ctrl;
             if (ctrl & 4) {                                      // abandoned (hand-off time-out): this pass and the rest are still to do
@@ -558,8 +562,10 @@ __global__ __launch_bounds__(FL_VIO_NT, 2) void vio_multipass_kernel(const uint8
         const unsigned epoch = epoch0 + (unsigned)ps;
         const FlVioFirst pf = vio_prefetch_first(ref, pos, slevel, m, level, nprod);
         if (ps > 0) {
+            if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 20 + 4 * (ps - 5));
             bcast_wait(bcast, epoch, s_pose, &s_ctrl, spin_limit);
             __syncthreads();
+            if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 21 + 4 * (ps - 5));
             if (!force && (s_ctrl & 3)) break;
             if (s_ctrl & 4) break;
 #pragma unroll
@@ -567,8 +573,9 @@ __global__ __launch_bounds__(FL_VIO_NT, 2) void vio_multipass_kernel(const uint8
 #pragma unroll
             for (int i = 0; i < 3; i++) Pcw[i] = s_pose[9 + i];
         }
-        vio_produce(img, ref, pos, slevel, errors, m, level, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags,
-                    err_base ? err_base + (size_t)((pass0 + ps) & 1) * err_cap : nullptr, s_res);
+        vio_produce(img, ref, pos, slevel, errors, m, level, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records,
+                    (ps == 5 || ps == 6) ? 0 : (flags & ~FL_ITER_STAMP), err_base ? err_base + (size_t)((pass0 + ps) & 1) * err_cap : nullptr, s_res);
+        if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 23 + 4 * (ps - 5));
         __syncthreads();
     }
 }

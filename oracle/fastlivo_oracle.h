@@ -229,6 +229,10 @@ int orc_ikfom_update_iterated(orc_state23 *x, double *P, const float *body_xyz, 
                               void *knn_ctx, int nthreads, uint8_t *sel_out, float *normvec_out,
                               orc_ikfom_out *out);
 
+/* bench.py's "generous" CPU baseline: threads for the VIO patch loop / column sums (1 = the reference's single thread; results
+ * are bit-identical for any value, see orc_vio.c). */
+void orc_vio_set_threads(int n);
+
 /* The same update around ANY measurement callback of the reference's shape -- measurementModel_dyn_share, esekfom.hpp:129:
  * `void (state &, dyn_share_datastruct<scalar_type> &)`, registered by init_dyn_share (:238-254), invoked at :1636.  The callback
  * receives the state and the in/out flags valid (true on entry) / converge, and returns h_x (rows x 12 row-major) and h (rows).

@@ -98,6 +98,13 @@ static void vio_init_extr(const orc_vio_config *cfg, vio_extr *e)
     e->fy = fabs(4.0 * cfg->fx * cfg->fy) / (4. * e->fx); /* errorMultiplier()/(4 fx) */
 }
 
+/* The reference runs this loop on ONE thread (lidar_selection.cpp:789-853 has no OpenMP pragma). For the "generous" CPU baseline of
+ * bench.py the patch loop and the 42 column sums can be spread over threads WITHOUT changing a bit of the result: rows
+ * of different patches are independent, the float running sum `error += patch_error` is taken afterwards in patch order, and every
+ * H^T H / H^T z entry is still one sequential sum. 1 = the reference. */
+static int g_vio_threads = 1;
+void orc_vio_set_threads(int n) { g_vio_threads = n > 1 ? n : 1; }
+
 float orc_vio_update_state(const orc_vio_config *cfg, orc_state18 *x, const orc_state18 *x_prop,
                            const uint8_t *img, const float *ref_patch, const double *pos,
                            const int32_t *search_level, int m, float total_residual, int level,
@@ -135,6 +142,9 @@ float orc_vio_update_state(const orc_vio_config *cfg, orc_state18 *x, const orc_
         }
         memcpy(Jdp_dt, Rcw, sizeof Rcw);                 /* Jdp_dt = Rci * Rwi^T */
 
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(g_vio_threads) if (g_vio_threads > 1) schedule(static) private(patch_error)
+#endif
         for (int i = 0; i < m; i++) {
             patch_error = 0.0f;
             const int pyramid_level = level + search_level[i];
@@ -191,14 +201,13 @@ float orc_vio_update_state(const orc_vio_config *cfg, orc_state18 *x, const orc_
                     const int row = i * pst + xr * patch_size + y;
                     z[row] = res;
                     patch_error = (float)(patch_error + res * res);
-                    n_meas++;
                     H_sub[row * 6 + 0] = JdR[0]; H_sub[row * 6 + 1] = JdR[1]; H_sub[row * 6 + 2] = JdR[2];
                     H_sub[row * 6 + 3] = Jdt[0]; H_sub[row * 6 + 4] = Jdt[1]; H_sub[row * 6 + 5] = Jdt[2];
                 }
             }
             errors[i] = patch_error;
-            error += patch_error;
         }
+        for (int i = 0; i < m; i++) { error += errors[i]; n_meas += pst; }      /* `error += patch_error; n_meas++` in patch order (:849-857) */
         error = error / n_meas;
 
         /* not part of the reference: note when the test below is decided within the rounding noise of the float running sum
@@ -207,15 +216,19 @@ float orc_vio_update_state(const orc_vio_config *cfg, orc_state18 *x, const orc_
         if (error <= last_error) {
             old_state = *x;
             last_error = error;
-            for (int a = 0; a < 6; a++) {
-                for (int b = 0; b < 6; b++) {
-                    double s = 0.0;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(g_vio_threads) if (g_vio_threads > 1) schedule(static)
+#endif
+            for (int ab = 0; ab < 42; ab++) {
+                const int a = ab / 7, b = ab % 7;
+                double s = 0.0;
+                if (b < 6) {
                     for (int k = 0; k < H_DIM; k++) s += H_sub[k * 6 + a] * H_sub[k * 6 + b];
                     HTH[a * 6 + b] = s;
+                } else {
+                    for (int k = 0; k < H_DIM; k++) s += H_sub[k * 6 + a] * z[k];
+                    HTz[a] = s;
                 }
-                double s = 0.0;
-                for (int k = 0; k < H_DIM; k++) s += H_sub[k * 6 + a] * z[k];
-                HTz[a] = s;
             }
             orc_solve18(x, x_prop, HTH, HTz, cfg->img_point_cov, -1.0, G, solution);
             accepted++;

@@ -35,6 +35,35 @@ int emul_lio18_accumulate(const float *body, const float *plane, unsigned char *
     return 0;
 }
 
+// the per-point gate threshold (fl_gate_threshold) against the reference's expression evaluated directly:
+// for every point, the threshold T and the number of probes a around T (T-3ulp .. T+3ulp, plus a few far ones) for which
+// `a <= T` and the expression disagree
+int emul_gate_thresholds(const float *body, int n, float *T_out, int *mismatches)
+{
+    int bad = 0;
+    for (int i = 0; i < n; i++) {
+        const float *pb = body + (size_t)i * 3;
+        const float T = fl_gate_threshold(pb);
+        T_out[i] = T;
+        const double b0 = pb[0], b1 = pb[1], b2 = pb[2];
+        const double q = sqrt(sqrt(b0 * b0 + b1 * b1 + b2 * b2));
+        float probes[16];
+        int np = 0;
+        probes[np++] = 0.0f; probes[np++] = 1e-30f; probes[np++] = 1.0f; probes[np++] = 2.0f; probes[np++] = 3.4e38f;
+        if (T >= 0.0f) {
+            const unsigned u = fl_float_bits(T);
+            for (int d = -3; d <= 3; d++) {
+                const long long v = (long long)u + d;
+                if (v >= 0 && v <= 0x7F7FFFFFll) probes[np++] = fl_bits_float((unsigned)v);
+            }
+        }
+        for (int k = 0; k < np; k++)
+            if ((probes[k] <= T) != (fl_gate_expr(probes[k], q) != 0)) bad++;
+    }
+    *mismatches = bad;
+    return 0;
+}
+
 int emul_solve18(double *x, const double *xprop, const double *P, double meas_cov, const double *sums, double sign,
                  double *G6, double *delta)
 {

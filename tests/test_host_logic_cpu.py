@@ -60,6 +60,26 @@ def test_plane_fit_gates_rows_and_solve_match_oracle(oracle_lib, emul_lib, scene
         assert np.abs(G6.reshape(18, 6) - r["G"][:, :6]).max() <= 1e-9
 
 
+def test_gate_threshold_is_the_reference_expression(emul_lib, scene):
+    """fl_gate_threshold (fl_math.h): `|pd2| <= T` must be the reference's `s > 0.9`, s = (float)(1 - 0.9*|pd2|/sqrt(|p_b|))
+    (laserMapping.cpp:1574-1576), for every float |pd2| -- probed at T +- 3 ulp and at far values, for scan points, tiny and huge
+    ranges, the origin and non-finite coordinates."""
+    from fast_livo_amd import synth
+    fr = synth.make_lio_frame(20000, scene=scene)
+    rng = np.random.default_rng(0)
+    extra = np.array([[0, 0, 0], [1e-20, 0, 0], [1e18, 1e18, 1e18], [np.inf, 0, 0], [np.nan, 1, 1], [3e-4, 2e-4, 1e-4], [1e4, -2e4, 3e3]],
+                     dtype=np.float32)
+    body = np.concatenate([fr.body_xyz, (rng.normal(0, 1, (5000, 3)) * 10.0 ** rng.uniform(-6, 6, (5000, 1))).astype(np.float32), extra])
+    body = np.ascontiguousarray(body, dtype=np.float32)
+    T = np.zeros(len(body), dtype=np.float32)
+    bad = C.c_int(0)
+    emul_lib.emul_gate_thresholds(p(body, C.c_float), len(body), p(T, C.c_float), C.byref(bad))
+    assert bad.value == 0
+    assert T[len(body) - 7] == -1.0 and T[len(body) - 3] == -1.0          # the origin and a NaN coordinate never pass
+    rngs = np.sqrt(np.linalg.norm(fr.body_xyz.astype(np.float64), axis=1))
+    assert np.allclose(T[:fr.n], rngs / 9.0, rtol=1e-5)                  # the analytic crossing: |pd2| < sqrt(|p_b|) / 9
+
+
 def test_degenerate_neighbours_never_selected(emul_lib):
     E = emul_lib
     nb = np.zeros((3, 5, 3), dtype=np.float32)

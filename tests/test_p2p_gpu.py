@@ -154,6 +154,18 @@ def test_bench_n2_path_on_one_device(gpu_lib):
     assert out.returncode == 0, out.stderr[-3000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["state_finite"] and d["scaling"] == "weak"
-    assert "in-kernel peer-to-peer" in d["config"]["parallelism"]
+    # default N > 1 = STRONG scaling of the metric's own frame: 50 k points + 2 k patches split over the ranks, value = frame iterations/s
+    assert d["n_gpus"] == 2 and d["state_finite"] and d["scaling"] == "strong"
+    assert d["config"]["frame_points"] == 50000 and d["config"]["points_per_gpu"] == 25000 and d["config"]["patches_per_gpu"] == 1000
+    assert d["value"] == d["frame_iterations_per_s"] and "shard_iterations_per_s" not in d
+    assert "in-kernel peer-to-peer" in d["config"]["parallelism"] and "xGMI between" not in d["config"]["parallelism"]   # both ranks on ONE device here
+    assert d["exchange"]["used"] == "in-kernel p2p" and d["exchange"]["p2p_selftest"] == "passed" and d["exchange"]["ranks_on_distinct_devices"] is False
     assert d["roofline"]["lio_pass_us"] < 100 and d["roofline"]["vio_pass_us"] < 100      # no time-outs hidden in the launches
+    # weak scaling and BASELINE config 4 (200 k points over the ranks) are flags away
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "10",
+                          "--scaling", "weak"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["scaling"] == "weak" and d["config"]["frame_points"] == 100000 and d["config"]["points_per_gpu"] == 50000
+    assert abs(d["shard_iterations_per_s"] - 2 * d["value"]) < 1e-6 * d["value"]
