@@ -312,7 +312,7 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
         int b_lio = 0, b_vio = 0, b_ik = 0;
         HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_lio, lio18_multipass_kernel, FL_LIO_NT, 0));
         HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_vio, vio_multipass_kernel, FL_VIO_NT, 0));
-        b_ik = b_lio;
+        HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_ik, ikfom_multipass_kernel, FL_IK_NT, 0));
         int b = b_lio < b_vio ? b_lio : b_vio;
         if (b_ik < b) b = b_ik;
         h->mp_capacity = b * h->num_cus;

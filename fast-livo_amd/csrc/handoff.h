@@ -186,13 +186,15 @@ __device__ __forceinline__ void bcast_publish(unsigned long long *words, const d
 // Wave 0 of a producer workgroup polls (measured: letting all four waves poll with staggered phases costs more in extra
 // traffic than it gains in detection latency: 7.2-7.8 vs 7.1 us per pass). After the caller's __syncthreads
 // out12[0..11] = pose, *ctrl_out = control bits (bit 2 set on a timeout: bounded spin).
-__device__ __forceinline__ void bcast_wait(const unsigned long long *words, unsigned epoch, double *out12 /* LDS */, int *ctrl_out /* LDS */,
+template <int NWORDS = FL_BCAST_WORDS>      // NWORDS - 1 payload words (halves of doubles) + the control word, <= 64
+__device__ __forceinline__ void bcast_wait(const unsigned long long *words, unsigned epoch, double *out12 /* LDS, (NWORDS-1)/2 */, int *ctrl_out /* LDS */,
                                            int spin_limit = FL_GATHER_SPIN_LIMIT)
 {
+    static_assert(NWORDS <= 64 && (NWORDS & 1) == 1, "one wavefront polls the words");
     const int tid = threadIdx.x;
     if (tid >= 64) return;
     words += (size_t)(blockIdx.x % FL_BCAST_REPL) * FL_BCAST_STRIDE;
-    const bool mine = tid < FL_BCAST_WORDS;
+    const bool mine = tid < NWORDS;
     const unsigned long long *src = words + (mine ? tid : 0);
     unsigned long long w = 0ull;
     bool timeout = false;
@@ -221,8 +223,8 @@ __device__ __forceinline__ void bcast_wait(const unsigned long long *words, unsi
 #endif
     const unsigned payload = (unsigned)(w >> 32);
     const unsigned other = (unsigned)__shfl_xor((int)payload, 1, 64);
-    if (tid < 24 && (tid & 1) == 0) out12[tid >> 1] = f64_make(payload, other);
-    if (tid == 24) *ctrl_out = timeout ? 5 : (int)payload;
+    if (tid < NWORDS - 1 && (tid & 1) == 0) out12[tid >> 1] = f64_make(payload, other);
+    if (tid == NWORDS - 1) *ctrl_out = timeout ? 5 : (int)payload;
 }
 
 

@@ -36,56 +36,49 @@ struct FlDev23 {
     int32_t iters_run;
     int32_t max_iter;
     int32_t searched_at;      // device k-NN: value of iters_run the last search was made for (-1: none)
+    int32_t resume_count;     // passes an abandoned launch chain left undone (FL_NUM_TIMEOUT; see solve18.h)
+    int32_t pad23;
 };
 
 #include "ikfom_solve_block.h"
 
 #define FL_IK_NT 256
 
-template <int MODE>
-__global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float *__restrict__ body, const float4 *__restrict__ plane,
-                                                             uint8_t *__restrict__ sel, float4 *__restrict__ normvec, int n,
-                                                             FlDev23 *__restrict__ D, void *__restrict__ records,
-                                                             unsigned *__restrict__ epoch_ptr, double *__restrict__ sums_out,
-                                                             int flags)
+// no-op launch? (abandoned chain: count what is skipped; stopped / waiting for a search) -- as fl_pass_skipped of lio_kernels.h
+__device__ __forceinline__ bool ik_pass_skipped(FlDev23 *__restrict__ D, int flags, int passes, bool counter_thread)
+{
+    if (D->status & FL_NUM_TIMEOUT) {
+        if (counter_thread) D->resume_count += passes;
+        return true;
+    }
+    return !(flags & FL_ITER_FORCE) && (D->stop || (D->need_search && D->searched_at != D->iters_run));
+}
+
+// one producer workgroup's share of a pass at state x: rows [n, A, B, C] reduced to the 96-double record and published.
+// The scan arrives as (x, y, z, T) with the selection threshold T of fl_math.h (fl_gate_threshold) and a NaN normal marks a point
+// that is not selected (lio_fit_planes_kernel): 32 bytes and two loads per point, no sqrt / division in the gate.
+__device__ __forceinline__ void ikfom_produce(const float4 *__restrict__ body4, float4 *__restrict__ plane, uint8_t *__restrict__ sel,
+                                              float4 *__restrict__ normvec, int n, const double (&x)[FL_X23_LEN], int nprod, int flags,
+                                              double *s_red, unsigned epoch, void *__restrict__ records)
 {
     constexpr int NT = FL_IK_NT;
-    if (!(flags & FL_ITER_FORCE) && (D->stop || (D->need_search && D->searched_at != D->iters_run))) return;
-    const unsigned epoch = *epoch_ptr;
-    const int nprod = gridDim.x - 1;
-
-    if (blockIdx.x == nprod) {
-        __shared__ double s_fin[2 * NT];
-        __shared__ double s_sums[FL_SUMS23];
-        __shared__ FlIkLds s_ik;
-        const int gst = gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums);
-        if (threadIdx.x == 0) *epoch_ptr = epoch + 1u;
-        if (MODE == 0) {
-            ikfom_solver_block(D, s_sums, s_ik, gst);
-        } else {
-            if (threadIdx.x < FL_SUMS23) sums_out[threadIdx.x] = s_sums[threadIdx.x];
-        }
-        return;
-    }
-
-    __shared__ double s_red[(NT / 64) * FL_SUMS23];
-    double x[FL_X23_LEN];
-#pragma unroll
-    for (int i = 0; i < FL_X23_LEN; i++) x[i] = D->x[i];
     double v[FL_SUMS23];
 #pragma unroll
     for (int k = 0; k < FL_SUMS23; k++) v[k] = 0.0;
     for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += nprod * NT) {
-        if (!sel[i]) continue;
-        const float pb[3] = {body[i * 3 + 0], body[i * 3 + 1], body[i * 3 + 2]};
         const float4 plq = plane[i];
+        if (!(plq.x == plq.x)) continue;
+        const float4 bq = body4[i];
+        const float pb[3] = {bq.x, bq.y, bq.z};
         const float pl[4] = {plq.x, plq.y, plq.z, plq.w};
         double p_i[3];
-        float pw[3], pd2;
-        int eff;
+        float pw[3];
         fl_world_point23(x, pb, p_i, pw);
-        const int s = fl_gates_from_pw(pb, pl, pw, &pd2, &eff);
-        if (!s) sel[i] = 0;
+        const float pd2 = pl[0] * pw[0] + pl[1] * pw[1] + pl[2] * pw[2] + pl[3];
+        const float a = fabsf(pd2);
+        const int s = (a <= bq.w) ? 1 : 0;
+        const int eff = (s && (a <= 2.0f)) ? 1 : 0;
+        if (!s) { sel[i] = 0; plane[i].x = __builtin_nanf(""); }
         if ((flags & FL_ITER_KEEP_NORMVEC) && s) normvec[i] = make_float4(pl[0], pl[1], pl[2], pd2);
         if (eff) {
             double row[12], z;
@@ -100,15 +93,142 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float *__res
     publish_record<FL_SUMS23>(mine, epoch, records);
 }
 
+template <int MODE>
+__global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float4 *__restrict__ body4, float4 *__restrict__ plane,
+                                                             uint8_t *__restrict__ sel, float4 *__restrict__ normvec, int n,
+                                                             FlDev23 *__restrict__ D, void *__restrict__ records,
+                                                             unsigned *__restrict__ epoch_ptr, double *__restrict__ sums_out,
+                                                             int flags)
+{
+    constexpr int NT = FL_IK_NT;
+    if (ik_pass_skipped(D, flags, 1, blockIdx.x == 0 && threadIdx.x == 0)) return;
+    const unsigned epoch = *epoch_ptr;
+    const int nprod = gridDim.x - 1;
+
+    if (blockIdx.x == nprod) {
+        __shared__ double s_fin[2 * NT];
+        __shared__ double s_sums[FL_SUMS23];
+        __shared__ FlIkLds s_ik;
+#ifdef FL_IK_STAMPS
+        if (threadIdx.x == 0) g_fl_stamps[32] = (long long)wall_clock64();
+#endif
+        if (MODE == 0) { ikfom_stage_once(D, s_ik);
+#ifdef FL_IK_STAMPS
+        if (threadIdx.x == 0) g_fl_stamps[33] = (long long)wall_clock64();
+#endif
+            ikfom_pre(s_ik); }       // while the producers work
+#ifdef FL_IK_STAMPS
+        if (threadIdx.x == 0) g_fl_stamps[34] = (long long)wall_clock64();
+#endif
+        const int gst = gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums);
+#ifdef FL_IK_STAMPS
+        if (threadIdx.x == 0) g_fl_stamps[35] = (long long)wall_clock64();
+#endif
+        if (threadIdx.x == 0) *epoch_ptr = epoch + 1u;
+        if (MODE == 0) {
+            ikfom_post(D, s_sums, s_ik, gst);
+#ifdef FL_IK_STAMPS
+            if (threadIdx.x == 0) g_fl_stamps[40] = (long long)wall_clock64();
+#endif
+        } else {
+            if (threadIdx.x < FL_SUMS23) sums_out[threadIdx.x] = s_sums[threadIdx.x];
+        }
+        return;
+    }
+
+    __shared__ double s_red[(NT / 64) * FL_SUMS23];
+    double x[FL_X23_LEN];
+#pragma unroll
+    for (int i = 0; i < FL_X23_LEN; i++) x[i] = D->x[i];
+    ikfom_produce(body4, plane, sel, normvec, n, x, nprod, flags, s_red, epoch, records);
+}
+
+// Up to `count` passes of update_iterated_dyn_share_modified in ONE launch (as lio18_multipass_kernel): the solver broadcasts the
+// whole state_ikfom (26 doubles: the producers need pos, rot, offset_R_L_I, offset_T_L_I) plus the stop / search-wanted bits, stages
+// the next pass's state-only work (ikfom_pre) while the producers compute, and runs the final covariance block in the pass that
+// finishes. Needs every workgroup resident (host: admission check); all waits are bounded, a time-out abandons the pass.
+#define FL_IK_BCAST_WORDS (2 * FL_X23_LEN + 1)
+__global__ __launch_bounds__(FL_IK_NT) void ikfom_multipass_kernel(const float4 *__restrict__ body4, float4 *__restrict__ plane,
+                                                                  uint8_t *__restrict__ sel, float4 *__restrict__ normvec, int n,
+                                                                  FlDev23 *__restrict__ D, void *__restrict__ records,
+                                                                  unsigned *__restrict__ epoch_ptr, unsigned long long *__restrict__ bcast,
+                                                                  int count, int flags, unsigned *__restrict__ done_word, unsigned done_seq)
+{
+    constexpr int NT = FL_IK_NT;
+    const int nprod = gridDim.x - 1;
+    const bool force = (flags & FL_ITER_FORCE) != 0;
+    if (ik_pass_skipped(D, flags, count, blockIdx.x == 0 && threadIdx.x == 0)) {
+        fl_mp_done(done_word, done_seq, blockIdx.x == nprod);
+        return;
+    }
+    const unsigned epoch0 = *epoch_ptr;
+
+    if (blockIdx.x == nprod) {
+        __shared__ double s_fin[2 * NT];
+        __shared__ double s_sums[FL_SUMS23];
+        __shared__ FlIkLds s_ik;
+        ikfom_stage_once(D, s_ik);
+        int done = 0;
+        bool wrote_P = false;
+        for (int p = 0; p < count; p++) {
+            const unsigned epoch = epoch0 + (unsigned)p;
+            ikfom_pre(s_ik);                                      // state-only half of the iteration, while the producers work
+            const int gst = gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums);
+            ikfom_post(D, s_sums, s_ik, gst, bcast, epoch + 1u, false);
+            __syncthreads();
+            done = p + 1;
+            if (s_ik.ctl[4]) {                                    // abandoned
+                if (threadIdx.x == 0) D->resume_count = count - p;
+                break;
+            }
+            wrote_P = s_ik.ctl[2] != 0;                           // the finishing pass wrote the final P_
+            if (!force && (s_ik.ctl[5] || s_ik.ctl[1])) break;    // stop, or the next pass wants a search first
+        }
+        if (!wrote_P) {                                           // a reader of the device block finds the projected P_ of the last pass
+            for (int e = threadIdx.x; e < FL_N23 * FL_N23; e += NT) D->P[e] = s_ik.P[e];
+        }
+        if (threadIdx.x == 0) *epoch_ptr = epoch0 + (unsigned)done;
+        fl_mp_done(done_word, done_seq, true);
+        return;
+    }
+
+    __shared__ double s_red[(NT / 64) * FL_SUMS23];
+    __shared__ double s_state[FL_X23_LEN];
+    __shared__ int s_ctrl;
+    double x[FL_X23_LEN];
+#pragma unroll
+    for (int i = 0; i < FL_X23_LEN; i++) x[i] = D->x[i];
+    for (int ps = 0; ps < count; ps++) {
+        const unsigned epoch = epoch0 + (unsigned)ps;
+        if (ps > 0) {
+            bcast_wait<FL_IK_BCAST_WORDS>(bcast, epoch, s_state, &s_ctrl);
+            __syncthreads();
+            if (s_ctrl & 4) break;
+            if (!force && (s_ctrl & 3)) break;
+#pragma unroll
+            for (int i = 0; i < FL_X23_LEN; i++) x[i] = s_state[i];
+        }
+        ikfom_produce(body4, plane, sel, normvec, n, x, nprod, flags, s_red, epoch, records);
+        __syncthreads();
+    }
+}
+
 // Solve from an externally reduced record (sharded form).
 __global__ __launch_bounds__(FL_IK_NT) void ikfom_solve_kernel(FlDev23 *__restrict__ D, const double *__restrict__ sums_in, int flags)
 {
+    if (D->status & FL_NUM_TIMEOUT) return;
     if (!(flags & FL_ITER_FORCE) && (D->stop || (D->need_search && D->searched_at != D->iters_run))) return;
     __shared__ double s_sums[FL_SUMS23];
     __shared__ FlIkLds s_ik;
     if (threadIdx.x < FL_SUMS23) s_sums[threadIdx.x] = sums_in[threadIdx.x];
-    __syncthreads();
-    ikfom_solver_block(D, s_sums, s_ik, 0);
+    ikfom_stage_once(D, s_ik);
+    ikfom_pre(s_ik);
+    ikfom_post(D, s_sums, s_ik, 0);
+}
+
+__global__ void ikfom_resume_kernel(FlDev23 *__restrict__ D)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { D->status &= ~FL_NUM_TIMEOUT; D->resume_count = 0; }
 }
 
 // world points at the current state_ikfom (laserMapping.cpp:980-984) for the host kNN

@@ -1,11 +1,22 @@
 // ikfom_solve_block.h -- workgroup-cooperative form of one iteration of
 // esekf::update_iterated_dyn_share_modified (esekfom.hpp:1644-1926): same mathematics as the one-thread
 // fl_ikfom_iterate (fl_ikfom_math.h, unit-tested on the host), with the O(n^2 k) / O(n^3) loops spread over
-// the 256 threads of the solver workgroup and every matrix in LDS. ~290 us -> ~20 us per pass.
+// the 256 threads of the solver workgroup and every matrix in LDS.
 //
 // The reference applies the SO3/S2 projection Jacobians block by block, in place; the blocks are
 // disjoint, so the result equals Jf P Jf^T with the block-diagonal Jf = diag(I3, J_rot, J_off, I12, J_S2)
 // -- formed here element-wise (rounding-level differences only, compared by tolerance).
+//
+// Round 2: the iteration is split where the measurement enters.
+//   ikfom_pre   everything that depends on the state alone -- dx = x (-) x_prop with its three manifold logarithms, the
+//               projection Jacobians, P = Jf P_prop Jf^T (23x23), dx_new, A12 = sym(P[0:12,0:12]) / R -- runs BEFORE the
+//               records arrive, while the producers are still working (it was 6 of the solver's 14 us, all of it on the pass's
+//               critical path);
+//   ikfom_post  S = h_x^T h_x enters: M = A12 + A12 S A12, rhs; the 12x12 SPD solve as a right-looking LDL^T held in the
+//               registers of every lane of wavefront 0 (reciprocal + Newton steps; no square roots, no divisions, no cross-lane
+//               traffic: the v_readlane Cholesky with 12 sqrt and 36 divisions took 4.6 us), dx_, the three boxplus segments,
+//               judgement, and -- on the finishing pass only -- the final covariance block (esekfom.hpp:1831-1924).
+// A pass whose hand-off timed out is ABANDONED as in solve18.h: state untouched, FL_NUM_TIMEOUT sticky, the host resumes.
 #pragma once
 
 #include "fl_device.h"
@@ -14,16 +25,19 @@
 struct FlIkLds {
     double P[529];       // projected P_ (then the final P_ on the finishing pass)
     double Pc[529];      // P_ with columns re-projected (final block)
-    double L[529];       // L_
+    double L[529];       // L_ (final block)
+    double Pp[529];      // P_propagated, staged once per launch
     double S[144], A12[144], SA[144], M[144], X[144];
     double Kx[276];      // 23 x 12
     double x[FL_X23_LEN], xp[FL_X23_LEN];
     double dx[23], dxn[23], dxo[23];
-    double rhs[12], y[12];
+    double rhs[12], y[12], y0[12];
     double J[3][9];      // J_rot, J_off (3x3), J_S2 (2x2 in the first 4 entries)
-    int ctl[8];          // 0 t_count, 1 converge, 2 finished, 3 status
-    double limit[23];    // convergence limits, staged once (the judging lane would otherwise walk them with dependent global loads)
-    int cnt[4];          // t_count, iter_i, max_iter, iters_run of D at the start of the pass
+    int ctl[8];          // 0 t_count, 1 converge, 2 finishing, 3 status of this pass, 4 abandoned, 5 stop
+    double limit[23];    // convergence limits, staged once
+    int cnt[4];          // t_count, iter_i, max_iter, iters_run: kept current across the passes of a multi-pass launch
+    int sticky;          // status bits accumulated since fl_ikfom_begin
+    double R;
 };
 
 // block-diagonal Jf: element (r, a); blk = start index of r's block, bs = its size
@@ -46,31 +60,82 @@ __device__ __forceinline__ void ik_make_J(FlIkLds &L, const double *seg, int tid
     else if (tid == 64) fl_ikfom_J_so3(seg + 6, L.J[1]);
     else if (tid == 128) fl_ikfom_J_s2(L.x + FL_X23_GRAV, L.xp + FL_X23_GRAV, seg + 21, L.J[2]);
 }
-// value of `v` in lane `lane` (compile-time constant) for the whole wave: two v_readlane instead of two ds_bpermute
-__device__ __forceinline__ double ik_lane(double v, int lane /* wave-uniform */)
+__device__ __forceinline__ constexpr int ik_tri(int i, int j) { return i * (i + 1) / 2 + j; }   // j <= i
+__device__ __forceinline__ double ik_rcp_nr(double d)
 {
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)f64_lo(v), lane);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)f64_hi(v), lane);
-    return f64_make(lo, hi);
+#pragma clang fp contract(fast)
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    return r;
+}
+// M y = w for the SPD 12x12 M = sym(X) (LDS), entirely in the registers of the calling lane: right-looking LDL^T with w as a 13th
+// row (the forward substitution falls out of the elimination), reciprocal + Newton steps for the pivots, back substitution.
+// Every lane may bring its own right-hand side. Returns 1 if a pivot is not positive.
+__device__ __forceinline__ int ik_ldl_solve_regs(const double *X /* LDS, 144 */, const double (&w_in)[12], double (&y)[12])
+{
+#pragma clang fp contract(fast)
+    double c[12][12];       // lower triangle used
+    double w[12];
+    int bad = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+#pragma unroll
+        for (int j = 0; j < 12; j++)
+            if (j <= i) c[i][j] = (i == j) ? X[i * 12 + i] : 0.5 * (X[i * 12 + j] + X[j * 12 + i]);
+        w[i] = w_in[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        const double dj = c[j][j];
+        if (!(dj > 0.0)) bad = 1;
+        const double inv = ik_rcp_nr(dj);
+        double u[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++)
+            if (i > j) { u[i] = c[i][j]; c[i][j] = u[i] * inv; }
+        const double wj = w[j] * inv;
+        w[j] = wj;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            if (i > j) {
+#pragma unroll
+                for (int k = 0; k < 12; k++)
+                    if (k > j && k <= i) c[i][k] = fma(-c[i][j], u[k], c[i][k]);
+                w[i] = fma(-wj, u[i], w[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 11; i >= 0; i--) {
+        double yi = w[i];
+#pragma unroll
+        for (int k = 0; k < 12; k++)
+            if (k > i) yi = fma(-c[k][i], y[k], yi);
+        y[i] = yi;
+    }
+    return bad;
 }
 
-__device__ __forceinline__ void ikfom_solver_block(FlDev23 *__restrict__ D, const double *s_sums, FlIkLds &L, int gst)
+// once per launch: state, propagated covariance, limits, counters
+__device__ __forceinline__ void ikfom_stage_once(const FlDev23 *__restrict__ D, FlIkLds &L)
 {
     const int tid = threadIdx.x, NTH = blockDim.x, n = FL_N23;
-#ifdef FL_IK_STAMPS
-    if (tid == 0) g_fl_stamps[32] = (long long)wall_clock64();
-#endif
-    // ---- stage 0: state, propagated covariance (into L.L, free until the finishing block), limits and counters to LDS
     if (tid < FL_X23_LEN) { L.x[tid] = D->x[tid]; L.xp[tid] = D->xprop[tid]; }
-    for (int e = tid; e < n * n; e += NTH) L.L[e] = D->Pprop[e];
+    for (int e = tid; e < n * n; e += NTH) L.Pp[e] = D->Pprop[e];
     if (tid >= 64 && tid < 64 + 23) L.limit[tid - 64] = D->limit[tid - 64];
-    if (tid == 96) { L.cnt[0] = D->t_count; L.cnt[1] = D->iter_i; L.cnt[2] = D->max_iter; L.cnt[3] = D->iters_run; }
+    if (tid == 96) { L.cnt[0] = D->t_count; L.cnt[1] = D->iter_i; L.cnt[2] = D->max_iter; L.cnt[3] = D->iters_run; L.sticky = D->status; L.R = D->meas_cov; }
     __syncthreads();
-#ifdef FL_IK_STAMPS
-    if (tid == 0) g_fl_stamps[33] = (long long)wall_clock64();
-#endif
-    // ---- stage 1: dx = x (-) x_prop and the projection Jacobians at dx. The three manifold segments (SO3 rot, SO3 offset_R,
-    // S2 grav -- each a Log with acos/atan2 and a Jacobian with sin/cos) are independent: one lane of three different waves each
+}
+
+// before the records arrive: dx, Jacobians, projected covariance, dx_new, A12. All threads; ends with a barrier.
+__device__ __forceinline__ void ikfom_pre(FlIkLds &L)
+{
+    const int tid = threadIdx.x, NTH = blockDim.x, n = FL_N23;
+    // dx = x (-) x_prop and the projection Jacobians at dx. The three manifold segments (SO3 rot, SO3 offset_R, S2 grav -- each a Log
+    // with acos/atan2 and a Jacobian with sin/cos) are independent: one lane of three different waves each
     if (tid == 0 || tid == 64 || tid == 128) {
         const double *x = L.x, *o = L.xp;
         double oc[4], r[4], d3[3];
@@ -104,10 +169,7 @@ __device__ __forceinline__ void ikfom_solver_block(FlDev23 *__restrict__ D, cons
         }
     }
     __syncthreads();
-#ifdef FL_IK_STAMPS
-    if (tid == 0) g_fl_stamps[34] = (long long)wall_clock64();
-#endif
-    // ---- stage 2: P = Jf Pprop Jf^T ; dx_new = Jf dx
+    // P = Jf Pprop Jf^T ; dx_new = Jf dx
     for (int e = tid; e < n * n; e += NTH) {
         const int r = e / n, c = e % n;
         int rb, rs, rw, cb, cs, cw;
@@ -116,7 +178,7 @@ __device__ __forceinline__ void ikfom_solver_block(FlDev23 *__restrict__ D, cons
         double s = 0.0;
         for (int a = 0; a < rs; a++) {
             const double jr = ik_J(L, rw, rs, r - rb, a);
-            for (int b = 0; b < cs; b++) s += jr * L.L[(rb + a) * n + (cb + b)] * ik_J(L, cw, cs, c - cb, b);
+            for (int b = 0; b < cs; b++) s += jr * L.Pp[(rb + a) * n + (cb + b)] * ik_J(L, cw, cs, c - cb, b);
         }
         L.P[e] = s;
     }
@@ -127,6 +189,34 @@ __device__ __forceinline__ void ikfom_solver_block(FlDev23 *__restrict__ D, cons
         for (int a = 0; a < rs; a++) s += ik_J(L, rw, rs, tid - rb, a) * L.dx[rb + a];
         L.dxn[tid] = s;
     }
+    __syncthreads();
+    if (tid < 144) {
+        const int i = tid / 12, j = tid % 12;
+        L.A12[tid] = 0.5 * (L.P[i * n + j] + L.P[j * n + i]) / L.R;
+    }
+    __syncthreads();
+}
+
+// state words of the multi-pass broadcast: 26 doubles + control = 53 words (handoff.h)
+#define FL_IK_BCAST_DOUBLES FL_X23_LEN
+
+// after the gather. All threads call it; on return (after the caller's barrier) L.ctl is valid for everybody.
+// bcast != nullptr (multi-pass kernel): the new state and the control word are published for the producers' next pass.
+__device__ __forceinline__ void ikfom_post(FlDev23 *__restrict__ D, const double *s_sums, FlIkLds &L, int gst,
+                                           unsigned long long *bcast = nullptr, unsigned bepoch = 0u, bool write_P = true)
+{
+    const int tid = threadIdx.x, NTH = blockDim.x, n = FL_N23;
+    const double R = L.R;
+    if (gst) {            // hand-off timed out: abandon the pass (see solve18.h)
+        if (tid < FL_IK_BCAST_DOUBLES && bcast) fl_bcast_store(bcast, tid, L.x[tid], bepoch);
+        if (tid == 64) {
+            L.sticky |= FL_NUM_TIMEOUT;
+            D->status = L.sticky;
+            L.ctl[2] = 0; L.ctl[4] = 1; L.ctl[5] = 1;
+            if (bcast) fl_bcast_ctrl_at(bcast, 2 * FL_IK_BCAST_DOUBLES, 1 | 4, bepoch);
+        }
+        return;
+    }
     if (tid >= 64 && tid < 64 + 78) {   // unpack S (upper triangle, row-major)
         int k = tid - 64, i = 0, rowlen = 12;
         while (k >= rowlen) { k -= rowlen; rowlen--; i++; }
@@ -136,134 +226,82 @@ __device__ __forceinline__ void ikfom_solver_block(FlDev23 *__restrict__ D, cons
         L.S[j * 12 + i] = v;
     }
     __syncthreads();
-#ifdef FL_IK_STAMPS
-    if (tid == 0) g_fl_stamps[35] = (long long)wall_clock64();
-#endif
-    const double R = D->meas_cov;
-    if (tid < 144) {
-        const int i = tid / 12, j = tid % 12;
-        L.A12[tid] = 0.5 * (L.P[i * n + j] + L.P[j * n + i]) / R;
-    }
-    __syncthreads();
     if (tid < 144) {
         const int i = tid / 12, j = tid % 12;
         double s = 0.0;
+#pragma unroll
         for (int k = 0; k < 12; k++) s += L.S[i * 12 + k] * L.A12[k * 12 + j];
         L.SA[tid] = s;
+    } else if (tid >= 160 && tid < 172) {          // rhs = HTh + S dx_new12
+        const int i = tid - 160;
+        double s = s_sums[FL_S23_HTZ + i];
+#pragma unroll
+        for (int k = 0; k < 12; k++) s += L.S[i * 12 + k] * L.dxn[k];
+        L.rhs[i] = s;
     }
     __syncthreads();
     if (tid < 144) {
         const int i = tid / 12, j = tid % 12;
         double s = L.A12[tid];
+#pragma unroll
         for (int k = 0; k < 12; k++) s += L.A12[i * 12 + k] * L.SA[k * 12 + j];
         L.X[tid] = s;                       // unsymmetrised M, staged in X
-    }
-    __syncthreads();
-    if (tid < 144) {
-        const int i = tid / 12, j = tid % 12;
-        L.M[tid] = (i == j) ? L.X[tid] : 0.5 * (L.X[i * 12 + j] + L.X[j * 12 + i]);
-    }
-    if (tid >= 160 && tid < 172) {          // rhs = HTh + S dx_new12
+    } else if (tid >= 160 && tid < 172) {   // y0 = A12 rhs
         const int i = tid - 160;
-        double s = s_sums[FL_S23_HTZ + i];
-        for (int k = 0; k < 12; k++) s += L.S[i * 12 + k] * L.dxn[k];
-        L.rhs[i] = s;
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) s += L.A12[i * 12 + k] * L.rhs[k];
+        L.y0[i] = s;
     }
     __syncthreads();
 #ifdef FL_IK_STAMPS
     if (tid == 0) g_fl_stamps[36] = (long long)wall_clock64();
 #endif
-    // ---- stage 3: Cholesky of M (12x12) and the solve for y in wave 0: lane i owns row i in registers, pivots and
-    // multipliers are broadcast with v_readlane (right-looking; no workgroup barrier, instead of 24 of them)
+    // ---- wavefront 0: M (symmetrised on the way in) and y0 into registers, right-looking LDL^T with y0 as a 13th row, back
+    // substitution; lane r < 23 then forms dx_[r].  No barrier, no cross-lane traffic until the results are written.
     int bad = 0;
     if (tid < 64) {
-        const int i = tid;
-        double a[12];
+        double w[12], y[12];
 #pragma unroll
-        for (int k = 0; k < 12; k++) a[k] = (i < 12) ? L.M[i * 12 + k] : 0.0;
-        double yi = 0.0;                                  // y0 = A12 rhs
-        if (i < 12) {
+        for (int i = 0; i < 12; i++) w[i] = L.y0[i];
+        bad = ik_ldl_solve_regs(L.X, w, y);
+        if (tid < n) {                          // dx_ = A[:,0:12] y - dx_new
+            double s2 = 0.0;
 #pragma unroll
-            for (int k = 0; k < 12; k++) yi += L.A12[i * 12 + k] * L.rhs[k];
+            for (int cc = 0; cc < 12; cc++) s2 += (L.P[tid * n + cc] / R) * y[cc];
+            L.dxo[tid] = s2 - L.dxn[tid];
         }
-#pragma unroll
-        for (int j = 0; j < 12; j++) {
-            const double ajj = ik_lane(a[j], j);
-            if (!(ajj > 0.0)) bad = 1;
-            const double ljj = sqrt(ajj);
-            const double lij = (i == j) ? ljj : a[j] / ljj;
-            a[j] = lij;
-#pragma unroll
-            for (int k = j + 1; k < 12; k++) {
-                const double lkj = ik_lane(lij, k);
-                if (i >= k) a[k] -= lij * lkj;
-            }
-        }
-        if (i < 12) {
-#pragma unroll
-            for (int k = 0; k < 12; k++) if (k <= i) L.M[i * 12 + k] = a[k];
-        }
-        // forward substitution L z = y0 (lane i holds component i), then back substitution L^T y = z
-#pragma unroll
-        for (int j = 0; j < 12; j++) {
-            const double zj = ik_lane(yi, j) / ik_lane(a[j], j);      // component j is final once rows < j are eliminated
-            if (i == j) yi = zj;
-            if (i > j) yi -= a[j] * zj;
-        }
-#pragma unroll
-        for (int j = 11; j >= 0; j--) {
-            const double yj = ik_lane(yi, j) / ik_lane(a[j], j);
-            if (i == j) yi = yj;
-#pragma unroll
-            for (int r = 0; r < 12; r++) {
-                if (r < j) {
-                    const double ljr = ik_lane(a[r], j);               // L[j][r] = L^T[r][j]
-                    if (i == r) yi -= ljr * yj;
-                }
-            }
-        }
-        if (i < 12) L.y[i] = yi;
     }
     bad = __syncthreads_or(bad);
 #ifdef FL_IK_STAMPS
     if (tid == 0) g_fl_stamps[37] = (long long)wall_clock64();
 #endif
-    if (tid < n) {                          // dx_ = A[:,0:12] y - dx_new
-        double s = 0.0;
-        for (int c = 0; c < 12; c++) s += (L.P[tid * n + c] / R) * L.y[c];
-        L.dxo[tid] = s - L.dxn[tid];
-    }
-    __syncthreads();
-#ifdef FL_IK_STAMPS
-    if (tid == 0) g_fl_stamps[38] = (long long)wall_clock64();
-#endif
-    // ---- stage 4: boxplus on three lanes of three waves (SO3 rot | SO3 offset_R | additive + S2), judgement on a fourth
+    // ---- boxplus on three lanes of three waves (SO3 rot | SO3 offset_R | additive + S2), judgement on a fourth
     if (tid == 0 || tid == 64 || tid == 128) {
         double e[4], q[4];
         if (tid == 0) {
-            for (int i = 0; i < 3; i++) { const double v = L.x[FL_X23_POS + i] + L.dxo[i]; L.x[FL_X23_POS + i] = v; D->x[FL_X23_POS + i] = v; }
+            for (int i = 0; i < 3; i++) { const double v = L.x[FL_X23_POS + i] + L.dxo[i]; L.x[FL_X23_POS + i] = v; }
             fl_mtk_exp3(L.dxo + 3, 0.5, e);
             for (int i = 0; i < 4; i++) q[i] = L.x[FL_X23_ROT + i];
             flq_mul(q, e, q);
-            for (int i = 0; i < 4; i++) { L.x[FL_X23_ROT + i] = q[i]; D->x[FL_X23_ROT + i] = q[i]; }
+            for (int i = 0; i < 4; i++) L.x[FL_X23_ROT + i] = q[i];
         } else if (tid == 64) {
             fl_mtk_exp3(L.dxo + 6, 0.5, e);
             for (int i = 0; i < 4; i++) q[i] = L.x[FL_X23_ORLI + i];
             flq_mul(q, e, q);
-            for (int i = 0; i < 4; i++) { L.x[FL_X23_ORLI + i] = q[i]; D->x[FL_X23_ORLI + i] = q[i]; }
-            for (int i = 0; i < 3; i++) { const double v = L.x[FL_X23_OTLI + i] + L.dxo[9 + i]; L.x[FL_X23_OTLI + i] = v; D->x[FL_X23_OTLI + i] = v; }
+            for (int i = 0; i < 4; i++) L.x[FL_X23_ORLI + i] = q[i];
+            for (int i = 0; i < 3; i++) { const double v = L.x[FL_X23_OTLI + i] + L.dxo[9 + i]; L.x[FL_X23_OTLI + i] = v; }
         } else {
             for (int i = 0; i < 3; i++) {
                 const double v = L.x[FL_X23_VEL + i] + L.dxo[12 + i], g = L.x[FL_X23_BG + i] + L.dxo[15 + i], a = L.x[FL_X23_BA + i] + L.dxo[18 + i];
-                L.x[FL_X23_VEL + i] = v; D->x[FL_X23_VEL + i] = v; L.x[FL_X23_BG + i] = g; D->x[FL_X23_BG + i] = g;
-                L.x[FL_X23_BA + i] = a; D->x[FL_X23_BA + i] = a;
+                L.x[FL_X23_VEL + i] = v; L.x[FL_X23_BG + i] = g; L.x[FL_X23_BA + i] = a;
             }
             double gv[3] = {L.x[FL_X23_GRAV], L.x[FL_X23_GRAV + 1], L.x[FL_X23_GRAV + 2]};
             fl_s2_boxplus(gv, L.dxo + 21);
-            for (int i = 0; i < 3; i++) { L.x[FL_X23_GRAV + i] = gv[i]; D->x[FL_X23_GRAV + i] = gv[i]; }
+            for (int i = 0; i < 3; i++) L.x[FL_X23_GRAV + i] = gv[i];
         }
     } else if (tid == 192) {
-        int converge = 1, st = gst | bad;
+        int converge = 1, st = bad;
         for (int i = 0; i < n; i++) {
             if (fabs(L.dxo[i]) > L.limit[i]) { converge = 0; break; }
         }
@@ -274,49 +312,62 @@ __device__ __forceinline__ void ikfom_solver_block(FlDev23 *__restrict__ D, cons
         if (converge) t++;
         if (!t && i_loop == max_iter - 2) converge = 1;
         const int finishing = (t > 1 || i_loop == max_iter - 1) ? 1 : 0;
-        L.ctl[0] = t; L.ctl[1] = converge; L.ctl[2] = finishing; L.ctl[3] = st;
+        const int stop = (finishing || (i_loop + 1) >= max_iter) ? 1 : 0;
+        L.ctl[0] = t; L.ctl[1] = converge; L.ctl[2] = finishing; L.ctl[3] = st; L.ctl[4] = 0; L.ctl[5] = stop;
+        L.cnt[0] = t; L.cnt[1] = i_loop + 1; L.cnt[3] = L.cnt[3] + 1;
         D->t_count = t;
         D->need_search = converge;
         D->converged = converge;
         D->iter_i = i_loop + 1;
-        D->stop = (finishing || (i_loop + 1) >= max_iter) ? 1 : 0;
+        D->stop = stop;
         D->neff = (int)s_sums[FL_S23_NEFF];
         D->total_residual = s_sums[FL_S23_RES];
-        D->status = st;
-        D->iters_run = L.cnt[3] + 1;
+        L.sticky |= st;
+        D->status = L.sticky;
+        D->iters_run = L.cnt[3];
     } else if (tid >= 200 && tid < 223) {
         D->solution[tid - 200] = L.dxo[tid - 200];
     }
-#ifdef FL_IK_STAMPS
-    if (tid == 0) g_fl_stamps[39] = (long long)wall_clock64();
-#endif
     if (tid >= 64 && tid < 64 + FL_SUMS23) D->sums[tid - 64] = s_sums[tid - 64];
     __syncthreads();
 #ifdef FL_IK_STAMPS
-    if (tid == 0) g_fl_stamps[40] = (long long)wall_clock64();
+    if (tid == 0) g_fl_stamps[38] = (long long)wall_clock64();
 #endif
-    if (!L.ctl[2]) {                        // not finishing: publish the projected P_ and return
-        for (int e = tid; e < n * n; e += NTH) D->P[e] = L.P[e];
+    // the new state: to the device block, and to the producers of the next pass
+    if (tid < FL_X23_LEN) {
+        const double v = L.x[tid];
+        D->x[tid] = v;
+        if (bcast) fl_bcast_store(bcast, tid, v, bepoch);
+    }
+    if (tid == 64 && bcast) fl_bcast_ctrl_at(bcast, 2 * FL_IK_BCAST_DOUBLES, (L.ctl[5] ? 1 : 0) | (L.ctl[1] ? 2 : 0), bepoch);
+    if (!L.ctl[2]) {                        // not finishing: the projected P_ is what a reader of the device block finds
+        if (write_P)
+            for (int e = tid; e < n * n; e += NTH) D->P[e] = L.P[e];
         return;
     }
-    // ---- stage 5: final covariance block, esekfom.hpp:1831-1924
+    // ---- final covariance block, esekfom.hpp:1831-1924
     ik_make_J(L, L.dxo, tid);               // Jacobians at dx_ (S2: Nx at the UPDATED state, L.x)
-    if (tid >= 32 && tid < 44) {            // X[:,c] = M^-1 (A12 S)[:,c]
-        const int c = tid - 32;
-        double col[12];
+    if (tid < 64) {                         // column c of M^-1 (A12 S): lane c < 12 of wavefront 0, the register solve again
+        const int c = tid < 12 ? tid : 0;
+        double col[12], sol[12];
+#pragma unroll
         for (int i = 0; i < 12; i++) {
-            double s = 0.0;
-            for (int k = 0; k < 12; k++) s += L.A12[i * 12 + k] * L.S[k * 12 + c];
-            col[i] = s;
+            double s2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 12; k++) s2 += L.A12[i * 12 + k] * L.S[k * 12 + c];
+            col[i] = s2;
         }
-        fl_chol_solve(L.M, 12, col);
-        for (int i = 0; i < 12; i++) L.X[i * 12 + c] = col[i];
+        (void)ik_ldl_solve_regs(L.X, col, sol);
+        if (tid < 12) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) L.M[i * 12 + c] = sol[i];
+        }
     }
     __syncthreads();
     for (int e = tid; e < n * 12; e += NTH) {   // Kx = A[:,0:12] X
         const int r = e / 12, c = e % 12;
         double s = 0.0;
-        for (int k = 0; k < 12; k++) s += (L.P[r * n + k] / R) * L.X[k * 12 + c];
+        for (int k = 0; k < 12; k++) s += (L.P[r * n + k] / R) * L.M[k * 12 + c];
         L.Kx[e] = s;
     }
     for (int e = tid; e < n * n; e += NTH) {    // Pc = P Jf^T (columns)
@@ -351,4 +402,10 @@ __device__ __forceinline__ void ikfom_solver_block(FlDev23 *__restrict__ D, cons
         for (int k = 0; k < 12; k++) s += L.P[r * 12 + k] * L.Pc[k * n + c];
         D->P[e] = L.L[e] - s;
     }
+}
+
+// one whole pass for a single launch (per-pass kernel, solve kernel): stage + pre + post
+__device__ __forceinline__ void ikfom_solver_block(FlDev23 *__restrict__ D, const double *s_sums, FlIkLds &L, int gst)
+{
+    ikfom_post(D, s_sums, L, gst);
 }

@@ -214,13 +214,14 @@ __device__ __forceinline__ void fl_bcast_store(unsigned long long *bcast, int id
         __hip_atomic_store(bcast + (size_t)r * FL_BCAST_STRIDE + 2 * idx + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-__device__ __forceinline__ void fl_bcast_ctrl(unsigned long long *bcast, int ctrl, unsigned bepoch)
+__device__ __forceinline__ void fl_bcast_ctrl_at(unsigned long long *bcast, int word, int ctrl, unsigned bepoch)
 {
 #pragma unroll
     for (int r = 0; r < FL_BCAST_REPL; r++)
-        __hip_atomic_store(bcast + (size_t)r * FL_BCAST_STRIDE + 24, ((unsigned long long)(unsigned)ctrl << 32) | (unsigned long long)bepoch, __ATOMIC_RELAXED,
+        __hip_atomic_store(bcast + (size_t)r * FL_BCAST_STRIDE + word, ((unsigned long long)(unsigned)ctrl << 32) | (unsigned long long)bepoch, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void fl_bcast_ctrl(unsigned long long *bcast, int ctrl, unsigned bepoch) { fl_bcast_ctrl_at(bcast, 24, ctrl, bepoch); }
 
 // Reciprocal for the pivots: v_rcp_f64 + two Newton steps (relative error ~1e-16; the solve is compared by tolerance).
 __device__ __forceinline__ double fl_rcp_nr(double d)

@@ -53,10 +53,14 @@ FL_HD void fl_patch_geom(const FlVioConst &c, const double *Rcw, const double *P
     g.Jdpi[3] = 0.0; g.Jdpi[4] = c.fy_abs * z_inv; g.Jdpi[5] = -c.fy_abs * g.pf[1] * z_inv_2;
     const float u_ref = (float)pc[0], v_ref = (float)pc[1];
     g.scale = scale;
-    g.u_i = (int)(floorf((float)(pc[0] / scale)) * scale);
-    g.v_i = (int)(floorf((float)(pc[1] / scale)) * scale);
-    const float su = (u_ref - g.u_i) / scale;
-    const float sv = (v_ref - g.v_i) / scale;
+    // scale is a power of two: x / scale == x * (1 / scale) bit for bit (no rounding in either), one multiply instead of an IEEE
+    // division sequence on the patch's critical path (lidar_selection.cpp:806-809 divides)
+    const double inv_sd = 1.0 / (double)scale;
+    const float inv_sf = 1.0f / (float)scale;
+    g.u_i = (int)(floorf((float)(pc[0] * inv_sd)) * scale);
+    g.v_i = (int)(floorf((float)(pc[1] * inv_sd)) * scale);
+    const float su = (u_ref - g.u_i) * inv_sf;
+    const float sv = (v_ref - g.v_i) * inv_sf;
     g.wtl = (float)((1.0 - su) * (1.0 - sv));
     g.wtr = (float)(su * (1.0 - sv));
     g.wbl = (float)((1.0 - su) * sv);
@@ -182,19 +186,23 @@ __global__ void vio_derive_kernel(FlDev18 *__restrict__ D, const FlVioConst *__r
 }
 
 #define FL_VIO_NT 256
+// Lanes per patch: 32 (a half-wave per patch, 2 pixels per lane) or 16 (a 16-lane DPP row per patch, 4 pixels per lane, 4 patches per
+// wavefront). The work that is uniform over a patch -- projection with its fp64 divisions, the 2x6 matrix M, the 6x6 update -- is
+// executed by the whole wavefront whatever the number of patches it serves, so 4 patches per wavefront halve it again, halve the
+// number of producer workgroups (125 records instead of 250 at 2000 patches) and shorten the per-patch cross-lane reduction by a stage.
+#ifndef FL_VIO_LPP
+#define FL_VIO_LPP 16
+#endif
+#define FL_VIO_PPL (64 / FL_VIO_LPP)          /* pixels per lane */
+#define FL_VIO_GPW (64 / FL_VIO_LPP)          /* patches (lane groups) per wavefront */
 
 // grid = producers + 1 ; MODE 0: fused pass ; MODE 1: accumulate only (sums -> sums_out).
-// Mapping: ONE HALF-WAVE PER PATCH, two pixels per lane (rows x and x+4 of the 8x8 patch). The
-// per-patch work that is uniform over a patch (projection with its fp64 divisions, the 2x6 matrix M,
-// the 6x6 update) dominates the instruction count and costs the same for 32 or 64 lanes, so two
-// patches per wavefront halve it: 2000 patches = 1000 waves = one wave per SIMD of the chip instead of
-// two sharing each SIMD (measured: producers 5.5 us -> see DESIGN.md). 256-thread workgroups, 8
-// patches each: 250 records, gathered in a single sweep.
-// The first patch's inputs do not depend on the state: their loads are issued before the state round trip.
+// 256-thread workgroups: 8 (16) patches each. The first patch's inputs do not depend on the state: their loads are issued before
+// the state round trip.
 struct FlVioFirst {
     int slevel;
     double pos0, pos1, pos2;
-    float ref0, ref1;
+    float ref[FL_VIO_PPL];
     bool have;
 };
 __device__ __forceinline__ FlVioFirst vio_prefetch_first(const float *__restrict__ ref, const double *__restrict__ pos,
@@ -202,23 +210,25 @@ __device__ __forceinline__ FlVioFirst vio_prefetch_first(const float *__restrict
 {
     constexpr int WPB = FL_VIO_NT / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int half = lane >> 5, hl = lane & 31;
-    const int i_first = (blockIdx.x * WPB + wave) * 2 + half;
+    const int grp = lane / FL_VIO_LPP, hl = lane % FL_VIO_LPP;
+    const int i_first = (blockIdx.x * WPB + wave) * FL_VIO_GPW + grp;
     FlVioFirst f;
     f.have = (blockIdx.x != nprod) && (i_first < m);
-    f.slevel = 0; f.pos0 = 0.0; f.pos1 = 0.0; f.pos2 = 0.0; f.ref0 = 0.f; f.ref1 = 0.f;
+    f.slevel = 0; f.pos0 = 0.0; f.pos1 = 0.0; f.pos2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < FL_VIO_PPL; k++) f.ref[k] = 0.f;
     if (f.have) {
         f.slevel = slevel[i_first];
         f.pos0 = pos[i_first * 3 + 0]; f.pos1 = pos[i_first * 3 + 1]; f.pos2 = pos[i_first * 3 + 2];
         if (level_arg >= 0) {
-            f.ref0 = ref[(size_t)i_first * 192 + 64 * level_arg + hl];
-            f.ref1 = ref[(size_t)i_first * 192 + 64 * level_arg + hl + 32];
+#pragma unroll
+            for (int k = 0; k < FL_VIO_PPL; k++) f.ref[k] = ref[(size_t)i_first * 192 + 64 * level_arg + hl + FL_VIO_LPP * k];
         }
     }
     return f;
 }
 
-// float patch_error of one patch from its 64 residuals in LDS (pixel order x*8+y), by the first lane of the patch's half-wave
+// float patch_error of one patch from its 64 residuals in LDS (pixel order x*8+y), by the first lane of the patch's lane group
 __device__ __forceinline__ void vio_patch_error(const float *r, int hl, bool active, int i, float *__restrict__ errors,
                                                 unsigned long long *__restrict__ err_words, unsigned epoch)
 {
@@ -251,6 +261,22 @@ __device__ __forceinline__ void vio_patch_error(const float *r, int hl, bool act
                            __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Totals of 6 values over the 16 lanes of a DPP row, in every lane of the row: a cyclic all-reduce (rotate by 8, by 4, then the
+// two quad exchanges) -- a fixed order, no selects, no final shuffles.
+#define FL_DPP_ROW_ROR4 0x124
+__device__ __forceinline__ void row_sum6(double (&w)[8], double (&T)[6])
+{
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        double x = w[k];
+        x = x + dpp_f64<FL_DPP_ROW_ROR8>(x);
+        x = x + dpp_f64<FL_DPP_ROW_ROR4>(x);
+        x = x + dpp_f64<FL_DPP_QUAD_XOR2>(x);
+        x = x + dpp_f64<FL_DPP_QUAD_XOR1>(x);
+        T[k] = x;
+    }
+}
+
 // One producer workgroup's share of a pass: residuals, rows, 6x6 update for its patches, reduced to one record and published.
 __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, const float *__restrict__ ref, const double *__restrict__ pos,
                                             const int32_t *__restrict__ slevel, float *__restrict__ errors, int m, int level_arg, int level,
@@ -259,14 +285,15 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
                                             unsigned long long *__restrict__ err_words /* this pass's half, nullable */, float *s_res /* LDS */)
 {
     constexpr int WPB = FL_VIO_NT / 64;
+    constexpr int LPP = FL_VIO_LPP, PPL = FL_VIO_PPL, GPW = FL_VIO_GPW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int half = lane >> 5, hl = lane & 31;
-    const int i_first = (blockIdx.x * WPB + wave) * 2 + half;
+    const int grp = lane / LPP, hl = lane % LPP;
+    const int slot = wave * GPW + grp;            // this lane group's slot in the workgroup's LDS arrays
+    const int i_first = (blockIdx.x * WPB + wave) * GPW + grp;
     const bool have_first = pf.have;
     const int pf_slevel = pf.slevel;
     const double pf_pos0 = pf.pos0, pf_pos1 = pf.pos1, pf_pos2 = pf.pos2;
-    const float pf_ref[2] = {pf.ref0, pf.ref1};
-    const int xr = hl >> 3, yc = hl & 7;          // this lane's pixels: (xr, yc) and (xr + 4, yc)
+    const int xr = hl >> 3, yc = hl & 7;          // this lane's pixels: (xr + (LPP / 8) k, yc), k = 0 .. PPL-1
     const int W = vc.stride, Hm1 = vc.height - 1, Wm1 = vc.width - 1;
 
     double v[FL_SUMS18];
@@ -274,12 +301,12 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
     for (int k = 0; k < FL_SUMS18; k++) v[k] = 0.0;
 
     if (blockIdx.x == 0) fl_stamp(flags, 0);
-    // trip count uniform over the wave: both halves iterate together, an inactive half (odd m) computes
+    // trip count uniform over the wave: all lane groups iterate together, an inactive group (m not a multiple of GPW) computes
     // on patch 0 and contributes nothing
     int def_i = 0;
     bool def_active = false;
-    for (int ib = (blockIdx.x * WPB + wave) * 2; ib < m; ib += nprod * WPB * 2) {
-        const int i = ib + half;
+    for (int ib = (blockIdx.x * WPB + wave) * GPW; ib < m; ib += nprod * WPB * GPW) {
+        const int i = ib + grp;
         const bool active = i < m;
         const int ii = active ? i : 0;
         const bool first = (i == i_first) && have_first;
@@ -289,13 +316,14 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
         else { ps[0] = pos[ii * 3 + 0]; ps[1] = pos[ii * 3 + 1]; ps[2] = pos[ii * 3 + 2]; }
         FlPatchGeom g;
         fl_patch_geom(vc, Rcw, Pcw, ps, scale, g);
+        if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(g.wbr), "v"(g.u_i)); fl_stamp(flags, 40); }
         const int col0 = g.u_i + (yc - 4) * scale;
-        float t[2][4][4];
+        float t[PPL][4][4];
         // taps span [anchor - 5*scale, anchor + 5*scale]: no clamping needed inside the image
         const bool inside = (g.v_i - 5 * scale >= 0) && (g.v_i + 5 * scale <= Hm1) && (g.u_i - 5 * scale >= 0) && (g.u_i + 5 * scale <= Wm1);
 #pragma unroll
-        for (int px = 0; px < 2; px++) {
-            const int row0 = g.v_i + (xr + 4 * px - 4) * scale;
+        for (int px = 0; px < PPL; px++) {
+            const int row0 = g.v_i + (xr + (LPP / 8) * px - 4) * scale;
             if (inside) {
                 const uint8_t *q = img + row0 * W + col0;
 #pragma unroll
@@ -324,55 +352,62 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
                 }
             }
         }
-        float refv[2];
-        if (first && level_arg >= 0) { refv[0] = pf_ref[0]; refv[1] = pf_ref[1]; }
-        else {
-            refv[0] = ref[(size_t)ii * 192 + 64 * level + hl];
-            refv[1] = ref[(size_t)ii * 192 + 64 * level + hl + 32];
+        float refv[PPL];
+        if (first && level_arg >= 0) {
+#pragma unroll
+            for (int k = 0; k < PPL; k++) refv[k] = pf.ref[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < PPL; k++) refv[k] = ref[(size_t)ii * 192 + 64 * level + hl + LPP * k];
         }
+        if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(t[0][1][1] + t[PPL - 1][2][2] + refv[PPL - 1])); fl_stamp(flags, 41); }
         double M[2][6];
-        fl_patch_M(g, vc.Jdphi_dR, vc.Jdp_dR, Rcw, M);          // uniform per half-wave, overlaps the tap loads
+        fl_patch_M(g, vc.Jdphi_dR, vc.Jdp_dR, Rcw, M);          // uniform per lane group, overlaps the tap loads
+        if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(M[1][5] + M[0][0])); fl_stamp(flags, 42); }
         double w8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int px = 0; px < 2; px++) {
+        for (int px = 0; px < PPL; px++) {
             float du, dv, resf;
             fl_pixel_grad(g, t[px], refv[px], &du, &dv, &resf);
-            s_res[(wave * 2 + half) * 64 + 32 * px + hl] = resf;        // pixel order of the reference: x * 8 + y
+            s_res[slot * 64 + LPP * px + hl] = resf;                    // pixel order of the reference: x * 8 + y
             const double dud = (double)du, dvd = (double)dv, res = (double)resf;
             w8[0] += dud * dud; w8[1] += dud * dvd; w8[2] += dvd * dvd;
             w8[3] += dud * res; w8[4] += dvd * res; w8[5] += res * res;
         }
+        if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(w8[5] + w8[0])); fl_stamp(flags, 43); }
         double T6[6];
-        half_sum6(w8, lane, T6);
+        if (LPP == 32) half_sum6(w8, lane, T6); else row_sum6(w8, T6);
+        if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(T6[5] + T6[0])); fl_stamp(flags, 44); }
         // patch_error exactly as the reference rounds it (lidar_selection.cpp:849: float patch_error; patch_error += res*res with a
         // double res): one lane per patch replays the 64 additions in pixel order (vio_patch_error). It feeds only the errors[]
-        // output and the rare exact accept test, never the record: for the wave's LAST patch pair it is deferred until the record is
+        // output and the rare exact accept test, never the record: for the wave's LAST patch group it is deferred until the record is
         // published, off the hand-off's critical path (the residuals wait in LDS).
-        const bool last_iter = (ib + nprod * WPB * 2 >= m);
+        const bool last_iter = (ib + nprod * WPB * GPW >= m);
         if (active) fl_patch_accum(v, M, T6);
+        if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(v[0] + v[26])); fl_stamp(flags, 45); }
         if (last_iter) { def_i = i; def_active = active; }
         else {
             __builtin_amdgcn_wave_barrier();
-            vio_patch_error(s_res + (wave * 2 + half) * 64, hl, active, i, errors, err_words, epoch);
+            vio_patch_error(s_res + slot * 64, hl, active, i, errors, err_words, epoch);
             __builtin_amdgcn_wave_barrier();
         }
     }
     if (blockIdx.x == 0) fl_stamp(flags, 1);
-    // every lane of a half-wave holds the same record: lanes 0 and 32 store it, 32 threads add them up
+    // every lane of a lane group holds the same record: its first lane stores it, 32 threads add the partials up
     if (hl == 0) {
 #pragma unroll
-        for (int k = 0; k < FL_SUMS18; k++) s_red[(wave * 2 + half) * FL_SUMS18 + k] = v[k];
+        for (int k = 0; k < FL_SUMS18; k++) s_red[slot * FL_SUMS18 + k] = v[k];
     }
     __syncthreads();
     double mine = 0.0;
     if (threadIdx.x < FL_SUMS18) {
         mine = s_red[threadIdx.x];
 #pragma unroll
-        for (int w = 1; w < 2 * WPB; w++) mine += s_red[w * FL_SUMS18 + threadIdx.x];
+        for (int w = 1; w < GPW * WPB; w++) mine += s_red[w * FL_SUMS18 + threadIdx.x];
     }
     publish_record<FL_SUMS18>(mine, epoch, records);
     __builtin_amdgcn_wave_barrier();
-    vio_patch_error(s_res + (wave * 2 + half) * 64, hl, def_active, def_i, errors, err_words, epoch);
+    vio_patch_error(s_res + slot * 64, hl, def_active, def_i, errors, err_words, epoch);
 }
 
 template <int MODE>
@@ -431,7 +466,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     }
 
     // -------------------------------------------------------------------- producer workgroups
-    __shared__ double s_red[2 * WPB * FL_SUMS18];
+    __shared__ double s_red[FL_VIO_GPW * WPB * FL_SUMS18];
     const int level = (level_arg >= 0) ? level_arg : D->level;
     // wave-uniform camera pose, derived from the state by the previous pass's solver (vio_derive_pose)
     const FlVioConst vc = *VC;
@@ -440,7 +475,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     for (int i = 0; i < 9; i++) Rcw[i] = D->Rcw[i];
 #pragma unroll
     for (int i = 0; i < 3; i++) Pcw[i] = D->Pcw[i];
-    __shared__ __attribute__((aligned(16))) float s_res[2 * WPB * 64];
+    __shared__ __attribute__((aligned(16))) float s_res[FL_VIO_GPW * WPB * 64];
     unsigned long long *ew = D->err_words ? D->err_words + (size_t)(D->iters_run & 1) * D->err_cap : nullptr;
     vio_produce(img, ref, pos, slevel, errors, m, level_arg, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags, ew, s_res);
     if (blockIdx.x == 0) fl_stamp(flags, 2);
@@ -547,10 +582,10 @@ __global__ __launch_bounds__(FL_VIO_NT, 2) void vio_multipass_kernel(const uint8
         return;
     }
 
-    __shared__ double s_red[2 * WPB * FL_SUMS18];
+    __shared__ double s_red[FL_VIO_GPW * WPB * FL_SUMS18];
     __shared__ double s_pose[12];
     __shared__ int s_ctrl;
-    __shared__ __attribute__((aligned(16))) float s_res[2 * WPB * 64];
+    __shared__ __attribute__((aligned(16))) float s_res[FL_VIO_GPW * WPB * 64];
     const int spin_limit = D->xchg_world > 1 ? FL_XCHG_SPIN_LIMIT : FL_GATHER_SPIN_LIMIT;   // the solver may be waiting for another process
     const FlVioConst vc = *VC;
     double Rcw[9], Pcw[3];

@@ -33,7 +33,10 @@ extern "C" {
 #define FL_NUM_SINGULAR 1     /* gain solve met a zero pivot */
 #define FL_NUM_NONFINITE 2    /* NaN/Inf in the state delta */
 #define FL_NUM_FEWPOINTS 4    /* no effective measurement */
-#define FL_NUM_TIMEOUT 8      /* a bounded in-kernel hand-off wait expired (the pass was abandoned) */
+#define FL_NUM_TIMEOUT 8      /* a bounded in-kernel hand-off wait expired: the pass was ABANDONED -- the state did not move, nothing enqueued
+                                 behind it ran. The synchronous entry points (frame drivers, fl_*_iterate with info) clear the bit and re-run
+                                 what was left with one launch per pass, up to three times, before it reaches the caller; status bits are
+                                 sticky on the device from fl_*_begin to the read-back */
 #define FL_NUM_FRAGILE 16     /* VIO: an accept test `error <= last_error` (lidar_selection.cpp:859) fell inside the rounding noise of the
                                  reference's float running sum of res^2 and was decided by replaying that sum in the reference's own
                                  arithmetic (informational). Only where the per-patch errors are not available -- the sharded
@@ -307,6 +310,9 @@ int32_t fl_ikfom_update_iterated_dev(fl_handle h, fl_state23 *x_io, double *P_io
  * called with them (feats_down_body never visits the host). out_xyzi (nullable) has room for n points.
  * xyzi == NULL: filter the n-point cloud that fl_imu_undistort left on the device.
  * leaf_too_small (nullable) reports PCL's "Leaf size is too small for the input dataset" case (output = input).
+ * Two deviations from PCL a caller should know: (1) in that pass-through case PCL copies EVERY input point, non-finite ones included;
+ * this library drops non-finite points there as it does everywhere else; (2) inside a voxel PCL adds the points in the order its
+ * (unstable) std::sort left them, here in ascending input index -- a centroid can differ from PCL's in its last float bit.
  * ---------------------------------------------------------------------------------------------- */
 int32_t fl_scan_voxel_filter(fl_handle h, const float *xyzi, int32_t n, float leaf_x, float leaf_y, float leaf_z,
                              int32_t stage_as_scan, float *out_xyzi, int32_t *out_n, int32_t *leaf_too_small);
@@ -439,7 +445,11 @@ int32_t fl_ikfom_iterate_sharded(fl_handle h, int32_t count, int32_t flags, fl_i
  * by the caller. The VIO accept test falls back to the fp64-reduced comparison (FL_NUM_FRAGILE = "may differ").
  *   separate processes:  fl_p2p_export on every rank -> exchange the 64-byte handles (any transport) -> fl_p2p_connect
  *   one process:         fl_p2p_connect_local(h, rank, world, all_handles) on every handle
- * Connect before fl_*_begin of the frame. Waiting for a peer is bounded (seconds): FL_NUM_TIMEOUT in the status, no hang.
+ * Connect before fl_*_begin of the frame, and put a barrier of the caller's transport between the connects and the first pass
+ * (connecting clears this rank's buffer and restarts the exchange epochs: no peer may still be writing an older session into it).
+ * Waiting for a peer is bounded (seconds): FL_NUM_TIMEOUT in the status, no hang. A timed-out pass is abandoned (state untouched)
+ * but NOT resumed automatically in the sharded form -- one rank may have completed the pass its peer abandoned -- so after
+ * FL_NUM_TIMEOUT the ranks connect again (fl_p2p_connect) and restart the frame together.
  * A pass kernel waits for its peers' kernels, so every rank must issue its passes in the same order and nothing a rank's kernel
  * waits for may be queued BEHIND it: give all connected handles of a process one stream (fl_set_stream; bench.py does), and when
  * several ranks share one device (tests) one stream per rank -- HIP multiplexes streams onto a few hardware queues.
