@@ -250,3 +250,26 @@ int orc_lio18_frame(orc_state18 *x, const float *body_xyz, int n, const double *
     free(world); free(nbr); free(valid); free(sel); free(normvec); free(res_last);
     return st;
 }
+
+
+/* Sensitivity of the plane fit and of the gates behind it to the association order of the QR's short float reductions (orc_sum_terms,
+ * orc_lio_common.h): per point the plane under `mode`, the planarity verdict, and the first-pass gate results at the given float world
+ * points (laserMapping.cpp:1571-1584,1593).  Report only -- nothing in the product or in the parity tests uses a mode other than 0. */
+int orc_plane_sensitivity(const float *nbr_xyz /* n x 5 x 3 */, const float *world_xyz /* n x 3 */, const float *body_xyz /* n x 3 */, int n,
+                          int mode, float *plane_out /* n x 4 */, uint8_t *planar_out, uint8_t *sel_out, uint8_t *eff_out)
+{
+    for (int i = 0; i < n; i++) {
+        float pabcd[4] = {0.f, 0.f, 0.f, 0.f};
+        const int ok = orc_esti_plane_mode(nbr_xyz + (size_t)i * 15, 0.1f, pabcd, mode);
+        for (int k = 0; k < 4; k++) plane_out[(size_t)i * 4 + k] = pabcd[k];
+        planar_out[i] = (uint8_t)ok;
+        const float *pw = world_xyz + (size_t)i * 3;
+        const double b0 = body_xyz[i * 3], b1 = body_xyz[i * 3 + 1], b2 = body_xyz[i * 3 + 2];
+        const float pd2 = pabcd[0] * pw[0] + pabcd[1] * pw[1] + pabcd[2] * pw[2] + pabcd[3];
+        const float s = (float)(1 - 0.9 * fabs((double)pd2) / sqrt(sqrt(b0 * b0 + b1 * b1 + b2 * b2)));
+        const int sel = ok && ((double)s > 0.9);
+        sel_out[i] = (uint8_t)sel;
+        eff_out[i] = (uint8_t)(sel && ((double)fabsf(pd2) <= 2.0));
+    }
+    return 0;
+}

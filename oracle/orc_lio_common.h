@@ -22,8 +22,25 @@
 
 #define ORC_NUM_MATCH_POINTS 5 /* common_lib.h:39 */
 
+/* How a reduction over <= 5 float terms is associated. 0 = left to right (what every parity test and the device use). 1 and 2 model
+ * what an x86 Eigen build may do instead for these short fixed-size reductions -- one SSE packet of four reduced horizontally, then the
+ * remaining terms: 1 = ((t0 + t2) + (t1 + t3)) + rest (movehl-style predux), 2 = ((t0 + t1) + (t2 + t3)) + rest (hadd-style). Used ONLY by
+ * the sensitivity report (orc_plane_sensitivity, tests/test_qr_sensitivity_cpu.py): Eigen is not available here, so which one a real
+ * build takes cannot be pinned -- the report bounds what that uncertainty can change. */
+static inline float orc_sum_terms(const float *t, int n, int mode)
+{
+    if (mode == 0 || n < 4) {
+        float s = 0.f;
+        for (int i = 0; i < n; i++) s += t[i];
+        return s;
+    }
+    float s = (mode == 1) ? ((t[0] + t[2]) + (t[1] + t[3])) : ((t[0] + t[1]) + (t[2] + t[3]));
+    for (int i = 4; i < n; i++) s += t[i];
+    return s;
+}
+
 /* Eigen ColPivHouseholderQR<Matrix<float,5,3>>::solve(b) with b = -1 (common_lib.h:451-463). */
-static inline void orc_colpiv_qr_solve_5x3(const float *near /*5x3 row-major*/, float *x /*3*/)
+static inline void orc_colpiv_qr_solve_5x3_mode(const float *near /*5x3 row-major*/, float *x /*3*/, int mode)
 {
     enum { ROWS = 5, COLS = 3 };
     float qr[ROWS][COLS];
@@ -34,8 +51,9 @@ static inline void orc_colpiv_qr_solve_5x3(const float *near /*5x3 row-major*/, 
         for (int c = 0; c < COLS; c++) qr[r][c] = near[r * 3 + c];
 
     for (int k = 0; k < COLS; k++) {
-        float s = 0.f;
-        for (int r = 0; r < ROWS; r++) s += qr[r][k] * qr[r][k];
+        float tt[ROWS];
+        for (int r = 0; r < ROWS; r++) tt[r] = qr[r][k] * qr[r][k];
+        const float s = orc_sum_terms(tt, ROWS, mode);
         nrmD[k] = sqrtf(s);
         nrmU[k] = nrmD[k];
     }
@@ -61,8 +79,9 @@ static inline void orc_colpiv_qr_solve_5x3(const float *near /*5x3 row-major*/, 
         }
         /* makeHouseholderInPlace on qr[k..,k] */
         float c0 = qr[k][k];
-        float tailSq = 0.f;
-        for (int r = k + 1; r < ROWS; r++) tailSq += qr[r][k] * qr[r][k];
+        float tq[ROWS];
+        for (int r = k + 1; r < ROWS; r++) tq[r - k - 1] = qr[r][k] * qr[r][k];
+        float tailSq = orc_sum_terms(tq, ROWS - k - 1, mode);
         float tau, beta;
         if (tailSq <= FLT_MIN) {
             tau = 0.f; beta = c0;
@@ -79,8 +98,9 @@ static inline void orc_colpiv_qr_solve_5x3(const float *near /*5x3 row-major*/, 
         /* apply H_k to the trailing columns */
         if (tau != 0.f) {
             for (int j = k + 1; j < COLS; j++) {
-                float tmp = 0.f;
-                for (int r = k + 1; r < ROWS; r++) tmp += qr[r][k] * qr[r][j];
+                float td[ROWS];
+                for (int r = k + 1; r < ROWS; r++) td[r - k - 1] = qr[r][k] * qr[r][j];
+                float tmp = orc_sum_terms(td, ROWS - k - 1, mode);
                 tmp += qr[k][j];
                 qr[k][j] -= tau * tmp;
                 for (int r = k + 1; r < ROWS; r++) qr[r][j] -= (tau * qr[r][k]) * tmp;
@@ -95,8 +115,9 @@ static inline void orc_colpiv_qr_solve_5x3(const float *near /*5x3 row-major*/, 
                 float ratio = nrmU[j] / nrmD[j];
                 float temp2 = temp * (ratio * ratio);
                 if (temp2 <= norm_downdate_threshold) {
-                    float s = 0.f;
-                    for (int r = k + 1; r < ROWS; r++) s += qr[r][j] * qr[r][j];
+                    float tn[ROWS];
+                    for (int r = k + 1; r < ROWS; r++) tn[r - k - 1] = qr[r][j] * qr[r][j];
+                    const float s = orc_sum_terms(tn, ROWS - k - 1, mode);
                     nrmD[j] = sqrtf(s);
                     nrmU[j] = nrmD[j];
                 } else {
@@ -114,8 +135,9 @@ static inline void orc_colpiv_qr_solve_5x3(const float *near /*5x3 row-major*/, 
     for (int k = 0; k < nonzero_pivots; k++) {
         float tau = hc[k];
         if (tau != 0.f) {
-            float tmp = 0.f;
-            for (int r = k + 1; r < ROWS; r++) tmp += qr[r][k] * c[r];
+            float tc[ROWS];
+            for (int r = k + 1; r < ROWS; r++) tc[r - k - 1] = qr[r][k] * c[r];
+            float tmp = orc_sum_terms(tc, ROWS - k - 1, mode);
             tmp += c[k];
             c[k] -= tau * tmp;
             for (int r = k + 1; r < ROWS; r++) c[r] -= (tau * qr[r][k]) * tmp;
@@ -130,11 +152,13 @@ static inline void orc_colpiv_qr_solve_5x3(const float *near /*5x3 row-major*/, 
     for (int i = 0; i < nonzero_pivots; i++) x[perm[i]] = c[i];
 }
 
+static inline void orc_colpiv_qr_solve_5x3(const float *near, float *x) { orc_colpiv_qr_solve_5x3_mode(near, x, 0); }
+
 /* common_lib.h:448-493 with threshold as passed (0.1f at both call sites). */
-static inline int orc_esti_plane(const float *near /*5x3*/, float threshold, float *pabcd /*4*/)
+static inline int orc_esti_plane_mode(const float *near /*5x3*/, float threshold, float *pabcd /*4*/, int mode)
 {
     float nv[3];
-    orc_colpiv_qr_solve_5x3(near, nv);
+    orc_colpiv_qr_solve_5x3_mode(near, nv, mode);
     float n = sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
     pabcd[0] = nv[0] / n;
     pabcd[1] = nv[1] / n;
@@ -146,6 +170,7 @@ static inline int orc_esti_plane(const float *near /*5x3*/, float threshold, flo
     }
     return 1;
 }
+static inline int orc_esti_plane(const float *near, float threshold, float *pabcd) { return orc_esti_plane_mode(near, threshold, pabcd, 0); }
 
 /* laserMapping.cpp:1569-1585: on entry *sel is point_selected_surf[i] (already AND-ed with the
  * kNN validity on search passes). Returns the new point_selected_surf[i]; on selection fills
