@@ -151,6 +151,73 @@ __device__ __forceinline__ int gather_records(const void *records, int nprod, un
 }
 
 
+// The 96-double records of Mode-23, up to 128 producers: gather_records walks the three 32-value groups one after the other (three
+// sweeps of a memory round trip each, 7 us measured); here wavefront g < 3 takes group g of EVERY record -- 32 loads of 16 bytes
+// in flight per lane, one sweep for the whole record set.  Same fixed summation order for every launch: per lane the records
+// 4 j + row in ascending j, then the four rows in order.  lds >= 3 * 128 doubles.
+__device__ __forceinline__ int gather_records96(const void *records, int nprod /* <= 128 */, unsigned epoch, double *lds, double *out_lds /* 96 */)
+{
+    constexpr int NV = 96, SLOTS = 32;
+    const int tid = threadIdx.x;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, kp = lane & 15, row = lane >> 4;
+    const unsigned tag = fl_epoch_tag(epoch);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)records, 0, nprod * NV * 8, 0x00020000);
+    int timeout = 0;
+    if (wave_u < 3) {
+        const int g = wave_u;
+        fl_u4 t[SLOTS];
+        unsigned need = 0u;                                  // wave-uniform: slot j covers records 4 j .. 4 j + 3
+#pragma unroll
+        for (int j = 0; j < SLOTS; j++) {
+            need |= (4 * j < nprod) ? (1u << j) : 0u;
+            t[j].x = 0u; t[j].y = 0u; t[j].z = 0u; t[j].w = 0u;
+        }
+        for (int spin = 0; need != 0u; spin++) {
+#pragma unroll
+            for (int j = 0; j < SLOTS; j++) {
+                if (need & (1u << j)) {
+                    const int b = 4 * j + row;
+                    t[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (b * NV + g * 32 + kp * 2) * 8, 0, 16 /* sc1 */);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < SLOTS; j++) {
+                if (need & (1u << j)) {
+                    const int b = 4 * j + row;
+                    const bool ok = (b >= nprod) || (((t[j].x & FL_TAG_MASK) == tag) && ((t[j].z & FL_TAG_MASK) == tag));
+                    if (__ballot(ok) == ~0ull) need &= ~(1u << j);
+                }
+            }
+            if (need != 0u) {
+                if (spin >= FL_GATHER_SPIN_LIMIT) { timeout = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < SLOTS; j++) {
+            const int b = 4 * j + row;
+            if (b < nprod) {
+                s0 += fl_untag(t[j].x, t[j].y);
+                s1 += fl_untag(t[j].z, t[j].w);
+            }
+        }
+        lds[(g * 64 + lane) * 2] = s0;
+        lds[(g * 64 + lane) * 2 + 1] = s1;
+    }
+    __syncthreads();
+    if (tid < NV) {
+        const int g = tid >> 5, k = tid & 31;                // value g*32 + k lives in lane kp = k / 2, component k & 1, of the four rows
+        double a = lds[(g * 64 + (k >> 1)) * 2 + (k & 1)];
+#pragma unroll
+        for (int r = 1; r < 4; r++) a += lds[(g * 64 + r * 16 + (k >> 1)) * 2 + (k & 1)];
+        out_lds[tid] = a;
+    }
+    __syncthreads();
+    return __syncthreads_or(timeout) ? FL_NUM_TIMEOUT : 0;
+}
+
 // ---- state broadcast of the multi-pass kernels: solver workgroup -> every producer workgroup, inside one launch.
 // The new pose (12 doubles) + a control word travel as 25 self-validating 8-byte words: high 32 bits = payload (one
 // half of a double, or the control bits), low 32 bits = the pass epoch the word belongs to. An aligned 8-byte store

@@ -65,6 +65,9 @@ __device__ __forceinline__ void ikfom_produce(const float4 *__restrict__ body4, 
     double v[FL_SUMS23];
 #pragma unroll
     for (int k = 0; k < FL_SUMS23; k++) v[k] = 0.0;
+#ifdef FL_IK_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_fl_stamps[41] = (long long)wall_clock64();
+#endif
     for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += nprod * NT) {
         const float4 plq = plane[i];
         if (!(plq.x == plq.x)) continue;
@@ -89,8 +92,14 @@ __device__ __forceinline__ void ikfom_produce(const float4 *__restrict__ body4, 
             v[FL_S23_RES2] += (double)pd2 * (double)pd2;
         }
     }
+#ifdef FL_IK_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0) { asm volatile("" ::"v"(v[0] + v[95])); g_fl_stamps[42] = (long long)wall_clock64(); }
+#endif
     const double mine = block_reduce_record<NT, FL_SUMS23>(v, s_red);
     publish_record<FL_SUMS23>(mine, epoch, records);
+#ifdef FL_IK_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_fl_stamps[43] = (long long)wall_clock64();
+#endif
 }
 
 template <int MODE>
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float4 *__re
 #ifdef FL_IK_STAMPS
         if (threadIdx.x == 0) g_fl_stamps[34] = (long long)wall_clock64();
 #endif
-        const int gst = gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums);
+        const int gst = ((nprod <= 128) ? gather_records96(records, nprod, epoch, s_fin, s_sums) : gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums));
 #ifdef FL_IK_STAMPS
         if (threadIdx.x == 0) g_fl_stamps[35] = (long long)wall_clock64();
 #endif
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_multipass_kernel(const float4 
         for (int p = 0; p < count; p++) {
             const unsigned epoch = epoch0 + (unsigned)p;
             ikfom_pre(s_ik);                                      // state-only half of the iteration, while the producers work
-            const int gst = gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums);
+            const int gst = ((nprod <= 128) ? gather_records96(records, nprod, epoch, s_fin, s_sums) : gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums));
             ikfom_post(D, s_sums, s_ik, gst, bcast, epoch + 1u, false);
             __syncthreads();
             done = p + 1;

@@ -11,9 +11,9 @@ h = capi.Handle(capi.config_from_frames(fr))
 x23 = capi.state23_from_frame(fr)
 h.lio_set_points(fr.body_xyz); h.ikfom_begin(x23, fr.cov23.copy()); h.lio_set_neighbours(nbr, valid)
 names = {32: "solver start", 33: "staged (x, Pprop)", 34: "pre done (dx, J, P, A12)", 35: "gather done", 36: "S, SA, M, rhs, y0", 37: "LDL^T + dx_", 38: "boxplus + judge",
-         40: "post returned"}
+         40: "post returned", 41: "producer0 loop start", 42: "producer0 loop end", 43: "producer0 published"}
 for _ in range(5): h.ikfom_iterate(1, capi.FL_ITER_FORCE, want_info=False)
 for _ in range(3):
     h.ikfom_iterate(1, capi.FL_ITER_FORCE, want_info=False); h.sync()
     st = np.array(h.debug_stamps(), dtype=np.int64)
-    print(json.dumps({names[k]: int(st[k] - st[32]) * 10 for k in sorted(names)}))
+    print(json.dumps({names[k]: int(st[k] - st[32]) * 10 for k in sorted(names, key=lambda k: st[k])}))
