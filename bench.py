@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--sweep", action="store_true", help="also print a kernel-only LIO size sweep to stderr")
     ap.add_argument("--no-extras", action="store_true", help="skip at_scale / vio sweep / mode23 / frame / restage")
     ap.add_argument("--only", choices=SECTIONS, default=None, help="run ONE extra section alone and print it (rocprofv3 runs)")
+    ap.add_argument("--at-scale-points", type=int, nargs="*", default=None, help="sizes of the at_scale section (default 8 M and 32 M)")
+    ap.add_argument("--vio-sweep-patches", type=int, nargs="*", default=None, help="sizes of the vio_sweep section (default 2 k, 200 k, 1 M)")
     return ap.parse_args()
 
 
@@ -169,7 +171,7 @@ def section_at_scale(capi, synth, scene, cfg, x0):
         out.append({"kernel": "lio18_pass_kernel", "points": n, "pass_us": us, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                     "algorithmic_bytes": LIO_BYTES_PER_POINT * n,
                     "note": "8 M points x 32 B read = 256 MB = the size of the Infinity Cache: part of it stays on chip between the passes of a "
-                            "frame; 32 M points stream from HBM" if n == AT_SCALE_POINTS[0] else "streams from HBM (1 GB per pass)"})
+                            "frame" if n <= 8000000 else "streams from HBM (32 B read per point and pass)"})
     return out
 
 
@@ -332,7 +334,12 @@ def section_restage(capi, synth, fr, cfg, x0, nbr, valid):
 
 # ------------------------------------------------------------------------------------------------ main
 def main():
+    global AT_SCALE_POINTS, VIO_SWEEP
     args = parse()
+    if args.at_scale_points:
+        AT_SCALE_POINTS = tuple(args.at_scale_points)
+    if args.vio_sweep_patches:
+        VIO_SWEEP = tuple(args.vio_sweep_patches)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     single_device = os.environ.get("FL_BENCH_SINGLE_DEVICE") == "1"

@@ -532,6 +532,11 @@ class Handle:
         self._chk(self.L.fl_debug_get_stamps(self.h, a), "fl_debug_get_stamps")
         return np.array(a[:], dtype=np.int64)
 
+    def debug_wall(self):
+        a = (C.c_longlong * 2048)()
+        self._chk(self.L.fl_debug_get_wall(self.h, a), "fl_debug_get_wall")
+        return np.array(a[:], dtype=np.int64)
+
     # ---- LIO
     def lio_set_points(self, body):
         body = np.ascontiguousarray(body, dtype=np.float32)

@@ -335,6 +335,7 @@ __device__ __forceinline__ double load_wt(const double *p)
 }
 
 typedef unsigned int fl_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int fl_u2 __attribute__((ext_vector_type(2)));
 
 // Optional phase timestamps (s_memtime) for tools/kstamps.py: slot i of workgroup 0 and of the last
 // workgroup. Enabled by the FL_ITER_STAMP flag; costs nothing when the flag is clear.

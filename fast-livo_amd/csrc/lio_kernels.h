@@ -358,6 +358,7 @@ __global__ __launch_bounds__(FL_LIO_NT, 2) void lio18_multipass_kernel(const flo
         publish_record<FL_SUMS18>(mine, epoch, records);
         __syncthreads();          // s_red / s_pose are reused by the next pass
         if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 23 + 4 * (ps - 5));
+        if ((flags & FL_ITER_STAMP) && ps == 5 && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();   // every producer's publish time
     }
 }
 

@@ -21,3 +21,15 @@ for rep in range(4):
              17: "solver p5 gather_done", 18: "solver p5 solve_done+sync", 24: "prod0 p6 wait_start", 25: "prod0 p6 pose_seen", 26: "prod0 p6 compute_done",
              27: "prod0 p6 published", 30: "solve: start", 31: "solve: C,rhs formed", 32: "solve: eliminated", 33: "solve: delta", 34: "solve: state", 35: "solve: returned", 36: "solve: stores issued", 37: "solve: judged"}
     print(json.dumps({names[k]: int(st[k] - t0) * 10 for k in sorted(names, key=lambda k: st[k])}))
+
+# spread of the producers' publish times of pass 5 (g_fl_wall), relative to producer 0's "published" stamp, and the solver's gather_done
+w = np.array(h.debug_wall(), dtype=np.int64) if hasattr(h, "debug_wall") else None
+if w is not None:
+    nprod = (50000 + 255) // 256
+    pub = (w[:nprod] - st[23]) * 10
+    print(json.dumps({"producers": int(nprod), "publish_ns_rel_prod0": {"min": int(pub.min()), "p50": int(np.median(pub)), "p90": int(np.percentile(pub, 90)), "max": int(pub.max())},
+                      "gather_done_ns_rel_prod0": int(st[17] - st[23]) * 10}))
+
+if os.environ.get("FL_LIB_PATH", "").endswith("gst.so"):       # library built with -DFL_GATHER_STAMPS: wave 0's sweeps of the LAST gather of the launch
+    k = int(st[47])
+    print(json.dumps({"sweeps_of_wave0": k, "sweep_end_ns_rel_first": [int(st[48 + i] - st[48]) * 10 for i in range(min(k, 8))]}))
