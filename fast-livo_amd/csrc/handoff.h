@@ -313,6 +313,11 @@ __device__ __forceinline__ void bcast_wait(const unsigned long long *words, unsi
 #define FL_MAX_PEERS 8
 #define FL_XCHG_WORDS 64
 #define FL_XCHG_SPIN_LIMIT (1 << 22)
+// behind the record words of a rank's buffer: four 8-byte mail slots of the sharded VIO accept replay (solve18.h): float payload in
+// the high half, exchange epoch of the pass in the low half.  0 / 2: carry from rank-1 (current / last-accepted chain), 1 / 3: the
+// final sum from the last rank.
+#define FL_XCHG_REPLAY_SLOTS 4
+#define FL_XCHG_TOTAL_WORDS(world) (2 * (size_t)(world) * FL_XCHG_WORDS + FL_XCHG_REPLAY_SLOTS)
 struct FlPeerView {
     unsigned long long *own;                   // this rank's buffer
     unsigned long long *const *peer;           // D->xchg_peer (read with constant indices: a register array indexed at run time would live in scratch)

@@ -59,15 +59,22 @@ struct FlVioExact {
     unsigned epoch;                    // of the current pass = tag of its words
     float *scratch;                    // LDS, FL_EXACT_CHUNK floats
     int enabled;                       // 0: forced passes (FL_ITER_FORCE, benchmark/diagnostic mode) keep the fast test only
+    // sharded form (in-kernel peer exchange): the reference's running sum `error += patch_error` runs over ALL patches in order, i.e.
+    // through the ranks' contiguous patch ranges one after the other: rank r starts from the float rank r-1 ended with, the last rank
+    // sends the total back to everybody. One hop per rank, on the rare fragile passes only.
+    unsigned long long *own;           // this rank's exchange buffer (nullptr: single rank)
+    unsigned long long *const *peer;   // everybody's buffers
+    int rank, world;
+    unsigned xe;                       // exchange epoch of this pass = tag of the mail
 };
 #define FL_EXACT_CHUNK 2048
 // The reference's `error += patch_error` over patches 0..m-1 as one chain of float additions (no contraction). All threads of the
 // workgroup stage the words (polling until their tag says they belong to pass `tag`); thread 0 adds. Result valid in thread 0.
-__device__ __forceinline__ float vio_exact_sum(const unsigned long long *w, int m, unsigned tag, float *scr, int *timeout_flag)
+__device__ __forceinline__ float vio_exact_sum(const unsigned long long *w, int m, unsigned tag, float *scr, int *timeout_flag, float init = 0.0f)
 {
 #pragma clang fp contract(off)
     const int tid = threadIdx.x, nt = blockDim.x;
-    float f = 0.0f;
+    float f = init;
     for (int base = 0; base < m; base += FL_EXACT_CHUNK) {
         const int cnt = min(FL_EXACT_CHUNK, m - base);
         for (int k = tid; k < cnt; k += nt) {
@@ -95,6 +102,46 @@ __device__ __forceinline__ float vio_exact_sum(const unsigned long long *w, int 
             for (; k < cnt; k++) f = f + scr[k];
         }
         __syncthreads();
+    }
+    return f;
+}
+
+// The running sum over the patches of ALL ranks (see FlVioExact): thread 0 waits for the carry of rank-1, the workgroup adds this
+// rank's patches, thread 0 passes the result on / collects the total. slot 0/1 (current pass) or 2/3 (last accepted pass).
+// Returns the total (valid in thread 0).
+__device__ __forceinline__ float vio_exact_chain(const FlVioExact &ex, const unsigned long long *w, unsigned wtag, int slot, float *carry_lds,
+                                                 int *timeout_flag)
+{
+    const size_t mail = 2 * (size_t)ex.world * FL_XCHG_WORDS;
+    if (threadIdx.x == 0) {
+        float c = 0.0f;
+        if (ex.world > 1 && ex.rank > 0) {
+            unsigned long long v = 0ull;
+            int spin = 0;
+            do { v = __hip_atomic_load(ex.own + mail + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); if ((unsigned)v != ex.xe) __builtin_amdgcn_s_sleep(2); }
+            while ((unsigned)v != ex.xe && ++spin < FL_XCHG_SPIN_LIMIT);
+            if ((unsigned)v != ex.xe) *timeout_flag = 1;
+            c = __uint_as_float((unsigned)(v >> 32));
+        }
+        *carry_lds = c;
+    }
+    __syncthreads();
+    float f = vio_exact_sum(w, ex.m, wtag, ex.scratch, timeout_flag, *carry_lds);
+    if (ex.world > 1 && threadIdx.x == 0) {
+        if (ex.rank < ex.world - 1) {
+            __hip_atomic_store(ex.peer[ex.rank + 1] + mail + slot, ((unsigned long long)__float_as_uint(f) << 32) | (unsigned long long)ex.xe, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+            unsigned long long v = 0ull;
+            int spin = 0;
+            do { v = __hip_atomic_load(ex.own + mail + slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); if ((unsigned)v != ex.xe) __builtin_amdgcn_s_sleep(2); }
+            while ((unsigned)v != ex.xe && ++spin < FL_XCHG_SPIN_LIMIT);
+            if ((unsigned)v != ex.xe) *timeout_flag = 1;
+            f = __uint_as_float((unsigned)(v >> 32));
+        } else {
+            for (int r = 0; r < ex.world - 1; r++)
+                __hip_atomic_store(ex.peer[r] + mail + slot + 1, ((unsigned long long)__float_as_uint(f) << 32) | (unsigned long long)ex.xe, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     return f;
 }
@@ -310,7 +357,8 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
         // closer than (m + 8) * 2^-24 relative (the worst-case distance between the two sums) the workgroup replays the reference's running sum
         // over those per-patch floats -- m dependent float additions by one lane, ~5 us, only on such passes -- for this pass and, if
         // not known yet, for the last accepted one, and decides on the reference's own float values (status bit 16 reports that the
-        // slow path ran). Without the per-patch words (sharded solve kernel: `ex` == nullptr) bit 16 means "may differ".
+        // slow path ran). With the patches spread over ranks (in-kernel exchange) the chain runs through the ranks (vio_exact_chain); without
+        // the per-patch words (solve kernel of the RCCL form: `ex.words` == nullptr) bit 16 means "may differ".
         // Every thread evaluates the trigger itself from pass-invariant inputs (G.last_error was read before the gather), so the
         // common case needs no barrier.
         const bool can_replay = ex.words != nullptr && ex.enabled;     // (by value: a nullable pointer to it kept the struct in scratch)
@@ -326,11 +374,14 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
         if (slow) {      // uniform over the workgroup
             __syncthreads();
             const int cur_buf = L.iters_run & 1;
-            const float fc = vio_exact_sum(ex.words + (size_t)cur_buf * ex.cap, ex.m, ex.epoch, ex.scratch, &L.exact_timeout);
-            if (tid == 0) L.exact_cur = fc / (float)(64 * ex.m);
+            const float n_all = (float)s_sums[FL_S_NEFF];          // 64 x the patches of ALL ranks, as the reference's n_meas
+            const float fc = vio_exact_chain(ex, ex.words + (size_t)cur_buf * ex.cap, ex.epoch, 0, &L.exact_cur, &L.exact_timeout);
+            __syncthreads();
+            if (tid == 0) L.exact_cur = fc / n_all;
             if (!L.last_exact_valid && L.acc_buf != cur_buf) {   // (same half: only when forced passes ran on after a rejection)
-                const float fl = vio_exact_sum(ex.words + (size_t)L.acc_buf * ex.cap, ex.m, L.acc_epoch, ex.scratch, &L.exact_timeout);
-                if (tid == 0) { L.last_exact = fl / (float)(64 * ex.m); L.last_exact_valid = 1; }
+                const float fl = vio_exact_chain(ex, ex.words + (size_t)L.acc_buf * ex.cap, L.acc_epoch, 2, &L.last_exact, &L.exact_timeout);
+                __syncthreads();
+                if (tid == 0) { L.last_exact = fl / n_all; L.last_exact_valid = 1; }
             }
             __syncthreads();
         }

@@ -445,18 +445,21 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
         fl_stamp(flags, 10);
         if (threadIdx.x == 0) *epoch_ptr = epoch + 1u;
         const int world = (MODE == 0) ? D->xchg_world : 1;
+        unsigned xe_pass = 0u;                              // exchange epoch of this pass (tag of the replay mail, solve18.h)
         if (world > 1) {                                    // sharded form: totals over the ranks (handoff.h)
             __shared__ double s_xchg[FL_MAX_PEERS * 32];
             const FlPeerView PV = fl_peer_view(D);
             const unsigned xe = *D->xchg_epoch;
+            xe_pass = xe;
             gst |= peer_allreduce32(PV, xe, s_sums, s_xchg);
             if (threadIdx.x == 0) *D->xchg_epoch = xe + 1u;
         }
         if (MODE == 0) {
             __shared__ __attribute__((aligned(16))) float s_ex[FL_EXACT_CHUNK];
             FlVioExact ex;
-            // (the replay of the reference's float error sum needs every patch's error: not with the patches spread over ranks)
-            ex.words = D->err_words; ex.m = m; ex.cap = D->err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !(flags & FL_ITER_FORCE) && world <= 1;
+            ex.words = D->err_words; ex.m = m; ex.cap = D->err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !(flags & FL_ITER_FORCE);
+            ex.own = (world > 1) ? D->xchg_peer[D->xchg_rank] : nullptr; ex.peer = D->xchg_peer; ex.rank = D->xchg_rank; ex.world = world;
+            ex.xe = xe_pass;
             eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, gst, nullptr, 0u, ex, VC);   // incl. the camera pose for the next pass's producers
         } else {
             if (threadIdx.x < FL_SUMS18) sums_out[threadIdx.x] = s_sums[threadIdx.x];
@@ -551,7 +554,8 @@ __global__ __launch_bounds__(FL_VIO_NT, 2) void vio_multipass_kernel(const uint8
             if (PV.world > 1) gst |= peer_allreduce32(PV, xe0 + (unsigned)p, s_sums, s_xchg);      // sharded form: totals over the ranks
             if (p == 5) fl_stamp(flags, 17);
             FlVioExact ex;
-            ex.words = err_base; ex.m = m; ex.cap = err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !force && PV.world <= 1;
+            ex.words = err_base; ex.m = m; ex.cap = err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !force;
+            ex.own = PV.own; ex.peer = PV.peer; ex.rank = PV.rank; ex.world = PV.world; ex.xe = xe0 + (unsigned)p;
             // wave 0 solves, derives the camera pose of the new state and publishes it (+ the control word) for the producers
             eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, gst, bcast, epoch + 1u, ex, VC, (p == 5) ? (flags & FL_ITER_STAMP) : 0);
             if (p == 5) fl_stamp(flags, 35);

@@ -39,8 +39,9 @@ extern "C" {
                                  sticky on the device from fl_*_begin to the read-back */
 #define FL_NUM_FRAGILE 16     /* VIO: an accept test `error <= last_error` (lidar_selection.cpp:859) fell inside the rounding noise of the
                                  reference's float running sum of res^2 and was decided by replaying that sum in the reference's own
-                                 arithmetic (informational). Only where the per-patch errors are not available -- the sharded
-                                 forms (fl_vio_solve, fl_p2p_*) -- or under FL_ITER_FORCE it means "the reference may take the other
+                                 arithmetic (informational; also with the patches spread over ranks by fl_p2p_*: the sum runs through the
+                                 ranks). Only where the per-patch errors are not available -- the collective forms fl_vio_solve /
+                                 fl_vio_iterate_sharded -- or under FL_ITER_FORCE it means "the reference may take the other
                                  branch here". */
 
 #define FL_DIM18 18           /* DIM_STATE, include/common_lib.h:34 */
@@ -442,7 +443,10 @@ int32_t fl_ikfom_iterate_sharded(fl_handle h, int32_t count, int32_t flags, fl_i
  * device memory, 8-byte self-validating words, over xGMI between GPUs) and adds up what the peers sent in rank order, so all
  * ranks solve on bitwise-identical totals -- and the passes of a frame remain ONE launch per rank. Every rank must issue the
  * same sequence of passes (it is a collective). State, covariance, configuration replicated; map / image replicated or sharded
- * by the caller. The VIO accept test falls back to the fp64-reduced comparison (FL_NUM_FRAGILE = "may differ").
+ * by the caller. The VIO accept test stays the reference's: on the fragile passes the float running sum over the patches is handed
+ * from rank to rank (rank r continues from the float rank r-1 ended with; the last rank sends the total back), so accept / revert
+ * sequences equal the single-GPU ones. (Only the collective forms fl_vio_solve / fl_vio_iterate_sharded, which never see the other
+ * ranks' patches, keep the fp64 comparison: FL_NUM_FRAGILE = "may differ" there.)
  *   separate processes:  fl_p2p_export on every rank -> exchange the 64-byte handles (any transport) -> fl_p2p_connect
  *   one process:         fl_p2p_connect_local(h, rank, world, all_handles) on every handle
  * Connect before fl_*_begin of the frame, and put a barrier of the caller's transport between the connects and the first pass

@@ -83,6 +83,6 @@ def test_ntu_viral_full_frame_one_gpu_and_two_ranks(gpu_lib, oracle_lib, scene):
     assert np.array_equal(xa.vec(), xb.vec()) and np.array_equal(xa.cov_np(), xb.cov_np())        # ranks bitwise equal
     assert np.abs(xa.vec() - xo.vec()).max() <= 1e-9 and np.abs(xa.cov_np() - xo.cov_np()).max() <= 1e-11
     assert np.array_equal(va.vec(), vb.vec())
-    assert np.abs(va.vec() - xvo.vec()).max() <= 1e-6      # (sharded accept test = fp64 comparison)
+    assert np.abs(va.vec() - xvo.vec()).max() <= 1e-8      # (VIO starts from each side's own LIO posterior, equal to 1e-9)
     for hh in hs:
         hh.close()

@@ -122,9 +122,53 @@ def test_vio_levels_and_all_device_frame_sharded_in_kernel(gpu_lib, oracle_lib, 
     assert np.array_equal(xa.vec(), xb.vec()) and np.array_equal(xa.cov_np(), xb.cov_np())
     assert np.abs(xa.vec() - xr.vec()).max() <= 1e-9 and np.abs(xa.cov_np() - xr.cov_np()).max() <= 1e-11
     assert np.array_equal(va.vec(), vb.vec())
-    assert np.abs(va.vec() - xv.vec()).max() <= 1e-6          # (the accept test of the sharded form is the fp64 one: DESIGN.md section 6)
+    assert np.abs(va.vec() - xv.vec()).max() <= 1e-9          # (the accept test runs through the ranks in the reference's float arithmetic)
     for h in hs:
         h.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exact_accept_replay_runs_through_the_ranks(gpu_lib, oracle_lib, world):
+    """The reference decides `error <= last_error` on a float running sum over ALL patches in order (lidar_selection.cpp:849-859).
+    Sharded, that sum runs through the ranks' contiguous patch ranges one after the other: on the fragile passes rank r continues the
+    chain from the float rank r-1 ended with and the last rank sends the total back (solve18.h: vio_exact_chain). The accept/revert
+    sequences, iteration counts and the final state then equal the oracle's on every frame -- at N > 1 as on one GPU -- and status
+    bit 16 means what it means there ("decided in the reference's float arithmetic"), not "may differ"."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    replayed = 0
+    for seed in range(1, 9):
+        lio = synth.make_lio_frame(500, seed=synth.SEED + seed % 7)
+        vf = synth.make_vio_frame(1000, lio, max_iterations=10, patch_seed=seed * 7919)
+        cfg = capi.config_from_frames(lio, vf, max_iterations=10)
+        xo = orc.state18_from_frame(lio)
+        ro = orc.vio_compute_j(vf, xo, xo.copy())
+        hs = [capi.Handle(cfg) for _ in range(world)]
+        capi.p2p_connect_local(hs)
+        cuts = np.linspace(0, vf.m, world + 1).astype(int)
+
+        def rank(r):
+            def go():
+                h = hs[r]
+                sl = slice(cuts[r], cuts[r + 1])
+                h.vio_set_frame(vf.img); h.vio_set_patches(vf.ref_patch[sl], vf.pos[sl], vf.search_level[sl])
+                xg = capi.state18_from_frame(lio); xp = capi.state18_from_frame(lio)
+                infos = h.vio_compute_j(xg, xp)
+                return infos, xg, h.vio_get_errors(cuts[r + 1] - cuts[r])
+            return go
+        res = _run_ranks([rank(r) for r in range(world)])
+        for r, (infos, xg, eg) in enumerate(res):
+            for l in range(3):
+                assert infos[l].iterations == ro["outs"][l].iterations and infos[l].accepted == ro["outs"][l].accepted, (seed, r, l)
+                assert not (infos[l].status & 8), (seed, r, l)
+            assert np.array_equal(xg.vec(), res[0][1].vec()) and np.array_equal(xg.cov_np(), res[0][1].cov_np())      # ranks bitwise equal
+            assert np.abs(xg.vec() - xo.vec()).max() <= 1e-9, (seed, r)
+            assert np.abs(xg.cov_np() - xo.cov_np()).max() <= 1e-11, (seed, r)
+            assert np.array_equal(eg.view(np.uint32), ro["errors"][cuts[r]:cuts[r + 1]].view(np.uint32)), (seed, r)
+        replayed += any(i.status & 16 for i in res[0][0])
+        for h in hs:
+            h.close()
+    assert replayed >= 1          # the chain through the ranks was exercised
 
 
 def test_two_processes_over_hip_ipc(gpu_lib, tmp_path):
