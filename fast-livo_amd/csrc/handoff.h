@@ -282,6 +282,7 @@ __device__ __forceinline__ void bcast_wait(const unsigned long long *words, unsi
         wa = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (__ballot(!mine || (unsigned)wb == epoch) == ~0ull) { w = wb; break; }
         if (spin > spin_limit) { timeout = true; break; }
+        if (spin > 32) __builtin_amdgcn_s_sleep(8);      // a long wait (a peer rank, a delayed solver): back off instead of hammering the words
     }
 #else
     bool ok = !mine;
