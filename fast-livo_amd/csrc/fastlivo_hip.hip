@@ -45,7 +45,8 @@ struct fl_context {
     bool begun18 = false;         // an 18-state is on the device (fl_lio_begin18 / fl_vio_begin / frame drivers)
     int last_state_mode = 0;      // 18 / 23: which filter state was staged last (fl_map_add_points(NULL) registers the scan under it)
     int num_cus = 0;              // compute units of the device: the multi-pass kernels need every workgroup resident (<= 1 per CU)
-    int mp_capacity = 0;          // workgroups of a multi-pass kernel the device can hold at once (occupancy x CUs)
+    int mp_capacity = 0;          // workgroups of the LIO / VIO multi-pass kernels the device can hold at once (occupancy x CUs)
+    int mp_capacity_ik = 0;       // ... of the Mode-23 multi-pass kernel (more registers: fewer per CU)
     unsigned *h_mp_done = nullptr;   // pinned host word the solver workgroup of a multi-pass launch writes its sequence number to when it ends
     unsigned *d_mp_done = nullptr;   // ... as the device addresses it
     unsigned mp_seq = 0;             // sequence number of this handle's last multi-pass launch
@@ -231,7 +232,7 @@ static std::mutex g_mp_mu;
 static std::vector<fl_context *> g_mp_handles;      // live handles of this process
 // in flight = launched and its completion word not written yet (one store by the launch's last action; no events, no
 // extra commands in the stream -- an event per launch cost ~0.5 us per pass of GPU time)
-static bool mp_admit(fl_handle h, int grid)
+static bool mp_admit(fl_handle h, int grid, int capacity)
 {
     std::lock_guard<std::mutex> lk(g_mp_mu);
     int busy = 0;
@@ -239,10 +240,15 @@ static bool mp_admit(fl_handle h, int grid)
         if (o == h || o->cfg.device != h->cfg.device || o->stream == h->stream) continue;
         if (o->mp_seq != __atomic_load_n(o->h_mp_done, __ATOMIC_RELAXED)) busy += o->mp_last_grid;
     }
-    if (busy + grid > h->mp_capacity) { h->mp_fallbacks++; return false; }
-    h->mp_seq++;                    // the launch that follows carries this number
-    h->mp_last_grid = grid;
+    if (busy + grid > capacity) { h->mp_fallbacks++; return false; }
     return true;
+}
+// right before a multi-pass launch: the sequence number it carries (and writes to h_mp_done when it ends)
+static unsigned mp_begin(fl_handle h, int grid)
+{
+    std::lock_guard<std::mutex> lk(g_mp_mu);
+    h->mp_last_grid = grid;
+    return ++h->mp_seq;
 }
 // FL_NUM_TIMEOUT handling: clears the abandoned mark so that the enqueued per-pass chain runs (solve18.h, fl_pass_skipped)
 __global__ void eskf18_resume_kernel(FlDev18 *__restrict__ D)
@@ -313,10 +319,10 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
         HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_lio, lio18_multipass_kernel, FL_LIO_NT, 0));
         HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_vio, vio_multipass_kernel, FL_VIO_NT, 0));
         HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_ik, ikfom_multipass_kernel, FL_IK_NT, 0));
-        int b = b_lio < b_vio ? b_lio : b_vio;
-        if (b_ik < b) b = b_ik;
+        const int b = b_lio < b_vio ? b_lio : b_vio;
         h->mp_capacity = b * h->num_cus;
-        if (const char *e = getenv("FL_MP_CAPACITY")) h->mp_capacity = atoi(e);     // test aid
+        h->mp_capacity_ik = b_ik * h->num_cus;
+        if (const char *e = getenv("FL_MP_CAPACITY")) h->mp_capacity = h->mp_capacity_ik = atoi(e);     // test aid
     }
     { std::lock_guard<std::mutex> lk(g_mp_mu); g_mp_handles.push_back(h); }
     *out = h;
@@ -648,14 +654,17 @@ static void ensure_gates(fl_handle h)
     h->gate_valid = true;
 }
 // may this handle use the multi-pass form for a grid of `grid` workgroups right now?
-static bool multipass_ok(fl_handle h, int grid) { return grid <= h->num_cus && fl_multipass_enabled() && mp_admit(h, grid); }
+static bool multipass_ok(fl_handle h, int grid, bool mode23 = false)
+{
+    return grid <= h->num_cus && fl_multipass_enabled() && mp_admit(h, grid, mode23 ? h->mp_capacity_ik : h->mp_capacity);
+}
 static void launch_lio_passes(fl_handle h, int grid, int count, int flags, bool allow_multi = true)
 {
     if (flags & FL_ITER_KEEP_NORMVEC) h->normvec_valid = true;
     ensure_gates(h);
     if (allow_multi && count > 1 && multipass_ok(h, grid)) {
         hipLaunchKernelGGL(lio18_multipass_kernel, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_gate, h->d_plane, h->d_sel, h->d_normvec,
-                           h->n, h->d_dev, records_lio(h), h->d_epoch, h->d_bcast, (int)count, (int)flags, h->d_mp_done, h->mp_seq);
+                           h->n, h->d_dev, records_lio(h), h->d_epoch, h->d_bcast, (int)count, (int)flags, h->d_mp_done, mp_begin(h, grid));
         return;
     }
     for (int i = 0; i < count; i++)

@@ -93,7 +93,10 @@ def test_abandoned_pass_is_resumed_with_identical_result(gpu_lib, scene):
     x_ref = capi.state18_from_frame(fr)
     i_ref = h.lio_frame18_dev(x_ref, fr.body_xyz)
     c = h.debug_counters()
-    h.debug_hog(c["cus"], 150 * 1024, 120000)               # every CU's LDS taken for 120 ms
+    # ALL of the LDS of 3/4 of the CUs taken for 120 ms: the 197 workgroups of the launch find room on 64 CUs only, those that get on
+    # the device wait for the others in vain (with every CU taken the launch would simply queue behind the foreign kernel: no wait
+    # expires, nothing to resume)
+    h.debug_hog(c["cus"] * 3 // 4, 160 * 1024, 120000)
     import time
     time.sleep(0.02)                                        # (the foreign kernel is on the device before the frame is enqueued)
     x = capi.state18_from_frame(fr)
@@ -102,4 +105,5 @@ def test_abandoned_pass_is_resumed_with_identical_result(gpu_lib, scene):
     assert info.status == 0 and info.iterations == i_ref.iterations
     assert np.array_equal(x.vec(), x_ref.vec()) and np.array_equal(x.cov_np(), x_ref.cov_np())
     print(f"\n[co-residency] resumes {c2['resumes'] - c['resumes']}, admission fallbacks {c2['fallbacks'] - c['fallbacks']}")
+    assert c2["resumes"] - c["resumes"] >= 1                # the frame really was abandoned and resumed
     h.close()
