@@ -177,6 +177,7 @@ SYMBOLS = {
     "fl_debug_get_stamps": (C.c_int32, [_H, C.POINTER(C.c_longlong)]),
     "fl_debug_hog": (C.c_int32, [_H, C.c_int32, C.c_int32, C.c_int32]),
     "fl_debug_counters": (C.c_int32, [_H, _i32p]),
+    "fl_debug_chain": (C.c_int32, [_H, C.POINTER(C.c_float), C.c_int32, C.c_float, C.POINTER(C.c_float)]),
     "fl_lio_set_points": (C.c_int32, [_H, _fp, C.c_int32]),
     "fl_lio_set_neighbours": (C.c_int32, [_H, _fp, _u8p, C.c_int32]),
     "fl_lio_get_selection": (C.c_int32, [_H, _u8p, _fp]),
@@ -824,6 +825,13 @@ def _knn_methods():
     def debug_hog(self, blocks, lds_bytes, usec):
         self._chk(self.L.fl_debug_hog(self.h, int(blocks), int(lds_bytes), int(usec)), "fl_debug_hog")
 
+    def debug_chain(self, e, init=0.0):
+        """(lane-parallel, one-lane) float running sums of init + e[0] + e[1] + ... on the device (csrc/exact_chain.h)"""
+        e = np.ascontiguousarray(e, dtype=np.float32)
+        out = np.zeros(2, dtype=np.float32)
+        self._chk(self.L.fl_debug_chain(self.h, _p(e, C.c_float), len(e), C.c_float(init), _p(out, C.c_float)), "fl_debug_chain")
+        return out[0], out[1]
+
     def debug_counters(self):
         """dict(fallbacks, resumes, capacity, cus): multi-pass launches refused by the admission check, frames resumed after an
         abandoned pass, workgroups of a multi-pass kernel the device holds at once, compute units."""
@@ -851,7 +859,7 @@ def _knn_methods():
         return info
 
     for f in (map_set_points, map_clear, map_add_points, map_delete_boxes, map_get_points, lio_search18, ikfom_search, lio_frame18_dev, ikfom_update_iterated_dev,
-              debug_hog, debug_counters):
+              debug_hog, debug_counters, debug_chain):
         setattr(Handle, f.__name__, f)
 
 

@@ -88,7 +88,6 @@ struct fl_context {
     int32_t *d_slevel = nullptr;
     int cap_patches = 0, m = 0;
     bool have_img = false;
-    void *d_vio_li = nullptr;      // per-level results of fl_vio_compute_j
     // Mode-23
     FlDev23 *d_dev23 = nullptr;
     FlDev23 *h_dev23 = nullptr;
@@ -284,8 +283,10 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
     HIPCHK(h, hipSetDevice(cfg->device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
-    HIPCHK(h, hipMalloc(&h->d_dev, sizeof(FlDev18)));
-    HIPCHK(h, hipHostMalloc(&h->h_dev, sizeof(FlDev18)));
+    // + FL_DEV18_TAIL bytes behind the block for per-call results that travel back with it in the same copy (fl_vio_compute_j's
+    // three FlVioLevelInfo)
+    HIPCHK(h, hipMalloc(&h->d_dev, sizeof(FlDev18) + FL_DEV18_TAIL));
+    HIPCHK(h, hipHostMalloc(&h->h_dev, sizeof(FlDev18) + FL_DEV18_TAIL));
     HIPCHK(h, hipMalloc(&h->d_dev23, sizeof(FlDev23)));
     HIPCHK(h, hipHostMalloc(&h->h_dev23, sizeof(FlDev23)));
     HIPCHK(h, hipMalloc(&h->d_records, (size_t)16 * FL_MAX_BLOCKS * FL_SUMS23));
@@ -305,7 +306,7 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
         HIPCHK(h, hipMemset(h->d_epoch, 0, 64));
         HIPCHK(h, hipMemcpy(h->d_epoch, &one, sizeof one, hipMemcpyHostToDevice));
     }
-    HIPCHK(h, hipMemset(h->d_dev, 0, sizeof(FlDev18)));
+    HIPCHK(h, hipMemset(h->d_dev, 0, sizeof(FlDev18) + FL_DEV18_TAIL));
     HIPCHK(h, hipMemset(h->d_dev23, 0, sizeof(FlDev23)));
     build_vio_const(h->cfg, h->h_vc);
     HIPCHK(h, hipMemcpy(h->d_vc, &h->h_vc, sizeof(FlVioConst), hipMemcpyHostToDevice));
@@ -346,7 +347,7 @@ int32_t fl_destroy(fl_handle h)
     hipFree(h->d_body); hipFree(h->d_nbr); hipFree(h->d_world); hipFree(h->d_valid); hipFree(h->d_sel); hipFree(h->d_gate);
     hipFree(h->d_plane); hipFree(h->d_normvec); hipFree(h->d_dev); hipFree(h->d_dev23); hipFree(h->d_records);
     hipFree(h->d_epoch); hipFree(h->d_sums_tmp); hipFree(h->d_bcast); hipFree(h->d_vc); hipFree(h->d_img); hipFree(h->d_ref);
-    hipFree(h->d_errors); hipFree(h->d_err_words); hipFree(h->d_pos); hipFree(h->d_slevel); hipFree(h->d_vio_li);
+    hipFree(h->d_errors); hipFree(h->d_err_words); hipFree(h->d_pos); hipFree(h->d_slevel);
     map_free(h);
     mapupd_free(h);
     vox_free(h);
@@ -573,7 +574,7 @@ static void unpack_state18(const double *x24, const double *P, fl_state18 *s)
     memcpy(s->cov, P, sizeof(double) * 324);
 }
 
-static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_state18 *prop, double meas_cov)
+static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_state18 *prop, double meas_cov, bool vio = false)
 {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));   // h_dev is reused
@@ -602,7 +603,8 @@ static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_sta
     D->xchg_rank = h->xchg_rank;
     D->xchg_world = h->xchg_world;
     HIPCHK(h, hipMemcpyAsync(h->d_dev, D, sizeof(FlDev18), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(eskf18_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev);
+    if (vio) hipLaunchKernelGGL(vio_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev, (const FlVioConst *)h->d_vc);   // + the camera pose
+    else hipLaunchKernelGGL(eskf18_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev);
     HIPCHK(h, hipGetLastError());
     h->begun18 = true;
     h->last_state_mode = 18;
@@ -621,7 +623,7 @@ int32_t fl_lio_begin18(fl_handle h, const fl_state18 *state, const fl_state18 *p
 
 static int32_t read_info18(fl_handle h, fl_iter_info *info)
 {
-    HIPCHK(h, hipMemcpyAsync(h->h_dev, h->d_dev, sizeof(FlDev18), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_dev, h->d_dev, sizeof(FlDev18) + FL_DEV18_TAIL, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (!info) return FL_OK;
     const FlDev18 *D = h->h_dev;
@@ -803,6 +805,23 @@ int32_t fl_debug_counters(fl_handle h, int32_t *out4)
 {
     if (!h || !out4) return fail_arg(h, "fl_debug_counters: null argument");
     out4[0] = h->mp_fallbacks; out4[1] = h->mp_resumes; out4[2] = h->mp_capacity; out4[3] = h->num_cus;
+    return FL_OK;
+}
+
+// Debug / test: init + e[0] + ... + e[n-1] as one chain of float additions, by exact_chain.h's lane-parallel form (out2[0]) and
+// by one lane adding one by one (out2[1]); e is a host array.
+int32_t fl_debug_chain(fl_handle h, const float *e, int32_t n, float init, float *out2)
+{
+    if (!h || n < 0 || (n > 0 && !e) || !out2) return fail_arg(h, "fl_debug_chain: bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    float *d = nullptr;
+    HIPCHK(h, hipMalloc(&d, sizeof(float) * ((size_t)n + 2)));
+    if (n > 0) HIPCHK(h, hipMemcpyAsync(d + 2, e, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(fl_chain_debug_kernel, dim3(1), dim3(256), 0, h->stream, (const float *)(d + 2), (int)n, init, d);
+    hipError_t err = hipMemcpyAsync(out2, d, sizeof(float) * 2, hipMemcpyDeviceToHost, h->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    HIPCHK(h, err);
     return FL_OK;
 }
 

@@ -179,6 +179,7 @@ __device__ __forceinline__ void fl_sin_omc(double x, double *s, double *omc)
 }
 
 __device__ long long g_fl_stamps[64];
+#define FL_DEV18_TAIL 512                  /* bytes behind FlDev18 in its device and pinned-host allocations (fastlivo_hip.hip) */
 __device__ long long g_fl_wall[2048];   // debug: per-workgroup start/end wall clock (100 MHz)
 
 // ---- wavefront reduction --------------------------------------------------------------------

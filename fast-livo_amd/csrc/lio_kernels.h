@@ -65,7 +65,7 @@ __global__ __launch_bounds__(FL_BLOCK) void lio_gate_kernel(const float *__restr
 // 128 threads; the arithmetic per output element is fl_prepare18's (threads 0..5 each eliminate one column of the
 // 6x6 inverse -- the pivoting depends on the matrix only, so a column solved alone is bit-identical to the same
 // column solved with the others; threads 0..107 each form one element of T).
-__global__ __launch_bounds__(128) void eskf18_prepare_kernel(FlDev18 *__restrict__ D)
+__device__ __forceinline__ void eskf18_prepare_body(FlDev18 *__restrict__ D)
 {
     __shared__ double s_B[36], s_Q[36];
     __shared__ int s_st[6];
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(128) void eskf18_prepare_kernel(FlDev18 *__restrict
     }
     if (t == 0) D->status = s_st[0] | s_st[1] | s_st[2] | s_st[3] | s_st[4] | s_st[5];
 }
+__global__ __launch_bounds__(128) void eskf18_prepare_kernel(FlDev18 *__restrict__ D) { eskf18_prepare_body(D); }
 
 // A multi-pass launch tells the host that its workgroups are gone (admission check of fastlivo_hip.hip): one system-scope
 // store of the launch's sequence number into a pinned host word, by the solver workgroup as its last action.

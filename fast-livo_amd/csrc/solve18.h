@@ -24,6 +24,7 @@
 #include "fl_device.h"
 #include "fl_math.h"
 #include "handoff.h"
+#include "exact_chain.h"
 
 struct FlSolveLds {
     double Q[36];
@@ -47,11 +48,12 @@ struct FlSolveLds {
     float last_error;
     int accept;
     int st;
-    int pad;
+    int audited;
 };
 
 enum { FL_EPI_LIO = 0, FL_EPI_VIO = 1 };
 
+#define FL_AUDIT_RING 16               /* slots of the auditor's ring of per-pass totals (vio_kernels.h vio_audit_pass) */
 // Per-patch errors of one pass for the exact VIO accept test (see eskf18_solve_block)
 struct FlVioExact {
     const unsigned long long *words;   // [2][cap]
@@ -66,41 +68,61 @@ struct FlVioExact {
     unsigned long long *const *peer;   // everybody's buffers
     int rank, world;
     unsigned xe;                       // exchange epoch of this pass = tag of the mail
+    // single rank: the auditor workgroup's ring of per-pass totals (vio_kernels.h vio_audit_pass), slot = epoch & 15; nullptr otherwise
+    const unsigned long long *audit;
 };
+// total of pass `tag` out of the auditor's ring (thread 0); false when it does not arrive within `spins` polls or the auditor gave
+// up on that pass (payload FL_AUDIT_NONE)
+#define FL_AUDIT_NONE 0xffffffffu
+__device__ __forceinline__ bool vio_audit_read(const unsigned long long *ring, unsigned tag, int spins, float *out)
+{
+    unsigned long long v = 0ull;
+    int spin = 0;
+    do { v = __hip_atomic_load(ring + (tag & (FL_AUDIT_RING - 1u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)v != tag && ++spin < spins);
+    *out = __uint_as_float((unsigned)(v >> 32));
+    return (unsigned)v == tag && (unsigned)(v >> 32) != FL_AUDIT_NONE;
+}
 #define FL_EXACT_CHUNK 2048
-// The reference's `error += patch_error` over patches 0..m-1 as one chain of float additions (no contraction). All threads of the
-// workgroup stage the words (polling until their tag says they belong to pass `tag`); thread 0 adds. Result valid in thread 0.
+// The reference's `error += patch_error` over patches 0..m-1 as one chain of float additions (no contraction), bit for bit. All
+// threads of the workgroup stage the words (polling until their tag says they belong to pass `tag`); wavefront 0 adds them up
+// binade-wise over its 64 lanes (exact_chain.h: ~3 us for 2 k patches instead of ~20 us for one lane adding one by one). Result
+// valid in thread 0. A word of a NEWER pass (the double-buffered half was reused: the caller is two passes late) or one that never
+// arrives sets *timeout_flag.
 __device__ __forceinline__ float vio_exact_sum(const unsigned long long *w, int m, unsigned tag, float *scr, int *timeout_flag, float init = 0.0f)
 {
-#pragma clang fp contract(off)
     const int tid = threadIdx.x, nt = blockDim.x;
     float f = init;
     for (int base = 0; base < m; base += FL_EXACT_CHUNK) {
         const int cnt = min(FL_EXACT_CHUNK, m - base);
-        for (int k = tid; k < cnt; k += nt) {
-            unsigned long long v = 0ull;
+        constexpr int PER = 8;                               // first loads of a thread's words all in flight at once
+        unsigned long long v[PER];
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int k = tid + j * nt;
+            v[j] = (k < cnt) ? __hip_atomic_load(w + base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int k = tid + j * nt;
+            if (k < cnt) {
+                unsigned long long x = v[j];
+                int spin = 0;
+                while ((unsigned)x != tag && (int)((unsigned)x - tag) < 0 && ++spin < 4096)
+                    x = __hip_atomic_load(w + base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)x != tag) *timeout_flag = 1;
+                scr[k] = __uint_as_float((unsigned)(x >> 32));
+            }
+        }
+        for (int k = tid + PER * nt; k < cnt; k += nt) {      // (workgroups of fewer than 256 threads)
+            unsigned long long x = 0ull;
             int spin = 0;
-            do {
-                v = __hip_atomic_load(w + base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } while ((unsigned)v != tag && ++spin < 4096);
-            if ((unsigned)v != tag) *timeout_flag = 1;
-            scr[k] = __uint_as_float((unsigned)(v >> 32));
+            do { x = __hip_atomic_load(w + base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            while ((unsigned)x != tag && (int)((unsigned)x - tag) < 0 && ++spin < 4096);
+            if ((unsigned)x != tag) *timeout_flag = 1;
+            scr[k] = __uint_as_float((unsigned)(x >> 32));
         }
         __syncthreads();
-        if (tid == 0) {
-            // one dependent float addition per patch; the operands come from LDS sixteen at a time so that the chain waits for
-            // the adder, not for LDS
-            int k = 0;
-            for (; k + 16 <= cnt; k += 16) {
-                const float4 a = *reinterpret_cast<const float4 *>(scr + k), b = *reinterpret_cast<const float4 *>(scr + k + 4);
-                const float4 c = *reinterpret_cast<const float4 *>(scr + k + 8), d = *reinterpret_cast<const float4 *>(scr + k + 12);
-                f = f + a.x; f = f + a.y; f = f + a.z; f = f + a.w;
-                f = f + b.x; f = f + b.y; f = f + b.z; f = f + b.w;
-                f = f + c.x; f = f + c.y; f = f + c.z; f = f + c.w;
-                f = f + d.x; f = f + d.y; f = f + d.z; f = f + d.w;
-            }
-            for (; k < cnt; k++) f = f + scr[k];
-        }
+        if (tid < 64) f = fl_chain_f32_wave(scr, cnt, f);
         __syncthreads();
     }
     return f;
@@ -361,7 +383,10 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
         // the per-patch words (solve kernel of the RCCL form: `ex.words` == nullptr) bit 16 means "may differ".
         // Every thread evaluates the trigger itself from pass-invariant inputs (G.last_error was read before the gather), so the
         // common case needs no barrier.
-        const bool can_replay = ex.words != nullptr && ex.enabled;     // (by value: a nullable pointer to it kept the struct in scratch)
+        bool can_replay = ex.words != nullptr && ex.enabled;     // (by value: a nullable pointer to it kept the struct in scratch)
+#ifdef FL_AB_NO_EXACT
+        can_replay = false;                                            // A/B build: what the replays cost (tools/computej_breakdown.py)
+#endif
         const float n_meas = (float)s_sums[FL_S_NEFF];
         const float error = (float)s_sums[FL_S_RES] / n_meas;
         const float last = G.last_error;
@@ -375,6 +400,22 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
             __syncthreads();
             const int cur_buf = L.iters_run & 1;
             const float n_all = (float)s_sums[FL_S_NEFF];          // 64 x the patches of ALL ranks, as the reference's n_meas
+            bool audited = false;
+            if (ex.audit) {      // single rank: the auditor workgroup has been adding this pass's chain up since its words arrived
+                if (tid == 0) {
+                    float fc = 0.f, fl = 0.f;
+                    bool ok = vio_audit_read(ex.audit, ex.epoch, 1 << 12, &fc);
+                    if (ok && !L.last_exact_valid) {
+                        ok = vio_audit_read(ex.audit, L.acc_epoch, 64, &fl);     // (a pass long finished: there, or never audited)
+                        if (ok) { L.last_exact = fl / n_all; L.last_exact_valid = 1; }
+                    }
+                    L.exact_cur = fc / n_all;
+                    L.audited = ok ? 1 : 0;
+                }
+                __syncthreads();
+                audited = L.audited != 0;
+            }
+            if (!audited) {
             const float fc = vio_exact_chain(ex, ex.words + (size_t)cur_buf * ex.cap, ex.epoch, 0, &L.exact_cur, &L.exact_timeout);
             __syncthreads();
             if (tid == 0) L.exact_cur = fc / n_all;
@@ -382,6 +423,7 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
                 const float fl = vio_exact_chain(ex, ex.words + (size_t)L.acc_buf * ex.cap, L.acc_epoch, 2, &L.last_exact, &L.exact_timeout);
                 __syncthreads();
                 if (tid == 0) { L.last_exact = fl / n_all; L.last_exact_valid = 1; }
+            }
             }
             __syncthreads();
         }

@@ -162,9 +162,8 @@ FL_HD void fl_patch_accum(double *v /*32*/, const double (&M)[2][6], const doubl
 // Camera pose of the current state, Rcw = Rci Rwi^T, Pcw = -Rci Rwi^T Pwi + Pci (lidar_selection.cpp:780-784),
 // in exactly the reference's operation order (it feeds the float sub-pixel weights). Threads 0..11 of
 // the calling workgroup each form one element from xn = {rot(9), pos(3)}.
-__device__ __forceinline__ void vio_derive_pose(const double *xn, const FlVioConst *__restrict__ VC, FlDev18 *__restrict__ D)
+__device__ __forceinline__ void vio_derive_pose(const double *xn, const FlVioConst *__restrict__ VC, FlDev18 *__restrict__ D, int t)
 {
-    const int t = threadIdx.x;
     if (t < 9) {
         const int i = t / 3, j = t % 3;   // Rcw[i][j] = sum_k Rci[i][k] * Rwi[j][k]
         D->Rcw[t] = VC->Rci[i * 3 + 0] * xn[j * 3 + 0] + VC->Rci[i * 3 + 1] * xn[j * 3 + 1] + VC->Rci[i * 3 + 2] * xn[j * 3 + 2];
@@ -182,7 +181,14 @@ __global__ void vio_derive_kernel(FlDev18 *__restrict__ D, const FlVioConst *__r
     __shared__ double xn[12];
     if (threadIdx.x < 12) xn[threadIdx.x] = D->x[threadIdx.x];
     __syncthreads();
-    vio_derive_pose(xn, VC, D);
+    vio_derive_pose(xn, VC, D, (int)threadIdx.x);
+}
+// fl_vio_begin in one launch: the gain-solve constants of the state block (eskf18_prepare_kernel) and, by the last 12 threads, the
+// camera pose of the initial state
+__global__ __launch_bounds__(128) void vio_prepare_kernel(FlDev18 *__restrict__ D, const FlVioConst *__restrict__ VC)
+{
+    if (threadIdx.x >= 116) vio_derive_pose(D->x, VC, D, (int)threadIdx.x - 116);
+    eskf18_prepare_body(D);
 }
 
 #define FL_VIO_NT 256
@@ -193,10 +199,15 @@ __global__ void vio_derive_kernel(FlDev18 *__restrict__ D, const FlVioConst *__r
 #ifndef FL_VIO_LPP
 #define FL_VIO_LPP 16
 #endif
+#ifdef FL_AUDIT_STAMPS                      /* debug build: time line of the auditor and the solver (tools/vio_audit_stamps.py) */
+#define FL_AUDIT_STAMP(i, v) do { if (threadIdx.x == 0) g_fl_wall[(i)] = (long long)(v); } while (0)
+#else
+#define FL_AUDIT_STAMP(i, v) do { } while (0)
+#endif
 #define FL_VIO_PPL (64 / FL_VIO_LPP)          /* pixels per lane */
 #define FL_VIO_GPW (64 / FL_VIO_LPP)          /* patches (lane groups) per wavefront */
 
-// grid = producers + 1 ; MODE 0: fused pass ; MODE 1: accumulate only (sums -> sums_out).
+// grid = producers + 2 (the auditor workgroup, then the solver workgroup) ; MODE 0: fused pass ; MODE 1: accumulate only (sums -> sums_out).
 // 256-thread workgroups: 8 (16) patches each. The first patch's inputs do not depend on the state: their loads are issued before
 // the state round trip.
 struct FlVioFirst {
@@ -213,7 +224,7 @@ __device__ __forceinline__ FlVioFirst vio_prefetch_first(const float *__restrict
     const int grp = lane / FL_VIO_LPP, hl = lane % FL_VIO_LPP;
     const int i_first = (blockIdx.x * WPB + wave) * FL_VIO_GPW + grp;
     FlVioFirst f;
-    f.have = (blockIdx.x != nprod) && (i_first < m);
+    f.have = ((int)blockIdx.x < nprod) && (i_first < m);
     f.slevel = 0; f.pos0 = 0.0; f.pos1 = 0.0; f.pos2 = 0.0;
 #pragma unroll
     for (int k = 0; k < FL_VIO_PPL; k++) f.ref[k] = 0.f;
@@ -410,6 +421,25 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
     vio_patch_error(s_res + slot * 64, hl, def_active, def_i, errors, err_words, epoch);
 }
 
+// The AUDITOR workgroup (block `nprod`): the reference's float running sum `error += patch_error` over the patches in order
+// (lidar_selection.cpp:849-857; solve18.h, eskf18_solve_block) for EVERY pass, computed beside the producers and the solver instead of
+// by the solver when it finds the accept test fragile: the m additions start as soon as the
+// per-patch words arrive and overlap the gather and the solve, so a fragile pass waits for the tail of the chain only, and the value
+// of the last accepted pass is always at hand (no second chain). The result goes into a 16-slot ring behind the per-patch words,
+// slot = epoch & 15, tagged with the epoch like every hand-off word. The chain itself is exact_chain.h's lane-parallel form (~3 us
+// at 2 k patches): the auditor is done before the solver asks.
+__device__ __forceinline__ void vio_audit_pass(unsigned long long *__restrict__ err_base, int err_cap, int buf, int m, unsigned epoch,
+                                               float *s_aud, int *s_to)
+{
+    if (threadIdx.x == 0) *s_to = 0;
+    __syncthreads();
+    const float f = vio_exact_sum(err_base + (size_t)buf * err_cap, m, epoch, s_aud, s_to);
+    if (threadIdx.x == 0)         // (no total: the solver workgroup replays the pass itself, solve18.h)
+        __hip_atomic_store(err_base + 2 * (size_t)err_cap + (epoch & (FL_AUDIT_RING - 1)),
+                           ((unsigned long long)(*s_to ? FL_AUDIT_NONE : __float_as_uint(f)) << 32) | (unsigned long long)epoch, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__restrict__ img, const float *__restrict__ ref,
                                                             const double *__restrict__ pos, const int32_t *__restrict__ slevel,
@@ -420,11 +450,12 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
 {
     constexpr int NT = FL_VIO_NT;
     constexpr int WPB = NT / 64;
-    const int nprod = gridDim.x - 1;
+    const int nprod = gridDim.x - 2;              // then the auditor (nprod) and the solver (nprod + 1)
+    const int solver_block = nprod + 1;
     if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();
     const FlVioFirst pf = vio_prefetch_first(ref, pos, slevel, m, level_arg, nprod);
     double pf_solver = 0.0;
-    if (MODE == 0 && blockIdx.x == nprod) pf_solver = eskf18_prefetch_issue(D);
+    if (MODE == 0 && blockIdx.x == solver_block) pf_solver = eskf18_prefetch_issue(D);
     if (D->status & FL_NUM_TIMEOUT) {             // an earlier pass of the chain was abandoned (solve18.h): the host resumes
         if (blockIdx.x == 0 && threadIdx.x == 0) D->resume_count += 1;
         return;
@@ -433,6 +464,15 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     const unsigned epoch = *epoch_ptr;
 
     if (blockIdx.x == nprod) {
+        // ------------------------------------------------------------------ auditor workgroup (single-rank fused passes only: the
+        // sharded form chains the sum through the ranks, solve18.h vio_exact_chain)
+        if (MODE != 0 || (flags & FL_ITER_FORCE) || !D->err_words || D->xchg_world > 1) return;
+        __shared__ __attribute__((aligned(16))) float s_aud[FL_EXACT_CHUNK];
+        __shared__ int s_to;
+        vio_audit_pass(D->err_words, D->err_cap, D->iters_run & 1, m, epoch, s_aud, &s_to);
+        return;
+    }
+    if (blockIdx.x == solver_block) {
         // ------------------------------------------------------------------ solver workgroup
         __shared__ double s_fin[2 * NT];
         __shared__ double s_sums[FL_SUMS18];
@@ -460,6 +500,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
             ex.words = D->err_words; ex.m = m; ex.cap = D->err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !(flags & FL_ITER_FORCE);
             ex.own = (world > 1) ? D->xchg_peer[D->xchg_rank] : nullptr; ex.peer = D->xchg_peer; ex.rank = D->xchg_rank; ex.world = world;
             ex.xe = xe_pass;
+            ex.audit = (world > 1 || !D->err_words) ? nullptr : D->err_words + 2 * (size_t)D->err_cap;
             eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, gst, nullptr, 0u, ex, VC);   // incl. the camera pose for the next pass's producers
         } else {
             if (threadIdx.x < FL_SUMS18) sums_out[threadIdx.x] = s_sums[threadIdx.x];
@@ -485,6 +526,25 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();
 }
 
+// Debug / test: exact_chain.h's lane-parallel chain beside the plain one-lane chain over the same floats
+__global__ __launch_bounds__(256) void fl_chain_debug_kernel(const float *__restrict__ e, int n, float init, float *__restrict__ out2)
+{
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) float scr[FL_EXACT_CHUNK];
+    float f = init, g = init;
+    for (int base = 0; base < n; base += FL_EXACT_CHUNK) {
+        const int cnt = min(FL_EXACT_CHUNK, n - base);
+        for (int k = threadIdx.x; k < cnt; k += blockDim.x) scr[k] = e[base + k];
+        __syncthreads();
+        if (threadIdx.x < 64) f = fl_chain_f32_wave(scr, cnt, f);
+        if (threadIdx.x == 64)
+            for (int k = 0; k < cnt; k++) g = g + scr[k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out2[0] = f;
+    if (threadIdx.x == 64) out2[1] = g;
+}
+
 struct FlVioLevelInfo {
     double solution[18];
     float error;
@@ -508,7 +568,8 @@ __global__ __launch_bounds__(FL_VIO_NT, 2) void vio_multipass_kernel(const uint8
     // needs one launch per level instead of three.
     constexpr int NT = FL_VIO_NT;
     constexpr int WPB = NT / 64;
-    const int nprod = gridDim.x - 1;
+    const int nprod = gridDim.x - 2;              // then the auditor (nprod) and the solver (nprod + 1)
+    const int solver_block = nprod + 1;
     const bool force = (flags & FL_ITER_FORCE) != 0;
     const bool begin = begin_residual >= 0.f;
     if (D->status & FL_NUM_TIMEOUT) {             // an earlier pass of the chain was abandoned: nothing runs until the host has resumed
@@ -523,6 +584,29 @@ __global__ __launch_bounds__(FL_VIO_NT, 2) void vio_multipass_kernel(const uint8
     const int pass0 = begin ? 0 : D->iters_run;          // index of this launch's first pass within its pyramid level
 
     if (blockIdx.x == nprod) {
+        // auditor workgroup (see vio_audit_pass): follows the passes through the broadcast like a producer
+        if (force || !err_base || D->xchg_world > 1) return;
+        __shared__ __attribute__((aligned(16))) float s_aud[FL_EXACT_CHUNK];
+        __shared__ int s_to;
+        __shared__ double s_apose[12];
+        __shared__ int s_actrl;
+        for (int ps = 0; ps < count; ps++) {
+            const unsigned epoch = epoch0 + (unsigned)ps;
+            FL_AUDIT_STAMP(16 * ps + 0, wall_clock64());
+            if (ps > 0) {
+                bcast_wait(bcast, epoch, s_apose, &s_actrl, FL_GATHER_SPIN_LIMIT);
+                __syncthreads();
+                if (s_actrl & 7) break;
+            }
+            FL_AUDIT_STAMP(16 * ps + 1, wall_clock64());
+            vio_audit_pass(err_base, err_cap, (pass0 + ps) & 1, m, epoch, s_aud, &s_to);
+            __syncthreads();
+            FL_AUDIT_STAMP(16 * ps + 2, wall_clock64());
+            FL_AUDIT_STAMP(16 * ps + 3, s_to);
+        }
+        return;
+    }
+    if (blockIdx.x == solver_block) {
         __shared__ double s_fin[2 * NT];
         __shared__ double s_sums[FL_SUMS18];
         __shared__ FlSolveLds s_solve;
@@ -552,14 +636,18 @@ __global__ __launch_bounds__(FL_VIO_NT, 2) void vio_multipass_kernel(const uint8
             if (p == 5) fl_stamp(flags, 16);
             int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
             if (PV.world > 1) gst |= peer_allreduce32(PV, xe0 + (unsigned)p, s_sums, s_xchg);      // sharded form: totals over the ranks
+            FL_AUDIT_STAMP(16 * p + 8, wall_clock64());
             if (p == 5) fl_stamp(flags, 17);
             FlVioExact ex;
             ex.words = err_base; ex.m = m; ex.cap = err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !force;
             ex.own = PV.own; ex.peer = PV.peer; ex.rank = PV.rank; ex.world = PV.world; ex.xe = xe0 + (unsigned)p;
+            ex.audit = (PV.world > 1 || !err_base) ? nullptr : err_base + 2 * (size_t)err_cap;
             // wave 0 solves, derives the camera pose of the new state and publishes it (+ the control word) for the producers
             eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, gst, bcast, epoch + 1u, ex, VC, (p == 5) ? (flags & FL_ITER_STAMP) : 0);
             if (p == 5) fl_stamp(flags, 35);
             __syncthreads();
+            FL_AUDIT_STAMP(16 * p + 9, wall_clock64());
+            FL_AUDIT_STAMP(16 * p + 10, s_solve.fragile + 2 * s_solve.audited + 4 * s_solve.exact_timeout);
             if (p == 5) fl_stamp(flags, 18);
             done = p + 1;
             const int ctrl = s_solve.ctrl;

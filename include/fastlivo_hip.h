@@ -137,6 +137,10 @@ int32_t fl_get_last_kernel_ms(fl_handle h, float *ms);
  * workgroups of a multi-pass kernel the device can hold, compute units}. */
 int32_t fl_debug_hog(fl_handle h, int32_t blocks, int32_t lds_bytes, int32_t usec);
 int32_t fl_debug_counters(fl_handle h, int32_t *out4);
+/* Debug / test aid for the exact VIO accept test: init + e[0] + ... + e[n-1] (host array) as ONE chain of float additions, as the
+ * reference's `error += patch_error` (lidar_selection.cpp:857) rounds it: out2[0] by the lane-parallel form the kernels use
+ * (csrc/exact_chain.h), out2[1] by one lane adding one by one. They must be the same bits. */
+int32_t fl_debug_chain(fl_handle h, const float *e, int32_t n, float init, float *out2);
 /* Debug: shader-clock phase stamps of the last pass launched with flag FL_ITER_STAMP (64 slots). */
 #define FL_ITER_STAMP 4
 int32_t fl_debug_get_stamps(fl_handle h, long long *out64);

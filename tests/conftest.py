@@ -40,7 +40,7 @@ def emul_lib():
     so = os.path.join(d, "libemul.so")
     src = os.path.join(d, "emul.cpp")
     hdr = os.path.join(ROOT, "fast-livo_amd", "csrc", "fl_math.h")
-    hdrs = [hdr, os.path.join(ROOT, "fast-livo_amd", "csrc", "fl_ikfom_math.h")]
+    hdrs = [hdr, os.path.join(ROOT, "fast-livo_amd", "csrc", "fl_ikfom_math.h"), os.path.join(ROOT, "fast-livo_amd", "csrc", "exact_chain.h")]
     hdrs = [h for h in hdrs if os.path.exists(h)]
     if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src, "-lm"])

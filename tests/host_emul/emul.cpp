@@ -123,3 +123,59 @@ int emul_ikfom_iterate(double *x, const double *xprop, const double *Pprop, doub
 void emul_x23_boxplus(double *x, const double *dx) { fl_x23_boxplus(x, dx); }
 void emul_x23_boxminus(const double *x, const double *o, double *dx) { fl_x23_boxminus(x, o, dx); }
 }
+
+// ---- exact_chain.h: the wave-parallel float running sum, its 64 lanes run one after the other per phase
+#include "../../fast-livo_amd/csrc/exact_chain.h"
+extern "C" {
+float emul_chain_f32(const float *scr, int cnt, float init, int *steps_out)
+{
+    float s = init;
+    int k = 0, steps = 0;
+    const int lead = cnt < FL_CHAIN_LEAD ? cnt : FL_CHAIN_LEAD;
+    for (; k < lead; k++) s = s + scr[k];
+    while (k < cnt) {
+        if (fl_chain_plain_only(s)) break;
+        const int E = fl_chain_binade(s);
+        const double scale = fl_chain_scale(E);
+        const int S = (int)((double)s * scale);
+        FlChainLane L[64];
+        unsigned long long Cm = 0, Xm = 0, xm = 0;
+        int bad = 0;
+        for (int l = 0; l < 64; l++) {
+            fl_chain_phase1(L[l], scr, cnt, k + FL_CHAIN_EPL * l, scale);
+            bad |= L[l].bad;
+            Cm |= (unsigned long long)(L[l].isc & 1) << l;
+            Xm |= (unsigned long long)(L[l].xr & 1) << l;
+        }
+        if (bad) break;
+        steps++;
+        int inc[64], run = 0;
+        for (int l = 0; l < 64; l++) {
+            fl_chain_phase2(L[l], fl_chain_parity_in(Cm, Xm, l, S));
+            run += L[l].Qc;
+            inc[l] = run;
+        }
+        for (int l = 0; l < 64; l++) {
+            fl_chain_phase3(L[l], l, S + inc[l] - L[l].Qc);
+            if (L[l].cidx >= 0) xm |= 1ull << l;
+        }
+        if (xm) {
+            const int Lc = __builtin_ctzll(xm);
+            s = fl_chain_from_units(L[Lc].sprev, E) + L[Lc].ec;
+            k += L[Lc].cidx + 1;
+        } else {
+            s = fl_chain_from_units(S + inc[63], E);
+            k += 64 * FL_CHAIN_EPL;
+        }
+    }
+    for (; k < cnt; k++) s = s + scr[k];
+    if (steps_out) *steps_out = steps;
+    return s;
+}
+float emul_chain_f32_plain(const float *scr, int cnt, float init)
+{
+    volatile float s = init;
+    for (int k = 0; k < cnt; k++) s = s + scr[k];
+    return s;
+}
+}
