@@ -8,13 +8,15 @@
 //   fl(s + e) = (S + q) u with q = e/u rounded to the nearest integer -- INDEPENDENT of S, except on an exact tie (frac(e/u) = 1/2),
 //   where round-half-even makes the RESULT even: q = floor(e/u) + (parity(S) ^ parity(floor)), and the parity after a tie is 0
 //   whatever it was before. So the integer increments of a block of elements are a function of one bit of state that composes
-//   associatively (x -> x ^ c, or x -> 0): 256 elements per step (4 per lane) need two ballots for the parities and one integer
-//   prefix sum for the S values. The first element whose exact sum reaches 2^24 u leaves the binade: the adder itself does that one
-//   addition (its rounding unit is 2u or more and does depend on S), and the next step starts from the new binade.
+//   associatively (x -> x ^ c, or x -> 0): 256 elements per step (4 per lane) need, when the block holds a tie at all, two ballots
+//   for the parities, and one integer prefix sum for the S values. The first element whose exact sum reaches 2^24 u leaves the
+//   binade: the adder itself does that one addition (its rounding unit is 2u or more and does depend on S), and the next step
+//   starts from the new binade.
 //
 // ~8 steps for 2 k patches plus one per binade the sum climbs through (the first 16 additions, which climb fastest, are done
-// plainly): ~3 us instead of ~20. Elements are >= 0 by construction (sums of squares); a negative/NaN element or a non-finite
-// running sum falls back to the plain chain for the rest.
+// plainly). A step is ~70 fp32/integer instructions when nothing special happens in it (no tie, no crossing). Elements are >= 0 by
+// construction (sums of squares); a negative/NaN element (`bad`, found while staging) or a non-finite running sum falls back to the
+// plain chain.
 //
 // The per-lane phases are plain functions (FL_HD): tests/host_emul runs them lane by lane on the CPU against the plain loop
 // (tests/test_exact_chain_cpu.py); fl_debug_chain runs the device driver against the plain loop on the GPU.
@@ -22,93 +24,113 @@
 #include "fl_math.h"
 
 #define FL_CHAIN_EPL 4                       /* elements per lane and step */
+#define FL_CHAIN_STEP (64 * FL_CHAIN_EPL)    /* elements per step; the array is zero-padded by this much behind its end */
 #define FL_CHAIN_LEAD 16                     /* leading elements added plainly */
 #define FL_CHAIN_LIMIT (1 << 24)             /* S of the next binade, in units u */
 
 struct FlChainLane {
     float e[FL_CHAIN_EPL];
-    int q[FL_CHAIN_EPL];                     // integer increment (floor for a tie until phase 2 decides)
+    int q[FL_CHAIN_EPL];                     // integer increment (floor for a tie until fl_chain_ties decides)
     int tie;                                 // bit i: element i is an exact tie
-    int isc, xr;                             // the lane's parity map: out = isc ? xr : in ^ xr
-    int bad;                                 // a negative or NaN element
-    int Q, Qc;                               // sum of the increments, capped at 2^24 (a lane that large has left the binade anyway)
+    int Qc;                                  // sum of the increments, capped at 2^24 (a lane that large has left the binade anyway)
     int cidx, sprev;                         // first element (index within the step) whose sum reaches 2^24, S before it
     float ec;
 };
 
-// binade of a finite s >= 0: E = max(exponent, -126) (subnormals share u = 2^-149 with the first normal binade)
-FL_HD int fl_chain_binade(float s)
-{
-    union { float f; unsigned u; } b; b.f = s;
-    const int ex = (int)((b.u >> 23) & 0xffu) - 127;
-    return ex < -126 ? -126 : ex;
-}
+FL_HD unsigned fl_chain_bits(float s) { union { float f; unsigned u; } b; b.f = s; return b.u; }
 FL_HD bool fl_chain_plain_only(float s)      // inf / NaN / negative running sum
 {
-    union { float f; unsigned u; } b; b.f = s;
-    return ((b.u >> 23) & 0xffu) == 255u || (b.u >> 31) != 0u;
+    const unsigned b = fl_chain_bits(s);
+    return ((b >> 23) & 0xffu) == 255u || (b >> 31) != 0u;
 }
-FL_HD double fl_chain_scale(int E)           // 2^(23 - E) = 1 / u
+// finite s >= 0 as S u with u = 2^(Eb - 150): Eb = max(biased exponent, 1) (subnormals share u = 2^-149 with the first normal binade)
+FL_HD void fl_chain_split(float s, int *S, int *Eb)
 {
-    union { double d; unsigned long long u; } b;
-    b.u = (unsigned long long)(1023 + 23 - E) << 52;
-    return b.d;
+    const unsigned b = fl_chain_bits(s);
+    const unsigned eb = b >> 23;
+    *S = (int)(eb ? ((b & 0x7fffffu) | 0x800000u) : b);
+    *Eb = (int)(eb ? eb : 1u);
 }
-FL_HD float fl_chain_from_units(int S, int E) { return ldexpf((float)S, E - 23); }     // S < 2^24: exact
+FL_HD float fl_chain_from_units(int S, int Eb) { return ldexpf((float)S, Eb - 150); }     // S <= 2^24: exact
 
-// phase 1: this lane's elements as increments + the lane's parity map
-FL_HD void fl_chain_phase1(FlChainLane &L, const float *scr, int cnt, int first, double scale)
+FL_HD float fl_chain_fract(float x)          // x >= 0, exact
 {
-    L.tie = 0; L.isc = 0; L.xr = 0; L.bad = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fractf(x);
+#else
+    return x - floorf(x);
+#endif
+}
+
+// phase 1: this lane's elements as increments in units u = 2^(Eb - 150). Everything is exact in fp32: a power-of-two scaling, a
+// fraction of a number below 2^24. Returns the tie mask.
+FL_HD int fl_chain_phase1(FlChainLane &L, const float *scr, int first, int Eb)
+{
+    L.tie = 0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int i = 0; i < FL_CHAIN_EPL; i++) {
-        const int idx = first + i;
-        const float e = idx < cnt ? scr[idx] : 0.0f;
+        const float e = scr[first + i];                  // (zero-padded behind the end)
         L.e[i] = e;
-        if (!(e >= 0.0f)) L.bad = 1;
-        double x = (double)e * scale;                    // exact: a power of two
-        x = x < 16777216.0 ? x : 16777216.0;             // (also inf; NaN is `bad`)
-        const double f = floor(x), fr = x - f;           // exact
-        const int t = (fr == 0.5) ? 1 : 0;
-        L.q[i] = (int)f + ((fr > 0.5) ? 1 : 0);
-        L.tie |= t << i;
-        if (t) { L.isc = 1; L.xr = 0; } else L.xr ^= L.q[i] & 1;
+        float x = ldexpf(e, 150 - Eb);                   // e / u (inf when far outside: clamped; an underflow is far below 1/2)
+        x = x < 16777216.0f ? x : 16777216.0f;
+        const float fr = fl_chain_fract(x);
+        L.q[i] = (int)(x - fr) + ((fr > 0.5f) ? 1 : 0);
+        L.tie |= ((fr == 0.5f) ? 1 : 0) << i;
     }
+    return L.tie;
+}
+FL_HD void fl_chain_sum(FlChainLane &L)
+{
+    int Q = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < FL_CHAIN_EPL; i++) Q += L.q[i];
+    L.Qc = Q < FL_CHAIN_LIMIT ? Q : FL_CHAIN_LIMIT;
 }
 
+// ---- only when the step holds a tie
+// the lane's parity map: out = isc ? xr : in ^ xr
+FL_HD void fl_chain_parity_map(const FlChainLane &L, int *isc, int *xr)
+{
+    int c = 0, x = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < FL_CHAIN_EPL; i++) {
+        if ((L.tie >> i) & 1) { c = 1; x = 0; } else x ^= L.q[i] & 1;
+    }
+    *isc = c; *xr = x;
+}
 // parity of S before this lane's first element, from the ballots of (isc, xr) over the lanes and the parity of the step's S
 FL_HD int fl_chain_parity_in(unsigned long long Cm, unsigned long long Xm, int lane, int S)
 {
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const unsigned long long cb = Cm & below;
     if (cb) {
-        int t = 63;
-        while (!((cb >> t) & 1ull)) t--;                 // (device: 63 - clz)
+        const int t = 63 - __builtin_clzll(cb);
         return (int)(__builtin_popcountll(Xm & below & ~((1ull << t) - 1ull)) & 1);       // lane t's bit is its constant
     }
     return (int)(((unsigned)S + (unsigned)__builtin_popcountll(Xm & below)) & 1u);
 }
-
-// phase 2: ties decided, the lane's total increment
-FL_HD void fl_chain_phase2(FlChainLane &L, int parity_in)
+// ties decided: round half to even, i.e. the sum becomes even
+FL_HD void fl_chain_ties(FlChainLane &L, int parity_in)
 {
-    int p = parity_in, Q = 0;
+    int p = parity_in;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int i = 0; i < FL_CHAIN_EPL; i++) {
-        if ((L.tie >> i) & 1) { L.q[i] += (p ^ L.q[i]) & 1; p = 0; }      // round half to even: the sum becomes even
+        if ((L.tie >> i) & 1) { L.q[i] += (p ^ L.q[i]) & 1; p = 0; }
         else p ^= L.q[i] & 1;
-        Q += L.q[i];
     }
-    L.Q = Q;
-    L.Qc = Q < FL_CHAIN_LIMIT ? Q : FL_CHAIN_LIMIT;
 }
 
-// phase 3: first element of the lane whose sum reaches the next binade; s_before = S before the lane's first element
-FL_HD void fl_chain_phase3(FlChainLane &L, int lane, int s_before)
+// ---- only when the step leaves the binade: first element of the lane whose sum reaches 2^24; s_before = S before the lane's
+// first element
+FL_HD void fl_chain_crossing(FlChainLane &L, int lane, int s_before)
 {
     int t = s_before;
     L.cidx = -1; L.sprev = 0; L.ec = 0.0f;
@@ -137,50 +159,51 @@ __device__ __forceinline__ int fl_wave_prefix_i32(int v, int lane)
 }
 
 // init + scr[0] + scr[1] + ... + scr[cnt-1] as ONE chain of float additions, computed by the 64 lanes of the calling wavefront
-// (arguments uniform over the wavefront, scr in LDS). The result is in every lane.
-__device__ __forceinline__ float fl_chain_f32_wave(const float *scr, int cnt, float init)
+// (arguments uniform over the wavefront; scr in LDS with scr[cnt .. cnt + FL_CHAIN_STEP) == 0; bad: an element is negative or NaN).
+// The result is in every lane.
+__device__ __forceinline__ float fl_chain_f32_wave(const float *scr, int cnt, float init, bool bad)
 {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x & 63;
     float s = init;
     int k = 0;
-    const int lead = cnt < FL_CHAIN_LEAD ? cnt : FL_CHAIN_LEAD;
+    const int lead = bad ? cnt : (cnt < FL_CHAIN_LEAD ? cnt : FL_CHAIN_LEAD);
     for (; k < lead; k++) s = s + scr[k];
     while (k < cnt) {
         if (fl_chain_plain_only(s)) break;
-        const int E = fl_chain_binade(s);
-        const double scale = fl_chain_scale(E);
-        const int S = (int)((double)s * scale);
-        FlChainLane L;
-        fl_chain_phase1(L, scr, cnt, k + FL_CHAIN_EPL * lane, scale);
-        if (__ballot(L.bad) != 0ull) break;
-        const unsigned long long Cm = __ballot(L.isc), Xm = __ballot(L.xr & 1);
-        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        const unsigned long long cb = Cm & below;
-        int pin;
-        if (cb) {
-            const int t = 63 - __clzll((long long)cb);
-            pin = __popcll(Xm & below & ~((1ull << t) - 1ull)) & 1;
-        } else {
-            pin = (S + __popcll(Xm & below)) & 1;
-        }
-        fl_chain_phase2(L, pin);
-        const int inc = fl_wave_prefix_i32(L.Qc, lane);
-        fl_chain_phase3(L, lane, S + inc - L.Qc);
-        const unsigned long long xm = __ballot(L.cidx >= 0);
-        if (xm) {                                        // lowest lane = earliest element
-            const int Lc = __builtin_amdgcn_readfirstlane(__ffsll((long long)xm) - 1);
-            const int c = __builtin_amdgcn_readlane(L.cidx, Lc);
-            const int sp = __builtin_amdgcn_readlane(L.sprev, Lc);
-            const float ec = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(L.ec), Lc));
-            s = fl_chain_from_units(sp, E) + ec;         // the addition that leaves the binade: the adder rounds it
-            k += c + 1;
-        } else {
-            s = fl_chain_from_units(S + __builtin_amdgcn_readlane(inc, 63), E);
-            k += 64 * FL_CHAIN_EPL;
-        }
+        int S, Eb;
+        fl_chain_split(s, &S, &Eb);
+        bool crossed = false;
+        do {                                             // steps inside the binade: S stays an integer, no conversions
+            FlChainLane L;
+            const int tie = fl_chain_phase1(L, scr, k + FL_CHAIN_EPL * lane, Eb);
+            if (__ballot(tie != 0) != 0ull) {
+                int isc, xr;
+                fl_chain_parity_map(L, &isc, &xr);
+                const unsigned long long Cm = __ballot(isc), Xm = __ballot(xr & 1);
+                fl_chain_ties(L, fl_chain_parity_in(Cm, Xm, lane, S));
+            }
+            fl_chain_sum(L);
+            const int inc = fl_wave_prefix_i32(L.Qc, lane);
+            const int total = __builtin_amdgcn_readlane(inc, 63);
+            if (S + total < FL_CHAIN_LIMIT) {
+                S += total;
+                k += FL_CHAIN_STEP;
+            } else {
+                fl_chain_crossing(L, lane, S + inc - L.Qc);
+                const unsigned long long xm = __ballot(L.cidx >= 0);
+                const int Lc = __builtin_amdgcn_readfirstlane(__ffsll((long long)xm) - 1);       // lowest lane = earliest element
+                const int c = __builtin_amdgcn_readlane(L.cidx, Lc);
+                const int sp = __builtin_amdgcn_readlane(L.sprev, Lc);
+                const float ec = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(L.ec), Lc));
+                s = fl_chain_from_units(sp, Eb) + ec;    // the addition that leaves the binade: the adder rounds it
+                k += c + 1;
+                crossed = true;
+            }
+        } while (!crossed && k < cnt);
+        if (!crossed) s = fl_chain_from_units(S, Eb);
     }
-    for (; k < cnt; k++) s = s + scr[k];                 // (only after a `break` above)
+    for (; k < cnt; k++) s = s + scr[k];                 // (only after the `break` above)
     return s;
 }
 #endif

@@ -59,7 +59,7 @@ struct FlVioExact {
     const unsigned long long *words;   // [2][cap]
     int m, cap;
     unsigned epoch;                    // of the current pass = tag of its words
-    float *scratch;                    // LDS, FL_EXACT_CHUNK floats
+    float *scratch;                    // LDS, FL_EXACT_LDS floats
     int enabled;                       // 0: forced passes (FL_ITER_FORCE, benchmark/diagnostic mode) keep the fast test only
     // sharded form (in-kernel peer exchange): the reference's running sum `error += patch_error` runs over ALL patches in order, i.e.
     // through the ranks' contiguous patch ranges one after the other: rank r starts from the float rank r-1 ended with, the last rank
@@ -68,12 +68,16 @@ struct FlVioExact {
     unsigned long long *const *peer;   // everybody's buffers
     int rank, world;
     unsigned xe;                       // exchange epoch of this pass = tag of the mail
-    // single rank: the auditor workgroup's ring of per-pass totals (vio_kernels.h vio_audit_pass), slot = epoch & 15; nullptr otherwise
-    const unsigned long long *audit;
 };
+// single rank: the auditor workgroup's ring of per-pass totals sits behind the words (vio_kernels.h vio_audit_pass), slot = epoch & 15
 // total of pass `tag` out of the auditor's ring (thread 0); false when it does not arrive within `spins` polls or the auditor gave
 // up on that pass (payload FL_AUDIT_NONE)
 #define FL_AUDIT_NONE 0xffffffffu
+#ifdef FL_AUDIT_STAMPS                      /* debug build (tools/vio_audit_stamps.py): entry / staged / added, per pass tag */
+#define FL_CHAIN_STAMP(tag, j) do { if (threadIdx.x == 0) g_fl_wall[1024 + 4 * ((tag) & 63u) + (j)] = (long long)wall_clock64(); } while (0)
+#else
+#define FL_CHAIN_STAMP(tag, j) do { } while (0)
+#endif
 __device__ __forceinline__ bool vio_audit_read(const unsigned long long *ring, unsigned tag, int spins, float *out)
 {
     unsigned long long v = 0ull;
@@ -83,19 +87,23 @@ __device__ __forceinline__ bool vio_audit_read(const unsigned long long *ring, u
     return (unsigned)v == tag && (unsigned)(v >> 32) != FL_AUDIT_NONE;
 }
 #define FL_EXACT_CHUNK 2048
+#define FL_EXACT_LDS (FL_EXACT_CHUNK + FL_CHAIN_STEP)      /* staging buffer of vio_exact_sum: a chunk + the chain's zero padding */
 // The reference's `error += patch_error` over patches 0..m-1 as one chain of float additions (no contraction), bit for bit. All
 // threads of the workgroup stage the words (polling until their tag says they belong to pass `tag`); wavefront 0 adds them up
 // binade-wise over its 64 lanes (exact_chain.h: ~3 us for 2 k patches instead of ~20 us for one lane adding one by one). Result
 // valid in thread 0. A word of a NEWER pass (the double-buffered half was reused: the caller is two passes late) or one that never
 // arrives sets *timeout_flag.
-__device__ __forceinline__ float vio_exact_sum(const unsigned long long *w, int m, unsigned tag, float *scr, int *timeout_flag, float init = 0.0f)
+__device__ __forceinline__ float vio_exact_sum(const unsigned long long *w, int m, unsigned tag, float *scr /* FL_EXACT_LDS floats */, int *timeout_flag,
+                                               float init = 0.0f)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
     float f = init;
+    FL_CHAIN_STAMP(tag, 0);
     for (int base = 0; base < m; base += FL_EXACT_CHUNK) {
         const int cnt = min(FL_EXACT_CHUNK, m - base);
         constexpr int PER = 8;                               // first loads of a thread's words all in flight at once
         unsigned long long v[PER];
+        bool bad = false;                                    // a negative / NaN element: the plain chain (exact_chain.h)
 #pragma unroll
         for (int j = 0; j < PER; j++) {
             const int k = tid + j * nt;
@@ -110,7 +118,9 @@ __device__ __forceinline__ float vio_exact_sum(const unsigned long long *w, int 
                 while ((unsigned)x != tag && (int)((unsigned)x - tag) < 0 && ++spin < 4096)
                     x = __hip_atomic_load(w + base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)x != tag) *timeout_flag = 1;
-                scr[k] = __uint_as_float((unsigned)(x >> 32));
+                const float e = __uint_as_float((unsigned)(x >> 32));
+                bad |= !(e >= 0.0f);
+                scr[k] = e;
             }
         }
         for (int k = tid + PER * nt; k < cnt; k += nt) {      // (workgroups of fewer than 256 threads)
@@ -119,10 +129,15 @@ __device__ __forceinline__ float vio_exact_sum(const unsigned long long *w, int 
             do { x = __hip_atomic_load(w + base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             while ((unsigned)x != tag && (int)((unsigned)x - tag) < 0 && ++spin < 4096);
             if ((unsigned)x != tag) *timeout_flag = 1;
-            scr[k] = __uint_as_float((unsigned)(x >> 32));
+            const float e = __uint_as_float((unsigned)(x >> 32));
+            bad |= !(e >= 0.0f);
+            scr[k] = e;
         }
-        __syncthreads();
-        if (tid < 64) f = fl_chain_f32_wave(scr, cnt, f);
+        for (int k = cnt + tid; k < cnt + FL_CHAIN_STEP; k += nt) scr[k] = 0.0f;       // the zero padding the chain's steps read into
+        const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;
+        FL_CHAIN_STAMP(tag, 1);
+        if (tid < 64) f = fl_chain_f32_wave(scr, cnt, f, any_bad);
+        FL_CHAIN_STAMP(tag, 2);
         __syncthreads();
     }
     return f;
@@ -341,6 +356,44 @@ __device__ __forceinline__ double vio_cam_element(int t, const double *xn, const
 // tolerance, never bitwise). bcast != nullptr (multi-pass kernels): wavefront 0 publishes the pose for the producers' next pass
 // (LIO: R, p; VIO: the derived Rcw, Pcw) and the control word as self-validating words tagged bepoch.
 // On return (after the CALLER's __syncthreads) L.ctrl, L.xn, L.xadd, L.cam are valid for everybody.
+// The slow path of the VIO accept test (see eskf18_solve_block): the reference's float values of this pass's error and of the last
+// accepted one into L.exact_cur / L.last_exact. Called by the whole workgroup on the rare fragile passes; NOT inlined -- its
+// registers (staging, the chain) stay out of the pass loop's allocation, where they cost spills on every pass.
+__device__ __attribute__((noinline)) void vio_exact_decide(const FlVioExact ex, FlSolveLds *Lp, float n_all /* 64 x the patches of ALL ranks */)
+{
+    FlSolveLds &L = *Lp;
+    const int tid = threadIdx.x;
+    __syncthreads();
+    const int cur_buf = L.iters_run & 1;
+    bool audited = false;
+    const unsigned long long *audit = ex.words + 2 * (size_t)ex.cap;
+    if (ex.world <= 1) {     // single rank: the auditor workgroup has been adding this pass's chain up since its words arrived
+        if (tid == 0) {
+            float fc = 0.f, fl = 0.f;
+            bool ok = vio_audit_read(audit, ex.epoch, 1 << 12, &fc);
+            if (ok && !L.last_exact_valid) {
+                ok = vio_audit_read(audit, L.acc_epoch, 64, &fl);     // (a pass long finished: there, or never audited)
+                if (ok) { L.last_exact = fl / n_all; L.last_exact_valid = 1; }
+            }
+            L.exact_cur = fc / n_all;
+            L.audited = ok ? 1 : 0;
+        }
+        __syncthreads();
+        audited = L.audited != 0;
+    }
+    if (!audited) {          // no auditor (sharded form: the chain runs through the ranks) or it gave up: the workgroup replays
+        const float fc = vio_exact_chain(ex, ex.words + (size_t)cur_buf * ex.cap, ex.epoch, 0, &L.exact_cur, &L.exact_timeout);
+        __syncthreads();
+        if (tid == 0) L.exact_cur = fc / n_all;
+        if (!L.last_exact_valid && L.acc_buf != cur_buf) {   // (same half: only when forced passes ran on after a rejection)
+            const float fl = vio_exact_chain(ex, ex.words + (size_t)L.acc_buf * ex.cap, L.acc_epoch, 2, &L.last_exact, &L.exact_timeout);
+            __syncthreads();
+            if (tid == 0) { L.last_exact = fl / n_all; L.last_exact_valid = 1; }
+        }
+    }
+    __syncthreads();
+}
+
 template <int KIND>
 __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, const double *s_sums, FlSolveLds &L, const FlSolveRegs &G,
                                                    int gather_status, unsigned long long *bcast = nullptr, unsigned bepoch = 0u,
@@ -396,37 +449,7 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
         need_exact = (last < 1e9f && fabsf(error - last) <= thr * fabsf(error));
         slow = need_exact && can_replay;
         if (slow && tid == 0) L.exact_timeout = 0;
-        if (slow) {      // uniform over the workgroup
-            __syncthreads();
-            const int cur_buf = L.iters_run & 1;
-            const float n_all = (float)s_sums[FL_S_NEFF];          // 64 x the patches of ALL ranks, as the reference's n_meas
-            bool audited = false;
-            if (ex.audit) {      // single rank: the auditor workgroup has been adding this pass's chain up since its words arrived
-                if (tid == 0) {
-                    float fc = 0.f, fl = 0.f;
-                    bool ok = vio_audit_read(ex.audit, ex.epoch, 1 << 12, &fc);
-                    if (ok && !L.last_exact_valid) {
-                        ok = vio_audit_read(ex.audit, L.acc_epoch, 64, &fl);     // (a pass long finished: there, or never audited)
-                        if (ok) { L.last_exact = fl / n_all; L.last_exact_valid = 1; }
-                    }
-                    L.exact_cur = fc / n_all;
-                    L.audited = ok ? 1 : 0;
-                }
-                __syncthreads();
-                audited = L.audited != 0;
-            }
-            if (!audited) {
-            const float fc = vio_exact_chain(ex, ex.words + (size_t)cur_buf * ex.cap, ex.epoch, 0, &L.exact_cur, &L.exact_timeout);
-            __syncthreads();
-            if (tid == 0) L.exact_cur = fc / n_all;
-            if (!L.last_exact_valid && L.acc_buf != cur_buf) {   // (same half: only when forced passes ran on after a rejection)
-                const float fl = vio_exact_chain(ex, ex.words + (size_t)L.acc_buf * ex.cap, L.acc_epoch, 2, &L.last_exact, &L.exact_timeout);
-                __syncthreads();
-                if (tid == 0) { L.last_exact = fl / n_all; L.last_exact_valid = 1; }
-            }
-            }
-            __syncthreads();
-        }
+        if (slow) vio_exact_decide(ex, &L, (float)s_sums[FL_S_NEFF]);      // uniform over the workgroup
     }
     if (wave != 0) return;
 

@@ -204,6 +204,13 @@ __global__ __launch_bounds__(128) void vio_prepare_kernel(FlDev18 *__restrict__ 
 #else
 #define FL_AUDIT_STAMP(i, v) do { } while (0)
 #endif
+#ifdef FL_AB_AUDITOR_FIRST
+#define FL_VIO_SOLVER_BLOCK(nprod) ((nprod) + 1)
+#define FL_VIO_AUDITOR_BLOCK(nprod) (nprod)
+#else
+#define FL_VIO_SOLVER_BLOCK(nprod) (nprod)
+#define FL_VIO_AUDITOR_BLOCK(nprod) ((nprod) + 1)
+#endif
 #define FL_VIO_PPL (64 / FL_VIO_LPP)          /* pixels per lane */
 #define FL_VIO_GPW (64 / FL_VIO_LPP)          /* patches (lane groups) per wavefront */
 
@@ -428,16 +435,21 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
 // of the last accepted pass is always at hand (no second chain). The result goes into a 16-slot ring behind the per-patch words,
 // slot = epoch & 15, tagged with the epoch like every hand-off word. The chain itself is exact_chain.h's lane-parallel form (~3 us
 // at 2 k patches): the auditor is done before the solver asks.
-__device__ __forceinline__ void vio_audit_pass(unsigned long long *__restrict__ err_base, int err_cap, int buf, int m, unsigned epoch,
-                                               float *s_aud, int *s_to)
+// (not inlined: its registers and its staging stay out of the pass kernels' allocation)
+__device__ __attribute__((noinline)) int vio_audit_pass(unsigned long long *__restrict__ err_base, int err_cap, int buf, int m, unsigned epoch)
 {
-    if (threadIdx.x == 0) *s_to = 0;
+    __shared__ __attribute__((aligned(16))) float s_aud[FL_EXACT_LDS];
+    __shared__ int s_to;
+    if (threadIdx.x == 0) s_to = 0;
     __syncthreads();
-    const float f = vio_exact_sum(err_base + (size_t)buf * err_cap, m, epoch, s_aud, s_to);
+    const float f = vio_exact_sum(err_base + (size_t)buf * err_cap, m, epoch, s_aud, &s_to);
+    const int to = s_to;
     if (threadIdx.x == 0)         // (no total: the solver workgroup replays the pass itself, solve18.h)
         __hip_atomic_store(err_base + 2 * (size_t)err_cap + (epoch & (FL_AUDIT_RING - 1)),
-                           ((unsigned long long)(*s_to ? FL_AUDIT_NONE : __float_as_uint(f)) << 32) | (unsigned long long)epoch, __ATOMIC_RELAXED,
+                           ((unsigned long long)(to ? FL_AUDIT_NONE : __float_as_uint(f)) << 32) | (unsigned long long)epoch, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return to;
 }
 
 template <int MODE>
@@ -450,8 +462,8 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
 {
     constexpr int NT = FL_VIO_NT;
     constexpr int WPB = NT / 64;
-    const int nprod = gridDim.x - 2;              // then the auditor (nprod) and the solver (nprod + 1)
-    const int solver_block = nprod + 1;
+    const int nprod = gridDim.x - 2;              // then the solver and the auditor (FL_VIO_SOLVER_BLOCK / FL_VIO_AUDITOR_BLOCK)
+    const int solver_block = FL_VIO_SOLVER_BLOCK(nprod), auditor_block = FL_VIO_AUDITOR_BLOCK(nprod);
     if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();
     const FlVioFirst pf = vio_prefetch_first(ref, pos, slevel, m, level_arg, nprod);
     double pf_solver = 0.0;
@@ -463,13 +475,11 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     if (!(flags & FL_ITER_FORCE) && D->stop) return;
     const unsigned epoch = *epoch_ptr;
 
-    if (blockIdx.x == nprod) {
+    if (blockIdx.x == auditor_block) {
         // ------------------------------------------------------------------ auditor workgroup (single-rank fused passes only: the
         // sharded form chains the sum through the ranks, solve18.h vio_exact_chain)
         if (MODE != 0 || (flags & FL_ITER_FORCE) || !D->err_words || D->xchg_world > 1) return;
-        __shared__ __attribute__((aligned(16))) float s_aud[FL_EXACT_CHUNK];
-        __shared__ int s_to;
-        vio_audit_pass(D->err_words, D->err_cap, D->iters_run & 1, m, epoch, s_aud, &s_to);
+        vio_audit_pass(D->err_words, D->err_cap, D->iters_run & 1, m, epoch);
         return;
     }
     if (blockIdx.x == solver_block) {
@@ -495,12 +505,11 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
             if (threadIdx.x == 0) *D->xchg_epoch = xe + 1u;
         }
         if (MODE == 0) {
-            __shared__ __attribute__((aligned(16))) float s_ex[FL_EXACT_CHUNK];
+            __shared__ __attribute__((aligned(16))) float s_ex[FL_EXACT_LDS];
             FlVioExact ex;
             ex.words = D->err_words; ex.m = m; ex.cap = D->err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !(flags & FL_ITER_FORCE);
             ex.own = (world > 1) ? D->xchg_peer[D->xchg_rank] : nullptr; ex.peer = D->xchg_peer; ex.rank = D->xchg_rank; ex.world = world;
             ex.xe = xe_pass;
-            ex.audit = (world > 1 || !D->err_words) ? nullptr : D->err_words + 2 * (size_t)D->err_cap;
             eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, gst, nullptr, 0u, ex, VC);   // incl. the camera pose for the next pass's producers
         } else {
             if (threadIdx.x < FL_SUMS18) sums_out[threadIdx.x] = s_sums[threadIdx.x];
@@ -530,13 +539,15 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
 __global__ __launch_bounds__(256) void fl_chain_debug_kernel(const float *__restrict__ e, int n, float init, float *__restrict__ out2)
 {
 #pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) float scr[FL_EXACT_CHUNK];
+    __shared__ __attribute__((aligned(16))) float scr[FL_EXACT_LDS];
     float f = init, g = init;
     for (int base = 0; base < n; base += FL_EXACT_CHUNK) {
         const int cnt = min(FL_EXACT_CHUNK, n - base);
-        for (int k = threadIdx.x; k < cnt; k += blockDim.x) scr[k] = e[base + k];
-        __syncthreads();
-        if (threadIdx.x < 64) f = fl_chain_f32_wave(scr, cnt, f);
+        bool bad = false;
+        for (int k = threadIdx.x; k < cnt; k += blockDim.x) { const float v = e[base + k]; scr[k] = v; bad |= !(v >= 0.0f); }
+        for (int k = cnt + threadIdx.x; k < cnt + FL_CHAIN_STEP; k += blockDim.x) scr[k] = 0.0f;
+        const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;
+        if (threadIdx.x < 64) f = fl_chain_f32_wave(scr, cnt, f, any_bad);
         if (threadIdx.x == 64)
             for (int k = 0; k < cnt; k++) g = g + scr[k];
         __syncthreads();
@@ -568,26 +579,25 @@ __global__ __launch_bounds__(FL_VIO_NT, 2) void vio_multipass_kernel(const uint8
     // needs one launch per level instead of three.
     constexpr int NT = FL_VIO_NT;
     constexpr int WPB = NT / 64;
-    const int nprod = gridDim.x - 2;              // then the auditor (nprod) and the solver (nprod + 1)
-    const int solver_block = nprod + 1;
+    const int nprod = gridDim.x - 2;              // then the solver and the auditor (FL_VIO_SOLVER_BLOCK / FL_VIO_AUDITOR_BLOCK)
+    const int solver_block = FL_VIO_SOLVER_BLOCK(nprod), auditor_block = FL_VIO_AUDITOR_BLOCK(nprod);
     const bool force = (flags & FL_ITER_FORCE) != 0;
     const bool begin = begin_residual >= 0.f;
     if (D->status & FL_NUM_TIMEOUT) {             // an earlier pass of the chain was abandoned: nothing runs until the host has resumed
         if (blockIdx.x == 0 && threadIdx.x == 0) D->resume_count += count;
-        fl_mp_done(done_word, done_seq, blockIdx.x == gridDim.x - 1);
+        fl_mp_done(done_word, done_seq, blockIdx.x == solver_block);
         return;
     }
-    if (!force && !begin && D->stop) { fl_mp_done(done_word, done_seq, blockIdx.x == gridDim.x - 1); return; }
+    if (!force && !begin && D->stop) { fl_mp_done(done_word, done_seq, blockIdx.x == solver_block); return; }
     const unsigned epoch0 = *epoch_ptr;
     unsigned long long *err_base = D->err_words;
     const int err_cap = D->err_cap;
     const int pass0 = begin ? 0 : D->iters_run;          // index of this launch's first pass within its pyramid level
 
-    if (blockIdx.x == nprod) {
+    if (blockIdx.x == auditor_block) {
         // auditor workgroup (see vio_audit_pass): follows the passes through the broadcast like a producer
         if (force || !err_base || D->xchg_world > 1) return;
-        __shared__ __attribute__((aligned(16))) float s_aud[FL_EXACT_CHUNK];
-        __shared__ int s_to;
+#ifndef FL_AB_NO_AUDITOR
         __shared__ double s_apose[12];
         __shared__ int s_actrl;
         for (int ps = 0; ps < count; ps++) {
@@ -599,18 +609,18 @@ __global__ __launch_bounds__(FL_VIO_NT, 2) void vio_multipass_kernel(const uint8
                 if (s_actrl & 7) break;
             }
             FL_AUDIT_STAMP(16 * ps + 1, wall_clock64());
-            vio_audit_pass(err_base, err_cap, (pass0 + ps) & 1, m, epoch, s_aud, &s_to);
-            __syncthreads();
+            const int to = vio_audit_pass(err_base, err_cap, (pass0 + ps) & 1, m, epoch);
             FL_AUDIT_STAMP(16 * ps + 2, wall_clock64());
-            FL_AUDIT_STAMP(16 * ps + 3, s_to);
+            FL_AUDIT_STAMP(16 * ps + 3, to);
         }
+#endif
         return;
     }
     if (blockIdx.x == solver_block) {
         __shared__ double s_fin[2 * NT];
         __shared__ double s_sums[FL_SUMS18];
         __shared__ FlSolveLds s_solve;
-        __shared__ __attribute__((aligned(16))) float s_ex[FL_EXACT_CHUNK];
+        __shared__ __attribute__((aligned(16))) float s_ex[FL_EXACT_LDS];
         eskf18_prefetch(D, s_solve);
         if (begin) {
             __syncthreads();
@@ -641,7 +651,6 @@ __global__ __launch_bounds__(FL_VIO_NT, 2) void vio_multipass_kernel(const uint8
             FlVioExact ex;
             ex.words = err_base; ex.m = m; ex.cap = err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !force;
             ex.own = PV.own; ex.peer = PV.peer; ex.rank = PV.rank; ex.world = PV.world; ex.xe = xe0 + (unsigned)p;
-            ex.audit = (PV.world > 1 || !err_base) ? nullptr : err_base + 2 * (size_t)err_cap;
             // wave 0 solves, derives the camera pose of the new state and publishes it (+ the control word) for the producers
             eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, gst, bcast, epoch + 1u, ex, VC, (p == 5) ? (flags & FL_ITER_STAMP) : 0);
             if (p == 5) fl_stamp(flags, 35);

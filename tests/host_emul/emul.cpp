@@ -4,6 +4,7 @@
 // object is never linked into libfastlivo_hip.so and is not a fallback path.
 #include "../../fast-livo_amd/csrc/fl_math.h"
 #include <string.h>
+#include <stdlib.h>
 
 extern "C" {
 
@@ -127,48 +128,55 @@ void emul_x23_boxminus(const double *x, const double *o, double *dx) { fl_x23_bo
 // ---- exact_chain.h: the wave-parallel float running sum, its 64 lanes run one after the other per phase
 #include "../../fast-livo_amd/csrc/exact_chain.h"
 extern "C" {
-float emul_chain_f32(const float *scr, int cnt, float init, int *steps_out)
+float emul_chain_f32(const float *in, int cnt, float init, int *steps_out)
 {
+    float *scr = (float *)calloc((size_t)cnt + FL_CHAIN_STEP, sizeof(float));     // zero-padded like the LDS staging buffer
+    bool bad = false;
+    for (int i = 0; i < cnt; i++) { scr[i] = in[i]; if (!(in[i] >= 0.0f)) bad = true; }
     float s = init;
     int k = 0, steps = 0;
-    const int lead = cnt < FL_CHAIN_LEAD ? cnt : FL_CHAIN_LEAD;
+    const int lead = bad ? cnt : (cnt < FL_CHAIN_LEAD ? cnt : FL_CHAIN_LEAD);
     for (; k < lead; k++) s = s + scr[k];
     while (k < cnt) {
         if (fl_chain_plain_only(s)) break;
-        const int E = fl_chain_binade(s);
-        const double scale = fl_chain_scale(E);
-        const int S = (int)((double)s * scale);
-        FlChainLane L[64];
-        unsigned long long Cm = 0, Xm = 0, xm = 0;
-        int bad = 0;
-        for (int l = 0; l < 64; l++) {
-            fl_chain_phase1(L[l], scr, cnt, k + FL_CHAIN_EPL * l, scale);
-            bad |= L[l].bad;
-            Cm |= (unsigned long long)(L[l].isc & 1) << l;
-            Xm |= (unsigned long long)(L[l].xr & 1) << l;
-        }
-        if (bad) break;
-        steps++;
-        int inc[64], run = 0;
-        for (int l = 0; l < 64; l++) {
-            fl_chain_phase2(L[l], fl_chain_parity_in(Cm, Xm, l, S));
-            run += L[l].Qc;
-            inc[l] = run;
-        }
-        for (int l = 0; l < 64; l++) {
-            fl_chain_phase3(L[l], l, S + inc[l] - L[l].Qc);
-            if (L[l].cidx >= 0) xm |= 1ull << l;
-        }
-        if (xm) {
-            const int Lc = __builtin_ctzll(xm);
-            s = fl_chain_from_units(L[Lc].sprev, E) + L[Lc].ec;
-            k += L[Lc].cidx + 1;
-        } else {
-            s = fl_chain_from_units(S + inc[63], E);
-            k += 64 * FL_CHAIN_EPL;
-        }
+        int S, Eb;
+        fl_chain_split(s, &S, &Eb);
+        bool crossed = false;
+        do {
+            FlChainLane L[64];
+            int any_tie = 0;
+            for (int l = 0; l < 64; l++) any_tie |= fl_chain_phase1(L[l], scr, k + FL_CHAIN_EPL * l, Eb);
+            if (any_tie) {
+                unsigned long long Cm = 0, Xm = 0;
+                for (int l = 0; l < 64; l++) {
+                    int isc, xr;
+                    fl_chain_parity_map(L[l], &isc, &xr);
+                    Cm |= (unsigned long long)(isc & 1) << l;
+                    Xm |= (unsigned long long)(xr & 1) << l;
+                }
+                for (int l = 0; l < 64; l++) fl_chain_ties(L[l], fl_chain_parity_in(Cm, Xm, l, S));
+            }
+            steps++;
+            int inc[64], run = 0;
+            for (int l = 0; l < 64; l++) { fl_chain_sum(L[l]); run += L[l].Qc; inc[l] = run; }
+            if (S + inc[63] < FL_CHAIN_LIMIT) {
+                S += inc[63];
+                k += FL_CHAIN_STEP;
+            } else {
+                int Lc = -1;
+                for (int l = 0; l < 64; l++) {
+                    fl_chain_crossing(L[l], l, S + inc[l] - L[l].Qc);
+                    if (Lc < 0 && L[l].cidx >= 0) Lc = l;
+                }
+                s = fl_chain_from_units(L[Lc].sprev, Eb) + L[Lc].ec;
+                k += L[Lc].cidx + 1;
+                crossed = true;
+            }
+        } while (!crossed && k < cnt);
+        if (!crossed) s = fl_chain_from_units(S, Eb);
     }
     for (; k < cnt; k++) s = s + scr[k];
+    free(scr);
     if (steps_out) *steps_out = steps;
     return s;
 }

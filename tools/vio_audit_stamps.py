@@ -22,3 +22,9 @@ for p in range(int(infos[0].iterations) if False else 6):
     us = lambda v: (v - t0) / 100.0
     print(f"pass {p}: auditor loop {us(a[0]):8.2f} bcast {us(a[1]):8.2f} chain done {us(a[2]):8.2f} to={a[3]} | solver gathered {us(a[8]):8.2f} "
           f"pass done {us(a[9]):8.2f} flags(fragile16,audited2,timeout4)={a[10]}")
+
+c = w[1024:1024 + 256].reshape(64, 4)
+rows = sorted((r for r in c if r[0] > 0), key=lambda r: r[0])[-6:]
+for r in rows:
+    print("chain: entry %8.2f staged %8.2f (+%.2f) added %8.2f (+%.2f)" % ((r[0] - t0) / 100.0, (r[1] - t0) / 100.0, (r[1] - r[0]) / 100.0,
+                                                                          (r[2] - t0) / 100.0, (r[2] - r[1]) / 100.0))
