@@ -612,6 +612,32 @@ FL_HD int fl_solve18_fast(double *x, const double *xprop, const double *Q, const
     return st;
 }
 
+// Column c of X = (Q+S)^-1 S -- what fl_gain18 does for its six columns one after the other, for the covariance kernels that give
+// each column to a thread of its own (the same factorisation six times in parallel: identical values).
+FL_HD int fl_gain18_column(const double *Q, const double *sums, int c, double *xcol /*6*/)
+{
+    double S[6][6], C[6][6];
+    fl_unpack_S(sums, S);
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) C[i][j] = Q[i * 6 + j] + S[i][j];
+    FlLdl6 f;
+    const int bad = fl_ldl6(C, f);
+    double b[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double v = S[i][0];
+#pragma unroll
+        for (int k = 1; k < 6; k++) v = (c == k) ? S[i][k] : v;      // (static indices: S stays in registers)
+        b[i] = v;
+    }
+    fl_ldl6_solve(f, b);
+#pragma unroll
+    for (int i = 0; i < 6; i++) xcol[i] = b[i];
+    return bad;
+}
+
 // G[:,0:6] = T (Q+S)^-1 S  (18x6), from the record of the last executed/accepted pass.
 FL_HD int fl_gain18(const double *Q, const double *T, const double *sums, double *G6)
 {

@@ -384,6 +384,31 @@ __global__ __launch_bounds__(FL_BLOCK) void eskf18_solve_kernel(FlDev18 *__restr
 
 // -------------------------------------------------------------------------------------------- K4
 // P <- P - G6 * P[0:6,:]  (== (I - G) P with G's columns 6..17 zero); G from the last executed pass.
+// G[:,0:6] = T (Q+S)^-1 S of the last executed/accepted pass into LDS and D->G6, by the calling workgroup (>= 108 threads, barriers
+// inside): six threads solve one column of (Q+S)^-1 S each, 108 threads form one element of G each (fl_math.h fl_gain18, in
+// parallel -- one thread doing all of it was half the kernel).
+__device__ __forceinline__ void eskf18_gain_block(FlDev18 *__restrict__ D, double *sG /*108, LDS*/)
+{
+    __shared__ double sX[36];
+    const int t = threadIdx.x;
+    if (t < 6) {
+        double xc[6];
+        fl_gain18_column(D->Q, D->sums_acc, t, xc);
+#pragma unroll
+        for (int i = 0; i < 6; i++) sX[i * 6 + t] = xc[i];
+    }
+    __syncthreads();
+    if (t < 108) {
+        const int r = t / 6, c = t % 6;
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += D->T[r * 6 + k] * sX[k * 6 + c];
+        sG[t] = s;
+        D->G6[t] = s;
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(384) void eskf18_cov_update_kernel(FlDev18 *__restrict__ D)
 {
     __shared__ double sP[324];
@@ -391,12 +416,7 @@ __global__ __launch_bounds__(384) void eskf18_cov_update_kernel(FlDev18 *__restr
     const int t = threadIdx.x;
     if (D->status & FL_NUM_TIMEOUT) return;          // abandoned frame: the host resumes it and enqueues this kernel again
     if (t < 324) sP[t] = D->P[t];
-    if (t == 0) {
-        double G6[108];
-        fl_gain18(D->Q, D->T, D->sums_acc, G6);
-        for (int i = 0; i < 108; i++) { sG[i] = G6[i]; D->G6[i] = G6[i]; }
-    }
-    __syncthreads();
+    eskf18_gain_block(D, sG);
     if (t < 324) {
         const int r = t / 18, c = t % 18;
         double s = 0.0;

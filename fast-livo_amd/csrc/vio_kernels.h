@@ -753,12 +753,7 @@ __global__ __launch_bounds__(384) void vio_cov_update_kernel(FlDev18 *__restrict
     const bool apply = D->last_error < 1e10f;
     if (D->status & FL_NUM_TIMEOUT) return;       // abandoned frame: enqueued again after the resume
     if (t < 324) sP[t] = D->P[t];
-    if (t == 0) {   // G[:,0:6] of the last ACCEPTED iteration (G is only rewritten on acceptance, :877)
-        double G6[108];
-        fl_gain18(D->Q, D->T, D->sums_acc, G6);
-        for (int i = 0; i < 108; i++) { sG[i] = G6[i]; D->G6[i] = G6[i]; }
-    }
-    __syncthreads();
+    eskf18_gain_block(D, sG);         // G[:,0:6] of the last ACCEPTED iteration (G is only rewritten on acceptance, :877)
     if (apply && t < 324) {
         const int r = t / 18, c = t % 18;
         double s = 0.0;
