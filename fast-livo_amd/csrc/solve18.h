@@ -54,6 +54,7 @@ struct FlSolveLds {
 enum { FL_EPI_LIO = 0, FL_EPI_VIO = 1 };
 
 #define FL_AUDIT_RING 16               /* slots of the auditor's ring of per-pass totals (vio_kernels.h vio_audit_pass) */
+#define FL_AUDIT_WORDS (FL_AUDIT_RING + 8) /* + word FL_AUDIT_RING: the epoch the auditor is working on (its progress) */
 // Per-patch errors of one pass for the exact VIO accept test (see eskf18_solve_block)
 struct FlVioExact {
     const unsigned long long *words;   // [2][cap]
@@ -370,7 +371,9 @@ __device__ __attribute__((noinline)) void vio_exact_decide(const FlVioExact ex, 
     if (ex.world <= 1) {     // single rank: the auditor workgroup has been adding this pass's chain up since its words arrived
         if (tid == 0) {
             float fc = 0.f, fl = 0.f;
-            bool ok = vio_audit_read(audit, ex.epoch, 1 << 12, &fc);
+            // an auditor that has not reached this pass yet (many patches: its chain takes longer than a pass) is not waited for
+            const unsigned at = (unsigned)__hip_atomic_load(audit + FL_AUDIT_RING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool ok = (int)(at - ex.epoch) >= 0 && vio_audit_read(audit, ex.epoch, 1 << 12, &fc);
             if (ok && !L.last_exact_valid) {
                 ok = vio_audit_read(audit, L.acc_epoch, 64, &fl);     // (a pass long finished: there, or never audited)
                 if (ok) { L.last_exact = fl / n_all; L.last_exact_valid = 1; }

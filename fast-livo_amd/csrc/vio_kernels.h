@@ -440,7 +440,10 @@ __device__ __attribute__((noinline)) int vio_audit_pass(unsigned long long *__re
 {
     __shared__ __attribute__((aligned(16))) float s_aud[FL_EXACT_LDS];
     __shared__ int s_to;
-    if (threadIdx.x == 0) s_to = 0;
+    if (threadIdx.x == 0) {
+        s_to = 0;
+        __hip_atomic_store(err_base + 2 * (size_t)err_cap + FL_AUDIT_RING, (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     const float f = vio_exact_sum(err_base + (size_t)buf * err_cap, m, epoch, s_aud, &s_to);
     const int to = s_to;

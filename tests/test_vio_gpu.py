@@ -169,3 +169,30 @@ def test_accept_test_is_replayed_in_the_reference_arithmetic(gpu_lib, oracle_lib
         assert np.array_equal(eg.view(np.uint32), ro["errors"].view(np.uint32)), seed
         h.close()
     assert replayed >= 1          # the slow path is exercised by ordinary frames
+
+
+@pytest.mark.parametrize("m", [3000, 9000])
+def test_accept_replay_with_more_patches_than_the_auditor_keeps_up_with(gpu_lib, oracle_lib, m):
+    """Beyond ~3 k patches the auditor workgroup's chain takes longer than a pass, beyond 2 k it spans several staging chunks: the solver
+    then does not wait for a pass the auditor has not reached (progress word) and replays the chain itself. Same decisions, same
+    state, same per-patch errors as the oracle."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    replayed = 0
+    for seed in (3, 8):
+        lio = synth.make_lio_frame(500, seed=synth.SEED + seed)
+        vf = synth.make_vio_frame(m, lio, max_iterations=10, patch_seed=seed * 104729)
+        h = capi.Handle(capi.config_from_frames(lio, vf, max_iterations=10))
+        xg = capi.state18_from_frame(lio); xp = capi.state18_from_frame(lio)
+        h.vio_set_frame(vf.img); h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+        infos = h.vio_compute_j(xg, xp)
+        eg = h.vio_get_errors(vf.m)
+        xo = orc.state18_from_frame(lio)
+        ro = orc.vio_compute_j(vf, xo, xo.copy())
+        replayed += any(i.status & 16 for i in infos)
+        for l in range(3):
+            assert infos[l].iterations == ro["outs"][l].iterations and infos[l].accepted == ro["outs"][l].accepted, (seed, l)
+        assert np.abs(xg.vec() - xo.vec()).max() <= 1e-9, seed
+        assert np.array_equal(eg.view(np.uint32), ro["errors"].view(np.uint32)), seed
+        h.close()
+    assert replayed >= 1

@@ -11,7 +11,7 @@ scene = synth.make_scene()
 fr = synth.make_lio_frame(n, scene=scene, point_seed=synth.SEED + 101)
 vf = synth.make_vio_frame(2000, fr, patch_seed=synth.SEED + 103)
 h = capi.Handle(capi.config_from_frames(fr, vf, max_iterations=10, device=0))
-h.map_set_points(scene.map_xyz, 0.5)
+h.map_set_points(scene.map_xyz, float(os.environ.get("FL_CELL", "0.5")))
 ts = []
 for rep in range(60):
     x = capi.state18_from_frame(fr)
