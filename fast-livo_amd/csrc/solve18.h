@@ -87,14 +87,16 @@ __device__ __forceinline__ bool vio_audit_read(const unsigned long long *ring, u
     *out = __uint_as_float((unsigned)(v >> 32));
     return (unsigned)v == tag && (unsigned)(v >> 32) != FL_AUDIT_NONE;
 }
+#ifndef FL_EXACT_CHUNK
 #define FL_EXACT_CHUNK 2048
+#endif
 #define FL_EXACT_LDS (FL_EXACT_CHUNK + FL_CHAIN_STEP)      /* staging buffer of vio_exact_sum: a chunk + the chain's zero padding */
 // The reference's `error += patch_error` over patches 0..m-1 as one chain of float additions (no contraction), bit for bit. All
 // threads of the workgroup stage the words (polling until their tag says they belong to pass `tag`); wavefront 0 adds them up
 // binade-wise over its 64 lanes (exact_chain.h: ~3 us for 2 k patches instead of ~20 us for one lane adding one by one). Result
 // valid in thread 0. A word of a NEWER pass (the double-buffered half was reused: the caller is two passes late) or one that never
 // arrives sets *timeout_flag.
-__device__ __forceinline__ float vio_exact_sum(const unsigned long long *w, int m, unsigned tag, float *scr /* FL_EXACT_LDS floats */, int *timeout_flag,
+__device__ __attribute__((noinline)) float vio_exact_sum(const unsigned long long *w, int m, unsigned tag, float *scr /* FL_EXACT_LDS floats */, int *timeout_flag,
                                                float init = 0.0f)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -360,7 +362,7 @@ __device__ __forceinline__ double vio_cam_element(int t, const double *xn, const
 // The slow path of the VIO accept test (see eskf18_solve_block): the reference's float values of this pass's error and of the last
 // accepted one into L.exact_cur / L.last_exact. Called by the whole workgroup on the rare fragile passes; NOT inlined -- its
 // registers (staging, the chain) stay out of the pass loop's allocation, where they cost spills on every pass.
-__device__ __attribute__((noinline)) void vio_exact_decide(const FlVioExact ex, FlSolveLds *Lp, float n_all /* 64 x the patches of ALL ranks */)
+__device__ __forceinline__ void vio_exact_decide(const FlVioExact ex, FlSolveLds *Lp, float n_all /* 64 x the patches of ALL ranks */)
 {
     FlSolveLds &L = *Lp;
     const int tid = threadIdx.x;
@@ -398,12 +400,13 @@ __device__ __attribute__((noinline)) void vio_exact_decide(const FlVioExact ex, 
 }
 
 template <int KIND>
-__device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, const double *s_sums, FlSolveLds &L, const FlSolveRegs &G,
+__device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, const double *s_sums, FlSolveLds &L, const FlSolveRegs &G_in,
                                                    int gather_status, unsigned long long *bcast = nullptr, unsigned bepoch = 0u,
                                                    const FlVioExact ex = FlVioExact{}, const FlVioConst *__restrict__ VC = nullptr, int dbg = 0)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    FlSolveRegs G = G_in;
 
     // ---- a hand-off timed out: abandon the pass. Nothing of the state moves; the launch chain ends (stop), the host resumes.
     if (gather_status) {
@@ -452,7 +455,10 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
         need_exact = (last < 1e9f && fabsf(error - last) <= thr * fabsf(error));
         slow = need_exact && can_replay;
         if (slow && tid == 0) L.exact_timeout = 0;
-        if (slow) vio_exact_decide(ex, &L, (float)s_sums[FL_S_NEFF]);      // uniform over the workgroup
+        if (slow) {      // uniform over the workgroup
+            vio_exact_decide(ex, &L, (float)s_sums[FL_S_NEFF]);
+            eskf18_load_regs(L, G, VC);      // the operands come back from LDS: nothing of them has to survive the call in registers
+        }
     }
     if (wave != 0) return;
 
