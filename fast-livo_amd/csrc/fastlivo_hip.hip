@@ -56,6 +56,7 @@ struct fl_context {
     // 18-state block, reduction scratch
     FlDev18 *d_dev = nullptr;
     FlDev18 *h_dev = nullptr;      // pinned mirror
+    bool hdev_busy = false, hdev23_busy = false;   // an async copy from the pinned mirror may still be in flight (begin without a read-back since)
     void *d_records = nullptr;      // tagged per-workgroup records (handoff.h)
     size_t rec_fresh_bytes = 0;     // bytes of d_records the previous pass launch covered (records_for)
     unsigned *d_epoch = nullptr;    // launch epoch of the records, advanced on the device
@@ -577,7 +578,9 @@ static void unpack_state18(const double *x24, const double *P, fl_state18 *s)
 static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_state18 *prop, double meas_cov, bool vio = false)
 {
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));   // h_dev is reused
+    // h_dev is reused: wait only if a copy out of it can still be in flight. (A frame driver's begin follows the previous frame's
+    // read-back, and then this wait would only serialise the host with the scan copy just enqueued in front of it.)
+    if (h->hdev_busy) HIPCHK(h, hipStreamSynchronize(h->stream));
     FlDev18 *D = h->h_dev;
     memset(D, 0, sizeof(FlDev18));
     pack_state18(state, D->x);
@@ -603,6 +606,7 @@ static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_sta
     D->xchg_rank = h->xchg_rank;
     D->xchg_world = h->xchg_world;
     HIPCHK(h, hipMemcpyAsync(h->d_dev, D, sizeof(FlDev18), hipMemcpyHostToDevice, h->stream));
+    h->hdev_busy = true;
     if (vio) hipLaunchKernelGGL(vio_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev, (const FlVioConst *)h->d_vc);   // + the camera pose
     else hipLaunchKernelGGL(eskf18_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev);
     HIPCHK(h, hipGetLastError());
@@ -625,6 +629,7 @@ static int32_t read_info18(fl_handle h, fl_iter_info *info)
 {
     HIPCHK(h, hipMemcpyAsync(h->h_dev, h->d_dev, sizeof(FlDev18) + FL_DEV18_TAIL, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->hdev_busy = false; h->hdev23_busy = false;
     if (!info) return FL_OK;
     const FlDev18 *D = h->h_dev;
     memset(info, 0, sizeof *info);
