@@ -157,67 +157,87 @@ __device__ __forceinline__ int gather_records(const void *records, int nprod, un
 }
 
 
-// The 96-double records of Mode-23, up to 128 producers: gather_records walks the three 32-value groups one after the other (three
-// sweeps of a memory round trip each, 7 us measured); here wavefront g < 3 takes group g of EVERY record -- 32 loads of 16 bytes
-// in flight per lane, one sweep for the whole record set.  Same fixed summation order for every launch: per lane the records
-// 4 j + row in ascending j, then the four rows in order.  lds >= 3 * 128 doubles.
+// The 96-double records of Mode-23, up to 128 producers. gather_records walks the three 32-value groups one after the other (three
+// sweeps of a memory round trip each, 7 us measured). Here every wavefront of the workgroup takes its share of the RECORDS, all three
+// groups of each, every load in flight at once: a wavefront's sweep costs ~0.1 us per 16-byte load instruction (32 per lane took
+// 3.3 us when three wavefronts each swept one group of all 128 records), so the loads are spread over all NT / 64 wavefronts --
+// 24 per lane with 4 wavefronts, 12 with 8.  Same fixed summation order for every launch: per lane the wavefront's records
+// 4 j + row in ascending j, then the wavefronts in order, then the four rows.  lds >= (NT / 64) * 3 * 128 doubles.
+template <int NT>
 __device__ __forceinline__ int gather_records96(const void *records, int nprod /* <= 128 */, unsigned epoch, double *lds, double *out_lds /* 96 */)
 {
-    constexpr int NV = 96, SLOTS = 32;
+    constexpr int NV = 96, W = NT / 64;
+    constexpr int RPW = ((128 + W - 1) / W + 3) & ~3;        // records per wavefront (a multiple of the 4 rows of a load)
+    constexpr int SLOTS = RPW / 4;                           // per group
+    static_assert(SLOTS * 3 <= 32, "the missing-mask is 32 bits");
     const int tid = threadIdx.x;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, kp = lane & 15, row = lane >> 4;
     const unsigned tag = fl_epoch_tag(epoch);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)records, 0, nprod * NV * 8, 0x00020000);
     int timeout = 0;
-    if (wave_u < 3) {
-        const int g = wave_u;
-        fl_u4 t[SLOTS];
-        unsigned need = 0u;                                  // wave-uniform: slot j covers records 4 j .. 4 j + 3
+    {
+        const int rec0 = wave_u * RPW;
+        fl_u4 t[3][SLOTS];
+        unsigned need = 0u;                                  // wave-uniform: bit g * SLOTS + j covers group g of records rec0 + 4 j .. + 3
 #pragma unroll
-        for (int j = 0; j < SLOTS; j++) {
-            need |= (4 * j < nprod) ? (1u << j) : 0u;
-            t[j].x = 0u; t[j].y = 0u; t[j].z = 0u; t[j].w = 0u;
-        }
+        for (int g = 0; g < 3; g++)
+#pragma unroll
+            for (int j = 0; j < SLOTS; j++) {
+                need |= (rec0 + 4 * j < nprod) ? (1u << (g * SLOTS + j)) : 0u;
+                t[g][j].x = 0u; t[g][j].y = 0u; t[g][j].z = 0u; t[g][j].w = 0u;
+            }
         for (int spin = 0; need != 0u; spin++) {
 #pragma unroll
-            for (int j = 0; j < SLOTS; j++) {
-                if (need & (1u << j)) {
-                    const int b = 4 * j + row;
-                    t[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (b * NV + g * 32 + kp * 2) * 8, 0, 16 /* sc1 */);
-                }
-            }
+            for (int g = 0; g < 3; g++)
 #pragma unroll
-            for (int j = 0; j < SLOTS; j++) {
-                if (need & (1u << j)) {
-                    const int b = 4 * j + row;
-                    const bool ok = (b >= nprod) || (((t[j].x & FL_TAG_MASK) == tag) && ((t[j].z & FL_TAG_MASK) == tag));
-                    if (__ballot(ok) == ~0ull) need &= ~(1u << j);
+                for (int j = 0; j < SLOTS; j++) {
+                    if (need & (1u << (g * SLOTS + j))) {
+                        const int b = rec0 + 4 * j + row;
+                        t[g][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (b * NV + g * 32 + kp * 2) * 8, 0, 16 /* sc1 */);
+                    }
                 }
-            }
+#pragma unroll
+            for (int g = 0; g < 3; g++)
+#pragma unroll
+                for (int j = 0; j < SLOTS; j++) {
+                    if (need & (1u << (g * SLOTS + j))) {
+                        const int b = rec0 + 4 * j + row;
+                        const bool ok = (b >= nprod) || (((t[g][j].x & FL_TAG_MASK) == tag) && ((t[g][j].z & FL_TAG_MASK) == tag));
+                        if (__ballot(ok) == ~0ull) need &= ~(1u << (g * SLOTS + j));
+                    }
+                }
+#ifdef FL_IK_STAMPS
+            if (wave_u == 0 && lane == 0 && spin < 6) { g_fl_stamps[48 + spin] = (long long)wall_clock64(); g_fl_stamps[56 + spin] = (long long)__popc(need); }
+#endif
             if (need != 0u) {
                 if (spin >= FL_GATHER_SPIN_LIMIT) { timeout = 1; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
         }
-        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-        for (int j = 0; j < SLOTS; j++) {
-            const int b = 4 * j + row;
-            if (b < nprod) {
-                s0 += fl_untag(t[j].x, t[j].y);
-                s1 += fl_untag(t[j].z, t[j].w);
+        for (int g = 0; g < 3; g++) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < SLOTS; j++) {
+                const int b = rec0 + 4 * j + row;
+                if (b < nprod) {
+                    s0 += fl_untag(t[g][j].x, t[g][j].y);
+                    s1 += fl_untag(t[g][j].z, t[g][j].w);
+                }
             }
+            lds[((wave_u * 3 + g) * 64 + lane) * 2] = s0;
+            lds[((wave_u * 3 + g) * 64 + lane) * 2 + 1] = s1;
         }
-        lds[(g * 64 + lane) * 2] = s0;
-        lds[(g * 64 + lane) * 2 + 1] = s1;
     }
     __syncthreads();
     if (tid < NV) {
         const int g = tid >> 5, k = tid & 31;                // value g*32 + k lives in lane kp = k / 2, component k & 1, of the four rows
-        double a = lds[(g * 64 + (k >> 1)) * 2 + (k & 1)];
+        double a = 0.0;
 #pragma unroll
-        for (int r = 1; r < 4; r++) a += lds[(g * 64 + r * 16 + (k >> 1)) * 2 + (k & 1)];
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int w = 0; w < W; w++) a += lds[((w * 3 + g) * 64 + r * 16 + (k >> 1)) * 2 + (k & 1)];
         out_lds[tid] = a;
     }
     __syncthreads();

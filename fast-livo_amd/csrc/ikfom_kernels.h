@@ -42,7 +42,9 @@ struct FlDev23 {
 
 #include "ikfom_solve_block.h"
 
+#ifndef FL_IK_NT
 #define FL_IK_NT 256
+#endif
 
 // no-op launch? (abandoned chain: count what is skipped; stopped / waiting for a search) -- as fl_pass_skipped of lio_kernels.h
 __device__ __forceinline__ bool ik_pass_skipped(FlDev23 *__restrict__ D, int flags, int passes, bool counter_thread)
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float4 *__re
     const int nprod = gridDim.x - 1;
 
     if (blockIdx.x == nprod) {
-        __shared__ double s_fin[2 * NT];
+        __shared__ double s_fin[(NT / 64) * 3 * 128];          // gather_records96 (>= 2 NT of gather_records)
         __shared__ double s_sums[FL_SUMS23];
         __shared__ FlIkLds s_ik;
 #ifdef FL_IK_STAMPS
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float4 *__re
 #ifdef FL_IK_STAMPS
         if (threadIdx.x == 0) g_fl_stamps[34] = (long long)wall_clock64();
 #endif
-        const int gst = ((nprod <= 128) ? gather_records96(records, nprod, epoch, s_fin, s_sums) : gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums));
+        const int gst = ((nprod <= 128) ? gather_records96<NT>(records, nprod, epoch, s_fin, s_sums) : gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums));
 #ifdef FL_IK_STAMPS
         if (threadIdx.x == 0) g_fl_stamps[35] = (long long)wall_clock64();
 #endif
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_multipass_kernel(const float4 
     const unsigned epoch0 = *epoch_ptr;
 
     if (blockIdx.x == nprod) {
-        __shared__ double s_fin[2 * NT];
+        __shared__ double s_fin[(NT / 64) * 3 * 128];          // gather_records96 (>= 2 NT of gather_records)
         __shared__ double s_sums[FL_SUMS23];
         __shared__ FlIkLds s_ik;
         ikfom_stage_once(D, s_ik);
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_multipass_kernel(const float4 
         for (int p = 0; p < count; p++) {
             const unsigned epoch = epoch0 + (unsigned)p;
             ikfom_pre(s_ik);                                      // state-only half of the iteration, while the producers work
-            const int gst = ((nprod <= 128) ? gather_records96(records, nprod, epoch, s_fin, s_sums) : gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums));
+            const int gst = ((nprod <= 128) ? gather_records96<NT>(records, nprod, epoch, s_fin, s_sums) : gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums));
             ikfom_post(D, s_sums, s_ik, gst, bcast, epoch + 1u, false);
             __syncthreads();
             done = p + 1;

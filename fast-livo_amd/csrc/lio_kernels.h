@@ -123,8 +123,11 @@ __device__ __forceinline__ bool fl_pass_skipped(FlDev18 *__restrict__ D, int fla
 
 // -------------------------------------------------------------------------------------------- K1
 // grid = producers + 1 ; MODE 0: fused pass ; MODE 1: accumulate only (sums -> sums_out)
+#ifndef FL_LIO_PASS_WAVES
+#define FL_LIO_PASS_WAVES 1
+#endif
 template <int MODE>
-__global__ __launch_bounds__(FL_LIO_NT) void lio18_pass_kernel(const float4 *__restrict__ body4,
+__global__ __launch_bounds__(FL_LIO_NT, FL_LIO_PASS_WAVES) void lio18_pass_kernel(const float4 *__restrict__ body4,
                                                               float4 *__restrict__ plane,
                                                               uint8_t *__restrict__ sel, float4 *__restrict__ normvec, int n,
                                                               FlDev18 *__restrict__ D, void *__restrict__ records,

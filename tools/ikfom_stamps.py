@@ -17,3 +17,4 @@ for _ in range(3):
     h.ikfom_iterate(1, capi.FL_ITER_FORCE, want_info=False); h.sync()
     st = np.array(h.debug_stamps(), dtype=np.int64)
     print(json.dumps({names[k]: int(st[k] - st[32]) * 10 for k in sorted(names, key=lambda k: st[k])}))
+    print("  gather sweeps (ns after solver start, slots still missing):", [(int(st[48 + i] - st[32]) * 10, int(st[56 + i])) for i in range(6) if st[48 + i] > st[32]])
