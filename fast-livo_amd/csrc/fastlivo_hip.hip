@@ -464,7 +464,10 @@ static inline int lio_grid(int n)
     // let each lane take several points; spread over more workgroups only when the point loop
     // dominates (measured crossover, bench.py --sweep: 200k pts 9.8 us @255 vs 14.4 us @1023;
     // 1M pts 17.5 us @511; 8M pts 75 us @1023).
-    int cap = (n <= 300000) ? 255 : ((n <= 2000000) ? 511 : (FL_MAX_BLOCKS - 1));
+    // Round 2, multi-pass kernel: a wavefront of the gather pays ~0.1 us per 16-byte load instruction (one per 16 records) while a
+    // producer lane's second point costs about as much -- 50 k pts: 7.05 us @196 (one point per lane), 6.72 @160; 65 k: 7.56 @254,
+    // 6.8 @96..160; 100 k: 7.64 @255, 7.25..7.32 @128..160; 200 k: 8.05 @255, 8.27 @160.
+    int cap = (n <= 130000) ? 160 : ((n <= 300000) ? 255 : ((n <= 2000000) ? 511 : (FL_MAX_BLOCKS - 1)));
     if (cap > fl_max_producers()) cap = fl_max_producers();
     if (b > cap) b = cap;
     return b + 1;
