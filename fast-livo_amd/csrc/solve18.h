@@ -435,10 +435,12 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
         // `error += patch_error` over the patches in order (:849-857). Its last digits depend on that order, which no tree reduction
         // reproduces, and near convergence the test is decided inside that noise. So: the producers leave every patch's
         // `patch_error` exactly as the reference rounds it (vio_produce), the fast test uses the fp64-reduced sum, and whenever it is
-        // closer than (m + 8) * 2^-24 relative (the worst-case distance between the two sums) the workgroup replays the reference's running sum
-        // over those per-patch floats -- m dependent float additions by one lane, ~5 us, only on such passes -- for this pass and, if
-        // not known yet, for the last accepted one, and decides on the reference's own float values (status bit 16 reports that the
-        // slow path ran). With the patches spread over ranks (in-kernel exchange) the chain runs through the ranks (vio_exact_chain); without
+        // closer than (m + 8) * 2^-24 relative (the worst-case distance between the two sums) the decision is taken on the reference's
+        // running sum over those per-patch floats, for this pass and for the last accepted one (status bit 16 reports that the slow
+        // path ran). Single rank: the auditor workgroup of the pass kernels has been adding that chain up beside the pass
+        // (vio_kernels.h vio_audit_pass; exact_chain.h: bit-identical to the m dependent additions, lane-parallel) and the solver reads
+        // its ring; if the auditor is not there yet or gave up, the workgroup replays the chain itself (vio_exact_decide).
+        // With the patches spread over ranks (in-kernel exchange) the chain runs through the ranks (vio_exact_chain); without
         // the per-patch words (solve kernel of the RCCL form: `ex.words` == nullptr) bit 16 means "may differ".
         // Every thread evaluates the trigger itself from pass-invariant inputs (G.last_error was read before the gather), so the
         // common case needs no barrier.
