@@ -24,7 +24,9 @@
 #define FL_KNN_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define FL_KNN_QPB 64            // queries per workgroup of the search kernel
 #define FL_KNN_NT 256
-#define FL_KNN_BATCH 8           // point loads in flight per lane
+#ifndef FL_KNN_BATCH
+#define FL_KNN_BATCH 8           // point loads in flight per lane (4: the same 39 us per 50 k-point search, 16: 42.5 us -- the walk is VALU bound)
+#endif
 
 // hash-table entry: cell key, first sorted point of the cell, number of points in the cell
 struct __attribute__((aligned(16))) FlCellEntry {
