@@ -56,6 +56,9 @@ struct fl_context {
     // 18-state block, reduction scratch
     FlDev18 *d_dev = nullptr;
     FlDev18 *h_dev = nullptr;      // pinned mirror
+#define FL_UP_SLOTS 12
+    void *h_small = nullptr;        // page-locked scratch: 4 KB for the small per-call read-backs (counts, control blocks) + FL_UP_SLOTS x 1 KB for parameter uploads
+    unsigned up_slot = 0;
     bool hdev_busy = false, hdev23_busy = false;   // an async copy from the pinned mirror may still be in flight (begin without a read-back since)
     void *d_records = nullptr;      // tagged per-workgroup records (handoff.h)
     size_t rec_fresh_bytes = 0;     // bytes of d_records the previous pass launch covered (records_for)
@@ -290,6 +293,7 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
     HIPCHK(h, hipHostMalloc(&h->h_dev, sizeof(FlDev18) + FL_DEV18_TAIL));
     HIPCHK(h, hipMalloc(&h->d_dev23, sizeof(FlDev23)));
     HIPCHK(h, hipHostMalloc(&h->h_dev23, sizeof(FlDev23)));
+    HIPCHK(h, hipHostMalloc(&h->h_small, 4096 + FL_UP_SLOTS * 1024));
     HIPCHK(h, hipMalloc(&h->d_records, (size_t)16 * FL_MAX_BLOCKS * FL_SUMS23));
     HIPCHK(h, hipMalloc(&h->d_epoch, 64));
     {
@@ -359,6 +363,7 @@ int32_t fl_destroy(fl_handle h)
     fl_p2p_disconnect(h);
     if (h->h_dev) hipHostFree(h->h_dev);
     if (h->h_dev23) hipHostFree(h->h_dev23);
+    if (h->h_small) hipHostFree(h->h_small);
     {
         std::lock_guard<std::mutex> lk(g_mp_mu);
         for (size_t i = 0; i < g_mp_handles.size(); i++)
@@ -576,6 +581,29 @@ static void unpack_state18(const double *x24, const double *P, fl_state18 *s)
     memcpy(s->ba, x24 + 18, sizeof(double) * 3);
     memcpy(s->grav, x24 + 21, sizeof(double) * 3);
     memcpy(s->cov, P, sizeof(double) * 324);
+}
+
+// A small device block into a host variable: copy into the handle's page-locked scratch, wait, copy out. (hipMemcpyAsync straight
+// into a stack variable -- pageable memory -- is a staged, synchronous copy of its own: ~20 us instead of ~5.)
+static int32_t read_small(fl_handle h, void *dst, const void *d_src, size_t bytes)
+{
+    if (bytes > 4096) return fail_arg(h, "read_small: block too large");
+    HIPCHK(h, hipMemcpyAsync(h->h_small, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    memcpy(dst, h->h_small, bytes);
+    return FL_OK;
+}
+
+// A small parameter block from a host variable to the device through the page-locked scratch (an asynchronous copy from pageable
+// memory is staged synchronously). The slot is reused FL_UP_SLOTS uploads later: every entry point that uploads also ends with a
+// synchronisation, and none uploads more than a handful of blocks.
+static int32_t upload_small(fl_handle h, void *d_dst, const void *src, size_t bytes)
+{
+    if (bytes > 1024) return fail_arg(h, "upload_small: block too large");
+    char *slot = (char *)h->h_small + 4096 + (size_t)(h->up_slot++ % FL_UP_SLOTS) * 1024;
+    memcpy(slot, src, bytes);
+    HIPCHK(h, hipMemcpyAsync(d_dst, slot, bytes, hipMemcpyHostToDevice, h->stream));
+    return FL_OK;
 }
 
 static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_state18 *prop, double meas_cov, bool vio = false)
