@@ -119,6 +119,57 @@ __device__ __forceinline__ int ik_ldl_solve_regs(const double *X /* LDS, 144 */,
     return bad;
 }
 
+// The same solve with ONE right-hand side, spread over the wavefront: lane i < 12 holds row i of sym(X) and w_i as a 13th column.
+// Step j: row j (pivot, the row's tail and its right-hand side) is broadcast from lane j through scalar registers (v_readlane with a
+// constant lane), every lane i > j scales its element of column j and updates its whole row tail -- the Schur complement stays
+// symmetric, so the column a lane needs for the update IS row j. Lane j's row is final after step j: it holds d_j and d_j l_kj, i.e.
+// column j of L, which is what the back substitution needs in lane j. 13 doubles per lane instead of 90, a dependent chain of
+// 12 x (reciprocal + 2 fused multiply-adds) instead of 12 x (reciprocal + up to 11 updates deep): ~1.1 us instead of ~3 us (the full
+// register version spilled into AGPRs). All 64 lanes call it; y (the whole solution) is returned in every lane.
+__device__ __forceinline__ double ik_bcast_lane(double v, int src_lane /* compile-time constant after unrolling */)
+{
+    const int lo = __builtin_amdgcn_readlane((int)f64_lo(v), src_lane), hi = __builtin_amdgcn_readlane((int)f64_hi(v), src_lane);
+    return f64_make((unsigned)lo, (unsigned)hi);
+}
+__device__ __forceinline__ int ik_ldl_solve_rows(const double *X /* LDS, 144 */, const double *w_lds /* LDS, 12 */, double (&y)[12])
+{
+#pragma clang fp contract(fast)
+    const int lane = threadIdx.x & 63;
+    const int r = lane < 12 ? lane : 0;
+    double c[13];
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const double v = (k == r) ? X[r * 12 + r] : 0.5 * (X[r * 12 + k] + X[k * 12 + r]);
+        c[k] = lane < 12 ? v : 0.0;                      // (lanes >= 12 carry zero rows: their updates are no-ops)
+    }
+    c[12] = lane < 12 ? w_lds[r] : 0.0;
+    int bad = 0;
+    double myinv = 0.0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        const double dj = ik_bcast_lane(c[j], j);
+        if (!(dj > 0.0)) bad = 1;
+        const double inv = ik_rcp_nr(dj);
+        if (lane == j) myinv = inv;
+        const double l = (lane > j) ? c[j] * inv : 0.0;  // l_ij
+#pragma unroll
+        for (int k = j + 1; k < 13; k++) {
+            const double u = ik_bcast_lane(c[k], j);     // a_jk = a_kj (k = 12: the right-hand side of row j)
+            c[k] = fma(-l, u, c[k]);
+        }
+    }
+    // back substitution L^T y = D^-1 z: lane j holds z_j (c[12]) and column j of d_j L (c[k], k > j)
+    double acc = c[12] * myinv;
+#pragma unroll
+    for (int i = 11; i >= 0; i--) {
+        const double yi = ik_bcast_lane(acc, i);
+        y[i] = yi;
+        const double lt = (lane < i) ? c[i] * myinv : 0.0;   // l_i,lane
+        acc = fma(-lt, yi, acc);
+    }
+    return bad;
+}
+
 // once per launch: state, propagated covariance, limits, counters
 __device__ __forceinline__ void ikfom_stage_once(const FlDev23 *__restrict__ D, FlIkLds &L)
 {
@@ -261,10 +312,8 @@ __device__ __forceinline__ void ikfom_post(FlDev23 *__restrict__ D, const double
     // substitution; lane r < 23 then forms dx_[r].  No barrier, no cross-lane traffic until the results are written.
     int bad = 0;
     if (tid < 64) {
-        double w[12], y[12];
-#pragma unroll
-        for (int i = 0; i < 12; i++) w[i] = L.y0[i];
-        bad = ik_ldl_solve_regs(L.X, w, y);
+        double y[12];
+        bad = ik_ldl_solve_rows(L.X, L.y0, y);
         if (tid < n) {                          // dx_ = A[:,0:12] y - dx_new
             double s2 = 0.0;
 #pragma unroll
