@@ -19,10 +19,10 @@ for i in range(N):
     info = h.lio_frame18_dev(x, fr.body_xyz)
     b = bytes(x)
     if first is None: first = b
-    bad += (b != first); badstatus += (info.status != 0)
+    bad += (b != first); badstatus += int((info.status & ~16) != 0)
     xv = capi.state18_from_frame(fr); xp = capi.state18_from_frame(fr)
     infos = hv.vio_compute_j(xv, xp)
     bv = bytes(xv)
     if firstv is None: firstv = bv
-    bad += (bv != firstv); badstatus += sum(int(i_.status != 0) for i_ in infos)
-print(json.dumps({"frames": N, "different_results": bad, "nonzero_status": badstatus, "seconds": round(time.perf_counter() - t0, 1)}))
+    bad += (bv != firstv); badstatus += sum(int((i_.status & ~16) != 0) for i_ in infos)      # bit 16 = the exact accept test ran: not an error
+print(json.dumps({"frames": N, "different_results": bad, "status_other_than_fragile": badstatus, "seconds": round(time.perf_counter() - t0, 1)}))
