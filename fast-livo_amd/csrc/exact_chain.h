@@ -30,7 +30,7 @@
 
 struct FlChainLane {
     float e[FL_CHAIN_EPL];
-    int q[FL_CHAIN_EPL];                     // integer increment (floor for a tie until fl_chain_ties decides)
+    int q[FL_CHAIN_EPL];                     // integer increment (of a tie: set by fl_chain_ties)
     int tie;                                 // bit i: element i is an exact tie
     int Qc;                                  // sum of the increments, capped at 2^24 (a lane that large has left the binade anyway)
     int cidx, sprev;                         // first element (index within the step) whose sum reaches 2^24, S before it
@@ -75,9 +75,10 @@ FL_HD int fl_chain_phase1(FlChainLane &L, const float *scr, int first, int Eb)
         L.e[i] = e;
         float x = ldexpf(e, 150 - Eb);                   // e / u (inf when far outside: clamped; an underflow is far below 1/2)
         x = x < 16777216.0f ? x : 16777216.0f;
-        const float fr = fl_chain_fract(x);
-        L.q[i] = (int)(x - fr) + ((fr > 0.5f) ? 1 : 0);
-        L.tie |= ((fr == 0.5f) ? 1 : 0) << i;
+        // nearest integer, ties to even ON x -- right for every non-tie; a tie (fraction exactly 1/2) is marked and gets its floor
+        // and its parity-dependent increment in fl_chain_ties
+        L.q[i] = (int)rintf(x);
+        L.tie |= ((fl_chain_fract(x) == 0.5f) ? 1 : 0) << i;
     }
     return L.tie;
 }
@@ -100,7 +101,7 @@ FL_HD void fl_chain_parity_map(const FlChainLane &L, int *isc, int *xr)
 #pragma unroll
 #endif
     for (int i = 0; i < FL_CHAIN_EPL; i++) {
-        if ((L.tie >> i) & 1) { c = 1; x = 0; } else x ^= L.q[i] & 1;
+        if ((L.tie >> i) & 1) { c = 1; x = 0; } else x ^= L.q[i] & 1;     // (a tie's q is not looked at here)
     }
     *isc = c; *xr = x;
 }
@@ -116,15 +117,18 @@ FL_HD int fl_chain_parity_in(unsigned long long Cm, unsigned long long Xm, int l
     return (int)(((unsigned)S + (unsigned)__builtin_popcountll(Xm & below)) & 1u);
 }
 // ties decided: round half to even, i.e. the sum becomes even
-FL_HD void fl_chain_ties(FlChainLane &L, int parity_in)
+FL_HD void fl_chain_ties(FlChainLane &L, int parity_in, int Eb)
 {
     int p = parity_in;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int i = 0; i < FL_CHAIN_EPL; i++) {
-        if ((L.tie >> i) & 1) { L.q[i] += (p ^ L.q[i]) & 1; p = 0; }
-        else p ^= L.q[i] & 1;
+        if ((L.tie >> i) & 1) {
+            const int fl = (int)(ldexpf(L.e[i], 150 - Eb) - 0.5f);     // floor of n + 1/2 (exact; a tie is never clamped)
+            L.q[i] = fl + ((p ^ fl) & 1);
+            p = 0;
+        } else p ^= L.q[i] & 1;
     }
 }
 
@@ -181,7 +185,7 @@ __device__ __forceinline__ float fl_chain_f32_wave(const float *scr, int cnt, fl
                 int isc, xr;
                 fl_chain_parity_map(L, &isc, &xr);
                 const unsigned long long Cm = __ballot(isc), Xm = __ballot(xr & 1);
-                fl_chain_ties(L, fl_chain_parity_in(Cm, Xm, lane, S));
+                fl_chain_ties(L, fl_chain_parity_in(Cm, Xm, lane, S), Eb);
             }
             fl_chain_sum(L);
             const int inc = fl_wave_prefix_i32(L.Qc, lane);

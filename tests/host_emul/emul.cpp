@@ -154,7 +154,7 @@ float emul_chain_f32(const float *in, int cnt, float init, int *steps_out)
                     Cm |= (unsigned long long)(isc & 1) << l;
                     Xm |= (unsigned long long)(xr & 1) << l;
                 }
-                for (int l = 0; l < 64; l++) fl_chain_ties(L[l], fl_chain_parity_in(Cm, Xm, l, S));
+                for (int l = 0; l < 64; l++) fl_chain_ties(L[l], fl_chain_parity_in(Cm, Xm, l, S), Eb);
             }
             steps++;
             int inc[64], run = 0;
