@@ -96,8 +96,8 @@ __device__ __forceinline__ bool vio_audit_read(const unsigned long long *ring, u
 // binade-wise over its 64 lanes (exact_chain.h: ~3 us for 2 k patches instead of ~20 us for one lane adding one by one). Result
 // valid in thread 0. A word of a NEWER pass (the double-buffered half was reused: the caller is two passes late) or one that never
 // arrives sets *timeout_flag.
-__device__ __attribute__((noinline)) float vio_exact_sum(const unsigned long long *w, int m, unsigned tag, float *scr /* FL_EXACT_LDS floats */, int *timeout_flag,
-                                               float init = 0.0f)
+__device__ __forceinline__ float vio_exact_sum_inl(const unsigned long long *w, int m, unsigned tag, float *scr /* FL_EXACT_LDS floats */, int *timeout_flag,
+                                                   float init = 0.0f)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
     float f = init;
@@ -144,6 +144,13 @@ __device__ __attribute__((noinline)) float vio_exact_sum(const unsigned long lon
         __syncthreads();
     }
     return f;
+}
+
+// Out of line for the solver workgroup's own (rare) replay: its registers and code stay out of the pass loop (the auditor, itself out
+// of line, inlines vio_exact_sum_inl so that its staging buffer is known to be LDS).
+__device__ __attribute__((noinline)) float vio_exact_sum(const unsigned long long *w, int m, unsigned tag, float *scr, int *timeout_flag, float init = 0.0f)
+{
+    return vio_exact_sum_inl(w, m, tag, scr, timeout_flag, init);
 }
 
 // The running sum over the patches of ALL ranks (see FlVioExact): thread 0 waits for the carry of rank-1, the workgroup adds this

@@ -445,7 +445,7 @@ __device__ __attribute__((noinline)) int vio_audit_pass(unsigned long long *__re
         __hip_atomic_store(err_base + 2 * (size_t)err_cap + FL_AUDIT_RING, (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    const float f = vio_exact_sum(err_base + (size_t)buf * err_cap, m, epoch, s_aud, &s_to);
+    const float f = vio_exact_sum_inl(err_base + (size_t)buf * err_cap, m, epoch, s_aud, &s_to);
     const int to = s_to;
     if (threadIdx.x == 0)         // (no total: the solver workgroup replays the pass itself, solve18.h)
         __hip_atomic_store(err_base + 2 * (size_t)err_cap + (epoch & (FL_AUDIT_RING - 1)),
