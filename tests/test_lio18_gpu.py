@@ -214,3 +214,37 @@ def test_large_scan_properties(gpu_lib, oracle_lib, scene):
     assert info.effct_feat_num == ro["out"].effct_feat_num
     assert_delta_close(np.array(info.solution)[:18], np.array(ro["out"].solution))
     h.close()
+
+
+def test_begin_behind_enqueue_only_calls_waits_for_the_state_mirror(gpu_lib, scene):
+    """fl_lio_begin18 stages the state in a page-locked mirror and skips the stream synchronisation when no copy out of that mirror can
+    be in flight (frame drivers: every begin follows a read-back). After enqueue-only calls (iterate without info) a copy MAY be in
+    flight: begin must wait. Ten begin / enqueue-only rounds with alternating states, then the result of the last one must be the
+    result of the same sequence on a fresh handle -- and the scan staged from page-locked memory gives the same bits as from a numpy
+    array."""
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    fr, h, nbr, valid = _setup(capi, synth, scene, 20000)
+    F = capi.FL_ITER_FORCE
+    h.lio_set_points(fr.body_xyz)
+    xa = capi.state18_from_frame(fr)
+    xb = capi.state18_from_frame(fr)
+    xb.pos[0] += 0.01
+    for r in range(10):
+        x = xa if r % 2 == 0 else xb
+        h.lio_begin18(x, x)
+        h.lio_set_neighbours(nbr, valid)
+        h.lio_iterate18(3, F, want_info=False)          # enqueue only: the H2D of the state mirror may still be in flight
+    info = h.lio_iterate18(1, F)
+    got = np.array(info.solution)
+    h2 = capi.Handle(capi.config_from_frames(fr, max_iterations=10))
+    pinned = h2.host_alloc(fr.body_xyz.shape, np.float32)
+    pinned[...] = fr.body_xyz
+    h2.lio_set_points(pinned)
+    h2.lio_begin18(xb, xb)
+    h2.lio_set_neighbours(nbr, valid)
+    h2.lio_iterate18(3, F, want_info=False)
+    ref = np.array(h2.lio_iterate18(1, F).solution)
+    assert np.array_equal(got, ref)
+    h2.host_free(pinned)
+    h.close(); h2.close()
