@@ -246,6 +246,17 @@ static bool mp_admit(fl_handle h, int grid, int capacity)
     if (busy + grid > capacity) { h->mp_fallbacks++; return false; }
     return true;
 }
+// workgroup slots (two per CU) of this process' other streams still on the device
+static int mp_busy(fl_handle h)
+{
+    std::lock_guard<std::mutex> lk(g_mp_mu);
+    int busy = 0;
+    for (fl_context *o : g_mp_handles) {
+        if (o == h || o->cfg.device != h->cfg.device || o->stream == h->stream) continue;
+        if (o->mp_seq != __atomic_load_n(o->h_mp_done, __ATOMIC_RELAXED)) busy += o->mp_last_grid;
+    }
+    return busy;
+}
 // right before a multi-pass launch: the sequence number it carries (and writes to h_mp_done when it ends)
 static unsigned mp_begin(fl_handle h, int grid)
 {
@@ -323,7 +334,7 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
     {
         int b_lio = 0, b_vio = 0, b_ik = 0;
         HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_lio, lio18_multipass_kernel, FL_LIO_NT, 0));
-        HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_vio, vio_multipass_kernel, FL_VIO_NT, 0));
+        HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_vio, vio_multipass_kernel<2>, FL_VIO_NT, 0));
         HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_ik, ikfom_multipass_kernel, FL_IK_NT, 0));
         const int b = b_lio < b_vio ? b_lio : b_vio;
         h->mp_capacity = b * h->num_cus;

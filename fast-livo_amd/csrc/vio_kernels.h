@@ -568,7 +568,11 @@ struct FlVioLevelInfo {
 // Up to `count` passes of one pyramid level in ONE launch (see lio18_multipass_kernel): the solver broadcasts the derived camera
 // pose (Rcw, Pcw: what the producers consume) and the stop bit; a rejected solve (error went up, lidar_selection.cpp:888-892)
 // reverts and stops like the reference. Bit-identical to `count` launches of vio_pass_kernel<0>.
-__global__ __launch_bounds__(FL_VIO_NT, 2) void vio_multipass_kernel(const uint8_t *__restrict__ img, const float *__restrict__ ref,
+// WAVES = the register budget (launch bound): 2 = two workgroups per CU (256 VGPRs), the form every concurrent or sharded use needs;
+// 1 = a CU's registers to one workgroup (256 VGPRs + AGPRs, no scratch): 8.5 instead of 9.2 us per pass, taken when the launch has the
+// device to itself (api_vio.inc vio_mp_variant). Same code, same arithmetic, same bits.
+template <int WAVES>
+__global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const uint8_t *__restrict__ img, const float *__restrict__ ref,
                                                                  const double *__restrict__ pos, const int32_t *__restrict__ slevel,
                                                                  float *__restrict__ errors, int m, int level,
                                                                  const FlVioConst *__restrict__ VC, FlDev18 *__restrict__ D,
