@@ -344,7 +344,8 @@ struct FlPeerView {
     unsigned long long *const *peer;           // D->xchg_peer (read with constant indices: a register array indexed at run time would live in scratch)
     int rank, world;
 };
-__device__ __forceinline__ FlPeerView fl_peer_view(const FlDev18 *D)
+template <typename DEV>
+__device__ __forceinline__ FlPeerView fl_peer_view(const DEV *D)
 {
     FlPeerView P;
     P.rank = D->xchg_rank; P.world = D->xchg_world;
@@ -354,7 +355,8 @@ __device__ __forceinline__ FlPeerView fl_peer_view(const FlDev18 *D)
 }
 // The same with the peers' addresses staged in LDS once per launch (multi-pass kernels: the state block is rewritten by the solver
 // every pass, so the compiler would re-load the eight pointers from memory in every exchange). All threads call it; ends with a barrier.
-__device__ __forceinline__ FlPeerView fl_peer_view_lds(const FlDev18 *D, unsigned long long **lds8)
+template <typename DEV>
+__device__ __forceinline__ FlPeerView fl_peer_view_lds(const DEV *D, unsigned long long **lds8)
 {
     if (threadIdx.x < FL_MAX_PEERS) lds8[threadIdx.x] = D->xchg_peer[threadIdx.x];
     FlPeerView P;
@@ -411,4 +413,15 @@ __device__ __forceinline__ int peer_allreduce32(const FlPeerView &P, unsigned xe
     __syncthreads();
     if (tid < 32) sums[tid] = tot;
     return __syncthreads_or(timeout) ? FL_NUM_TIMEOUT : 0;
+}
+
+// The 96-double record of Mode-23 as three exchanges of 32 (epochs xe, xe + 1, xe + 2: the buffer keeps two parities, and an exchange
+// is left only when every peer's words of it have arrived, so consecutive exchanges cannot overtake each other). Three cross-rank
+// round trips instead of one wider one: the price of sharing the buffer layout with the 18-state filters.
+__device__ __forceinline__ int peer_allreduce96(const FlPeerView &P, unsigned xe, double *sums96, double *tmp)
+{
+    int st = 0;
+#pragma unroll
+    for (int g = 0; g < 3; g++) st |= peer_allreduce32(P, xe + (unsigned)g, sums96 + 32 * g, tmp);
+    return st;
 }

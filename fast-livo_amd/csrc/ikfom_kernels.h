@@ -38,6 +38,10 @@ struct FlDev23 {
     int32_t searched_at;      // device k-NN: value of iters_run the last search was made for (-1: none)
     int32_t resume_count;     // passes an abandoned launch chain left undone (FL_NUM_TIMEOUT; see solve18.h)
     int32_t pad23;
+    // sharded form with the exchange inside the pass kernels (api_p2p.inc), as FlDev18
+    unsigned long long *xchg_peer[8];
+    unsigned *xchg_epoch;
+    int32_t xchg_rank, xchg_world;
 };
 
 #include "ikfom_solve_block.h"
@@ -131,11 +135,18 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float4 *__re
 #ifdef FL_IK_STAMPS
         if (threadIdx.x == 0) g_fl_stamps[34] = (long long)wall_clock64();
 #endif
-        const int gst = ((nprod <= 128) ? gather_records96<NT>(records, nprod, epoch, s_fin, s_sums) : gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums));
+        int gst = ((nprod <= 128) ? gather_records96<NT>(records, nprod, epoch, s_fin, s_sums) : gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums));
 #ifdef FL_IK_STAMPS
         if (threadIdx.x == 0) g_fl_stamps[35] = (long long)wall_clock64();
 #endif
         if (threadIdx.x == 0) *epoch_ptr = epoch + 1u;
+        if (MODE == 0 && D->xchg_world > 1) {               // sharded form: totals over the ranks (handoff.h)
+            __shared__ double s_xchg[FL_MAX_PEERS * 32];
+            const FlPeerView PV = fl_peer_view(D);
+            const unsigned xe = *D->xchg_epoch;
+            gst |= peer_allreduce96(PV, xe, s_sums, s_xchg);
+            if (threadIdx.x == 0) *D->xchg_epoch = xe + 3u;
+        }
         if (MODE == 0) {
             ikfom_post(D, s_sums, s_ik, gst);
 #ifdef FL_IK_STAMPS
@@ -179,12 +190,17 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_multipass_kernel(const float4 
         __shared__ double s_sums[FL_SUMS23];
         __shared__ FlIkLds s_ik;
         ikfom_stage_once(D, s_ik);
+        __shared__ double s_xchg[FL_MAX_PEERS * 32];
+        __shared__ unsigned long long *s_peers[FL_MAX_PEERS];
+        const FlPeerView PV = fl_peer_view_lds(D, s_peers);
+        const unsigned xe0 = PV.world > 1 ? *D->xchg_epoch : 0u;
         int done = 0;
         bool wrote_P = false;
         for (int p = 0; p < count; p++) {
             const unsigned epoch = epoch0 + (unsigned)p;
             ikfom_pre(s_ik);                                      // state-only half of the iteration, while the producers work
-            const int gst = ((nprod <= 128) ? gather_records96<NT>(records, nprod, epoch, s_fin, s_sums) : gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums));
+            int gst = ((nprod <= 128) ? gather_records96<NT>(records, nprod, epoch, s_fin, s_sums) : gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums));
+            if (PV.world > 1) gst |= peer_allreduce96(PV, xe0 + 3u * (unsigned)p, s_sums, s_xchg);      // sharded form: totals over the ranks
             ikfom_post(D, s_sums, s_ik, gst, bcast, epoch + 1u, false);
             __syncthreads();
             done = p + 1;
@@ -198,11 +214,15 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_multipass_kernel(const float4 
         if (!wrote_P) {                                           // a reader of the device block finds the projected P_ of the last pass
             for (int e = threadIdx.x; e < FL_N23 * FL_N23; e += NT) D->P[e] = s_ik.P[e];
         }
-        if (threadIdx.x == 0) *epoch_ptr = epoch0 + (unsigned)done;
+        if (threadIdx.x == 0) {
+            *epoch_ptr = epoch0 + (unsigned)done;
+            if (PV.world > 1) *D->xchg_epoch = xe0 + 3u * (unsigned)done;
+        }
         fl_mp_done(done_word, done_seq, true);
         return;
     }
 
+    const int spin_limit = D->xchg_world > 1 ? FL_XCHG_SPIN_LIMIT : FL_GATHER_SPIN_LIMIT;   // the solver may be waiting for another process
     __shared__ double s_red[(NT / 64) * FL_SUMS23];
     __shared__ double s_state[FL_X23_LEN];
     __shared__ int s_ctrl;
@@ -212,7 +232,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_multipass_kernel(const float4 
     for (int ps = 0; ps < count; ps++) {
         const unsigned epoch = epoch0 + (unsigned)ps;
         if (ps > 0) {
-            bcast_wait<FL_IK_BCAST_WORDS>(bcast, epoch, s_state, &s_ctrl);
+            bcast_wait<FL_IK_BCAST_WORDS>(bcast, epoch, s_state, &s_ctrl, spin_limit);
             __syncthreads();
             if (s_ctrl & 4) break;
             if (!force && (s_ctrl & 3)) break;

@@ -445,7 +445,9 @@ int32_t fl_ikfom_iterate_sharded(fl_handle h, int32_t count, int32_t flags, fl_i
  * points (fl_lio_iterate18, fl_lio_frame18_dev, fl_vio_iterate, fl_vio_compute_j, ...) run on this rank's range of the
  * points / patches: the solver workgroup of every pass publishes its 32 sums into every peer's exchange buffer (fine-grained
  * device memory, 8-byte self-validating words, over xGMI between GPUs) and adds up what the peers sent in rank order, so all
- * ranks solve on bitwise-identical totals -- and the passes of a frame remain ONE launch per rank. Every rank must issue the
+ * ranks solve on bitwise-identical totals -- and the passes of a frame remain ONE launch per rank. The Mode-23 entry points
+ * (fl_ikfom_begin after the connect, fl_ikfom_iterate, fl_ikfom_update_iterated_dev) exchange their 96 sums the same way, as three
+ * exchanges of 32 per pass. Every rank must issue the
  * same sequence of passes (it is a collective). State, covariance, configuration replicated; map / image replicated or sharded
  * by the caller. The VIO accept test stays the reference's: on the fragile passes the float running sum over the patches is handed
  * from rank to rank (rank r continues from the float rank r-1 ended with; the last rank sends the total back), so accept / revert

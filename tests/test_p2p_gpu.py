@@ -171,6 +171,57 @@ def test_exact_accept_replay_runs_through_the_ranks(gpu_lib, oracle_lib, world):
     assert replayed >= 1          # the chain through the ranks was exercised
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_mode23_passes_sharded_in_kernel(gpu_lib, scene, world):
+    """The 23-state IKFoM update with the points spread over ranks and the 96-double record exchanged inside the pass kernels
+    (three 32-double exchanges per pass, handoff.h peer_allreduce96): ranks bitwise equal, state and covariance equal to the
+    unsharded update within the re-association tolerance -- multi-pass launches and one launch per pass."""
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    n, max_iter = 18000, 6
+    fr = synth.make_lio_frame(n, scene=scene)
+    nbr, valid = synth.knn5(scene, fr.world_at(fr.R_prior, fr.p_prior))
+    cfg = capi.config_from_frames(fr, max_iterations=max_iter)
+    x0 = capi.state23_from_frame(fr)
+    P0 = fr.cov23.copy()
+
+    def run_ref(count, flags):
+        ref = capi.Handle(cfg)
+        ref.lio_set_points(fr.body_xyz); ref.ikfom_begin(x0, P0); ref.lio_set_neighbours(nbr, valid)
+        info = ref.ikfom_iterate(count, flags)
+        x, P = ref.ikfom_get()
+        ref.close()
+        return info, np.frombuffer(bytes(x), dtype=np.float64).copy(), P
+    iref, xref, Pref = run_ref(3, capi.FL_ITER_FORCE)
+    hs = [capi.Handle(cfg) for _ in range(world)]
+    capi.p2p_connect_local(hs)
+    cuts = np.linspace(0, n, world + 1).astype(int)
+
+    def rank(r):
+        def go():
+            h = hs[r]
+            sl = slice(cuts[r], cuts[r + 1])
+            h.lio_set_points(fr.body_xyz[sl]); h.ikfom_begin(x0, P0); h.lio_set_neighbours(nbr[sl], valid[sl])
+            info = h.ikfom_iterate(3, capi.FL_ITER_FORCE)
+            x, P = h.ikfom_get()
+            return info, np.frombuffer(bytes(x), dtype=np.float64).copy(), P
+        return go
+    for no_multi in (False, True):
+        if no_multi:
+            os.environ["FL_NO_MULTIPASS"] = "1"
+        try:
+            res = _run_ranks([rank(r) for r in range(world)])
+        finally:
+            os.environ.pop("FL_NO_MULTIPASS", None)
+        for info, x, P in res:
+            assert (info.status & 8) == 0 and info.effct_feat_num == iref.effct_feat_num
+            assert np.array_equal(x, res[0][1]) and np.array_equal(P, res[0][2])      # ranks bitwise equal
+            assert np.abs(x - xref).max() <= 1e-9
+            assert np.abs(P - Pref).max() <= 1e-11
+    for h in hs:
+        h.close()
+
+
 def test_two_processes_over_hip_ipc(gpu_lib, tmp_path):
     """Each rank its own process (as under torch.distributed.run), handles exchanged through files, both on device 0."""
     worker = os.path.join(ROOT, "tests", "p2p_worker.py")
