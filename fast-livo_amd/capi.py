@@ -79,6 +79,12 @@ class IterInfo(C.Structure):
                 ("need_search", C.c_int32), ("stop", C.c_int32), ("accepted", C.c_int32), ("reserved", C.c_int32)]
 
 
+class Diagnostics(C.Structure):
+    """fl_diagnostics"""
+    _fields_ = [("multipass_fallbacks", C.c_int32), ("frames_resumed", C.c_int32), ("multipass_capacity", C.c_int32),
+                ("compute_units", C.c_int32)]
+
+
 class ImuSample(C.Structure):
     _fields_ = [("t", C.c_double), ("gyr", C.c_double * 3), ("acc", C.c_double * 3)]
 
@@ -171,13 +177,10 @@ SYMBOLS = {
     "fl_ikfom_iterate_sharded": (C.c_int32, [_H, C.c_int32, C.c_int32, C.POINTER(IterInfo)]),
     "fl_host_alloc": (C.c_int32, [_H, C.c_size_t, C.POINTER(C.c_void_p)]),
     "fl_host_free": (C.c_int32, [_H, C.c_void_p]),
-    "fl_debug_get_wall": (C.c_int32, [_H, C.POINTER(C.c_longlong)]),
     "fl_set_timing": (C.c_int32, [_H, C.c_int32]),
     "fl_get_last_kernel_ms": (C.c_int32, [_H, _fp]),
-    "fl_debug_get_stamps": (C.c_int32, [_H, C.POINTER(C.c_longlong)]),
-    "fl_debug_hog": (C.c_int32, [_H, C.c_int32, C.c_int32, C.c_int32]),
-    "fl_debug_counters": (C.c_int32, [_H, _i32p]),
-    "fl_debug_chain": (C.c_int32, [_H, C.POINTER(C.c_float), C.c_int32, C.c_float, C.POINTER(C.c_float)]),
+    "fl_set_option": (C.c_int32, [_H, C.c_int32, C.c_int32]),
+    "fl_get_diagnostics": (C.c_int32, [_H, C.POINTER(Diagnostics)]),
     "fl_lio_set_points": (C.c_int32, [_H, _fp, C.c_int32]),
     "fl_lio_set_neighbours": (C.c_int32, [_H, _fp, _u8p, C.c_int32]),
     "fl_lio_get_selection": (C.c_int32, [_H, _u8p, _fp]),
@@ -231,44 +234,82 @@ SYMBOLS = {
     "fl_ikfom_update_iterated_dev": (C.c_int32, [_H, C.POINTER(State23), _dp, _fp, C.c_int32, C.c_double, _dp, C.POINTER(IterInfo)]),
 }
 
+# include/fastlivo_hip_debug.h: exported by the instrumented build (libfastlivo_hip_debug.so) only
+DEBUG_SYMBOLS = {
+    "fl_debug_get_wall": (C.c_int32, [_H, C.POINTER(C.c_longlong)]),
+    "fl_debug_get_stamps": (C.c_int32, [_H, C.POINTER(C.c_longlong)]),
+    "fl_debug_knn_stamp": (C.c_int32, [_H, C.c_int32]),
+    "fl_debug_hog": (C.c_int32, [_H, C.c_int32, C.c_int32, C.c_int32]),
+    "fl_debug_chain": (C.c_int32, [_H, C.POINTER(C.c_float), C.c_int32, C.c_float, C.POINTER(C.c_float)]),
+    "fl_debug_drop_record": (C.c_int32, [_H, C.c_int32]),
+}
+FL_OPT_MULTIPASS, FL_OPT_MAX_PRODUCERS, FL_OPT_IK_PRODUCERS, FL_OPT_MP_CAPACITY, FL_OPT_VIO_WHOLE_CU = 1, 2, 3, 4, 5
+DEBUG_LIB_PATH = os.path.join(PKG_DIR, "libfastlivo_hip_debug.so")
+
 _lib = None
+_lib_debug = None
 
 
-def build(force=False):
-    """Compile libfastlivo_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+def _sources():
     csrc = os.path.join(PKG_DIR, "csrc")
     srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)]
     srcs.append(os.path.join(os.path.dirname(PKG_DIR), "include", "fastlivo_hip.h"))
+    srcs.append(os.path.join(os.path.dirname(PKG_DIR), "include", "fastlivo_hip_debug.h"))
     srcs.append(os.path.join(PKG_DIR, "build.sh"))
-    if (not force and os.path.exists(LIB_PATH)
-            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+    return srcs
+
+
+def _fresh(path):
+    return os.path.exists(path) and all(os.path.getmtime(path) >= os.path.getmtime(s) for s in _sources())
+
+
+def build(force=False, debug=True):
+    """Compile libfastlivo_hip.so (and, debug=True, the instrumented libfastlivo_hip_debug.so) for gfx950; hipcc cross-compiles
+    without a GPU. The two compilations run side by side."""
+    procs = []
+    if os.environ.get("FL_LIB_PATH"):          # an A/B build selected by the caller (tools/): nothing to compile here
         return LIB_PATH
-    subprocess.check_call(["bash", os.path.join(PKG_DIR, "build.sh")])
+    if force or not _fresh(LIB_PATH):
+        procs.append(subprocess.Popen(["bash", os.path.join(PKG_DIR, "build.sh")]))
+    if debug and (force or not _fresh(DEBUG_LIB_PATH)):
+        procs.append(subprocess.Popen(["bash", os.path.join(PKG_DIR, "build.sh"), "debug"]))
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed (fast-livo_amd/build.sh)")
     return LIB_PATH
 
 
-def lib():
-    """Load the HIP library; raises (never falls back) when it is missing."""
-    global _lib
+def _load(path, symbols):
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                           "there is no CPU fallback for the ESKF hot path")
+    # One process must not mix two HIP/HSA runtimes: PyTorch bundles its own libamdhip64.so.7 and
+    # refuses to see the GPU if the system copy (our RUNPATH) was loaded first.  Importing torch
+    # first makes both share torch's copy (same soname); torch is only plumbing here.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(path)
+    for name, (res, args) in symbols.items():
+        fn = getattr(L, name)      # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+def lib(debug=False):
+    """Load the HIP library (debug=True: the instrumented build); raises (never falls back) when it is missing."""
+    global _lib, _lib_debug
+    if debug:
+        if _lib_debug is None:
+            path = DEBUG_LIB_PATH
+            if os.environ.get("FL_LIB_PATH"):      # tools/: an A/B variant built with -DFL_INSTRUMENT
+                path = LIB_PATH
+            _lib_debug = _load(path, {**SYMBOLS, **DEBUG_SYMBOLS})
+        return _lib_debug
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
-                               "there is no CPU fallback for the ESKF hot path")
-        # One process must not mix two HIP/HSA runtimes: PyTorch bundles its own libamdhip64.so.7 and
-        # refuses to see the GPU if the system copy (our RUNPATH) was loaded first.  Importing torch
-        # first makes both share torch's copy (same soname); torch is only plumbing here.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
-        L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
-            if name.startswith("fl_debug_") and os.environ.get("FL_LIB_PATH") and not hasattr(L, name):
-                continue               # an older A/B build (tools/) may lack a debug aid
-            fn = getattr(L, name)      # AttributeError if the library does not export a declared symbol
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        _lib = _load(LIB_PATH, SYMBOLS)
     return _lib
 
 
@@ -300,8 +341,9 @@ def make_config(R_LI, t_LI, Rcl, Pcl, cam, max_iterations=10, laser_point_cov=0.
 class Handle:
     """RAII wrapper of fl_handle with numpy-friendly methods (names follow the C ABI)."""
 
-    def __init__(self, cfg: Config):
-        self.L = lib()
+    def __init__(self, cfg: Config, debug=False):
+        """debug=True: a handle of the instrumented build (include/fastlivo_hip_debug.h)."""
+        self.L = lib(debug)
         self.h = _H()
         self.cfg = cfg
         st = self.L.fl_create(C.byref(cfg), C.byref(self.h))
@@ -309,6 +351,15 @@ class Handle:
             msg = self.L.fl_last_error_string(None)
             raise FlError(f"fl_create failed ({st}): {msg.decode() if msg else ''}")
         self._keep = []
+        # measurement scripts (tools/) select A/B behaviour through the environment of the PYTHON process; the library itself reads none
+        if os.environ.get("FL_NO_MULTIPASS"):
+            self.set_option(FL_OPT_MULTIPASS, 0)
+        if os.environ.get("FL_MAX_PRODUCERS"):
+            self.set_option(FL_OPT_MAX_PRODUCERS, int(os.environ["FL_MAX_PRODUCERS"]))
+        if os.environ.get("FL_IK_PRODUCERS"):
+            self.set_option(FL_OPT_IK_PRODUCERS, int(os.environ["FL_IK_PRODUCERS"]))
+        if os.environ.get("FL_VIO_OCC1") == "0":
+            self.set_option(FL_OPT_VIO_WHOLE_CU, 0)
 
     def close(self):
         if self.h:
@@ -832,12 +883,21 @@ def _knn_methods():
         self._chk(self.L.fl_debug_chain(self.h, _p(e, C.c_float), len(e), C.c_float(init), _p(out, C.c_float)), "fl_debug_chain")
         return out[0], out[1]
 
-    def debug_counters(self):
+    def debug_drop_record(self, passes_ahead=0):
+        self._chk(self.L.fl_debug_drop_record(self.h, int(passes_ahead)), "fl_debug_drop_record")
+
+    def debug_knn_stamp(self, on=True):
+        self._chk(self.L.fl_debug_knn_stamp(self.h, 1 if on else 0), "fl_debug_knn_stamp")
+
+    def set_option(self, option, value):
+        self._chk(self.L.fl_set_option(self.h, int(option), int(value)), "fl_set_option")
+
+    def diagnostics(self):
         """dict(fallbacks, resumes, capacity, cus): multi-pass launches refused by the admission check, frames resumed after an
-        abandoned pass, workgroups of a multi-pass kernel the device holds at once, compute units."""
-        a = np.zeros(4, dtype=np.int32)
-        self._chk(self.L.fl_debug_counters(self.h, a.ctypes.data_as(_i32p)), "fl_debug_counters")
-        return dict(fallbacks=int(a[0]), resumes=int(a[1]), capacity=int(a[2]), cus=int(a[3]))
+        abandoned pass, workgroups of a multi-pass kernel the device holds at once, compute units (fl_get_diagnostics)."""
+        d = Diagnostics()
+        self._chk(self.L.fl_get_diagnostics(self.h, C.byref(d)), "fl_get_diagnostics")
+        return dict(fallbacks=d.multipass_fallbacks, resumes=d.frames_resumed, capacity=d.multipass_capacity, cus=d.compute_units)
 
     def lio_frame18_dev(self, state, body):
         """body None: use the scan already staged on the device (lio_set_points / scan_voxel_filter)."""
@@ -859,7 +919,7 @@ def _knn_methods():
         return info
 
     for f in (map_set_points, map_clear, map_add_points, map_delete_boxes, map_get_points, lio_search18, ikfom_search, lio_frame18_dev, ikfom_update_iterated_dev,
-              debug_hog, debug_counters, debug_chain):
+              debug_hog, debug_chain, debug_drop_record, debug_knn_stamp, set_option, diagnostics):
         setattr(Handle, f.__name__, f)
 
 

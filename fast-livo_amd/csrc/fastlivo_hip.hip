@@ -2,6 +2,9 @@
 // Built by hipcc --offload-arch=gfx950 -ffp-contract=off into fast-livo_amd/libfastlivo_hip.so.
 // No CPU fallback: every entry point needs a live HIP device and fails loudly otherwise.
 #include "../../include/fastlivo_hip.h"
+#ifdef FL_INSTRUMENT
+#include "../../include/fastlivo_hip_debug.h"
+#endif
 
 #include "fl_device.h"
 #include "fl_math.h"
@@ -47,11 +50,14 @@ struct fl_context {
     int num_cus = 0;              // compute units of the device: the multi-pass kernels need every workgroup resident (<= 1 per CU)
     int mp_capacity = 0;          // workgroups of the LIO / VIO multi-pass kernels the device can hold at once (occupancy x CUs)
     int mp_capacity_ik = 0;       // ... of the Mode-23 multi-pass kernel (more registers: fewer per CU)
+    int mp_capacity_q = 0, mp_capacity_ik_q = 0;   // what the occupancy query said (FL_OPT_MP_CAPACITY 0 restores it)
     unsigned *h_mp_done = nullptr;   // pinned host word the solver workgroup of a multi-pass launch writes its sequence number to when it ends
     unsigned *d_mp_done = nullptr;   // ... as the device addresses it
     unsigned mp_seq = 0;             // sequence number of this handle's last multi-pass launch
     int mp_last_grid = 0;
     int mp_fallbacks = 0, mp_resumes = 0;   // diagnostics: launches sent down the per-pass path by the admission check / frames resumed
+    // fl_set_option (include/fastlivo_hip.h)
+    int opt_multipass = 1, opt_max_producers = 0, opt_ik_producers = 0, opt_vio_whole_cu = 1;
     bool normvec_valid = false;   // a pass with FL_ITER_KEEP_NORMVEC has run on the staged scan
     // 18-state block, reduction scratch
     FlDev18 *d_dev = nullptr;
@@ -160,6 +166,7 @@ struct fl_context {
     // misc
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
+    bool dbg_knn_stamp = false;   // FL_INSTRUMENT build only
     float last_ms = 0.f;
     int last_launches = 0;
     std::string err;
@@ -269,6 +276,7 @@ __global__ void eskf18_resume_kernel(FlDev18 *__restrict__ D)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) { D->status &= ~FL_NUM_TIMEOUT; D->resume_count = 0; }
 }
+#ifdef FL_INSTRUMENT
 // debug / test aid: occupies `blocks` workgroup slots for ~`usec` microseconds (tests/test_coresidency_gpu.py)
 __global__ __launch_bounds__(256) void fl_hog_kernel(long long ticks, int *sink)
 {
@@ -279,6 +287,7 @@ __global__ __launch_bounds__(256) void fl_hog_kernel(long long ticks, int *sink)
     while ((long long)wall_clock64() - t0 < ticks) { v++; __builtin_amdgcn_s_sleep(8); }
     if (v == -1) *sink = s_hog[0];
 }
+#endif
 
 extern "C" {
 
@@ -337,9 +346,8 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
         HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_vio, vio_multipass_kernel<2>, FL_VIO_NT, 0));
         HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_ik, ikfom_multipass_kernel, FL_IK_NT, 0));
         const int b = b_lio < b_vio ? b_lio : b_vio;
-        h->mp_capacity = b * h->num_cus;
-        h->mp_capacity_ik = b_ik * h->num_cus;
-        if (const char *e = getenv("FL_MP_CAPACITY")) h->mp_capacity = h->mp_capacity_ik = atoi(e);     // test aid
+        h->mp_capacity = h->mp_capacity_q = b * h->num_cus;
+        h->mp_capacity_ik = h->mp_capacity_ik_q = b_ik * h->num_cus;
     }
     { std::lock_guard<std::mutex> lk(g_mp_mu); g_mp_handles.push_back(h); }
     *out = h;
@@ -422,6 +430,40 @@ int32_t fl_host_free(fl_handle h, void *p)
     return FL_OK;
 }
 
+int32_t fl_set_option(fl_handle h, int32_t option, int32_t value)
+{
+    if (!h) return fail_arg(nullptr, "null handle");
+    switch (option) {
+    case FL_OPT_MULTIPASS: h->opt_multipass = value != 0; break;
+    case FL_OPT_MAX_PRODUCERS:
+        if (value < 0 || value > FL_MAX_BLOCKS - 1) return fail_arg(h, "fl_set_option: FL_OPT_MAX_PRODUCERS out of range");
+        if (value != h->opt_max_producers)   // the grid (number of records) changes: stale records must not carry a live tag
+            HIPCHK(h, hipMemsetAsync(h->d_records, 0, (size_t)16 * FL_MAX_BLOCKS * FL_SUMS23, h->stream));
+        h->opt_max_producers = value; break;
+    case FL_OPT_IK_PRODUCERS:
+        if (value < 0 || value > FL_MAX_BLOCKS - 1) return fail_arg(h, "fl_set_option: FL_OPT_IK_PRODUCERS out of range");
+        if (value != h->opt_ik_producers)
+            HIPCHK(h, hipMemsetAsync(h->d_records, 0, (size_t)16 * FL_MAX_BLOCKS * FL_SUMS23, h->stream));
+        h->opt_ik_producers = value; break;
+    case FL_OPT_MP_CAPACITY:
+        if (value < 0) return fail_arg(h, "fl_set_option: FL_OPT_MP_CAPACITY out of range");
+        if (value > 0) h->mp_capacity = h->mp_capacity_ik = value;
+        else { h->mp_capacity = h->mp_capacity_q; h->mp_capacity_ik = h->mp_capacity_ik_q; }
+        break;
+    case FL_OPT_VIO_WHOLE_CU: h->opt_vio_whole_cu = value != 0; break;
+    default: return fail_arg(h, "fl_set_option: unknown option");
+    }
+    return FL_OK;
+}
+
+int32_t fl_get_diagnostics(fl_handle h, fl_diagnostics *out)
+{
+    if (!h || !out) return fail_arg(h, "fl_get_diagnostics: null argument");
+    out->multipass_fallbacks = h->mp_fallbacks; out->frames_resumed = h->mp_resumes;
+    out->multipass_capacity = h->mp_capacity; out->compute_units = h->num_cus;
+    return FL_OK;
+}
+
 int32_t fl_set_timing(fl_handle h, int32_t enable)
 {
     if (!h) return fail_arg(nullptr, "null handle");
@@ -461,18 +503,8 @@ static int32_t ensure_points(fl_handle h, int n)
     return FL_OK;
 }
 
-// producers + 1 solver workgroup (handoff.h). FL_MAX_PRODUCERS (env, tuning aid) caps the producers.
-static int fl_max_producers()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("FL_MAX_PRODUCERS");
-        v = e ? atoi(e) : (FL_MAX_BLOCKS - 1);
-        if (v < 1 || v > FL_MAX_BLOCKS - 1) v = FL_MAX_BLOCKS - 1;
-    }
-    return v;
-}
-static inline int lio_grid(int n)
+// producers + 1 solver workgroup (handoff.h). fl_set_option(FL_OPT_MAX_PRODUCERS) caps the producers.
+static inline int lio_grid(fl_handle h, int n)
 {
     int b = (n + FL_LIO_NT - 1) / FL_LIO_NT;
     if (b < 1) b = 1;
@@ -484,7 +516,7 @@ static inline int lio_grid(int n)
     // producer lane's second point costs about as much -- 50 k pts: 7.05 us @196 (one point per lane), 6.72 @160; 65 k: 7.56 @254,
     // 6.8 @96..160; 100 k: 7.64 @255, 7.25..7.32 @128..160; 200 k: 8.05 @255, 8.27 @160.
     int cap = (n <= 130000) ? 160 : ((n <= 300000) ? 255 : ((n <= 2000000) ? 511 : (FL_MAX_BLOCKS - 1)));
-    if (cap > fl_max_producers()) cap = fl_max_producers();
+    if (h->opt_max_producers > 0 && cap > h->opt_max_producers) cap = h->opt_max_producers;
     if (b > cap) b = cap;
     return b + 1;
 }
@@ -494,7 +526,7 @@ static inline int lio_grid(int n)
 // grids and record sizes, and a stale tail could carry a matching tag once the epoch has advanced by a multiple of 63 in between.
 // Whatever lies beyond the bytes the previous launch covered is zeroed (tag 0 = "never written") before a larger launch reads it.
 static inline int vio_grid(int m);
-static inline int ik_grid(int n);
+static inline int ik_grid(fl_handle h, int n);
 static void *records_for(fl_handle h, size_t need_bytes)
 {
     if (need_bytes > h->rec_fresh_bytes)
@@ -502,9 +534,9 @@ static void *records_for(fl_handle h, size_t need_bytes)
     h->rec_fresh_bytes = need_bytes;
     return h->d_records;
 }
-static inline void *records_lio(fl_handle h) { return records_for(h, (size_t)lio_grid(h->n) * FL_SUMS18 * 8); }
+static inline void *records_lio(fl_handle h) { return records_for(h, (size_t)lio_grid(h, h->n) * FL_SUMS18 * 8); }
 static inline void *records_vio(fl_handle h) { return records_for(h, (size_t)vio_grid(h->m) * FL_SUMS18 * 8); }
-static inline void *records_ik(fl_handle h) { return records_for(h, (size_t)ik_grid(h->n) * FL_SUMS23 * 8); }
+static inline void *records_ik(fl_handle h) { return records_for(h, (size_t)ik_grid(h, h->n) * FL_SUMS23 * 8); }
 
 int32_t fl_lio_set_points(fl_handle h, const float *body_xyz, int32_t n)
 {
@@ -688,13 +720,7 @@ static int32_t read_info18(fl_handle h, fl_iter_info *info)
 }
 
 // `count` passes: one multi-pass launch when the grid is certainly co-resident (<= 256 workgroups, one per CU at most),
-// else one launch per pass. FL_NO_MULTIPASS=1 (env) forces the latter (A/B measurements).
-static bool fl_multipass_enabled()
-{
-    static int v = -1;
-    if (v < 0) v = getenv("FL_NO_MULTIPASS") ? 0 : 1;
-    return v == 1;
-}
+// else one launch per pass. fl_set_option(FL_OPT_MULTIPASS, 0) forces the latter (A/B measurements, tests).
 // per-point gate thresholds of the staged scan (fl_math.h: fl_gate_threshold): once per scan, before its first pass
 static void ensure_gates(fl_handle h)
 {
@@ -705,7 +731,7 @@ static void ensure_gates(fl_handle h)
 // may this handle use the multi-pass form for a grid of `grid` workgroups right now?
 static bool multipass_ok(fl_handle h, int grid, bool mode23 = false)
 {
-    return grid <= h->num_cus && fl_multipass_enabled() && mp_admit(h, grid, mode23 ? h->mp_capacity_ik : h->mp_capacity);
+    return grid <= h->num_cus && h->opt_multipass && mp_admit(h, grid, mode23 ? h->mp_capacity_ik : h->mp_capacity);
 }
 static void launch_lio_passes(fl_handle h, int grid, int count, int flags, bool allow_multi = true)
 {
@@ -745,7 +771,7 @@ int32_t fl_lio_iterate18(fl_handle h, int32_t count, int32_t flags, fl_iter_info
     if (!h || count < 0) return fail_arg(h, "fl_lio_iterate18: bad argument");
     if (h->n <= 0 || !h->have_nbr) return fail_arg(h, "fl_lio_iterate18: points/neighbours not staged");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    const int grid = lio_grid(h->n);
+    const int grid = lio_grid(h, h->n);
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     launch_lio_passes(h, grid, count, flags);
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
@@ -816,7 +842,7 @@ int32_t fl_lio_accumulate18(fl_handle h, double *d_sums, int32_t flags)
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     ensure_gates(h);
-    hipLaunchKernelGGL(lio18_pass_kernel<1>, dim3(lio_grid(h->n)), dim3(FL_LIO_NT), 0, h->stream, h->d_gate, h->d_plane,
+    hipLaunchKernelGGL(lio18_pass_kernel<1>, dim3(lio_grid(h, h->n)), dim3(FL_LIO_NT), 0, h->stream, h->d_gate, h->d_plane,
                        h->d_sel, h->d_normvec, h->n, h->d_dev, records_lio(h), h->d_epoch, d_sums, (int)flags);
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipGetLastError());
@@ -833,6 +859,7 @@ int32_t fl_lio_solve18(fl_handle h, const double *d_sums, int32_t flags, fl_iter
     return FL_OK;
 }
 
+#ifdef FL_INSTRUMENT     /* ---- include/fastlivo_hip_debug.h: present in libfastlivo_hip_debug.so only */
 // Debug / test aid: a foreign kernel that occupies `blocks` workgroup slots (256 threads, lds_bytes of LDS each) for ~usec
 // microseconds on a stream of its own -- what another process on the same GPU looks like to the multi-pass kernels.
 int32_t fl_debug_hog(fl_handle h, int32_t blocks, int32_t lds_bytes, int32_t usec)
@@ -846,15 +873,6 @@ int32_t fl_debug_hog(fl_handle h, int32_t blocks, int32_t lds_bytes, int32_t use
     HIPCHK(h, hipGetLastError());
     return FL_OK;
 }
-// out[0] multi-pass launches refused by the admission check (sent down the per-pass path), out[1] frames resumed after an
-// abandoned pass, out[2] workgroups of a multi-pass kernel the device holds at once, out[3] compute units
-int32_t fl_debug_counters(fl_handle h, int32_t *out4)
-{
-    if (!h || !out4) return fail_arg(h, "fl_debug_counters: null argument");
-    out4[0] = h->mp_fallbacks; out4[1] = h->mp_resumes; out4[2] = h->mp_capacity; out4[3] = h->num_cus;
-    return FL_OK;
-}
-
 // Debug / test: init + e[0] + ... + e[n-1] as one chain of float additions, by exact_chain.h's lane-parallel form (out2[0]) and
 // by one lane adding one by one (out2[1]); e is a host array.
 int32_t fl_debug_chain(fl_handle h, const float *e, int32_t n, float init, float *out2)
@@ -890,6 +908,29 @@ int32_t fl_debug_get_wall(fl_handle h, long long *out2048)
     HIPCHK(h, hipMemcpyFromSymbol(out2048, HIP_SYMBOL(g_fl_wall), sizeof(long long) * 2048));
     return FL_OK;
 }
+
+// Debug: per-workgroup wall-clock stamps of the device k-NN search launches (tools/knn_wall.py).
+int32_t fl_debug_knn_stamp(fl_handle h, int32_t enable)
+{
+    if (!h) return fail_arg(nullptr, "null handle");
+    h->dbg_knn_stamp = enable != 0;
+    return FL_OK;
+}
+
+// Fault injection for the abandon / resume machinery (tests/test_resume_gpu.py): producer workgroup 0 of the pass launched
+// `passes_ahead` passes from now does not publish its record -- the solver's bounded gather expires and the pass is abandoned.
+int32_t fl_debug_drop_record(fl_handle h, int32_t passes_ahead)
+{
+    if (!h || passes_ahead < 0) return fail_arg(h, "fl_debug_drop_record: bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    unsigned e = 0u;
+    HIPCHK(h, hipMemcpy(&e, h->d_epoch, sizeof e, hipMemcpyDeviceToHost));
+    e += (unsigned)passes_ahead;
+    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(g_fl_fault_epoch), &e, sizeof e));
+    return FL_OK;
+}
+#endif   /* FL_INSTRUMENT */
 
 #include "api_vio.inc"
 #include "api_ikfom.inc"

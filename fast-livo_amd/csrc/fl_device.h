@@ -178,9 +178,23 @@ __device__ __forceinline__ void fl_sin_omc(double x, double *s, double *omc)
     }
 }
 
-__device__ long long g_fl_stamps[64];
 #define FL_DEV18_TAIL 512                  /* bytes behind FlDev18 in its device and pinned-host allocations (fastlivo_hip.hip) */
-__device__ long long g_fl_wall[2048];   // debug: per-workgroup start/end wall clock (100 MHz)
+
+// ---- instrumentation: compiled ONLY into the -DFL_INSTRUMENT build (libfastlivo_hip_debug.so, include/fastlivo_hip_debug.h).
+// The release library carries no stamp, no debug global, no run-time branch on FL_ITER_STAMP: every site is FL_INSTR(...).
+// The finer-grained stamp sets (-DFL_GATHER_STAMPS, -DFL_IK_STAMPS, -DFL_AUDIT_STAMPS) and the A/B switches (-DFL_AB_*) of tools/
+// are further options of that build.
+#ifdef FL_INSTRUMENT
+#define FL_INSTR(...) __VA_ARGS__
+__device__ long long g_fl_stamps[64];
+__device__ long long g_fl_wall[2048];   // per-workgroup start/end wall clock (100 MHz)
+__device__ unsigned g_fl_fault_epoch;   // fault injection (fl_debug_drop_record): producer workgroup 0 drops its record of this epoch (0: never, epochs start at 1)
+#else
+#define FL_INSTR(...)
+#if defined(FL_GATHER_STAMPS) || defined(FL_IK_STAMPS) || defined(FL_AUDIT_STAMPS) || defined(FL_AB_NO_EXACT) || defined(FL_AB_NO_AUDITOR)
+#error "stamp sets and A/B switches are options of the -DFL_INSTRUMENT build"
+#endif
+#endif
 
 // ---- wavefront reduction --------------------------------------------------------------------
 // Transposing butterfly: every lane enters with V partial sums; on exit lane L holds in v[0] the
@@ -338,10 +352,12 @@ __device__ __forceinline__ double load_wt(const double *p)
 typedef unsigned int fl_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned int fl_u2 __attribute__((ext_vector_type(2)));
 
-// Optional phase timestamps (s_memtime) for tools/kstamps.py: slot i of workgroup 0 and of the last
-// workgroup. Enabled by the FL_ITER_STAMP flag; costs nothing when the flag is clear.
+// Phase timestamps for tools/kstamps.py (FL_INSTRUMENT build only): slot i of workgroup 0 and of the last workgroup, under the
+// FL_ITER_STAMP flag. The release build ignores the flag.
 #define FL_ITER_STAMP 4
+#ifdef FL_INSTRUMENT
 __device__ __forceinline__ void fl_stamp(int flags, int slot)
 {
     if ((flags & FL_ITER_STAMP) && threadIdx.x == 0) g_fl_stamps[slot] = (long long)wall_clock64();
 }
+#endif

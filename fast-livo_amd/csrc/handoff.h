@@ -71,6 +71,7 @@ template <int NV>
 __device__ __forceinline__ void publish_record(double mine, unsigned epoch, void *records)
 {
     const int tid = threadIdx.x;
+    FL_INSTR(if (blockIdx.x == 0 && epoch == g_fl_fault_epoch) return;)      // fault injection (debug build): this record never shows up
     if (tid < NV) {
         unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
         bits = (bits & ~(unsigned long long)FL_TAG_MASK) | fl_epoch_tag(epoch);

@@ -116,9 +116,9 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float4 *__re
                                                              int flags)
 {
     constexpr int NT = FL_IK_NT;
-    if (ik_pass_skipped(D, flags, 1, blockIdx.x == 0 && threadIdx.x == 0)) return;
-    const unsigned epoch = *epoch_ptr;
     const int nprod = gridDim.x - 1;
+    if (ik_pass_skipped(D, flags, 1, blockIdx.x == nprod && threadIdx.x == 0)) return;     // (counted by the solver workgroup only)
+    const unsigned epoch = *epoch_ptr;
 
     if (blockIdx.x == nprod) {
         __shared__ double s_fin[(NT / 64) * 3 * 128];          // gather_records96 (>= 2 NT of gather_records)
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_multipass_kernel(const float4 
     constexpr int NT = FL_IK_NT;
     const int nprod = gridDim.x - 1;
     const bool force = (flags & FL_ITER_FORCE) != 0;
-    if (ik_pass_skipped(D, flags, count, blockIdx.x == 0 && threadIdx.x == 0)) {
+    if (ik_pass_skipped(D, flags, count, blockIdx.x == nprod && threadIdx.x == 0)) {
         fl_mp_done(done_word, done_seq, blockIdx.x == nprod);
         return;
     }

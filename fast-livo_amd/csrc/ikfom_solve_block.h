@@ -265,6 +265,7 @@ __device__ __forceinline__ void ikfom_post(FlDev23 *__restrict__ D, const double
             D->status = L.sticky;
             L.ctl[2] = 0; L.ctl[4] = 1; L.ctl[5] = 1;
             if (bcast) fl_bcast_ctrl_at(bcast, 2 * FL_IK_BCAST_DOUBLES, 1 | 4, bepoch);
+            else D->resume_count = 1;                 // one launch per pass: THIS pass is still to do (the multi-pass loop writes count - p)
         }
         return;
     }

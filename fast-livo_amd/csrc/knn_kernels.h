@@ -265,7 +265,7 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
 {
     if ((cond & 1) && (!D->need_search || D->stop || (D->status & 8 /* FL_NUM_TIMEOUT: abandoned chain */))) return;
     const bool stamp = (cond & 2) && threadIdx.x == 0 && blockIdx.x < 512;
-    if (stamp) g_fl_wall[blockIdx.x] = (long long)wall_clock64();
+    FL_INSTR(if (stamp) g_fl_wall[blockIdx.x] = (long long)wall_clock64();)
     __shared__ int s_at[FL_KNN_QPB][5];
     __shared__ float s_d5[FL_KNN_QPB];
     __shared__ unsigned s_cstart[FL_KNN_QPB][28];
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
         if (j == 0) s_ccnt[ql][nocc] = 0x40000000u;      // terminator: the walk never advances past it
         const unsigned T = quad_sum_u32(mysum);
         __syncthreads();
-        if (stamp) g_fl_wall[512 + blockIdx.x] = (long long)wall_clock64();
+        FL_INSTR(if (stamp) g_fl_wall[512 + blockIdx.x] = (long long)wall_clock64();)
         // ---- phase 1b: the T candidates of the concatenated cell ranges are split evenly over the 4 lanes, lane j
         // takes [j*T/4, (j+1)*T/4) -- balanced however unevenly the cells are filled. One flat loop over the
         // candidates (the 16 queries of a wave have their points in different cells: a loop over cells would run
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
         }
     }
     __syncthreads();
-    if (stamp) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();
+    FL_INSTR(if (stamp) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();)
 
     // "the search for pass iters_run has been made": the pass kernels run when need_search is down or
     // searched_at == iters_run. No workgroup of this kernel reads searched_at, so one of them may write it.
@@ -438,5 +438,5 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
         for (int k = 0; k < 15; k++) nbr_out[(size_t)iq * 15 + k] = nb[k];
     }
     if (valid_out) valid_out[iq] = (uint8_t)valid;
-    if (stamp) g_fl_wall[1536 + blockIdx.x] = (long long)wall_clock64();
+    FL_INSTR(if (stamp) g_fl_wall[1536 + blockIdx.x] = (long long)wall_clock64();)
 }

@@ -111,7 +111,8 @@ __device__ __forceinline__ void fl_mp_done(unsigned *done_word, unsigned seq, bo
 
 // Is this launch a no-op?  (a) an earlier pass of the enqueued chain was ABANDONED (hand-off time-out, solve18.h): nothing runs
 // until the host has resumed the frame, and the launch adds the passes it would have run to D->resume_count so that the host
-// knows how much is left; (b) the filter stopped or waits for a search (not under FL_ITER_FORCE). Uniform over the grid.
+// knows how much is left -- by thread 0 of its SOLVER workgroup, the only writer of resume_count (a producer workgroup that becomes
+// resident after the same launch's solver has timed out sees the bit too and must not count); (b) the filter stopped or waits for a search (not under FL_ITER_FORCE). Uniform over the grid.
 __device__ __forceinline__ bool fl_pass_skipped(FlDev18 *__restrict__ D, int flags, int passes, bool counter_thread)
 {
     if (D->status & FL_NUM_TIMEOUT) {
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(FL_LIO_NT, FL_LIO_PASS_WAVES) void lio18_pass_kerne
                                                               int flags)
 {
     constexpr int NT = FL_LIO_NT;
-    if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();
+    FL_INSTR(if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();)
     const int nprod = gridDim.x - 1;
     // Software prefetch: the first point's inputs do not depend on the state, so their (vector)
     // loads are issued BEFORE the scalar loads of the control words and the state -- one memory
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(FL_LIO_NT, FL_LIO_PASS_WAVES) void lio18_pass_kerne
     }
     double pf_solver = 0.0;
     if (MODE == 0 && blockIdx.x == nprod) pf_solver = eskf18_prefetch_issue(D);
-    if (fl_pass_skipped(D, flags, 1, blockIdx.x == 0 && threadIdx.x == 0)) return;
+    if (fl_pass_skipped(D, flags, 1, blockIdx.x == nprod && threadIdx.x == 0)) return;
     const unsigned epoch = *epoch_ptr;
 
     if (blockIdx.x == nprod) {
@@ -160,12 +161,12 @@ __global__ __launch_bounds__(FL_LIO_NT, FL_LIO_PASS_WAVES) void lio18_pass_kerne
         __shared__ double s_fin[2 * NT];
         __shared__ double s_sums[FL_SUMS18];
         __shared__ FlSolveLds s_solve;
-        fl_stamp(flags, 8);
+        FL_INSTR(fl_stamp(flags, 8);)
         FlSolveRegs G;
         if (MODE == 0) { eskf18_prefetch_commit(pf_solver, s_solve); eskf18_load_regs(s_solve, G); }
-        fl_stamp(flags, 9);
+        FL_INSTR(fl_stamp(flags, 9);)
         int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
-        fl_stamp(flags, 10);
+        FL_INSTR(fl_stamp(flags, 10);)
         if (threadIdx.x == 0) *epoch_ptr = epoch + 1u;
         if (MODE == 0 && D->xchg_world > 1) {               // sharded form: totals over the ranks (handoff.h)
             __shared__ double s_xchg[FL_MAX_PEERS * 32];
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(FL_LIO_NT, FL_LIO_PASS_WAVES) void lio18_pass_kerne
         } else {
             if (threadIdx.x < FL_SUMS18) sums_out[threadIdx.x] = s_sums[threadIdx.x];
         }
-        fl_stamp(flags, 11);
+        FL_INSTR(fl_stamp(flags, 11);)
         return;
     }
 
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(FL_LIO_NT, FL_LIO_PASS_WAVES) void lio18_pass_kerne
     double v[FL_SUMS18];
 #pragma unroll
     for (int k = 0; k < FL_SUMS18; k++) v[k] = 0.0;
-    if (blockIdx.x == 0) fl_stamp(flags, 0);
+    FL_INSTR(if (blockIdx.x == 0) fl_stamp(flags, 0);)
 
     // rolling software prefetch: the next point's inputs (same lane, one grid stride ahead) are requested before the current
     // point's ~150 fp64 instructions, so that with several points per lane (n > 65 k) the loop is bound by issue/HBM, not by
@@ -227,11 +228,11 @@ __global__ __launch_bounds__(FL_LIO_NT, FL_LIO_PASS_WAVES) void lio18_pass_kerne
             v[FL_S_RES2] += (double)pd2 * (double)pd2;
         }
     }
-    if (blockIdx.x == 0) fl_stamp(flags, 1);
+    FL_INSTR(if (blockIdx.x == 0) fl_stamp(flags, 1);)
     const double mine = block_reduce_record<NT, FL_SUMS18>(v, s_red);
     publish_record<FL_SUMS18>(mine, epoch, records);
-    if (blockIdx.x == 0) fl_stamp(flags, 2);
-    if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();
+    FL_INSTR(if (blockIdx.x == 0) fl_stamp(flags, 2);)
+    FL_INSTR(if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();)
 }
 
 // -------------------------------------------------------------------------------------------- K1m
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(FL_LIO_NT, 2) void lio18_multipass_kernel(const flo
     constexpr int NT = FL_LIO_NT;
     const int nprod = gridDim.x - 1;
     const bool force = (flags & FL_ITER_FORCE) != 0;
-    if (fl_pass_skipped(D, flags, count, blockIdx.x == 0 && threadIdx.x == 0)) {
+    if (fl_pass_skipped(D, flags, count, blockIdx.x == nprod && threadIdx.x == 0)) {
         fl_mp_done(done_word, done_seq, blockIdx.x == nprod);
         return;
     }
@@ -273,14 +274,14 @@ __global__ __launch_bounds__(FL_LIO_NT, 2) void lio18_multipass_kernel(const flo
             const unsigned epoch = epoch0 + (unsigned)p;
             FlSolveRegs G;
             eskf18_load_regs(s_solve, G);                        // solve operands into wave 0's registers while the producers work
-            if (p == 5) fl_stamp(flags, 16);
+            FL_INSTR(if (p == 5) fl_stamp(flags, 16);)
             int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
             if (PV.world > 1) gst |= peer_allreduce32(PV, xe0 + (unsigned)p, s_sums, s_xchg);      // sharded form: totals over the ranks
-            if (p == 5) fl_stamp(flags, 17);
+            FL_INSTR(if (p == 5) fl_stamp(flags, 17);)
             eskf18_solve_block<FL_EPI_LIO>(D, s_sums, s_solve, G, gst, bcast, epoch + 1u, FlVioExact{}, nullptr, (p == 5) ? (flags & FL_ITER_STAMP) : 0);   // wave 0 publishes pose + control word
-            if (p == 5) fl_stamp(flags, 35);
+            FL_INSTR(if (p == 5) fl_stamp(flags, 35);)
             __syncthreads();
-            if (p == 5) fl_stamp(flags, 18);
+            FL_INSTR(if (p == 5) fl_stamp(flags, 18);)
             done = p + 1;
             const int ctrl = s_solve.ctrl;                       // bit 2: a hand-off time-out abandoned the pass and ends the launch
             if (ctrl & 4) {
@@ -320,10 +321,10 @@ __global__ __launch_bounds__(FL_LIO_NT, 2) void lio18_multipass_kernel(const flo
             pf_pl = plane[i_first];
         }
         if (ps > 0) {
-            if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 20 + 4 * (ps - 5));
+            FL_INSTR(if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 20 + 4 * (ps - 5));)
             bcast_wait(bcast, epoch, s_pose, &s_ctrl, spin_limit);
             __syncthreads();
-            if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 21 + 4 * (ps - 5));
+            FL_INSTR(if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 21 + 4 * (ps - 5));)
             if (!force && (s_ctrl & 3)) break;
             if (s_ctrl & 4) break;
 #pragma unroll
@@ -361,12 +362,12 @@ __global__ __launch_bounds__(FL_LIO_NT, 2) void lio18_multipass_kernel(const flo
                 v[FL_S_RES2] += (double)pd2 * (double)pd2;
             }
         }
-        if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 22 + 4 * (ps - 5));
+        FL_INSTR(if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 22 + 4 * (ps - 5));)
         const double mine = block_reduce_record<NT, FL_SUMS18>(v, s_red);
         publish_record<FL_SUMS18>(mine, epoch, records);
         __syncthreads();          // s_red / s_pose are reused by the next pass
-        if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 23 + 4 * (ps - 5));
-        if ((flags & FL_ITER_STAMP) && ps == 5 && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();   // every producer's publish time
+        FL_INSTR(if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 23 + 4 * (ps - 5));)
+        FL_INSTR(if ((flags & FL_ITER_STAMP) && ps == 5 && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();)   // every producer's publish time
     }
 }
 

@@ -428,6 +428,7 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
                 D->status = L.sticky;                 // every kernel of the chain checks this bit first: nothing else runs (D->stop stays as it is)
                 L.ctrl = 1 | 4;
                 if (bcast) fl_bcast_ctrl(bcast, 1 | 4, bepoch);
+                else D->resume_count = 1;             // one launch per pass: THIS pass is still to do (the multi-pass loops write count - p)
             }
         }
         return;
@@ -528,7 +529,7 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
 
     double dl, z[6];
     int bad = 0;
-    fl_stamp(dbg, 30);
+    FL_INSTR(fl_stamp(dbg, 30);)
     {
 #pragma clang fp contract(fast)
         const double sign = (KIND == FL_EPI_VIO) ? -1.0 : 1.0;
@@ -549,7 +550,7 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
             w[i] = b;
         }
 #undef FL_SIDX
-        if (dbg) { double keep = w[5] + c[5][0]; asm volatile("" ::"v"(keep)); fl_stamp(dbg, 31); }
+        FL_INSTR(if (dbg) { double keep = w[5] + c[5][0]; asm volatile("" ::"v"(keep)); fl_stamp(dbg, 31); })
         // right-looking LDL^T on the augmented lower triangle: after column j, c[i][j] = L_ij and w carries D^-1 L^-1 b
 #pragma unroll
         for (int j = 0; j < 6; j++) {
@@ -569,7 +570,7 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
                 w[i] = fma(-wj, u[i], w[i]);
             }
         }
-        if (dbg) { double keep = w[5] + c[5][4]; asm volatile("" ::"v"(keep)); fl_stamp(dbg, 32); }
+        FL_INSTR(if (dbg) { double keep = w[5] + c[5][4]; asm volatile("" ::"v"(keep)); fl_stamp(dbg, 32); })
         // back substitution L^T z = w
 #pragma unroll
         for (int i = 5; i >= 0; i--) {
@@ -583,7 +584,7 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
 #pragma unroll
         for (int cc = 0; cc < 6; cc++) dl = fma(G.trow[cc], z[cc], dl);
     }
-    if (dbg) { asm volatile("" ::"v"(dl)); fl_stamp(dbg, 33); }
+    FL_INSTR(if (dbg) { asm volatile("" ::"v"(dl)); fl_stamp(dbg, 33); })
     if (lane < 18) D->solution[lane] = dl;
     int st = bad;
     if (__ballot(lane < 18 && !(fabs(dl) <= DBL_MAX)) != 0ull) st |= 2;
@@ -643,7 +644,7 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
         const double dsh = __shfl(dl, (lane >= 6) ? lane - 6 : 0, FL_WAVE);
         if (lane >= 9 && lane < 24) xnew = G.xl + dsh;
     }
-    if (dbg) { asm volatile("" ::"v"(xnew)); fl_stamp(dbg, 34); }
+    FL_INSTR(if (dbg) { asm volatile("" ::"v"(xnew)); fl_stamp(dbg, 34); })
     if (lane < 24) {
         D->x[lane] = xnew;
         if (lane < 12) {
@@ -656,7 +657,7 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
     if (lane < FL_SUMS18) D->sums_acc[lane] = s_sums[lane];   // LIO: last executed pass ; VIO: last accepted pass
     if (KIND == FL_EPI_VIO && lane < 24) D->xold[lane] = G.xl;   // old_state = *state (:863)
 
-    fl_stamp(dbg, 36);
+    FL_INSTR(fl_stamp(dbg, 36);)
     // ---- judgement (uniform arithmetic; lane 0 writes)
     if (KIND == FL_EPI_LIO) {
         // laserMapping.cpp:1688-1728
@@ -668,7 +669,7 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
         const int ctrl = (stop ? 1 : 0) | (need_search ? 2 : 0);
         const int neff_lt1 = (s_sums[FL_S_NEFF] < 1.0) ? 4 : 0;
         __builtin_amdgcn_wave_barrier();
-        if (dbg) { asm volatile("" ::"v"(ctrl + neff_lt1)); fl_stamp(dbg, 37); }
+        FL_INSTR(if (dbg) { asm volatile("" ::"v"(ctrl + neff_lt1)); fl_stamp(dbg, 37); })
         if (lane == 0) {
             L.rematch = rematch; L.iterCount = it + 1; L.iters_run = iters;
             L.ctrl = ctrl;

@@ -204,13 +204,8 @@ __global__ __launch_bounds__(128) void vio_prepare_kernel(FlDev18 *__restrict__ 
 #else
 #define FL_AUDIT_STAMP(i, v) do { } while (0)
 #endif
-#ifdef FL_AB_AUDITOR_FIRST
-#define FL_VIO_SOLVER_BLOCK(nprod) ((nprod) + 1)
-#define FL_VIO_AUDITOR_BLOCK(nprod) (nprod)
-#else
 #define FL_VIO_SOLVER_BLOCK(nprod) (nprod)
 #define FL_VIO_AUDITOR_BLOCK(nprod) ((nprod) + 1)
-#endif
 #define FL_VIO_PPL (64 / FL_VIO_LPP)          /* pixels per lane */
 #define FL_VIO_GPW (64 / FL_VIO_LPP)          /* patches (lane groups) per wavefront */
 
@@ -251,9 +246,6 @@ __device__ __forceinline__ void vio_patch_error(const float *r, int hl, bool act
                                                 unsigned long long *__restrict__ err_words, unsigned epoch)
 {
     if (hl != 0 || !active) return;
-#ifdef FL_NO_PATCH_CHAIN
-    return;
-#endif
     float pe = 0.0f;
 #pragma unroll
     for (int k = 0; k < 64; k += 16) {               // operands from LDS sixteen at a time: the chain waits for the adder only
@@ -270,11 +262,7 @@ __device__ __forceinline__ void vio_patch_error(const float *r, int hl, bool act
         }
     }
     errors[i] = pe;
-#ifndef FL_AB_NO_ERRWORDS
     if (err_words)
-#else
-    if (false)
-#endif
         __hip_atomic_store(err_words + i, ((unsigned long long)__float_as_uint(pe) << 32) | (unsigned long long)epoch, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -318,7 +306,7 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
 #pragma unroll
     for (int k = 0; k < FL_SUMS18; k++) v[k] = 0.0;
 
-    if (blockIdx.x == 0) fl_stamp(flags, 0);
+    FL_INSTR(if (blockIdx.x == 0) fl_stamp(flags, 0);)
     // trip count uniform over the wave: all lane groups iterate together, an inactive group (m not a multiple of GPW) computes
     // on patch 0 and contributes nothing
     int def_i = 0;
@@ -334,7 +322,7 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
         else { ps[0] = pos[ii * 3 + 0]; ps[1] = pos[ii * 3 + 1]; ps[2] = pos[ii * 3 + 2]; }
         FlPatchGeom g;
         fl_patch_geom(vc, Rcw, Pcw, ps, scale, g);
-        if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(g.wbr), "v"(g.u_i)); fl_stamp(flags, 40); }
+        FL_INSTR(if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(g.wbr), "v"(g.u_i)); fl_stamp(flags, 40); })
         const int col0 = g.u_i + (yc - 4) * scale;
         float t[PPL][4][4];
         // taps span [anchor - 5*scale, anchor + 5*scale]: no clamping needed inside the image
@@ -378,10 +366,10 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
 #pragma unroll
             for (int k = 0; k < PPL; k++) refv[k] = ref[(size_t)ii * 192 + 64 * level + hl + LPP * k];
         }
-        if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(t[0][1][1] + t[PPL - 1][2][2] + refv[PPL - 1])); fl_stamp(flags, 41); }
+        FL_INSTR(if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(t[0][1][1] + t[PPL - 1][2][2] + refv[PPL - 1])); fl_stamp(flags, 41); })
         double M[2][6];
         fl_patch_M(g, vc.Jdphi_dR, vc.Jdp_dR, Rcw, M);          // uniform per lane group, overlaps the tap loads
-        if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(M[1][5] + M[0][0])); fl_stamp(flags, 42); }
+        FL_INSTR(if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(M[1][5] + M[0][0])); fl_stamp(flags, 42); })
         double w8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int px = 0; px < PPL; px++) {
@@ -392,17 +380,17 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
             w8[0] += dud * dud; w8[1] += dud * dvd; w8[2] += dvd * dvd;
             w8[3] += dud * res; w8[4] += dvd * res; w8[5] += res * res;
         }
-        if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(w8[5] + w8[0])); fl_stamp(flags, 43); }
+        FL_INSTR(if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(w8[5] + w8[0])); fl_stamp(flags, 43); })
         double T6[6];
         if (LPP == 32) half_sum6(w8, lane, T6); else row_sum6(w8, T6);
-        if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(T6[5] + T6[0])); fl_stamp(flags, 44); }
+        FL_INSTR(if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(T6[5] + T6[0])); fl_stamp(flags, 44); })
         // patch_error exactly as the reference rounds it (lidar_selection.cpp:849: float patch_error; patch_error += res*res with a
         // double res): one lane per patch replays the 64 additions in pixel order (vio_patch_error). It feeds only the errors[]
         // output and the rare exact accept test, never the record: for the wave's LAST patch group it is deferred until the record is
         // published, off the hand-off's critical path (the residuals wait in LDS).
         const bool last_iter = (ib + nprod * WPB * GPW >= m);
         if (active) fl_patch_accum(v, M, T6);
-        if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(v[0] + v[26])); fl_stamp(flags, 45); }
+        FL_INSTR(if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(v[0] + v[26])); fl_stamp(flags, 45); })
         if (last_iter) { def_i = i; def_active = active; }
         else {
             __builtin_amdgcn_wave_barrier();
@@ -410,7 +398,7 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
             __builtin_amdgcn_wave_barrier();
         }
     }
-    if (blockIdx.x == 0) fl_stamp(flags, 1);
+    FL_INSTR(if (blockIdx.x == 0) fl_stamp(flags, 1);)
     // every lane of a lane group holds the same record: its first lane stores it, 32 threads add the partials up
     if (hl == 0) {
 #pragma unroll
@@ -467,12 +455,12 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     constexpr int WPB = NT / 64;
     const int nprod = gridDim.x - 2;              // then the solver and the auditor (FL_VIO_SOLVER_BLOCK / FL_VIO_AUDITOR_BLOCK)
     const int solver_block = FL_VIO_SOLVER_BLOCK(nprod), auditor_block = FL_VIO_AUDITOR_BLOCK(nprod);
-    if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();
+    FL_INSTR(if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();)
     const FlVioFirst pf = vio_prefetch_first(ref, pos, slevel, m, level_arg, nprod);
     double pf_solver = 0.0;
     if (MODE == 0 && blockIdx.x == solver_block) pf_solver = eskf18_prefetch_issue(D);
     if (D->status & FL_NUM_TIMEOUT) {             // an earlier pass of the chain was abandoned (solve18.h): the host resumes
-        if (blockIdx.x == 0 && threadIdx.x == 0) D->resume_count += 1;
+        if (blockIdx.x == solver_block && threadIdx.x == 0) D->resume_count += 1;      // (the solver workgroup is the only writer)
         return;
     }
     if (!(flags & FL_ITER_FORCE) && D->stop) return;
@@ -490,12 +478,12 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
         __shared__ double s_fin[2 * NT];
         __shared__ double s_sums[FL_SUMS18];
         __shared__ FlSolveLds s_solve;
-        fl_stamp(flags, 8);
+        FL_INSTR(fl_stamp(flags, 8);)
         FlSolveRegs G;
         if (MODE == 0) { eskf18_prefetch_commit(pf_solver, s_solve); eskf18_load_regs(s_solve, G, VC); }
-        fl_stamp(flags, 9);
+        FL_INSTR(fl_stamp(flags, 9);)
         int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
-        fl_stamp(flags, 10);
+        FL_INSTR(fl_stamp(flags, 10);)
         if (threadIdx.x == 0) *epoch_ptr = epoch + 1u;
         const int world = (MODE == 0) ? D->xchg_world : 1;
         unsigned xe_pass = 0u;                              // exchange epoch of this pass (tag of the replay mail, solve18.h)
@@ -517,7 +505,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
         } else {
             if (threadIdx.x < FL_SUMS18) sums_out[threadIdx.x] = s_sums[threadIdx.x];
         }
-        fl_stamp(flags, 11);
+        FL_INSTR(fl_stamp(flags, 11);)
         return;
     }
 
@@ -534,10 +522,11 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     __shared__ __attribute__((aligned(16))) float s_res[FL_VIO_GPW * WPB * 64];
     unsigned long long *ew = D->err_words ? D->err_words + (size_t)(D->iters_run & 1) * D->err_cap : nullptr;
     vio_produce(img, ref, pos, slevel, errors, m, level_arg, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags, ew, s_res);
-    if (blockIdx.x == 0) fl_stamp(flags, 2);
-    if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();
+    FL_INSTR(if (blockIdx.x == 0) fl_stamp(flags, 2);)
+    FL_INSTR(if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();)
 }
 
+#ifdef FL_INSTRUMENT
 // Debug / test: exact_chain.h's lane-parallel chain beside the plain one-lane chain over the same floats
 __global__ __launch_bounds__(256) void fl_chain_debug_kernel(const float *__restrict__ e, int n, float init, float *__restrict__ out2)
 {
@@ -558,6 +547,7 @@ __global__ __launch_bounds__(256) void fl_chain_debug_kernel(const float *__rest
     if (threadIdx.x == 0) out2[0] = f;
     if (threadIdx.x == 64) out2[1] = g;
 }
+#endif
 
 struct FlVioLevelInfo {
     double solution[18];
@@ -591,7 +581,7 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
     const bool force = (flags & FL_ITER_FORCE) != 0;
     const bool begin = begin_residual >= 0.f;
     if (D->status & FL_NUM_TIMEOUT) {             // an earlier pass of the chain was abandoned: nothing runs until the host has resumed
-        if (blockIdx.x == 0 && threadIdx.x == 0) D->resume_count += count;
+        if (blockIdx.x == solver_block && threadIdx.x == 0) D->resume_count += count;  // (the solver workgroup is the only writer)
         fl_mp_done(done_word, done_seq, blockIdx.x == solver_block);
         return;
     }
@@ -650,21 +640,21 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
             const unsigned epoch = epoch0 + (unsigned)p;
             FlSolveRegs G;
             eskf18_load_regs(s_solve, G, VC);                    // solve operands into wave 0's registers while the producers work
-            if (p == 5) fl_stamp(flags, 16);
+            FL_INSTR(if (p == 5) fl_stamp(flags, 16);)
             int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
             if (PV.world > 1) gst |= peer_allreduce32(PV, xe0 + (unsigned)p, s_sums, s_xchg);      // sharded form: totals over the ranks
             FL_AUDIT_STAMP(16 * p + 8, wall_clock64());
-            if (p == 5) fl_stamp(flags, 17);
+            FL_INSTR(if (p == 5) fl_stamp(flags, 17);)
             FlVioExact ex;
             ex.words = err_base; ex.m = m; ex.cap = err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !force;
             ex.own = PV.own; ex.peer = PV.peer; ex.rank = PV.rank; ex.world = PV.world; ex.xe = xe0 + (unsigned)p;
             // wave 0 solves, derives the camera pose of the new state and publishes it (+ the control word) for the producers
             eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, gst, bcast, epoch + 1u, ex, VC, (p == 5) ? (flags & FL_ITER_STAMP) : 0);
-            if (p == 5) fl_stamp(flags, 35);
+            FL_INSTR(if (p == 5) fl_stamp(flags, 35);)
             __syncthreads();
             FL_AUDIT_STAMP(16 * p + 9, wall_clock64());
             FL_AUDIT_STAMP(16 * p + 10, s_solve.fragile + 2 * s_solve.audited + 4 * s_solve.exact_timeout);
-            if (p == 5) fl_stamp(flags, 18);
+            FL_INSTR(if (p == 5) fl_stamp(flags, 18);)
             done = p + 1;
             const int ctrl = s_solve.ctrl;
             if (ctrl & 4) {                                      // abandoned (hand-off time-out): this pass and the rest are still to do
@@ -705,10 +695,10 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
         const unsigned epoch = epoch0 + (unsigned)ps;
         const FlVioFirst pf = vio_prefetch_first(ref, pos, slevel, m, level, nprod);
         if (ps > 0) {
-            if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 20 + 4 * (ps - 5));
+            FL_INSTR(if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 20 + 4 * (ps - 5));)
             bcast_wait(bcast, epoch, s_pose, &s_ctrl, spin_limit);
             __syncthreads();
-            if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 21 + 4 * (ps - 5));
+            FL_INSTR(if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 21 + 4 * (ps - 5));)
             if (!force && (s_ctrl & 3)) break;
             if (s_ctrl & 4) break;
 #pragma unroll
@@ -718,7 +708,7 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
         }
         vio_produce(img, ref, pos, slevel, errors, m, level, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records,
                     (ps == 5 || ps == 6) ? 0 : (flags & ~FL_ITER_STAMP), err_base ? err_base + (size_t)((pass0 + ps) & 1) * err_cap : nullptr, s_res);
-        if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 23 + 4 * (ps - 5));
+        FL_INSTR(if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 23 + 4 * (ps - 5));)
         __syncthreads();
     }
 }

@@ -126,24 +126,34 @@ int32_t fl_sync(fl_handle h);
  * (PointCloudXYZI -> float xyz); it can write straight into a buffer obtained here. */
 int32_t fl_host_alloc(fl_handle h, size_t bytes, void **out);
 int32_t fl_host_free(fl_handle h, void *p);
-/* Debug: per-workgroup start/end wall-clock stamps (100 MHz) of the last stamped pass / search launch. */
-int32_t fl_debug_get_wall(fl_handle h, long long *out2048);
 /* Times the last fl_lio_iterate18 / fl_vio_iterate batch with HIP events on the handle's stream. */
 int32_t fl_set_timing(fl_handle h, int32_t enable);
 int32_t fl_get_last_kernel_ms(fl_handle h, float *ms);
-/* Debug / test aids for the resident-grid assumption of the multi-pass kernels: a foreign kernel that
- * occupies `blocks` workgroup slots (256 threads + lds_bytes of LDS each) for ~usec microseconds on a stream of its own, and the
- * counters {multi-pass launches the admission check sent down the per-pass path, frames resumed after an abandoned pass,
- * workgroups of a multi-pass kernel the device can hold, compute units}. */
-int32_t fl_debug_hog(fl_handle h, int32_t blocks, int32_t lds_bytes, int32_t usec);
-int32_t fl_debug_counters(fl_handle h, int32_t *out4);
-/* Debug / test aid for the exact VIO accept test: init + e[0] + ... + e[n-1] (host array) as ONE chain of float additions, as the
- * reference's `error += patch_error` (lidar_selection.cpp:857) rounds it: out2[0] by the lane-parallel form the kernels use
- * (csrc/exact_chain.h), out2[1] by one lane adding one by one. They must be the same bits. */
-int32_t fl_debug_chain(fl_handle h, const float *e, int32_t n, float init, float *out2);
-/* Debug: shader-clock phase stamps of the last pass launched with flag FL_ITER_STAMP (64 slots). */
-#define FL_ITER_STAMP 4
-int32_t fl_debug_get_stamps(fl_handle h, long long *out64);
+/* Per-handle options (all have working defaults; none is read from the environment):
+ *   FL_OPT_MULTIPASS      1 (default): fl_*_iterate(count > 1) and the frame drivers run the passes of a frame segment as ONE multi-pass
+ *                         launch when its workgroups fit the device; 0: always one launch per pass.
+ *   FL_OPT_MAX_PRODUCERS  cap of the producer workgroups of a Mode-18 LIO pass (0 = the built-in size policy).
+ *   FL_OPT_IK_PRODUCERS   the same for the Mode-23 pass (0 = 128).
+ *   FL_OPT_MP_CAPACITY    workgroups of a multi-pass kernel the device is assumed to hold at once (0 = occupancy query x CUs);
+ *                         lowering it sends concurrent launches down the per-pass path earlier.
+ *   FL_OPT_VIO_WHOLE_CU   1 (default): a VIO multi-pass launch that has the device to itself uses the one-workgroup-per-CU register
+ *                         budget; 0: always the co-resident form. Results are bit-identical either way. */
+#define FL_OPT_MULTIPASS 1
+#define FL_OPT_MAX_PRODUCERS 2
+#define FL_OPT_IK_PRODUCERS 3
+#define FL_OPT_MP_CAPACITY 4
+#define FL_OPT_VIO_WHOLE_CU 5
+int32_t fl_set_option(fl_handle h, int32_t option, int32_t value);
+/* Counters of the resident-grid machinery of the multi-pass kernels. */
+typedef struct fl_diagnostics {
+    int32_t multipass_fallbacks;   /* multi-pass launches the admission check sent down the one-launch-per-pass path */
+    int32_t frames_resumed;        /* frames / iterate calls resumed per pass after an ABANDONED pass (FL_NUM_TIMEOUT) */
+    int32_t multipass_capacity;    /* workgroups of a multi-pass kernel the device can hold at once */
+    int32_t compute_units;
+} fl_diagnostics;
+int32_t fl_get_diagnostics(fl_handle h, fl_diagnostics *out);
+/* Flag bit 4 of the iterate calls (FL_ITER_STAMP) is reserved for the instrumented build (include/fastlivo_hip_debug.h); this
+ * library ignores it. */
 
 /* ------------------------------------------------------------------------------------------------
  * LIO staging (both modes)

@@ -1,0 +1,39 @@
+/*
+ * include/fastlivo_hip_debug.h -- measurement and test aids of the INSTRUMENTED build only.
+ *
+ * libfastlivo_hip_debug.so = the same sources compiled with -DFL_INSTRUMENT (fast-livo_amd/build.sh debug): every entry point of
+ * include/fastlivo_hip.h plus the ones below, phase stamps inside the pass kernels (flag FL_ITER_STAMP) and a fault injector.
+ * The release library (libfastlivo_hip.so) exports none of these and carries no stamp code. tools/ and the tests of the
+ * abandon / resume machinery and of the exact float chain load this build; nothing else does.
+ */
+#ifndef FASTLIVO_HIP_DEBUG_H
+#define FASTLIVO_HIP_DEBUG_H
+
+#include "fastlivo_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Phase stamps (100 MHz wall clock) of the last pass launched with flag FL_ITER_STAMP: 64 slots of workgroup 0 / the solver. */
+#define FL_ITER_STAMP 4
+int32_t fl_debug_get_stamps(fl_handle h, long long *out64);
+/* Per-workgroup start/end wall-clock stamps of the last stamped pass / search launch. */
+int32_t fl_debug_get_wall(fl_handle h, long long *out2048);
+/* Stamp the device k-NN search launches of this handle (tools/knn_wall.py). */
+int32_t fl_debug_knn_stamp(fl_handle h, int32_t enable);
+/* A foreign kernel that occupies `blocks` workgroup slots (256 threads + lds_bytes of LDS each) for ~usec microseconds on a stream
+ * of its own: what another process on the same GPU looks like to the multi-pass kernels (tests/test_coresidency_gpu.py). */
+int32_t fl_debug_hog(fl_handle h, int32_t blocks, int32_t lds_bytes, int32_t usec);
+/* init + e[0] + ... + e[n-1] (host array) as ONE chain of float additions, as the reference's `error += patch_error`
+ * (lidar_selection.cpp:857) rounds it: out2[0] by the lane-parallel form the kernels use (csrc/exact_chain.h), out2[1] by one lane
+ * adding one by one. They must be the same bits. */
+int32_t fl_debug_chain(fl_handle h, const float *e, int32_t n, float init, float *out2);
+/* Fault injection: producer workgroup 0 of the pass launched `passes_ahead` passes from now (0 = the next one) does not publish its
+ * record, so that pass's bounded gather expires and the pass is ABANDONED (FL_NUM_TIMEOUT): exercises the resume paths. */
+int32_t fl_debug_drop_record(fl_handle h, int32_t passes_ahead);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

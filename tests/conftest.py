@@ -8,6 +8,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Several ranks of a sharded frame in ONE process on ONE device (tests/test_p2p_gpu.py, world up to 8) wait for each other inside
+# their kernels: each rank's stream needs a hardware queue of its own (HIP maps streams onto GPU_MAX_HW_QUEUES = 4 queues by default).
+# Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import fastlivo  # noqa: E402,F401  registers the package fast_livo_amd
 
 

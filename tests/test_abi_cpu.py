@@ -25,6 +25,25 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(L, name), name
 
 
+def test_debug_entry_points_live_in_the_instrumented_build_only():
+    """include/fastlivo_hip_debug.h: declared == bound == exported by libfastlivo_hip_debug.so; the release library exports no
+    fl_debug_* symbol, no stamp global, and reads nothing from the environment."""
+    import subprocess
+    hdr = open(os.path.join(REPO_ROOT, "include", "fastlivo_hip_debug.h")).read()
+    declared = set(re.findall(r"^\s*int32_t\s+(fl_debug_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    assert declared == set(capi.DEBUG_SYMBOLS), declared ^ set(capi.DEBUG_SYMBOLS)
+    Ld = capi.lib(debug=True)
+    for name in list(declared) + list(capi.SYMBOLS):
+        assert hasattr(Ld, name), name
+    dyn = subprocess.check_output(["nm", "-D", "--defined-only", LIB_PATH], text=True)
+    assert "fl_debug_" not in dyn
+    exported = set(re.findall(r"\bT (fl_[a-z0-9_]+)$", dyn, flags=re.M))
+    assert exported == set(capi.SYMBOLS), exported ^ set(capi.SYMBOLS)
+    csrc = os.path.join(REPO_ROOT, "fast-livo_amd", "csrc")           # no tuning knob comes from the environment (fl_set_option)
+    for f in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+
+
 def test_struct_sizes_match_header():
     import ctypes as C
     assert C.sizeof(capi.State18) == 8 * (24 + 324)
@@ -39,7 +58,7 @@ def test_struct_layouts_match_a_c_compiler(tmp_path):
     import subprocess
     pairs = {"fl_config": capi.Config, "fl_state18": capi.State18, "fl_state23": capi.State23, "fl_iter_info": capi.IterInfo,
              "fl_map_info": capi.MapInfo, "fl_imu_sample": capi.ImuSample, "fl_pose6d": capi.Pose6d, "fl_imu_proc": capi.ImuProc,
-             "fl_patch_candidate": capi.PatchCandidate, "fl_vmap_obs": capi.VmapObs}
+             "fl_patch_candidate": capi.PatchCandidate, "fl_vmap_obs": capi.VmapObs, "fl_diagnostics": capi.Diagnostics}
     hdr = open(os.path.join(REPO_ROOT, "include", "fastlivo_hip.h")).read()
     declared = set(re.findall(r"}\s*(fl_[a-z0-9_]+);", hdr))
     assert declared == set(pairs), declared ^ set(pairs)

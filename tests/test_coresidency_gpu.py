@@ -34,7 +34,7 @@ def test_six_concurrent_filters_and_a_foreign_kernel(gpu_lib, scene):
     xv_ref = capi.state18_from_frame(fr)
     h0.vio_compute_j(xv_ref, capi.state18_from_frame(fr))
     assert i_ref.status == 0
-    cap = h0.debug_counters()
+    cap = h0.diagnostics()
     h0.close()
 
     # ---- six filters at once, each on its own handle/stream/thread; a foreign kernel takes most of the chip meanwhile
@@ -61,7 +61,8 @@ def test_six_concurrent_filters_and_a_foreign_kernel(gpu_lib, scene):
             errors.append((k, repr(e)))
     ts = [threading.Thread(target=work, args=(k,)) for k in range(6)]
     # the foreign kernel: 3/4 of the CUs, nearly all of their LDS, for 150 ms
-    hs[0].debug_hog(int(cap["cus"] * 3 // 4), 150 * 1024, 150000)
+    hog = capi.Handle(capi.config_from_frames(fr, vf, max_iterations=10), debug=True)   # the hog lives in the instrumented build only
+    hog.debug_hog(int(cap["cus"] * 3 // 4), 150 * 1024, 150000)
     for t in ts:
         t.start()
     for t in ts:
@@ -75,7 +76,7 @@ def test_six_concurrent_filters_and_a_foreign_kernel(gpu_lib, scene):
             assert np.array_equal(xvio, xv_ref.vec())
     tot = dict(fallbacks=0, resumes=0)
     for h in hs:
-        c = h.debug_counters()
+        c = h.diagnostics()
         tot["fallbacks"] += c["fallbacks"]; tot["resumes"] += c["resumes"]
         h.close()
     print(f"\n[co-residency] capacity {cap['capacity']} workgroups on {cap['cus']} CUs; 6 filters x {frames} frames: "
@@ -92,16 +93,17 @@ def test_abandoned_pass_is_resumed_with_identical_result(gpu_lib, scene):
     h = _frame(capi, fr, scene)
     x_ref = capi.state18_from_frame(fr)
     i_ref = h.lio_frame18_dev(x_ref, fr.body_xyz)
-    c = h.debug_counters()
+    c = h.diagnostics()
     # ALL of the LDS of 3/4 of the CUs taken for 120 ms: the 197 workgroups of the launch find room on 64 CUs only, those that get on
     # the device wait for the others in vain (with every CU taken the launch would simply queue behind the foreign kernel: no wait
     # expires, nothing to resume)
-    h.debug_hog(c["cus"] * 3 // 4, 160 * 1024, 120000)
+    hog = capi.Handle(capi.config_from_frames(fr), debug=True)      # the foreign kernel comes from the instrumented build
+    hog.debug_hog(c["cus"] * 3 // 4, 160 * 1024, 120000)
     import time
     time.sleep(0.02)                                        # (the foreign kernel is on the device before the frame is enqueued)
     x = capi.state18_from_frame(fr)
     info = h.lio_frame18_dev(x, fr.body_xyz)
-    c2 = h.debug_counters()
+    c2 = h.diagnostics()
     assert info.status == 0 and info.iterations == i_ref.iterations
     assert np.array_equal(x.vec(), x_ref.vec()) and np.array_equal(x.cov_np(), x_ref.cov_np())
     print(f"\n[co-residency] resumes {c2['resumes'] - c['resumes']}, admission fallbacks {c2['fallbacks'] - c['fallbacks']}")

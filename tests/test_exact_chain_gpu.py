@@ -20,7 +20,7 @@ def test_device_chain_equals_plain_chain(gpu_lib, scene):
     from fast_livo_amd import synth
     fr = synth.make_lio_frame(2000, scene=scene)
     vf = synth.make_vio_frame(64, fr)
-    h = capi.Handle(capi.config_from_frames(fr, vf))
+    h = capi.Handle(capi.config_from_frames(fr, vf), debug=True)     # fl_debug_chain: instrumented build
     rng = np.random.default_rng(20240924)
     n_checked = 0
     with np.errstate(over="ignore", invalid="ignore"):

@@ -2,7 +2,11 @@
 of the frame's points / patches, exchange their 32 sums peer to peer in the solver workgroup. On the 1-GPU test box both ranks
 live on device 0 -- in one process (fl_p2p_connect_local, one host thread per rank) and in two processes (hipIpc handles):
 the kernels, the protocol and the IPC plumbing are the ones a multi-GPU node uses, only the wire is not xGMI.
-Required: both ranks end bitwise equal; equal to the unsharded run within the re-association tolerance (1e-9)."""
+Required: both ranks end bitwise equal; equal to the unsharded run within the re-association tolerance (1e-9).
+World sizes 2, 3, 4, 5 and 8: with four or more senders peer_allreduce32 polls them in more than one round (one wavefront per
+sender at a time) and the store fan-out reaches 7 peers -- the paths BASELINE configs 4 / 5 (8 GPUs) take. Ranks of one process
+on one device need one hardware queue each (tests/conftest.py raises GPU_MAX_HW_QUEUES): two ranks multiplexed onto one queue
+would wait for each other's kernels."""
 import os
 import subprocess
 import sys
@@ -33,7 +37,7 @@ def _run_ranks(fns):
     return out
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 5, 8])
 def test_lio_passes_sharded_in_kernel(gpu_lib, oracle_lib, scene, world):
     capi = gpu_lib
     from fast_livo_amd import synth
@@ -65,7 +69,8 @@ def test_lio_passes_sharded_in_kernel(gpu_lib, oracle_lib, scene, world):
         assert np.array_equal(x.vec(), res[0][1].vec())                 # ranks bitwise equal
         assert np.abs(x.vec() - xref.vec()).max() <= 1e-9
     # forced passes, one launch per pass (the non-multi-pass kernels exchange as well)
-    os.environ["FL_NO_MULTIPASS"] = "1"
+    for h in hs:
+        h.set_option(capi.FL_OPT_MULTIPASS, 0)
     try:
         def rank1(r):
             def go():
@@ -77,7 +82,8 @@ def test_lio_passes_sharded_in_kernel(gpu_lib, oracle_lib, scene, world):
             return go
         res1 = _run_ranks([rank1(r) for r in range(world)])
     finally:
-        del os.environ["FL_NO_MULTIPASS"]
+        for h in hs:
+            h.set_option(capi.FL_OPT_MULTIPASS, 1)
     assert all(np.array_equal(x.vec(), res1[0].vec()) for x in res1)
     for h in hs:
         h.close()
@@ -127,7 +133,7 @@ def test_vio_levels_and_all_device_frame_sharded_in_kernel(gpu_lib, oracle_lib, 
         h.close()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 5, 8])
 def test_exact_accept_replay_runs_through_the_ranks(gpu_lib, oracle_lib, world):
     """The reference decides `error <= last_error` on a float running sum over ALL patches in order (lidar_selection.cpp:849-859).
     Sharded, that sum runs through the ranks' contiguous patch ranges one after the other: on the fragile passes rank r continues the
@@ -171,7 +177,7 @@ def test_exact_accept_replay_runs_through_the_ranks(gpu_lib, oracle_lib, world):
     assert replayed >= 1          # the chain through the ranks was exercised
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 5, 8])
 def test_mode23_passes_sharded_in_kernel(gpu_lib, scene, world):
     """The 23-state IKFoM update with the points spread over ranks and the 96-double record exchanged inside the pass kernels
     (three 32-double exchanges per pass, handoff.h peer_allreduce96): ranks bitwise equal, state and covariance equal to the
@@ -207,12 +213,9 @@ def test_mode23_passes_sharded_in_kernel(gpu_lib, scene, world):
             return info, np.frombuffer(bytes(x), dtype=np.float64).copy(), P
         return go
     for no_multi in (False, True):
-        if no_multi:
-            os.environ["FL_NO_MULTIPASS"] = "1"
-        try:
-            res = _run_ranks([rank(r) for r in range(world)])
-        finally:
-            os.environ.pop("FL_NO_MULTIPASS", None)
+        for h in hs:
+            h.set_option(capi.FL_OPT_MULTIPASS, 0 if no_multi else 1)
+        res = _run_ranks([rank(r) for r in range(world)])
         for info, x, P in res:
             assert (info.status & 8) == 0 and info.effct_feat_num == iref.effct_feat_num
             assert np.array_equal(x, res[0][1]) and np.array_equal(P, res[0][2])      # ranks bitwise equal

@@ -7,7 +7,7 @@ from fast_livo_amd import capi, synth
 scene = synth.make_scene()
 fr = synth.make_lio_frame(50000, scene=scene)
 nbr, valid = synth.knn5(scene, fr.world_at(fr.R_prior, fr.p_prior))
-h = capi.Handle(capi.config_from_frames(fr))
+h = capi.Handle(capi.config_from_frames(fr), debug=True)
 x23 = capi.state23_from_frame(fr)
 h.lio_set_points(fr.body_xyz); h.ikfom_begin(x23, fr.cov23.copy()); h.lio_set_neighbours(nbr, valid)
 names = {32: "solver start", 33: "staged (x, Pprop)", 34: "pre done (dx, J, P, A12)", 35: "gather done", 36: "S, SA, M, rhs, y0", 37: "LDL^T + dx_", 38: "boxplus + judge",

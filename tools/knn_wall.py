@@ -1,14 +1,13 @@
-"""Per-workgroup timeline of the device k-NN search kernel (FL_KNN_STAMP debug stamps, 100 MHz wall clock)."""
+"""Per-workgroup timeline of the device k-NN search kernel (instrumented build, fl_debug_knn_stamp, 100 MHz wall clock)."""
 import os, sys, json, ctypes as C
-os.environ["FL_KNN_STAMP"] = "1"
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fastlivo  # noqa
 from fast_livo_amd import capi, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 fr = synth.make_lio_frame(n)
-h = capi.Handle(capi.config_from_frames(fr, max_iterations=10))
-L = capi.lib(); L.fl_debug_get_wall.restype = C.c_int32; L.fl_debug_get_wall.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+h = capi.Handle(capi.config_from_frames(fr, max_iterations=10), debug=True)
+L = capi.lib(debug=True); h.debug_knn_stamp(True)
 h.map_set_points(fr.scene.map_xyz, 0.5)
 x = capi.state18_from_frame(fr); h.lio_set_points(fr.body_xyz); h.lio_begin18(x, x)
 h.set_timing(True)

@@ -14,7 +14,7 @@ fr = synth.make_lio_frame(50000, scene=scene)
 vf = synth.make_vio_frame(2000, fr)
 nbr, valid = synth.knn5(scene, fr.world_at(fr.R_prior, fr.p_prior))
 cfg = capi.config_from_frames(fr, vf)
-hl = capi.Handle(cfg); hv = capi.Handle(cfg)
+hl = capi.Handle(cfg, debug=True); hv = capi.Handle(cfg, debug=True)
 x0 = capi.state18_from_frame(fr)
 hl.lio_set_points(fr.body_xyz); hl.lio_begin18(x0, x0); hl.lio_set_neighbours(nbr, valid)
 hv.vio_set_frame(vf.img); hv.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level); hv.vio_begin(x0, x0)

@@ -11,13 +11,13 @@ scene = synth.make_scene()
 fr = synth.make_lio_frame(50000, scene=scene)
 nbr, valid = synth.knn5(scene, fr.world_at(fr.R_prior, fr.p_prior))
 cfg = capi.config_from_frames(fr)
-hl = capi.Handle(cfg)
+hl = capi.Handle(cfg, debug=True)
 L = capi.lib(); L.fl_debug_get_wall.restype = C.c_int32; L.fl_debug_get_wall.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 x0 = capi.state18_from_frame(fr)
 hl.lio_set_points(fr.body_xyz); hl.lio_begin18(x0, x0); hl.lio_set_neighbours(nbr, valid)
 F = capi.FL_ITER_FORCE | capi.FL_ITER_STAMP
 vf = synth.make_vio_frame(2000, fr)
-hv = capi.Handle(capi.config_from_frames(fr, vf))
+hv = capi.Handle(capi.config_from_frames(fr, vf), debug=True)
 hv.vio_set_frame(vf.img); hv.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level); hv.vio_begin(x0, x0)
 for rep in range(6):
     vio = rep >= 3

@@ -7,7 +7,7 @@ from fast_livo_amd import capi, synth
 scene = synth.make_scene()
 fr = synth.make_lio_frame(50000, scene=scene)
 nbr, valid = synth.knn5(scene, fr.world_at(fr.R_prior, fr.p_prior))
-h = capi.Handle(capi.config_from_frames(fr))
+h = capi.Handle(capi.config_from_frames(fr), debug=True)
 x0 = capi.state18_from_frame(fr)
 h.lio_set_points(fr.body_xyz); h.lio_begin18(x0, x0); h.lio_set_neighbours(nbr, valid)
 F = capi.FL_ITER_FORCE

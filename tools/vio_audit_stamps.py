@@ -9,7 +9,7 @@ m = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 scene = synth.make_scene()
 fr = synth.make_lio_frame(50000, scene=scene, point_seed=synth.SEED + 101)
 vf = synth.make_vio_frame(m, fr, patch_seed=synth.SEED + 103)
-h = capi.Handle(capi.config_from_frames(fr, vf, max_iterations=10, device=0))
+h = capi.Handle(capi.config_from_frames(fr, vf, max_iterations=10, device=0), debug=True)
 h.vio_set_frame(vf.img)
 h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
 for rep in range(5):

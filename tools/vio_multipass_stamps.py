@@ -6,7 +6,7 @@ import fastlivo  # noqa
 from fast_livo_amd import capi, synth
 lio = synth.make_lio_frame(2000)
 vf = synth.make_vio_frame(2000, lio)
-h = capi.Handle(capi.config_from_frames(lio, vf))
+h = capi.Handle(capi.config_from_frames(lio, vf), debug=True)
 x0 = capi.state18_from_frame(lio)
 h.vio_set_frame(vf.img); h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level); h.vio_begin(x0, x0)
 F = capi.FL_ITER_FORCE
