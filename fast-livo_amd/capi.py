@@ -292,6 +292,8 @@ def _load(path, symbols):
         pass
     L = C.CDLL(path)
     for name, (res, args) in symbols.items():
+        if os.environ.get("FL_LIB_PATH") and not hasattr(L, name):
+            continue               # an A/B build of an older revision (tools/) may lack newer entry points
         fn = getattr(L, name)      # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
@@ -352,6 +354,8 @@ class Handle:
             raise FlError(f"fl_create failed ({st}): {msg.decode() if msg else ''}")
         self._keep = []
         # measurement scripts (tools/) select A/B behaviour through the environment of the PYTHON process; the library itself reads none
+        if not hasattr(self.L, "fl_set_option"):      # an older A/B build: it reads these variables itself
+            return
         if os.environ.get("FL_NO_MULTIPASS"):
             self.set_option(FL_OPT_MULTIPASS, 0)
         if os.environ.get("FL_MAX_PRODUCERS"):

@@ -110,7 +110,29 @@ __device__ __forceinline__ int gather_records(const void *records, int nprod, un
             for (int j = 0; j < BATCH; j++) need |= ((base + 4 * wave_u + j * ROWS) < nprod) ? (1u << j) : 0u;
 #pragma unroll
             for (int j = 0; j < BATCH; j++) { t[j].x = 0u; t[j].y = 0u; t[j].z = 0u; t[j].w = 0u; }
-            for (int spin = 0; need != 0u; spin++) {
+#ifdef FL_GATHER_SENTINEL
+            // (tried in round 3, off by default: every wavefront first polls ONE load instruction's worth -- its four records of batch 0 --
+            // and starts the full sweep when those have arrived. Per-wave stamps: polling done 1.84-2.04 us after workgroup 0's
+            // publication against 1.72-1.84 us with the speculative sweeps: the sentinel's detection round trip costs what the wasted
+            // first sweep cost.)
+            if (need & 1u) {
+                for (int spin = 0; ; spin++) {
+                    asm volatile("" ::: "memory");          // the load below is loop-invariant to the compiler: without this it is hoisted
+                    t[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (b0 * NV + g * 32 + kp * 2) * 8, 0, 16 /* sc1 */);
+                    const bool ok = (b0 >= nprod) || (((t[0].x & FL_TAG_MASK) == tag) && ((t[0].z & FL_TAG_MASK) == tag));
+                    if (__ballot(ok) == ~0ull) { need &= ~1u; break; }
+                    if (spin >= FL_GATHER_SPIN_LIMIT) { timeout = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+#ifdef FL_GATHER_STAMPS
+            if (tid == 0) g_fl_stamps[45] = (long long)wall_clock64();
+#endif
+#endif
+            for (int spin = 0; need != 0u && !timeout; spin++) {
+#ifdef FL_GATHER_STAMPS
+                if (tid == 0 && spin < 8) { g_fl_stamps[56 + spin] = (long long)wall_clock64(); g_fl_wall[2040 + spin] = (long long)__builtin_popcount(need); }
+#endif
 #pragma unroll
                 for (int j = 0; j < BATCH; j++) {
                     if (need & (1u << j)) {
@@ -134,27 +156,50 @@ __device__ __forceinline__ int gather_records(const void *records, int nprod, un
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
+#ifdef FL_GATHER_STAMPS
+            if ((tid & 63) == 0) g_fl_wall[2024 + wave_u] = (long long)wall_clock64();
+#endif
+            // this lane's records in ascending order. Batches beyond the grid were never loaded (t = 0), and a row beyond the grid inside
+            // a live batch read zeros (buffer bounds): both untag to +0.0, so the additions need no per-lane guard -- this tail runs on
+            // ONE wavefront per SIMD at ~13 cycles per instruction, and with a compare + branch per record it cost 0.7 us of every pass.
 #pragma unroll
             for (int j = 0; j < BATCH; j++) {
-                const int b = b0 + j * ROWS;
-                if (b < nprod) {
+                if (base + j * ROWS < nprod) {                      // uniform over the workgroup: a scalar branch
                     s0 += fl_untag(t[j].x, t[j].y);
                     s1 += fl_untag(t[j].z, t[j].w);
                 }
             }
         }
-        lds[tid * 2] = s0;
-        lds[tid * 2 + 1] = s1;
+        // the four 16-lane rows of a wavefront hold four different records' share of value pair kp: rows first (two lane swaps, no
+        // LDS), then the NT/64 wavefronts through LDS. Fixed order: (row 0 + row 1) + (row 2 + row 3), then wavefronts ascending.
+        swap16_f64(s0, s1);
+        double c = s0 + s1;                                         // even rows: value 2 kp, odd rows: value 2 kp + 1
+        {
+            double c2 = c;
+            swap32_f64(c, c2);
+            c = c + c2;
+        }
+        const int lane = tid & 63;
+        if (lane < 32) lds[wave_u * 32 + 2 * kp + (lane >> 4)] = c;
+        // the time-out flags ride through the same barrier (__syncthreads_or is a workgroup reduction of its own: LDS + two barriers)
+        int *lds_to = reinterpret_cast<int *>(lds + (NT / 64) * 32);
+        if (lane == 32) lds_to[wave_u] = timeout;
         __syncthreads();
+        timeout = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; w++) timeout |= lds_to[w];
         if (tid < 32) {
             double t2 = lds[tid];
 #pragma unroll
-            for (int j = 1; j < ROWS; j++) t2 += lds[j * 32 + tid];
+            for (int w = 1; w < NT / 64; w++) t2 += lds[w * 32 + tid];
             out_lds[g * 32 + tid] = t2;
         }
         __syncthreads();
+#ifdef FL_GATHER_STAMPS
+        if (tid == 0) g_fl_wall[2036] = (long long)wall_clock64();
+#endif
     }
-    return __syncthreads_or(timeout) ? FL_NUM_TIMEOUT : 0;
+    return timeout ? FL_NUM_TIMEOUT : 0;
 }
 
 
@@ -292,6 +337,9 @@ __device__ __forceinline__ void bcast_wait(const unsigned long long *words, unsi
     const unsigned long long *src = words + (mine ? tid : 0);
     unsigned long long w = 0ull;
     bool timeout = false;
+#ifdef FL_BCAST_PRESLEEP
+    __builtin_amdgcn_s_sleep(FL_BCAST_PRESLEEP);
+#endif
 #if FL_BCAST_PHASES == 2
     // two polls in flight, half a round trip apart: a poll answers one memory round trip (~0.6 us) after it was issued, so a
     // single poll loop notices the words up to one round trip late; two interleaved loops halve that

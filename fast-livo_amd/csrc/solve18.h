@@ -585,15 +585,36 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
         for (int cc = 0; cc < 6; cc++) dl = fma(G.trow[cc], z[cc], dl);
     }
     FL_INSTR(if (dbg) { asm volatile("" ::"v"(dl)); fl_stamp(dbg, 33); })
-    if (lane < 18) D->solution[lane] = dl;
-    int st = bad;
-    if (__ballot(lane < 18 && !(fabs(dl) <= DBL_MAX)) != 0ull) st |= 2;
 
     // ---- state update: lane l < 9 forms R(l/3, l%3) of R * Exp(d0,d1,d2) (so3_math.h:54-72, common_lib.h:345), lanes 9..23 add
     const double d0 = fl_lane_bcast(dl, 0), d1 = fl_lane_bcast(dl, 1), d2 = fl_lane_bcast(dl, 2);
     const double d3 = fl_lane_bcast(dl, 3), d4 = fl_lane_bcast(dl, 4), d5 = fl_lane_bcast(dl, 5);
     const double t2 = d0 * d0 + d1 * d1 + d2 * d2;
     const double p2 = d3 * d3 + d4 * d4 + d5 * d5;
+
+    // ---- judgement FIRST: it needs |delta_rot|, |delta_pos| and the loop counters only, and the producers of the next pass wait for
+    // the control word as for the pose words -- published behind the state update it arrived ~0.3 us after them (round 3 stamps).
+    // (uniform arithmetic; lane 0 publishes now and writes the bookkeeping at the end)
+    int ctrl = 0, j_converged = 0, j_rematch = 0, j_need_search = 0, j_stop = 0, j_it = 0, j_iters = 0, j_accepted = 0;
+    if (KIND == FL_EPI_LIO) {
+        // laserMapping.cpp:1688-1728
+        j_converged = (FL_NORM_BELOW(t2, 57.3, 0.01) && FL_NORM_BELOW(p2, 100.0, 0.015)) ? 1 : 0;
+        j_rematch = L.rematch;
+        j_it = L.iterCount; j_iters = L.iters_run + 1;
+        if (j_converged || ((j_rematch == 0) && (j_it == (L.max_iter - 2)))) { j_need_search = 1; j_rematch++; }
+        if (j_rematch >= 2 || (j_it == L.max_iter - 1)) j_stop = 1;
+        ctrl = (j_stop ? 1 : 0) | (j_need_search ? 2 : 0);
+    } else {
+        // lidar_selection.cpp:883-899
+        j_stop = (FL_NORM_BELOW(t2, (double)57.3f, (double)0.001f) && FL_NORM_BELOW(p2, (double)100.0f, (double)0.001f)) ? 1 : 0;
+        j_converged = j_stop;
+        j_iters = L.iters_run + 1;
+        if (j_iters >= L.max_iter) j_stop = 1;
+        j_accepted = L.accepted + 1;
+        ctrl = j_stop ? 1 : 0;
+    }
+    if (bcast && lane == 0) fl_bcast_ctrl(bcast, ctrl, bepoch);
+
     double xnew = G.xl;
     {
 #pragma clang fp contract(fast)
@@ -646,75 +667,57 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
     }
     FL_INSTR(if (dbg) { asm volatile("" ::"v"(xnew)); fl_stamp(dbg, 34); })
     if (lane < 24) {
-        D->x[lane] = xnew;
         if (lane < 12) {
+            if (KIND == FL_EPI_LIO && bcast) fl_bcast_store(bcast, lane, xnew, bepoch);     // the pose words first: the producers wait for them
             L.xn[lane] = xnew;
-            if (KIND == FL_EPI_LIO && bcast) fl_bcast_store(bcast, lane, xnew, bepoch);
         }
+        D->x[lane] = xnew;
         if (lane >= 9) L.xadd[lane - 9] = xnew;
     }
-    if (lane < 18) L.delta[lane] = dl;
-    if (lane < FL_SUMS18) D->sums_acc[lane] = s_sums[lane];   // LIO: last executed pass ; VIO: last accepted pass
-    if (KIND == FL_EPI_VIO && lane < 24) D->xold[lane] = G.xl;   // old_state = *state (:863)
-
-    FL_INSTR(fl_stamp(dbg, 36);)
-    // ---- judgement (uniform arithmetic; lane 0 writes)
-    if (KIND == FL_EPI_LIO) {
-        // laserMapping.cpp:1688-1728
-        const int converged = (FL_NORM_BELOW(t2, 57.3, 0.01) && FL_NORM_BELOW(p2, 100.0, 0.015)) ? 1 : 0;
-        int rematch = L.rematch, need_search = 0, stop = 0;
-        const int it = L.iterCount, iters = L.iters_run + 1;
-        if (converged || ((rematch == 0) && (it == (L.max_iter - 2)))) { need_search = 1; rematch++; }
-        if (rematch >= 2 || (it == L.max_iter - 1)) stop = 1;
-        const int ctrl = (stop ? 1 : 0) | (need_search ? 2 : 0);
-        const int neff_lt1 = (s_sums[FL_S_NEFF] < 1.0) ? 4 : 0;
-        __builtin_amdgcn_wave_barrier();
-        FL_INSTR(if (dbg) { asm volatile("" ::"v"(ctrl + neff_lt1)); fl_stamp(dbg, 37); })
-        if (lane == 0) {
-            L.rematch = rematch; L.iterCount = it + 1; L.iters_run = iters;
-            L.ctrl = ctrl;
-            if (bcast) fl_bcast_ctrl(bcast, ctrl, bepoch);
-            D->converged = converged;
-            D->rematch_num = rematch;
-            D->need_search = need_search;
-            D->stop = stop;
-            D->iterCount = it + 1;
-            D->iters_run = iters;
-            D->neff = (int)s_sums[FL_S_NEFF];
-            D->total_residual = s_sums[FL_S_RES];
-            L.sticky |= st | neff_lt1;
-            D->status = L.sticky;
-        }
-    } else {
-        // lidar_selection.cpp:883-899 ; the derived camera pose of the new state for the next pass's producers
+    if (KIND == FL_EPI_VIO) {
+        // the derived camera pose of the new state for the next pass's producers
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (VC && lane < 12) {
             const double ce = vio_cam_element(lane, L.xn, G.rci, G.pci);
+            if (bcast) fl_bcast_store(bcast, lane, ce, bepoch);
             if (lane < 9) D->Rcw[lane] = ce; else D->Pcw[lane - 9] = ce;
             L.cam[lane] = ce;
-            if (bcast) fl_bcast_store(bcast, lane, ce, bepoch);
         }
-        int stop = (FL_NORM_BELOW(t2, (double)57.3f, (double)0.001f) && FL_NORM_BELOW(p2, (double)100.0f, (double)0.001f)) ? 1 : 0;
-        const int converged = stop;
-        const int it = L.iters_run + 1;
-        if (it >= L.max_iter) stop = 1;
-        const int accepted = L.accepted + 1;
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-            L.accepted = accepted; L.iters_run = it;
-            L.ctrl = stop ? 1 : 0;
-            if (bcast) fl_bcast_ctrl(bcast, stop ? 1 : 0, bepoch);
-            D->converged = converged;
-            D->accepted = accepted;
-            D->iters_run = it;
-            D->stop = stop;
-            D->neff = (int)s_sums[FL_S_NEFF];
+    }
+    FL_INSTR(fl_stamp(dbg, 36);)
+    // ---- everything below is off the hand-off's critical path: bookkeeping for the host, the next pass's solver and the finish kernels
+    if (lane < 18) D->solution[lane] = dl;
+    if (lane < 18) L.delta[lane] = dl;
+    if (lane < FL_SUMS18) D->sums_acc[lane] = s_sums[lane];   // LIO: last executed pass ; VIO: last accepted pass
+    if (KIND == FL_EPI_VIO && lane < 24) D->xold[lane] = G.xl;   // old_state = *state (:863)
+    int st = bad;
+    if (__ballot(lane < 18 && !(fabs(dl) <= DBL_MAX)) != 0ull) st |= 2;
+    const int neff_lt1 = (KIND == FL_EPI_LIO && s_sums[FL_S_NEFF] < 1.0) ? 4 : 0;
+    __builtin_amdgcn_wave_barrier();
+    FL_INSTR(if (dbg) { asm volatile("" ::"v"(ctrl + neff_lt1)); fl_stamp(dbg, 37); })
+    if (lane == 0) {
+        L.ctrl = ctrl;
+        L.iters_run = j_iters;
+        D->converged = j_converged;
+        D->iters_run = j_iters;
+        D->stop = j_stop;
+        D->neff = (int)s_sums[FL_S_NEFF];
+        if (KIND == FL_EPI_LIO) {
+            L.rematch = j_rematch; L.iterCount = j_it + 1;
+            D->rematch_num = j_rematch;
+            D->need_search = j_need_search;
+            D->iterCount = j_it + 1;
+            D->total_residual = s_sums[FL_S_RES];
+            L.sticky |= st | neff_lt1;
+        } else {
+            L.accepted = j_accepted;
+            D->accepted = j_accepted;
             D->total_residual = (double)L.last_error;
             L.sticky |= st | L.fragile;
-            D->status = L.sticky;
         }
+        D->status = L.sticky;
     }
 }
 

@@ -30,6 +30,13 @@ if w is not None:
     print(json.dumps({"producers": int(nprod), "publish_ns_rel_prod0": {"min": int(pub.min()), "p50": int(np.median(pub)), "p90": int(np.percentile(pub, 90)), "max": int(pub.max())},
                       "gather_done_ns_rel_prod0": int(st[17] - st[23]) * 10}))
 
-if os.environ.get("FL_LIB_PATH", "").endswith("gst.so"):       # library built with -DFL_GATHER_STAMPS: wave 0's sweeps of the LAST gather of the launch
+if "gst" in os.environ.get("FL_LIB_PATH", ""):       # library built with -DFL_GATHER_STAMPS: wave 0's sweeps of the LAST gather of the launch
     k = int(st[47])
-    print(json.dumps({"sweeps_of_wave0": k, "sweep_end_ns_rel_first": [int(st[48 + i] - st[48]) * 10 for i in range(min(k, 8))]}))
+    # a 6-pass launch: the LAST gather is the one of pass 5, whose producer stamps are st[20..23]
+    h.lio_iterate18(6, F | capi.FL_ITER_STAMP, want_info=False); h.sync()
+    st = np.array(h.debug_stamps(), dtype=np.int64); w = np.array(h.debug_wall(), dtype=np.int64)
+    k = int(st[47]); t0 = st[23]
+    print(json.dumps({"rel": "prod0 published (pass 5)", "gather_start": int(st[16] - t0) * 10, "sentinel_done": int(st[45] - t0) * 10,
+                      "sweeps_of_wave0": k, "sweep_start": [int(st[56 + i] - t0) * 10 for i in range(min(k, 8))],
+                      "sweep_end": [int(st[48 + i] - t0) * 10 for i in range(min(k, 8))], "batches_needed_at_start": [int(w[2040 + i]) for i in range(min(k, 8))],
+                      "waves_polling_done": [int(w[2024 + i] - t0) * 10 for i in range(4)], "reduced": int(w[2036] - t0) * 10, "gather_done": int(st[17] - t0) * 10, "last_publish": int((w[:160] - t0).max()) * 10}))
