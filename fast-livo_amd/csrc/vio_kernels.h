@@ -258,7 +258,7 @@ __device__ __forceinline__ void vio_patch_error(const float *r, int hl, bool act
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const double rd = (double)q[j];
-            pe = (float)((double)pe + rd * rd);      // the product of two floats is exact in double: fused or not, same rounding
+            pe = (float)fma(rd, rd, (double)pe);     // the product of two floats is exact in double: fused or not, same rounding
         }
     }
     errors[i] = pe;
@@ -283,12 +283,72 @@ __device__ __forceinline__ void row_sum6(double (&w)[8], double (&T)[6])
     }
 }
 
+// ---- the 6x6 update of a patch, spread over the 16 lanes of its DPP row (round 3) ------------------------------------------
+// The patch's contribution is M^T G M (21 numbers), M^T g (6), the pixel count and sum res^2: 29 outputs of a 2x6 matrix M and six
+// row totals T. Every lane used to form all of M (60 fp64 instructions) and all 29 outputs (110) into a 32-double accumulator; now
+//   * lane e < 12 forms ONE entry M(e / 6, e % 6) from per-lane constants set up once per pass and drops it into LDS,
+//   * lane hl forms outputs hl and hl + 16 of the record from the four / eight entries of M they need (read back from LDS) and
+//     keeps TWO accumulators,
+//   * at the end of the pass the four rows of a wavefront are added up with two lane swaps -- value index == lane -- and the
+//     wavefronts through LDS.
+// Same algebra as fl_patch_M / fl_patch_accum (M^T G M as sum over the pixels of row_i row_j, row = [du dv] M); fused multiply-adds;
+// compared with the oracle by tolerance like every fp64 sum.
+#define FL_VIO_MROW 20                   /* doubles per lane group in the M exchange: M0[0..5], M1[0..5], 1.0 at 12, 0.0 at 18 */
+struct FlVioLaneRole {
+    double X1, X2, X3, Y1, Y2, Y3;      // B_r = q1 X1 + q2 X2 - X3, B_2 = -py Y1 + px Y2 - Y3 for this lane's column of M
+    int r;                              // row of M this lane forms
+    int o1a, o1b, o2a, o2b;             // entries (column i, column j) of outputs 1 and 2 inside the lane group's FL_VIO_MROW doubles
+    int kind2;                          // output 2: 0 H^T H entry, 1 H^T z entry, 2 pixel count, 3 sum res^2, 4 none
+};
+__device__ __forceinline__ void fl_vio_upper_ij(int k, int &i, int &j)       // record index k < 21 -> (i, j), i <= j, row-major
+{
+    int rowlen = 6;
+    i = 0;
+    while (k >= rowlen) { k -= rowlen; rowlen--; i++; }
+    j = i + k;
+}
+// Once per launch; the three entries that follow the pose (Jdp_dt = Rcw) are refreshed per pass by fl_vio_lane_role_pose. The
+// lane-dependent entries come straight from memory (VC: the constants in HBM; cam: Rcw, D->Rcw or the broadcast pose in LDS):
+// selecting them out of the by-value copies would index a register array at run time, i.e. put it in scratch.
+__device__ __forceinline__ FlVioLaneRole fl_vio_lane_role(int hl, const FlVioConst *__restrict__ VC)
+{
+    FlVioLaneRole R;
+    const int e = hl < 12 ? hl : 0, col = e % 6;
+    R.r = e / 6;
+    R.X1 = 0.0; R.X2 = 0.0; R.X3 = 0.0; R.Y1 = 0.0; R.Y2 = 0.0; R.Y3 = 0.0;
+    if (col < 3) {
+        const double A0 = VC->Jdphi_dR[col], A1 = VC->Jdphi_dR[3 + col], A2 = VC->Jdphi_dR[6 + col];
+        const double D0 = VC->Jdp_dR[col], D1 = VC->Jdp_dR[3 + col], D2 = VC->Jdp_dR[6 + col];
+        R.X1 = R.r ? A0 : A1; R.X2 = A2; R.X3 = R.r ? D1 : D0;
+        R.Y1 = A0; R.Y2 = A1; R.Y3 = D2;
+    }
+    int i, j;
+    fl_vio_upper_ij(hl, i, j);            // output 1: record index hl (< 21: an entry of H^T H)
+    R.o1a = i; R.o1b = j;
+    const int k2 = hl + 16;
+    R.o2a = 0; R.o2b = 0;
+    if (k2 < 21) { fl_vio_upper_ij(k2, i, j); R.o2a = i; R.o2b = j; R.kind2 = 0; }
+    else if (k2 < 27) { R.o2a = k2 - 21; R.o2b = 12; R.kind2 = 1; }       // column "12": M0 = 1, M1 = 0
+    else R.kind2 = (k2 == FL_S_NEFF) ? 2 : ((k2 == FL_S_RES) ? 3 : 4);
+    return R;
+}
+__device__ __forceinline__ void fl_vio_lane_role_pose(FlVioLaneRole &R, int hl, const double *cam /* Rcw, row-major */)
+{
+    const int e = hl < 12 ? hl : 0, col = e % 6;
+    if (col >= 3) {
+        const int cc = col - 3;
+        R.X3 = cam[(R.r ? 3 : 0) + cc];
+        R.Y3 = cam[6 + cc];
+    }
+}
+
 // One producer workgroup's share of a pass: residuals, rows, 6x6 update for its patches, reduced to one record and published.
 __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, const float *__restrict__ ref, const double *__restrict__ pos,
                                             const int32_t *__restrict__ slevel, float *__restrict__ errors, int m, int level_arg, int level,
                                             const FlVioConst &vc, const double (&Rcw)[9], const double (&Pcw)[3], const FlVioFirst &pf,
                                             int nprod, double *s_red, unsigned epoch, void *__restrict__ records, int flags,
-                                            unsigned long long *__restrict__ err_words /* this pass's half, nullable */, float *s_res /* LDS */)
+                                            unsigned long long *__restrict__ err_words /* this pass's half, nullable */, float *s_res /* LDS */,
+                                            const FlVioLaneRole &role /* fl_vio_lane_role + fl_vio_lane_role_pose of this pass */)
 {
     constexpr int WPB = FL_VIO_NT / 64;
     constexpr int LPP = FL_VIO_LPP, PPL = FL_VIO_PPL, GPW = FL_VIO_GPW;
@@ -302,9 +362,12 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
     const int xr = hl >> 3, yc = hl & 7;          // this lane's pixels: (xr + (LPP / 8) k, yc), k = 0 .. PPL-1
     const int W = vc.stride, Hm1 = vc.height - 1, Wm1 = vc.width - 1;
 
-    double v[FL_SUMS18];
-#pragma unroll
-    for (int k = 0; k < FL_SUMS18; k++) v[k] = 0.0;
+    static_assert(FL_VIO_LPP == 16, "the lane-distributed 6x6 update maps one patch to one 16-lane DPP row");
+    double *s_M = s_red + slot * FL_VIO_MROW;                     // this lane group's M exchange (GPW * WPB * FL_VIO_MROW doubles)
+    double *s_fin = s_red + GPW * WPB * FL_VIO_MROW;              // cross-wavefront sum of the record: WPB * 32 doubles
+    if (hl == 12) s_M[12] = 1.0;
+    if (hl == 13) s_M[18] = 0.0;
+    double acc1 = 0.0, acc2 = 0.0;
 
     FL_INSTR(if (blockIdx.x == 0) fl_stamp(flags, 0);)
     // trip count uniform over the wave: all lane groups iterate together, an inactive group (m not a multiple of GPW) computes
@@ -327,6 +390,30 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
         float t[PPL][4][4];
         // taps span [anchor - 5*scale, anchor + 5*scale]: no clamping needed inside the image
         const bool inside = (g.v_i - 5 * scale >= 0) && (g.v_i + 5 * scale <= Hm1) && (g.u_i - 5 * scale >= 0) && (g.u_i + 5 * scale <= Wm1);
+        // Finest level, every patch of the wavefront inside the image (the common case): a lane's four pixels sit two rows apart in
+        // one column, so their 4 x 4 tap windows are 10 image rows x 4 consecutive bytes. Ten aligned 8-byte loads + v_alignbyte
+        // instead of 48 single-byte loads (each a 64-address instruction for the texture addresser).
+        const bool fast_taps = (LPP == 16) && (__ballot(inside && scale == 1) == ~0ull);
+        if (fast_taps) {
+            const uint8_t *q = img + (g.v_i + xr - 5) * W + (col0 - 1);
+            unsigned rowv[10];
+#pragma unroll
+            for (int m2 = 0; m2 < 10; m2++) {
+                const uint8_t *a = q + m2 * W;
+                const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(a) & 3u);
+                const fl_u2 w2 = *reinterpret_cast<const fl_u2 *>(reinterpret_cast<uintptr_t>(a) & ~(uintptr_t)3);   // (the frame buffer is padded: api_vio.inc)
+                rowv[m2] = __builtin_amdgcn_alignbyte(w2.y, w2.x, sh);
+            }
+#pragma unroll
+            for (int px = 0; px < PPL; px++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const bool used = !((r == 0 && (c == 0 || c == 3)) || (r == 3 && (c == 0 || c == 3)));
+                        t[px][r][c] = used ? (float)((rowv[2 * px + r] >> (8 * c)) & 0xffu) : 0.f;
+                    }
+        } else {
 #pragma unroll
         for (int px = 0; px < PPL; px++) {
             const int row0 = g.v_i + (xr + (LPP / 8) * px - 4) * scale;
@@ -358,6 +445,7 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
                 }
             }
         }
+        }
         float refv[PPL];
         if (first && level_arg >= 0) {
 #pragma unroll
@@ -367,18 +455,45 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
             for (int k = 0; k < PPL; k++) refv[k] = ref[(size_t)ii * 192 + 64 * level + hl + LPP * k];
         }
         FL_INSTR(if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(t[0][1][1] + t[PPL - 1][2][2] + refv[PPL - 1])); fl_stamp(flags, 41); })
-        double M[2][6];
-        fl_patch_M(g, vc.Jdphi_dR, vc.Jdp_dR, Rcw, M);          // uniform per lane group, overlaps the tap loads
-        FL_INSTR(if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(M[1][5] + M[0][0])); fl_stamp(flags, 42); })
+        {   // this lane's entry of M (lanes 0..11), overlaps the tap loads
+            FL_FP_CONTRACT
+            const double inv_s = 1.0 / g.scale;
+            const double s1 = (role.r ? g.Jdpi[4] : g.Jdpi[0]) * inv_s, s2 = (role.r ? g.Jdpi[5] : g.Jdpi[2]) * inv_s;
+            const double q1 = role.r ? g.pf[2] : -g.pf[2], q2 = role.r ? -g.pf[0] : g.pf[1];
+            const double Br = (q1 * role.X1 + q2 * role.X2) - role.X3;
+            const double B2 = ((-g.pf[1]) * role.Y1 + g.pf[0] * role.Y2) - role.Y3;
+            const double Me = s1 * Br + s2 * B2;
+            if (hl < 12) s_M[hl] = Me;
+        }
+        FL_INSTR(if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { fl_stamp(flags, 42); })
         double w8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        // the float part two pixels at a time (v_pk_mul_f32 / v_pk_add_f32: IEEE per element, no contraction -- the same roundings as the
+        // scalar expressions of fl_pixel_grad, lidar_selection.cpp:826-829,837), the Gram sums in fp64 with fused multiply-adds
+        // (compared by tolerance)
 #pragma unroll
-        for (int px = 0; px < PPL; px++) {
-            float du, dv, resf;
-            fl_pixel_grad(g, t[px], refv[px], &du, &dv, &resf);
-            s_res[slot * 64 + LPP * px + hl] = resf;                    // pixel order of the reference: x * 8 + y
-            const double dud = (double)du, dvd = (double)dv, res = (double)resf;
-            w8[0] += dud * dud; w8[1] += dud * dvd; w8[2] += dvd * dvd;
-            w8[3] += dud * res; w8[4] += dvd * res; w8[5] += res * res;
+        for (int px = 0; px < PPL; px += 2) {
+            typedef float fl_f2 __attribute__((ext_vector_type(2)));
+            fl_f2 tt[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) { tt[r][c].x = t[px][r][c]; tt[r][c].y = t[px + 1][r][c]; }
+            const fl_f2 wtl = {g.wtl, g.wtl}, wtr = {g.wtr, g.wtr}, wbl = {g.wbl, g.wbl}, wbr = {g.wbr, g.wbr};
+            const fl_f2 half = {0.5f, 0.5f};
+            const fl_f2 rf = {refv[px], refv[px + 1]};
+            const fl_f2 du2 = half * ((wtl * tt[1][2] + wtr * tt[1][3] + wbl * tt[2][2] + wbr * tt[2][3])
+                                    - (wtl * tt[1][0] + wtr * tt[1][1] + wbl * tt[2][0] + wbr * tt[2][1]));
+            const fl_f2 dv2 = half * ((wtl * tt[2][1] + wtr * tt[2][2] + wbl * tt[3][1] + wbr * tt[3][2])
+                                    - (wtl * tt[0][1] + wtr * tt[0][2] + wbl * tt[1][1] + wbr * tt[1][2]));
+            const fl_f2 rs2 = wtl * tt[1][1] + wtr * tt[1][2] + wbl * tt[2][1] + wbr * tt[2][2] - rf;
+            s_res[slot * 64 + LPP * px + hl] = rs2.x;                       // pixel order of the reference: x * 8 + y
+            s_res[slot * 64 + LPP * (px + 1) + hl] = rs2.y;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const double dud = (double)(e ? du2.y : du2.x), dvd = (double)(e ? dv2.y : dv2.x), res = (double)(e ? rs2.y : rs2.x);
+                w8[0] = fma(dud, dud, w8[0]); w8[1] = fma(dud, dvd, w8[1]); w8[2] = fma(dvd, dvd, w8[2]);
+                w8[3] = fma(dud, res, w8[3]); w8[4] = fma(dvd, res, w8[4]); w8[5] = fma(res, res, w8[5]);
+            }
         }
         FL_INSTR(if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(w8[5] + w8[0])); fl_stamp(flags, 43); })
         double T6[6];
@@ -389,8 +504,20 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
         // output and the rare exact accept test, never the record: for the wave's LAST patch group it is deferred until the record is
         // published, off the hand-off's critical path (the residuals wait in LDS).
         const bool last_iter = (ib + nprod * WPB * GPW >= m);
-        if (active) fl_patch_accum(v, M, T6);
-        FL_INSTR(if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(v[0] + v[26])); fl_stamp(flags, 45); })
+        {   // this lane's two outputs of the patch
+            FL_FP_CONTRACT
+            __builtin_amdgcn_wave_barrier();
+            const double Ma1 = s_M[role.o1a], Mb1 = s_M[6 + role.o1a], Mc1 = s_M[role.o1b], Md1 = s_M[6 + role.o1b];
+            const double Ma2 = s_M[role.o2a], Mb2 = s_M[6 + role.o2a], Mc2 = s_M[role.o2b], Md2 = s_M[6 + role.o2b];
+            __builtin_amdgcn_wave_barrier();
+            const double out1 = Ma1 * (T6[0] * Mc1 + T6[1] * Md1) + Mb1 * (T6[1] * Mc1 + T6[2] * Md1);
+            const bool htz = role.kind2 == 1;
+            const double ta = htz ? T6[3] : T6[0], tb2 = htz ? T6[4] : T6[1];
+            double out2 = Ma2 * (ta * Mc2 + T6[1] * Md2) + Mb2 * (tb2 * Mc2 + T6[2] * Md2);
+            if (role.kind2 >= 2) out2 = (role.kind2 == 2) ? 64.0 : ((role.kind2 == 3) ? T6[5] : 0.0);
+            if (active) { acc1 += out1; acc2 += out2; }
+        }
+        FL_INSTR(if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(acc1 + acc2)); fl_stamp(flags, 45); })
         if (last_iter) { def_i = i; def_active = active; }
         else {
             __builtin_amdgcn_wave_barrier();
@@ -399,19 +526,26 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
         }
     }
     FL_INSTR(if (blockIdx.x == 0) fl_stamp(flags, 1);)
-    // every lane of a lane group holds the same record: its first lane stores it, 32 threads add the partials up
-    if (hl == 0) {
-#pragma unroll
-        for (int k = 0; k < FL_SUMS18; k++) s_red[slot * FL_SUMS18 + k] = v[k];
+    // lane hl of every row holds the row's outputs hl and hl + 16: the four rows of a wavefront with two lane swaps (even rows then
+    // hold index hl, odd rows index hl + 16, i.e. lane L < 32 holds the wavefront's total of record value L), the wavefronts via LDS
+    swap16_f64(acc1, acc2);
+    double c = acc1 + acc2;
+    {
+        double c2 = c;
+        swap32_f64(c, c2);
+        c = c + c2;
     }
+    if (lane < 32) s_fin[wave * 32 + lane] = c;
     __syncthreads();
     double mine = 0.0;
     if (threadIdx.x < FL_SUMS18) {
-        mine = s_red[threadIdx.x];
+        mine = s_fin[threadIdx.x];
 #pragma unroll
-        for (int w = 1; w < GPW * WPB; w++) mine += s_red[w * FL_SUMS18 + threadIdx.x];
+        for (int w = 1; w < WPB; w++) mine += s_fin[w * FL_SUMS18 + threadIdx.x];
     }
     publish_record<FL_SUMS18>(mine, epoch, records);
+    FL_INSTR(if (blockIdx.x == 0) fl_stamp(flags, 3);)
+    FL_INSTR(if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();)   // every producer's publish time
     __builtin_amdgcn_wave_barrier();
     vio_patch_error(s_res + slot * 64, hl, def_active, def_i, errors, err_words, epoch);
 }
@@ -521,7 +655,9 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     for (int i = 0; i < 3; i++) Pcw[i] = D->Pcw[i];
     __shared__ __attribute__((aligned(16))) float s_res[FL_VIO_GPW * WPB * 64];
     unsigned long long *ew = D->err_words ? D->err_words + (size_t)(D->iters_run & 1) * D->err_cap : nullptr;
-    vio_produce(img, ref, pos, slevel, errors, m, level_arg, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags, ew, s_res);
+    FlVioLaneRole role = fl_vio_lane_role((int)(threadIdx.x & 15), VC);
+    fl_vio_lane_role_pose(role, (int)(threadIdx.x & 15), D->Rcw);
+    vio_produce(img, ref, pos, slevel, errors, m, level_arg, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags, ew, s_res, role);
     FL_INSTR(if (blockIdx.x == 0) fl_stamp(flags, 2);)
     FL_INSTR(if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();)
 }
@@ -691,6 +827,8 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
     for (int i = 0; i < 9; i++) Rcw[i] = D->Rcw[i];
 #pragma unroll
     for (int i = 0; i < 3; i++) Pcw[i] = D->Pcw[i];
+    FlVioLaneRole role = fl_vio_lane_role((int)(threadIdx.x & 15), VC);
+    fl_vio_lane_role_pose(role, (int)(threadIdx.x & 15), D->Rcw);
     for (int ps = 0; ps < count; ps++) {
         const unsigned epoch = epoch0 + (unsigned)ps;
         const FlVioFirst pf = vio_prefetch_first(ref, pos, slevel, m, level, nprod);
@@ -705,9 +843,10 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
             for (int i = 0; i < 9; i++) Rcw[i] = s_pose[i];
 #pragma unroll
             for (int i = 0; i < 3; i++) Pcw[i] = s_pose[9 + i];
+            fl_vio_lane_role_pose(role, (int)(threadIdx.x & 15), s_pose);
         }
         vio_produce(img, ref, pos, slevel, errors, m, level, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records,
-                    (ps == 5 || ps == 6) ? 0 : (flags & ~FL_ITER_STAMP), err_base ? err_base + (size_t)((pass0 + ps) & 1) * err_cap : nullptr, s_res);
+                    (ps == 5) ? flags : (flags & ~FL_ITER_STAMP), err_base ? err_base + (size_t)((pass0 + ps) & 1) * err_cap : nullptr, s_res, role);
         FL_INSTR(if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 23 + 4 * (ps - 5));)
         __syncthreads();
     }

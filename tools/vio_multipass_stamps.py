@@ -19,4 +19,8 @@ for rep in range(4):
     h.vio_iterate(0, 10, F | capi.FL_ITER_STAMP, want_info=False); h.sync()
     st = np.array(h.debug_stamps(), dtype=np.int64)
     t0 = st[20]
-    print(json.dumps({names[k]: int(st[k] - t0) * 10 for k in sorted(names, key=lambda k: st[k])}))
+    print(json.dumps({names[k]: int(st[k] - t0) * 10 for k in sorted(names, key=lambda k: st[k]) if st[k] > 0}))
+    w = np.array(h.debug_wall(), dtype=np.int64)[:125]
+    pub = (w - t0) * 10
+    print(json.dumps({"pass 5: record published, ns after prod0 wait_start": {"prod0": int(st[3] - t0) * 10, "min": int(pub.min()), "p50": int(np.median(pub)), "p90": int(np.percentile(pub, 90)),
+                      "max": int(pub.max()), "argmax_block": int(pub.argmax())}, "gather_done": int(st[17] - t0) * 10}))

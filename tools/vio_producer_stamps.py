@@ -11,7 +11,7 @@ x0 = capi.state18_from_frame(lio)
 h.vio_set_frame(vf.img); h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level); h.vio_begin(x0, x0)
 F = capi.FL_ITER_FORCE
 names = {0: "loop start", 40: "geometry", 41: "taps + ref arrived", 42: "patch M", 43: "pixel math", 44: "half-wave sums", 45: "6x6 accumulated",
-         1: "loop end", 2: "reduced + published"}
+         1: "loop end", 3: "record published", 2: "patch_error chain done"}
 for rep in range(4):
     for _ in range(5): h.vio_iterate(0, 1, F, want_info=False)
     h.vio_iterate(0, 1, F | capi.FL_ITER_STAMP, want_info=False); h.sync()
