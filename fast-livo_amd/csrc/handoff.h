@@ -159,15 +159,13 @@ __device__ __forceinline__ int gather_records(const void *records, int nprod, un
 #ifdef FL_GATHER_STAMPS
             if ((tid & 63) == 0) g_fl_wall[2024 + wave_u] = (long long)wall_clock64();
 #endif
-            // this lane's records in ascending order. Batches beyond the grid were never loaded (t = 0), and a row beyond the grid inside
-            // a live batch read zeros (buffer bounds): both untag to +0.0, so the additions need no per-lane guard -- this tail runs on
-            // ONE wavefront per SIMD at ~13 cycles per instruction, and with a compare + branch per record it cost 0.7 us of every pass.
+            // this lane's records in ascending order, straight-line: batches beyond the grid were never loaded (t = 0) and a row beyond
+            // the grid inside a live batch read zeros (buffer bounds) -- both untag to +0.0. (This tail runs on ONE wavefront per SIMD:
+            // a compare + branch per record cost 0.7 us of every pass, a scalar branch per batch still 0.1 us.)
 #pragma unroll
             for (int j = 0; j < BATCH; j++) {
-                if (base + j * ROWS < nprod) {                      // uniform over the workgroup: a scalar branch
-                    s0 += fl_untag(t[j].x, t[j].y);
-                    s1 += fl_untag(t[j].z, t[j].w);
-                }
+                s0 += fl_untag(t[j].x, t[j].y);
+                s1 += fl_untag(t[j].z, t[j].w);
             }
         }
         // the four 16-lane rows of a wavefront hold four different records' share of value pair kp: rows first (two lane swaps, no
@@ -179,26 +177,32 @@ __device__ __forceinline__ int gather_records(const void *records, int nprod, un
             swap32_f64(c, c2);
             c = c + c2;
         }
-        const int lane = tid & 63;
-        if (lane < 32) lds[wave_u * 32 + 2 * kp + (lane >> 4)] = c;
-        // the time-out flags ride through the same barrier (__syncthreads_or is a workgroup reduction of its own: LDS + two barriers)
-        int *lds_to = reinterpret_cast<int *>(lds + (NT / 64) * 32);
-        if (lane == 32) lds_to[wave_u] = timeout;
-        __syncthreads();
-        timeout = 0;
-#pragma unroll
-        for (int w = 0; w < NT / 64; w++) timeout |= lds_to[w];
-        if (tid < 32) {
-            double t2 = lds[tid];
-#pragma unroll
-            for (int w = 1; w < NT / 64; w++) t2 += lds[w * 32 + tid];
-            out_lds[g * 32 + tid] = t2;
-        }
-        __syncthreads();
-#ifdef FL_GATHER_STAMPS
-        if (tid == 0) g_fl_wall[2036] = (long long)wall_clock64();
-#endif
+        if ((tid & 63) < 32) lds[(g * (NT / 64) + wave_u) * 32 + 2 * kp + ((tid & 63) >> 4)] = c;
     }
+    // ONE barrier: the time-out flags ride through it (__syncthreads_or is a workgroup reduction of its own), and behind it EVERY
+    // wavefront adds the NT/64 partials up itself (same order, same bits) and writes all of out_lds -- identical values from every
+    // wavefront, so whoever reads out_lds next reads what its own wavefront wrote and no second barrier is needed.
+    int *lds_to = reinterpret_cast<int *>(lds + (NV / 32) * (NT / 64) * 32);
+    if ((tid & 63) == 32) lds_to[wave_u] = timeout;
+    __syncthreads();
+    timeout = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w++) timeout |= lds_to[w];
+    if ((tid & 63) < 32) {
+#pragma unroll
+        for (int g = 0; g < NV / 32; g++) {
+            double t2 = lds[(g * (NT / 64)) * 32 + (tid & 63)];
+#pragma unroll
+            for (int w = 1; w < NT / 64; w++) t2 += lds[(g * (NT / 64) + w) * 32 + (tid & 63)];
+            out_lds[g * 32 + (tid & 63)] = t2;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef FL_GATHER_STAMPS
+    if (tid == 0) g_fl_wall[2036] = (long long)wall_clock64();
+#endif
     return timeout ? FL_NUM_TIMEOUT : 0;
 }
 

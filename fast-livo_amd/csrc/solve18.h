@@ -49,6 +49,8 @@ struct FlSolveLds {
     int accept;
     int st;
     int audited;
+    // hand-off of the judgement to wavefront 1 (eskf18_solve_block): passes judged so far / the flag wavefront 0 raises when delta is in LDS
+    int jpass, jflag;
 };
 
 enum { FL_EPI_LIO = 0, FL_EPI_VIO = 1 };
@@ -256,6 +258,7 @@ __device__ __forceinline__ void eskf18_prefetch_commit(double v, FlSolveLds &L)
     else if (tid == 200) L.acc_epoch = (unsigned)v;
     else if (tid == 201) L.last_exact_valid = (int)v;
     else if (tid == 202) L.last_exact = (float)v;
+    else if (tid == 203) { L.jpass = 0; L.jflag = 0; }
     __syncthreads();
     eskf18_form_vec(L);
     __syncthreads();
@@ -406,6 +409,63 @@ __device__ __forceinline__ void vio_exact_decide(const FlVioExact ex, FlSolveLds
     __syncthreads();
 }
 
+// The judgement of a pass (wavefront 1 of the solver workgroup, see eskf18_solve_block): delta and the solve's status bits come out
+// of LDS. Uniform arithmetic; lane 0 publishes the control word and writes the bookkeeping.
+template <int KIND>
+__device__ __forceinline__ void eskf18_judge(FlDev18 *__restrict__ D, const double *s_sums, FlSolveLds &L, unsigned long long *bcast, unsigned bepoch)
+{
+    const int lane = threadIdx.x & 63;
+    const double d0 = L.delta[0], d1 = L.delta[1], d2 = L.delta[2], d3 = L.delta[3], d4 = L.delta[4], d5 = L.delta[5];
+    const double t2 = d0 * d0 + d1 * d1 + d2 * d2;
+    const double p2 = d3 * d3 + d4 * d4 + d5 * d5;
+    const int st = L.st;
+    if (KIND == FL_EPI_LIO) {
+        // laserMapping.cpp:1688-1728
+        const int converged = (FL_NORM_BELOW(t2, 57.3, 0.01) && FL_NORM_BELOW(p2, 100.0, 0.015)) ? 1 : 0;
+        int rematch = L.rematch, need_search = 0, stop = 0;
+        const int it = L.iterCount, iters = L.iters_run + 1;
+        if (converged || ((rematch == 0) && (it == (L.max_iter - 2)))) { need_search = 1; rematch++; }
+        if (rematch >= 2 || (it == L.max_iter - 1)) stop = 1;
+        const int ctrl = (stop ? 1 : 0) | (need_search ? 2 : 0);
+        const int neff_lt1 = (s_sums[FL_S_NEFF] < 1.0) ? 4 : 0;
+        if (lane == 0) {
+            if (bcast) fl_bcast_ctrl(bcast, ctrl, bepoch);
+            L.rematch = rematch; L.iterCount = it + 1; L.iters_run = iters;
+            L.ctrl = ctrl;
+            D->converged = converged;
+            D->rematch_num = rematch;
+            D->need_search = need_search;
+            D->stop = stop;
+            D->iterCount = it + 1;
+            D->iters_run = iters;
+            D->neff = (int)s_sums[FL_S_NEFF];
+            D->total_residual = s_sums[FL_S_RES];
+            L.sticky |= st | neff_lt1;
+            D->status = L.sticky;
+        }
+    } else {
+        // lidar_selection.cpp:883-899
+        int stop = (FL_NORM_BELOW(t2, (double)57.3f, (double)0.001f) && FL_NORM_BELOW(p2, (double)100.0f, (double)0.001f)) ? 1 : 0;
+        const int converged = stop;
+        const int it = L.iters_run + 1;
+        if (it >= L.max_iter) stop = 1;
+        const int accepted = L.accepted + 1;
+        if (lane == 0) {
+            if (bcast) fl_bcast_ctrl(bcast, stop ? 1 : 0, bepoch);
+            L.accepted = accepted; L.iters_run = it;
+            L.ctrl = stop ? 1 : 0;
+            D->converged = converged;
+            D->accepted = accepted;
+            D->iters_run = it;
+            D->stop = stop;
+            D->neff = (int)s_sums[FL_S_NEFF];
+            D->total_residual = (double)L.last_error;
+            L.sticky |= st | L.fragile;
+            D->status = L.sticky;
+        }
+    }
+}
+
 template <int KIND>
 __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, const double *s_sums, FlSolveLds &L, const FlSolveRegs &G_in,
                                                    int gather_status, unsigned long long *bcast = nullptr, unsigned bepoch = 0u,
@@ -470,7 +530,26 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
             eskf18_load_regs(L, G, VC);      // the operands come back from LDS: nothing of them has to survive the call in registers
         }
     }
-    if (wave != 0) return;
+    if (wave >= 2) return;
+    // Wavefront 0 solves; WAVEFRONT 1 judges beside it (round 3): the rematch / stop decision and the control word the producers of
+    // the next pass wait for need |delta_rot|, |delta_pos| and the loop counters only, and on wavefront 0 they sat between delta and
+    // the pose (0.3 us of every pass). Wavefront 0 drops delta and its status bits into LDS and raises L.jflag (LDS operations of a
+    // wavefront are performed in order); wavefront 1 spins on the flag, judges, publishes the control word and does the bookkeeping
+    // that follows from the judgement, while wavefront 0 forms R Exp(delta) and publishes the pose. Nobody writes L.jpass before
+    // wavefront 0 has raised the flag, so both read the same tag.
+    const int jtag = L.jpass + 1;
+    if (wave == 1) {
+        int f = 0;
+        for (int spin = 0; spin < (1 << 22); spin++) {
+            f = __hip_atomic_load(&L.jflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (f == jtag || f == -jtag) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (f == jtag) eskf18_judge<KIND>(D, s_sums, L, bcast, bepoch);
+        if (lane == 0) L.jpass = jtag;
+        return;
+    }
 
     // =========================================================================== wavefront 0 from here on, no workgroup barrier
     int accept = 1;
@@ -511,6 +590,7 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
                 if (bcast) fl_bcast_store(bcast, lane, ce, bepoch);
             }
             if (lane == 0) {
+                __hip_atomic_store(&L.jflag, -jtag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // wavefront 1: nothing to judge
                 const int it = L.iters_run + 1;
                 L.iters_run = it;
                 D->iters_run = it;
@@ -586,34 +666,18 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
     }
     FL_INSTR(if (dbg) { asm volatile("" ::"v"(dl)); fl_stamp(dbg, 33); })
 
-    // ---- state update: lane l < 9 forms R(l/3, l%3) of R * Exp(d0,d1,d2) (so3_math.h:54-72, common_lib.h:345), lanes 9..23 add
-    const double d0 = fl_lane_bcast(dl, 0), d1 = fl_lane_bcast(dl, 1), d2 = fl_lane_bcast(dl, 2);
-    const double d3 = fl_lane_bcast(dl, 3), d4 = fl_lane_bcast(dl, 4), d5 = fl_lane_bcast(dl, 5);
-    const double t2 = d0 * d0 + d1 * d1 + d2 * d2;
-    const double p2 = d3 * d3 + d4 * d4 + d5 * d5;
-
-    // ---- judgement FIRST: it needs |delta_rot|, |delta_pos| and the loop counters only, and the producers of the next pass wait for
-    // the control word as for the pose words -- published behind the state update it arrived ~0.3 us after them (round 3 stamps).
-    // (uniform arithmetic; lane 0 publishes now and writes the bookkeeping at the end)
-    int ctrl = 0, j_converged = 0, j_rematch = 0, j_need_search = 0, j_stop = 0, j_it = 0, j_iters = 0, j_accepted = 0;
-    if (KIND == FL_EPI_LIO) {
-        // laserMapping.cpp:1688-1728
-        j_converged = (FL_NORM_BELOW(t2, 57.3, 0.01) && FL_NORM_BELOW(p2, 100.0, 0.015)) ? 1 : 0;
-        j_rematch = L.rematch;
-        j_it = L.iterCount; j_iters = L.iters_run + 1;
-        if (j_converged || ((j_rematch == 0) && (j_it == (L.max_iter - 2)))) { j_need_search = 1; j_rematch++; }
-        if (j_rematch >= 2 || (j_it == L.max_iter - 1)) j_stop = 1;
-        ctrl = (j_stop ? 1 : 0) | (j_need_search ? 2 : 0);
-    } else {
-        // lidar_selection.cpp:883-899
-        j_stop = (FL_NORM_BELOW(t2, (double)57.3f, (double)0.001f) && FL_NORM_BELOW(p2, (double)100.0f, (double)0.001f)) ? 1 : 0;
-        j_converged = j_stop;
-        j_iters = L.iters_run + 1;
-        if (j_iters >= L.max_iter) j_stop = 1;
-        j_accepted = L.accepted + 1;
-        ctrl = j_stop ? 1 : 0;
+    // ---- delta and the status bits of the solve to wavefront 1 (the judgement), then the state update
+    {
+        int st0 = bad;
+        if (__ballot(lane < 18 && !(fabs(dl) <= DBL_MAX)) != 0ull) st0 |= 2;
+        if (lane < 18) L.delta[lane] = dl;
+        if (lane == 18) L.st = st0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (compiler order only: the LDS performs a wavefront's operations in order)
+        if (lane == 0) __hip_atomic_store(&L.jflag, jtag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    if (bcast && lane == 0) fl_bcast_ctrl(bcast, ctrl, bepoch);
+    // lane l < 9 forms R(l/3, l%3) of R * Exp(d0,d1,d2) (so3_math.h:54-72, common_lib.h:345), lanes 9..23 add
+    const double d0 = fl_lane_bcast(dl, 0), d1 = fl_lane_bcast(dl, 1), d2 = fl_lane_bcast(dl, 2);
+    const double t2 = d0 * d0 + d1 * d1 + d2 * d2;
 
     double xnew = G.xl;
     {
@@ -687,38 +751,10 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
         }
     }
     FL_INSTR(fl_stamp(dbg, 36);)
-    // ---- everything below is off the hand-off's critical path: bookkeeping for the host, the next pass's solver and the finish kernels
+    // ---- off the hand-off's critical path: what the host, the next pass's solver and the finish kernels read
     if (lane < 18) D->solution[lane] = dl;
-    if (lane < 18) L.delta[lane] = dl;
     if (lane < FL_SUMS18) D->sums_acc[lane] = s_sums[lane];   // LIO: last executed pass ; VIO: last accepted pass
     if (KIND == FL_EPI_VIO && lane < 24) D->xold[lane] = G.xl;   // old_state = *state (:863)
-    int st = bad;
-    if (__ballot(lane < 18 && !(fabs(dl) <= DBL_MAX)) != 0ull) st |= 2;
-    const int neff_lt1 = (KIND == FL_EPI_LIO && s_sums[FL_S_NEFF] < 1.0) ? 4 : 0;
-    __builtin_amdgcn_wave_barrier();
-    FL_INSTR(if (dbg) { asm volatile("" ::"v"(ctrl + neff_lt1)); fl_stamp(dbg, 37); })
-    if (lane == 0) {
-        L.ctrl = ctrl;
-        L.iters_run = j_iters;
-        D->converged = j_converged;
-        D->iters_run = j_iters;
-        D->stop = j_stop;
-        D->neff = (int)s_sums[FL_S_NEFF];
-        if (KIND == FL_EPI_LIO) {
-            L.rematch = j_rematch; L.iterCount = j_it + 1;
-            D->rematch_num = j_rematch;
-            D->need_search = j_need_search;
-            D->iterCount = j_it + 1;
-            D->total_residual = s_sums[FL_S_RES];
-            L.sticky |= st | neff_lt1;
-        } else {
-            L.accepted = j_accepted;
-            D->accepted = j_accepted;
-            D->total_residual = (double)L.last_error;
-            L.sticky |= st | L.fragile;
-        }
-        D->status = L.sticky;
-    }
 }
 
 // Multi-pass kernels: after eskf18_solve_block (and a __syncthreads) make the new state the solve input of the next

@@ -455,14 +455,14 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
             for (int k = 0; k < PPL; k++) refv[k] = ref[(size_t)ii * 192 + 64 * level + hl + LPP * k];
         }
         FL_INSTR(if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(t[0][1][1] + t[PPL - 1][2][2] + refv[PPL - 1])); fl_stamp(flags, 41); })
-        {   // this lane's entry of M (lanes 0..11), overlaps the tap loads
-            FL_FP_CONTRACT
+        {   // this lane's entry of M (lanes 0..11), overlaps the tap loads. Explicit fma() in a fixed form: the kernel variants (launch
+            // bounds) must produce the same bits, and a contraction left to the compiler differs between instantiations.
             const double inv_s = 1.0 / g.scale;
             const double s1 = (role.r ? g.Jdpi[4] : g.Jdpi[0]) * inv_s, s2 = (role.r ? g.Jdpi[5] : g.Jdpi[2]) * inv_s;
             const double q1 = role.r ? g.pf[2] : -g.pf[2], q2 = role.r ? -g.pf[0] : g.pf[1];
-            const double Br = (q1 * role.X1 + q2 * role.X2) - role.X3;
-            const double B2 = ((-g.pf[1]) * role.Y1 + g.pf[0] * role.Y2) - role.Y3;
-            const double Me = s1 * Br + s2 * B2;
+            const double Br = fma(q1, role.X1, fma(q2, role.X2, -role.X3));
+            const double B2 = fma(-g.pf[1], role.Y1, fma(g.pf[0], role.Y2, -role.Y3));
+            const double Me = fma(s1, Br, s2 * B2);
             if (hl < 12) s_M[hl] = Me;
         }
         FL_INSTR(if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { fl_stamp(flags, 42); })
@@ -504,16 +504,15 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
         // output and the rare exact accept test, never the record: for the wave's LAST patch group it is deferred until the record is
         // published, off the hand-off's critical path (the residuals wait in LDS).
         const bool last_iter = (ib + nprod * WPB * GPW >= m);
-        {   // this lane's two outputs of the patch
-            FL_FP_CONTRACT
+        {   // this lane's two outputs of the patch (explicit fma(), see above)
             __builtin_amdgcn_wave_barrier();
             const double Ma1 = s_M[role.o1a], Mb1 = s_M[6 + role.o1a], Mc1 = s_M[role.o1b], Md1 = s_M[6 + role.o1b];
             const double Ma2 = s_M[role.o2a], Mb2 = s_M[6 + role.o2a], Mc2 = s_M[role.o2b], Md2 = s_M[6 + role.o2b];
             __builtin_amdgcn_wave_barrier();
-            const double out1 = Ma1 * (T6[0] * Mc1 + T6[1] * Md1) + Mb1 * (T6[1] * Mc1 + T6[2] * Md1);
+            const double out1 = fma(Ma1, fma(T6[0], Mc1, T6[1] * Md1), Mb1 * fma(T6[1], Mc1, T6[2] * Md1));
             const bool htz = role.kind2 == 1;
             const double ta = htz ? T6[3] : T6[0], tb2 = htz ? T6[4] : T6[1];
-            double out2 = Ma2 * (ta * Mc2 + T6[1] * Md2) + Mb2 * (tb2 * Mc2 + T6[2] * Md2);
+            double out2 = fma(Ma2, fma(ta, Mc2, T6[1] * Md2), Mb2 * fma(tb2, Mc2, T6[2] * Md2));
             if (role.kind2 >= 2) out2 = (role.kind2 == 2) ? 64.0 : ((role.kind2 == 3) ? T6[5] : 0.0);
             if (active) { acc1 += out1; acc2 += out2; }
         }

@@ -150,3 +150,26 @@ def test_non_finite_state_is_reported_not_hung(gpu_lib, scene):
     h.lio_set_points(fr.body_xyz); h.lio_begin18(x, x); h.lio_set_neighbours(nbr, valid)
     good = h.lio_iterate18(3, capi.FL_ITER_FORCE)
     assert good.status == 0 and good.effct_feat_num > 1000 and np.isfinite(h.lio_get_state18().vec()).all()
+
+
+def test_vio_kernel_variants_give_the_same_bits(gpu_lib):
+    """The VIO multi-pass kernel exists in two register budgets (a CU per workgroup / two workgroups per CU, api_vio.inc
+    vio_mp_variant) besides the one-launch-per-pass form: ComputeJ must not depend on which one a launch gets (the concurrent and
+    sharded uses get the co-resident one). Fused multiply-adds are written out (fma()) wherever the two instantiations could contract
+    differently."""
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    lio = synth.make_lio_frame(2000)
+    vf = synth.make_vio_frame(1800, lio)
+    outs = []
+    for opts in ({}, {capi.FL_OPT_VIO_WHOLE_CU: 0}, {capi.FL_OPT_MULTIPASS: 0}):
+        h = capi.Handle(capi.config_from_frames(lio, vf, max_iterations=10))
+        for k, v in opts.items():
+            h.set_option(k, v)
+        h.vio_set_frame(vf.img); h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+        x = capi.state18_from_frame(lio)
+        infos = h.vio_compute_j(x, capi.state18_from_frame(lio))
+        outs.append((x.vec().copy(), x.cov_np().copy(), h.vio_get_errors(vf.m).view(np.uint32).copy(), [(i.iterations, i.accepted) for i in infos]))
+        h.close()
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2]) and o[3] == outs[0][3]
