@@ -48,7 +48,7 @@ VIO_LEVEL = 0
 LIO_BYTES_PER_POINT = 12 + 16 + 1      # body xyz + cached plane (n,d) + selection flag (the kernel itself reads 16 + 16: DESIGN.md 4.2)
 VIO_BYTES_PER_PATCH = 405 + 4          # 256 ref + 121 image footprint + 24 pos + 4 level, + 4 written
 HBM_PEAK_GBS = 8000.0                  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-SECTIONS = ("at_scale", "vio_sweep", "mode23", "frame", "restage")
+SECTIONS = ("at_scale", "vio_sweep", "mode23", "frame", "restage", "config4", "config5", "cpu_frame")
 
 
 def parse():
@@ -342,6 +342,162 @@ def section_restage(capi, synth, fr, cfg, x0, nbr, valid):
             "what": "one LIO iteration = H2D of the 5-NN (n x 15 floats + n bytes) + lio_fit_planes_kernel + one pass, host wall time"}
 
 
+def _pass_rates(capi, torch, hl, hv):
+    """us per forced LIO / VIO pass of the staged frame, multi-pass launches of PASSES_PER_LAUNCH passes, HIP events on the launch stream"""
+    F, C = capi.FL_ITER_FORCE, PASSES_PER_LAUNCH
+    out = []
+    for fn in (lambda: hl.lio_iterate18(C, F, want_info=False), lambda: hv.vio_iterate(VIO_LEVEL, C, F, want_info=False)):
+        ev0, ev1 = _events(torch)
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        K = 100
+        ev0.record()
+        for _ in range(K):
+            fn()
+        ev1.record()
+        torch.cuda.synchronize()
+        out.append(ev0.elapsed_time(ev1) * 1e3 / (K * C))
+    return out
+
+
+def section_config4(capi, synth, scene):
+    """BASELINE config 4 at N = 1 (the anchor of the 8-GPU scaling curve): ONE frame of 200 000 points (+ the 2 000 patches of the
+    LIVO metric) on one GPU -- forced passes as in the headline, and the whole all-device LIO frame."""
+    import torch
+    fr = synth.make_lio_frame(200000, scene=scene, point_seed=synth.SEED + 101)
+    vf = synth.make_vio_frame(N_PATCHES, fr, patch_seed=synth.SEED + 103)
+    nbr, valid = synth.knn5(scene, fr.world_at(fr.R_prior, fr.p_prior))
+    cfg = capi.config_from_frames(fr, vf, max_iterations=10)
+    x0 = capi.state18_from_frame(fr)
+    stream = torch.cuda.current_stream().cuda_stream
+    hl, hv = capi.Handle(cfg), capi.Handle(cfg)
+    hl.set_stream(stream); hv.set_stream(stream)
+    hl.lio_set_points(fr.body_xyz); hl.lio_begin18(x0, x0); hl.lio_set_neighbours(nbr, valid)
+    hv.vio_set_frame(vf.img); hv.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level); hv.vio_begin(x0, x0)
+    lio_us, vio_us = _pass_rates(capi, torch, hl, hv)
+    hl.close(); hv.close()
+    h = capi.Handle(cfg)
+    h.map_set_points(scene.map_xyz, 0.5)
+    scan = h.host_alloc(fr.body_xyz.shape, np.float32)
+    scan[...] = fr.body_xyz
+    ts, its = [], 0
+    for rep in range(25):
+        x = capi.state18_from_frame(fr)
+        t0 = time.perf_counter()
+        info = h.lio_frame18_dev(x, scan)
+        if rep >= 5:
+            ts.append(time.perf_counter() - t0)
+        its = int(info.iterations)
+    h.host_free(scan); h.close()
+    return {"workload": f"BASELINE config 4 at N = 1: one frame of {fr.n} points + {vf.m} patches on ONE GPU (the 8-GPU form shards it 8 x 25 000)",
+            "lio_pass_us": lio_us, "vio_pass_us": vio_us, "iterations_per_s": 1e6 / (lio_us + vio_us),
+            "lio_frame_ms": float(np.median(ts)) * 1e3, "lio_frame_passes": its,
+            "what": "forced passes: multi-pass launches, HIP events; lio_frame_ms: fl_lio_frame18_dev (H2D, searches, plane fits, passes, covariance), host wall time"}
+
+
+def section_config5(capi, synth, scene):
+    """BASELINE config 5 at N = 1: NTU_VIRAL (752 x 480 radtan camera, img_point_cov 1000, zero LiDAR->IMU translation, max_iteration 10;
+    config/NTU_VIRAL.yaml:3,5,15,32-35,43-46), 200 000 points + 2 000 patches, the FULL LIVO frame on one GPU."""
+    import torch
+    fr = synth.make_lio_frame(200000, scene=scene, t_LI=synth.NTU_T_LI)
+    vf = synth.make_vio_frame(N_PATCHES, fr, cam=synth.NTU_CAM, Rcl=synth.NTU_RCL, Pcl=synth.NTU_PCL, distortion=True, img_point_cov=1000.0,
+                              max_iterations=10)
+    nbr, valid = synth.knn5(scene, fr.world_at(fr.R_prior, fr.p_prior))
+    cfg = capi.config_from_frames(fr, vf, max_iterations=10)
+    x0 = capi.state18_from_frame(fr)
+    stream = torch.cuda.current_stream().cuda_stream
+    hl, hv = capi.Handle(cfg), capi.Handle(cfg)
+    hl.set_stream(stream); hv.set_stream(stream)
+    hl.lio_set_points(fr.body_xyz); hl.lio_begin18(x0, x0); hl.lio_set_neighbours(nbr, valid)
+    hv.vio_set_frame(vf.img); hv.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level); hv.vio_begin(x0, x0)
+    lio_us, vio_us = _pass_rates(capi, torch, hl, hv)
+    hl.close(); hv.close()
+    h = capi.Handle(cfg)
+    h.map_set_points(scene.map_xyz, 0.5)
+    h.vio_set_frame(vf.img); h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+    scan = h.host_alloc(fr.body_xyz.shape, np.float32)
+    scan[...] = fr.body_xyz
+    tl, tv, its, acc = [], [], 0, 0
+    for rep in range(25):
+        x = capi.state18_from_frame(fr)
+        t0 = time.perf_counter()
+        info = h.lio_frame18_dev(x, scan)
+        t1 = time.perf_counter()
+        xv = capi.state18_from_frame(fr)
+        infos = h.vio_compute_j(xv, capi.state18_from_frame(fr))
+        t2 = time.perf_counter()
+        if rep >= 5:
+            tl.append(t1 - t0); tv.append(t2 - t1)
+        its, acc = int(info.iterations), int(sum(i.iterations for i in infos))
+    h.host_free(scan); h.close()
+    lio_ms, vio_ms = float(np.median(tl)) * 1e3, float(np.median(tv)) * 1e3
+    return {"workload": f"BASELINE config 5 at N = 1: NTU_VIRAL camera and extrinsics, {fr.n} points + {vf.m} patches, max_iteration 10, full LIVO frame on ONE GPU",
+            "lio_pass_us": lio_us, "vio_pass_us": vio_us, "iterations_per_s": 1e6 / (lio_us + vio_us),
+            "lio_frame_ms": lio_ms, "vio_computej_ms": vio_ms, "frame_ms": lio_ms + vio_ms, "lio_passes": its, "vio_passes_3_levels": acc,
+            "frame_iterations_per_s": (its + acc) / ((lio_ms + vio_ms) * 1e-3),
+            "what": "forced passes: multi-pass launches, HIP events; frame: fl_lio_frame18_dev + fl_vio_compute_j, host wall time incl. every synchronisation"}
+
+
+def section_cpu_frame(synth, scene, fr, vf, budget_s):
+    """The REFERENCE side of `frame`, timed on this box's host cores: the oracle's Mode-18 frame loop (laserMapping.cpp:1504-1733 restated)
+    with the 5-NN searches served by the reference's OWN ikd-Tree (oracle/_ref: include/ikd-Tree/ikd_Tree.cpp compiled unmodified,
+    KD_TREE::Nearest_Search under `#pragma omp parallel for` as laserMapping.cpp:1516-1519 calls it), followed by the oracle's ComputeJ
+    (single-threaded, as lidar_selection.cpp runs it). Twice: with the reference's threading (MP_PROC_NUM = 4) and with the best
+    thread count of a sweep up to all cores (VIO patch loop threaded too)."""
+    from oracle import oracle as orc, ikdref
+    if not ikdref.available():
+        return {"skipped": "oracle/_ref/libikdtree_ref.so not present"}
+    tree = ikdref.IkdTree(0.5)
+    t0 = time.perf_counter()
+    tree.build(scene.map_xyz)
+    build_ms = (time.perf_counter() - t0) * 1e3
+
+    def run(threads, vio_threads, budget):
+        knn_s = [0.0]
+
+        def knn(w):
+            t = time.perf_counter()
+            xyz, sq, found = tree.nearest(w, 5, nthreads=threads)
+            valid = ((found == 5) & (sq[:, 4] <= 5.0)).astype(np.uint8)          # laserMapping.cpp:1549
+            knn_s[0] += time.perf_counter() - t
+            return xyz, valid
+        orc.lib().orc_vio_set_threads(vio_threads)
+        tl, tv, tk, its, acc = [], [], [], 0, 0
+        t_end = time.perf_counter() + budget
+        rep = 0
+        while rep < 2 or (time.perf_counter() < t_end and rep < 40):
+            xo = orc.state18_from_frame(fr)
+            knn_s[0] = 0.0
+            t0 = time.perf_counter()
+            ro = orc.lio18_frame(xo, fr.body_xyz, fr.R_LI, fr.t_LI, fr.laser_point_cov, 10, knn, nthreads=threads)
+            t1 = time.perf_counter()
+            xv = orc.state18_from_frame(fr)
+            rv = orc.vio_compute_j(vf, xv, xv.copy())
+            t2 = time.perf_counter()
+            if rep >= 1:
+                tl.append(t1 - t0); tv.append(t2 - t1); tk.append(knn_s[0])
+            its = int(ro["out"].iterations); acc = int(sum(o.iterations for o in rv["outs"]))
+            rep += 1
+        orc.lib().orc_vio_set_threads(1)
+        lio_ms, vio_ms = float(np.median(tl)) * 1e3, float(np.median(tv)) * 1e3
+        return {"threads": threads, "vio_threads": vio_threads, "lio_frame_ms": lio_ms, "of_which_nearest_search_ms": float(np.median(tk)) * 1e3,
+                "vio_computej_ms": vio_ms, "frame_ms": lio_ms + vio_ms, "lio_passes": its, "vio_passes_3_levels": acc, "frames_timed": len(tl)}
+    ncpu = os.cpu_count() or 1
+    ref = run(min(4, ncpu), 1, budget_s)
+    best = None
+    for t in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
+        r = run(t, t, max(2.0, budget_s / 4))
+        if best is None or r["frame_ms"] < best["frame_ms"]:
+            best = r
+    tree.close()
+    return {"kind": "reference ikd-Tree (oracle/_ref, KD_TREE::Nearest_Search) + port of the frame loops (oracle/)", "host_cores_available": ncpu,
+            "map_points": int(len(scene.map_xyz)), "ikd_tree_build_ms": build_ms,
+            "reference_threading": ref, "best_over_thread_counts": best,
+            "what": f"one whole frame on the host: LIO ({fr.n} pts: searches by the reference's ikd-Tree + plane fits + passes + covariance) + ComputeJ ({vf.m} patches, 3 levels); "
+                    "the figure beside `frame` (same inputs, same pass counts)"}
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     global AT_SCALE_POINTS, VIO_SWEEP
@@ -418,7 +574,10 @@ def main():
                "vio_sweep": lambda: section_vio_sweep(capi, synth, fr, vf, cfg, x0),
                "mode23": lambda: section_mode23(capi, synth, scene, fr, cfg, nbr, valid),
                "frame": lambda: section_frame(capi, synth, scene, fr, vf, cfg),
-               "restage": lambda: section_restage(capi, synth, fr, cfg, x0, nbr, valid)}[args.only]()
+               "restage": lambda: section_restage(capi, synth, fr, cfg, x0, nbr, valid),
+               "config4": lambda: section_config4(capi, synth, scene),
+               "config5": lambda: section_config5(capi, synth, scene),
+               "cpu_frame": lambda: section_cpu_frame(synth, scene, fr, vf, args.cpu_seconds)}[args.only]()
         print(json.dumps({"section": args.only, "result": sec}), flush=True)
         return
 
@@ -643,6 +802,8 @@ def main():
         extras["mode23"] = section_mode23(capi, synth, scene, fr, cfg, nbr, valid)
         extras["frame"] = section_frame(capi, synth, scene, fr, vf, cfg)
         extras["restage"] = section_restage(capi, synth, fr, cfg, x0, nbr, valid)
+        extras["config4"] = section_config4(capi, synth, scene)
+        extras["config5"] = section_config5(capi, synth, scene)
         if args.sweep:
             sweep(capi, synth, scene, cfg, x0, sys.stderr)
 
@@ -650,6 +811,11 @@ def main():
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline(fr, vf, nbr, valid, args.cpu_seconds)
         cpu_all = cpu_baseline_all_cores(fr, vf, nbr, valid, args.cpu_seconds)
+        if not args.no_extras:
+            extras["cpu_frame"] = section_cpu_frame(synth, scene, fr, vf, args.cpu_seconds)
+            if "frame" in extras and "reference_threading" in extras["cpu_frame"]:
+                extras["frame"]["speedup_vs_cpu_frame"] = extras["cpu_frame"]["reference_threading"]["frame_ms"] / extras["frame"]["frame_ms"]
+                extras["frame"]["speedup_vs_cpu_frame_best_threads"] = extras["cpu_frame"]["best_over_thread_counts"]["frame_ms"] / extras["frame"]["frame_ms"]
 
     if distributed:
         torch.cuda.synchronize()

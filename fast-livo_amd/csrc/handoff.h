@@ -110,26 +110,12 @@ __device__ __forceinline__ int gather_records(const void *records, int nprod, un
             for (int j = 0; j < BATCH; j++) need |= ((base + 4 * wave_u + j * ROWS) < nprod) ? (1u << j) : 0u;
 #pragma unroll
             for (int j = 0; j < BATCH; j++) { t[j].x = 0u; t[j].y = 0u; t[j].z = 0u; t[j].w = 0u; }
-#ifdef FL_GATHER_SENTINEL
-            // (tried in round 3, off by default: every wavefront first polls ONE load instruction's worth -- its four records of batch 0 --
-            // and starts the full sweep when those have arrived. Per-wave stamps: polling done 1.84-2.04 us after workgroup 0's
+            // (tried in round 3 and removed: every wavefront first polling ONE load instruction's worth -- its four records of batch 0 --
+            // and starting the full sweep when those have arrived. Per-wave stamps: polling done 1.84-2.04 us after workgroup 0's
             // publication against 1.72-1.84 us with the speculative sweeps: the sentinel's detection round trip costs what the wasted
-            // first sweep cost.)
-            if (need & 1u) {
-                for (int spin = 0; ; spin++) {
-                    asm volatile("" ::: "memory");          // the load below is loop-invariant to the compiler: without this it is hoisted
-                    t[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (b0 * NV + g * 32 + kp * 2) * 8, 0, 16 /* sc1 */);
-                    const bool ok = (b0 >= nprod) || (((t[0].x & FL_TAG_MASK) == tag) && ((t[0].z & FL_TAG_MASK) == tag));
-                    if (__ballot(ok) == ~0ull) { need &= ~1u; break; }
-                    if (spin >= FL_GATHER_SPIN_LIMIT) { timeout = 1; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-#ifdef FL_GATHER_STAMPS
-            if (tid == 0) g_fl_stamps[45] = (long long)wall_clock64();
-#endif
-#endif
-            for (int spin = 0; need != 0u && !timeout; spin++) {
+            // first sweep cost. Note for anyone who retries it: a loop around ONE buffer load with a loop-invariant address needs a
+            // compiler barrier, the load is hoisted otherwise.)
+            for (int spin = 0; need != 0u; spin++) {
 #ifdef FL_GATHER_STAMPS
                 if (tid == 0 && spin < 8) { g_fl_stamps[56 + spin] = (long long)wall_clock64(); g_fl_wall[2040 + spin] = (long long)__builtin_popcount(need); }
 #endif

@@ -47,6 +47,7 @@ def lib():
         L.ikdref_wait_rebuild.argtypes = [C.c_void_p, C.c_int]
         L.ikdref_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.ikdref_nearest.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ikdref_nearest_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.ikdref_add_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.ikdref_delete_boxes.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.ikdref_flatten.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -94,13 +95,17 @@ class IkdTree:
     def wait_rebuild(self, timeout_ms=20000):
         return bool(self.L.ikdref_wait_rebuild(self.h, timeout_ms))
 
-    def nearest(self, query, k=5):
+    def nearest(self, query, k=5, nthreads=1):
+        """nthreads > 1: under `#pragma omp parallel for` as the reference calls it (laserMapping.cpp:1516-1519)."""
         q = _f32(query, 3)
         n = len(q)
         xyz = np.zeros((n, k, 3), np.float32)
         sq = np.zeros((n, k), np.float32)
         found = np.zeros(n, np.int32)
-        self.L.ikdref_nearest(self.h, q.ctypes.data, n, k, xyz.ctypes.data, sq.ctypes.data, found.ctypes.data)
+        if nthreads > 1:
+            self.L.ikdref_nearest_mt(self.h, q.ctypes.data, n, k, xyz.ctypes.data, sq.ctypes.data, found.ctypes.data, int(nthreads))
+        else:
+            self.L.ikdref_nearest(self.h, q.ctypes.data, n, k, xyz.ctypes.data, sq.ctypes.data, found.ctypes.data)
         return xyz, sq, found
 
     def add_points(self, xyz, downsample=True):

@@ -110,6 +110,27 @@ void ikdref_nearest(void *h, const float *query_xyz, int n, int k, float *out_xy
     }
 }
 
+// The same search as the reference runs it: KD_TREE::Nearest_Search inside `#pragma omp parallel for` over the scan points
+// (laserMapping.cpp:1516-1519 / :996, MP_PROC_NUM threads, CMakeLists.txt:23-26: 4 on a machine with more than 5 cores).
+void ikdref_nearest_mt(void *h, const float *query_xyz, int n, int k, float *out_xyz, float *out_sq, int32_t *found, int nthreads)
+{
+    KD_TREE *t = ((Ref *)h)->tree;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int i = 0; i < n; i++) {
+        PointVector near;
+        std::vector<float> sq;
+        t->Nearest_Search(mk(query_xyz + 3 * i), k, near, sq);
+        const int f = (int)near.size();
+        found[i] = f;
+        for (int j = 0; j < k; j++) {
+            float *o = out_xyz + ((size_t)i * k + j) * 3;
+            if (j < f) { o[0] = near[j].x; o[1] = near[j].y; o[2] = near[j].z; out_sq[(size_t)i * k + j] = sq[j]; }
+            else { o[0] = o[1] = o[2] = 0.f; out_sq[(size_t)i * k + j] = INFINITY; }
+        }
+    }
+}
+
 int ikdref_add_points(void *h, const float *xyz, int n, int downsample_on)
 {
     PointVector v((size_t)n);

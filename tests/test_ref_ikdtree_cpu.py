@@ -216,3 +216,28 @@ def test_delete_boxes_restatement_equals_the_tree(oracle_lib, scene):
     full = found == 5
     assert np.array_equal(sq[full], sq_o[full]) and np.array_equal(xyz[full], nbr_o[full])
     t.close()
+
+
+def test_threaded_search_is_the_same_search(scene):
+    """ikdref_nearest_mt = KD_TREE::Nearest_Search under `#pragma omp parallel for`, the way laserMapping.cpp:1516-1519 calls it (what
+    bench.py's cpu_frame times): same neighbours, same order, same distances as the sequential calls."""
+    from fast_livo_amd import synth
+    fr = synth.make_lio_frame(6000, scene=scene)
+    q = fr.world_at(fr.R_prior, fr.p_prior).astype(np.float32)
+    t = ikdref.IkdTree(0.5)
+    t.build(scene.map_xyz)
+    a = t.nearest(q)
+    b = t.nearest(q, nthreads=4)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    t.close()
+
+
+def test_bench_cpu_frame_section_runs(scene):
+    import bench
+    from fast_livo_amd import synth
+    fr = synth.make_lio_frame(3000, scene=scene)
+    vf = synth.make_vio_frame(100, fr)
+    r = bench.section_cpu_frame(synth, scene, fr, vf, 0.5)
+    assert r["reference_threading"]["threads"] == 4 and r["reference_threading"]["frame_ms"] > 0
+    assert r["reference_threading"]["lio_passes"] >= 2 and r["best_over_thread_counts"]["frame_ms"] > 0
