@@ -536,7 +536,7 @@ static void *records_for(fl_handle h, size_t need_bytes)
 }
 static inline void *records_lio(fl_handle h) { return records_for(h, (size_t)lio_grid(h, h->n) * FL_SUMS18 * 8); }
 static inline void *records_vio(fl_handle h) { return records_for(h, (size_t)vio_grid(h->m) * FL_SUMS18 * 8); }
-static inline void *records_ik(fl_handle h) { return records_for(h, (size_t)ik_grid(h, h->n) * FL_SUMS23 * 8); }
+static inline void *records_ik(fl_handle h) { return records_for(h, (size_t)ik_grid(h, h->n) * FL_SUMS23I * 8); }
 
 int32_t fl_lio_set_points(fl_handle h, const float *body_xyz, int32_t n)
 {

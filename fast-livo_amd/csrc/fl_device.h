@@ -11,7 +11,8 @@
 #define FL_WAVE 64
 #define FL_BLOCK 256
 #define FL_SUMS18 32
-#define FL_SUMS23 96
+#define FL_SUMS23 96          /* the PUBLIC Mode-23 record (fl_ikfom_accumulate / fl_ikfom_solve, fl_h_share_model_sums) */
+#define FL_SUMS23I 64         /* what the pass kernels hand from the producers to the solver: see fl_ikfom_math.h */
 
 // Reduction record layout (Mode-18 and VIO), FL_SUMS18 doubles:
 //   [0..20]  upper triangle of the 6x6 H^T H, row-major (i<=j)

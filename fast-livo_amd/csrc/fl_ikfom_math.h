@@ -36,6 +36,63 @@
 #define FL_X23_GRAV 23
 #define FL_X23_LEN 26
 
+// ---- small-angle forms for the DEVICE (round 3). The increments of an update are tiny (|x (-) x_prop| and |dx_| << 0.5 rad), and the
+// library sqrt / sin / cos / atan / atan2 behind the manifold operations ran on single lanes of the solver workgroup, on the pass's
+// critical path (ikfom_pre 5 us, the three boxplus segments 1.6 us). Power series in the squared argument (truncation < 1e-17
+// relative inside the stated range, no cancellation) replace them on the device; larger arguments and the host build (the unit
+// tests against the oracle) keep the library form. The update is compared with the oracle by tolerance (1e-9), never bitwise.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FL_IK_SERIES 1
+#else
+#define FL_IK_SERIES 0
+#endif
+// cos x and sin x / x from x^2 <= 0.25
+FL_HD void fl_series_cos_sinc(double x2, double *co, double *si)
+{
+    double c = 1.0 / 87178291200.0;
+    c = c * (-x2) + 1.0 / 479001600.0;
+    c = c * (-x2) + 1.0 / 3628800.0;
+    c = c * (-x2) + 1.0 / 40320.0;
+    c = c * (-x2) + 1.0 / 720.0;
+    c = c * (-x2) + 1.0 / 24.0;
+    c = c * (-x2) + 0.5;
+    *co = 1.0 - x2 * c;
+    double a = 1.0 / 1307674368000.0;
+    a = a * (-x2) + 1.0 / 6227020800.0;
+    a = a * (-x2) + 1.0 / 39916800.0;
+    a = a * (-x2) + 1.0 / 362880.0;
+    a = a * (-x2) + 1.0 / 5040.0;
+    a = a * (-x2) + 1.0 / 120.0;
+    a = a * (-x2) + 1.0 / 6.0;
+    *si = 1.0 - x2 * a;
+}
+// (1 - cos t) / t^2 and (1 - sin t / t) / t^2 from t^2 <= 0.25
+FL_HD void fl_series_A_coeffs(double t2, double *a, double *b)
+{
+    double c = 1.0 / 87178291200.0;
+    c = c * (-t2) + 1.0 / 479001600.0;
+    c = c * (-t2) + 1.0 / 3628800.0;
+    c = c * (-t2) + 1.0 / 40320.0;
+    c = c * (-t2) + 1.0 / 720.0;
+    c = c * (-t2) + 1.0 / 24.0;
+    *a = c * (-t2) + 0.5;
+    double d = 1.0 / 1307674368000.0;
+    d = d * (-t2) + 1.0 / 6227020800.0;
+    d = d * (-t2) + 1.0 / 39916800.0;
+    d = d * (-t2) + 1.0 / 362880.0;
+    d = d * (-t2) + 1.0 / 5040.0;
+    d = d * (-t2) + 1.0 / 120.0;
+    *b = d * (-t2) + 1.0 / 6.0;
+}
+// atan(r) / r from r^2 <= 1/16
+FL_HD double fl_series_atan_over(double r2)
+{
+    double p = 1.0 / 29.0;
+#pragma unroll
+    for (int k = 13; k >= 0; k--) p = p * (-r2) + 1.0 / (2 * k + 1);
+    return p;
+}
+
 // Mode-23 reduction record (FL_SUMS23 = 96 doubles): [0..77] upper triangle of the 12x12 h_x^T h_x
 // (row-major, i<=j), [78..89] h_x^T h, [90] n_eff, [91] sum|pd2|, [92] sum pd2^2, [93..95] zero.
 #define FL_S23_HTH 0
@@ -79,7 +136,10 @@ FL_HD void flq_to_R(const double *q, double *R)
 // mtkmath.hpp:142-174
 FL_HD void fl_cos_sinc_sqrt(double x2, double *co, double *si)
 {
-    const double taylor_n_bound = sqrt(sqrt(DBL_EPSILON));
+    const double taylor_n_bound = 1.220703125e-4;      // sqrt(sqrt(DBL_EPSILON))
+#if FL_IK_SERIES
+    if (x2 >= taylor_n_bound && x2 <= 0.25) { fl_series_cos_sinc(x2, co, si); return; }
+#endif
     if (x2 >= taylor_n_bound) {
         const double x = sqrt(x2);
         *co = cos(x); *si = sin(x) / x;
@@ -108,6 +168,17 @@ FL_HD void fl_mtk_exp3(const double *vec, double scale, double *q /*x,y,z,w*/)
 // SO3::log (SOn.hpp:293-297; mtkmath.hpp:268-288 with plus_minus_periodicity)
 FL_HD void fl_so3_log(const double *q, double *res)
 {
+#if FL_IK_SERIES
+    {
+        const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2], w = q[3];
+        if (n2 >= FL_MTK_TOL * FL_MTK_TOL && w > 0.0 && n2 <= 0.0625 * w * w) {       // 2 / nv * atan(nv / w) = 2 / w * (atan r / r), r = nv / w
+            const double inv_w = 1.0 / w;
+            const double s = 2.0 * inv_w * fl_series_atan_over(n2 * inv_w * inv_w);
+            res[0] = s * q[0]; res[1] = s * q[1]; res[2] = s * q[2];
+            return;
+        }
+    }
+#endif
     double nv = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
     if (nv < FL_MTK_TOL) nv = FL_MTK_TOL;
     const double s = 2.0 / nv * atan(nv / q[3]);
@@ -130,8 +201,18 @@ FL_HD void fl_m3mul(const double *A, const double *B, double *C)
 FL_HD void fl_A_matrix(const double *v, double *res)
 {
     const double sq = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-    const double norm = sqrt(sq);
     for (int i = 0; i < 9; i++) res[i] = (i % 4 == 0) ? 1.0 : 0.0;
+#if FL_IK_SERIES
+    if (sq >= FL_MTK_TOL * FL_MTK_TOL && sq <= 0.25) {
+        double K[9], KK[9], a, b;
+        fl_skew(v, K);
+        fl_m3mul(K, K, KK);
+        fl_series_A_coeffs(sq, &a, &b);
+        for (int i = 0; i < 9; i++) res[i] = res[i] + a * K[i] + b * KK[i];
+        return;
+    }
+#endif
+    const double norm = sqrt(sq);
     if (!(norm < FL_MTK_TOL)) {
         double K[9], KK[9];
         fl_skew(v, K);
@@ -144,6 +225,21 @@ FL_HD void fl_A_matrix(const double *v, double *res)
 FL_HD void fl_s2_Bx(const double *vec, double *Bx)
 {
     const double L = FL_S2_LEN;
+#if FL_IK_SERIES
+    if (vec[0] + L > FL_MTK_TOL) {       // device: one reciprocal (+ two Newton steps, ~1e-16) instead of nine IEEE divisions
+        const double den = L + vec[0];
+        double r = __builtin_amdgcn_rcp(den);
+        double e = fma(-den, r, 1.0);
+        r = fma(r, e, r);
+        e = fma(-den, r, 1.0);
+        r = fma(r, e, r);
+        const double iL = 1.0 / FL_S2_LEN;           // (a compile-time constant)
+        Bx[0] = -vec[1] * iL;                        Bx[1] = -vec[2] * iL;
+        Bx[2] = (L - vec[1] * vec[1] * r) * iL;      Bx[3] = (-vec[2] * vec[1] * r) * iL;
+        Bx[4] = Bx[3];                               Bx[5] = (L - vec[2] * vec[2] * r) * iL;
+        return;
+    }
+#endif
     if (vec[0] + L > FL_MTK_TOL) {
         Bx[0] = -vec[1];                              Bx[1] = -vec[2];
         Bx[2] = L - vec[1] * vec[1] / (L + vec[0]);   Bx[3] = -vec[2] * vec[1] / (L + vec[0]);
@@ -172,8 +268,23 @@ FL_HD void fl_s2_boxminus(const double *vec, const double *other, double *res)
     double K[9], hv[3];
     fl_skew(vec, K);
     for (int i = 0; i < 3; i++) hv[i] = K[i * 3] * other[0] + K[i * 3 + 1] * other[1] + K[i * 3 + 2] * other[2];
-    const double v_sin = sqrt(hv[0] * hv[0] + hv[1] * hv[1] + hv[2] * hv[2]);
     const double v_cos = vec[0] * other[0] + vec[1] * other[1] + vec[2] * other[2];
+#if FL_IK_SERIES
+    {
+        const double s2 = hv[0] * hv[0] + hv[1] * hv[1] + hv[2] * hv[2];
+        if (s2 >= FL_MTK_TOL * FL_MTK_TOL && v_cos > 0.0 && s2 <= 0.0625 * v_cos * v_cos) {   // theta / v_sin = (atan t / t) / v_cos, t = v_sin / v_cos
+            double Bx[6], Ko[9], w[3];
+            fl_s2_Bx(other, Bx);
+            fl_skew(other, Ko);
+            for (int i = 0; i < 3; i++) w[i] = Ko[i * 3] * vec[0] + Ko[i * 3 + 1] * vec[1] + Ko[i * 3 + 2] * vec[2];
+            const double inv_c = 1.0 / v_cos;
+            const double f = fl_series_atan_over(s2 * inv_c * inv_c) * inv_c;
+            for (int r = 0; r < 2; r++) res[r] = f * (Bx[0 * 2 + r] * w[0] + Bx[1 * 2 + r] * w[1] + Bx[2 * 2 + r] * w[2]);
+            return;
+        }
+    }
+#endif
+    const double v_sin = sqrt(hv[0] * hv[0] + hv[1] * hv[1] + hv[2] * hv[2]);
     const double theta = atan2(v_sin, v_cos);
     if (v_sin < FL_MTK_TOL) {
         res[0] = (fabs(theta) > FL_MTK_TOL) ? 3.1415926 : 0.0;
@@ -296,6 +407,50 @@ FL_HD void fl_row23(const double *x, const float *pb, const double *p_i, const f
     row[8] = b[0] * D[1] - b[1] * D[0];
     row[9] = C[0]; row[10] = C[1]; row[11] = C[2];
     *z = -(double)pd2;
+}
+// The record the pass kernels hand over (FL_SUMS23I = 64 doubles, round 3): the row is [n, A, B, C] with C = R^T n (R = rotation of
+// the state, the same for every point of a pass), so every sum that involves C follows from the sums over n: C C^T = R^T (n n^T) R,
+// X C^T = (X n^T) R, sum C z = R^T sum n z. The producers therefore accumulate only the 9 x 9 block over [n, A, B] -- 45 + 9 + 3
+// numbers instead of 78 + 12 + 3: a third less to accumulate, to reduce, to publish and to gather -- and the solver rebuilds the
+// 12 x 12 matrix (ikfom_solve_block.h ikfom_unpack). Layout: [0..44] upper triangle of the 9 x 9, row-major (i <= j);
+// [45..53] H^T z; [54] n_eff; [55] sum |pd2|; [56] sum pd2^2; rest zero. Rounding-level differences from summing C per point
+// (compared by tolerance, like every fp64 sum).
+#define FL_S23I_HTZ 45
+#define FL_S23I_NEFF 54
+#define FL_S23I_RES 55
+#define FL_S23I_RES2 56
+FL_HD void fl_accum9(double *v /*64*/, const double *row /* 9 used */, double z)
+{
+    FL_FP_CONTRACT
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = i; j < 9; j++) { v[k] += row[i] * row[j]; k++; }
+#pragma unroll
+    for (int i = 0; i < 9; i++) v[FL_S23I_HTZ + i] += row[i] * z;
+}
+FL_HD constexpr int fl_tri9(int i, int j) { return (i <= j) ? (i * 9 - i * (i - 1) / 2 + (j - i)) : (j * 9 - j * (j - 1) / 2 + (i - j)); }
+// entry (i, j) of the 12 x 12 h_x^T h_x and entry i of h_x^T h out of the internal record; Rm = flq_to_R(x.rot), row-major
+FL_HD double fl_s12_from_s9(const double *s /*64*/, const double *Rm, int i, int j)
+{
+    FL_FP_CONTRACT
+    if (i > j) { const int t = i; i = j; j = t; }
+    if (j < 9) return s[fl_tri9(i, j)];
+    const int c = j - 9;
+    if (i < 9) return Rm[c] * s[fl_tri9(i, 0)] + Rm[3 + c] * s[fl_tri9(i, 1)] + Rm[6 + c] * s[fl_tri9(i, 2)];
+    const int a = i - 9;
+    double acc = 0.0;
+    for (int k = 0; k < 3; k++)
+        acc += Rm[3 * k + a] * (Rm[c] * s[fl_tri9(k, 0)] + Rm[3 + c] * s[fl_tri9(k, 1)] + Rm[6 + c] * s[fl_tri9(k, 2)]);
+    return acc;
+}
+FL_HD double fl_htz12_from_s9(const double *s /*64*/, const double *Rm, int i)
+{
+    FL_FP_CONTRACT
+    if (i < 9) return s[FL_S23I_HTZ + i];
+    const int c = i - 9;
+    return Rm[c] * s[FL_S23I_HTZ] + Rm[3 + c] * s[FL_S23I_HTZ + 1] + Rm[6 + c] * s[FL_S23I_HTZ + 2];
 }
 FL_HD void fl_accum12(double *v /*96*/, const double *row, double z)
 {

@@ -84,12 +84,16 @@ __device__ __forceinline__ double fl_untag(unsigned lo, unsigned hi) { return f6
 
 // Solver workgroup: gather nprod records and leave the totals in out_lds[NV]. Returns 0, or
 // FL_NUM_TIMEOUT if some record never showed up (all threads agree).
+// All NV / 32 groups of a record are polled in the SAME sweep (slots (group, batch), 16 loads per lane in flight at most): one
+// sweep covers 16 * NT / 16 / (NV / 32) records -- 256 of the 32-double records, 128 of Mode-23's 64-double ones.
 template <int NT, int NV>
 __device__ __forceinline__ int gather_records(const void *records, int nprod, unsigned epoch, double *lds /* >= 2*NT */,
                                               double *out_lds /* NV */)
 {
     constexpr int ROWS = NT / 16;         // records covered by one load instruction of the workgroup
-    constexpr int BATCH = 16;             // up to ROWS*16 producers per sweep (256 @ NT=256)
+    constexpr int G = NV / 32;            // 32-value groups of a record
+    constexpr int BATCH = 16 / G;         // batches of ROWS records per sweep
+    static_assert(G == 1 || G == 2, "16 load slots per lane");
     const int tid = threadIdx.x;
     const int kp = tid & 15, row = tid >> 4;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,77 +102,88 @@ __device__ __forceinline__ int gather_records(const void *records, int nprod, un
     int timeout = 0;
     // (tried in round 2 and rejected: waiting for the records with a light one-word-per-record poll and only then doing ONE full
     // sweep -- 7.5 vs 6.9 us per LIO pass, 10.1 vs 9.0 per VIO pass: the speculative sweeps below pick the early records up while the
-    // late ones are still in flight, and the last sweep re-reads only the missing batches)
+    // late ones are still in flight, and the last sweep re-reads only the missing batches.
+    // Tried in round 3 and removed: every wavefront first polling ONE load instruction's worth -- its four records of batch 0 -- and
+    // starting the full sweep when those have arrived. Per-wave stamps: polling done 1.84-2.04 us after workgroup 0's publication
+    // against 1.72-1.84 us with the speculative sweeps: the sentinel's detection round trip costs what the wasted first sweep cost.
+    // Note for anyone who retries it: a loop around ONE buffer load with a loop-invariant address needs a compiler barrier, the load
+    // is hoisted otherwise.)
+    double s0[G], s1[G];
 #pragma unroll
-    for (int g = 0; g < NV / 32; g++) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int base = 0; base < nprod; base += ROWS * BATCH) {   // trip count uniform over the workgroup
-            const int b0 = base + row;
-            fl_u4 t[BATCH];
-            unsigned need = 0u;                                     // wave-uniform
+    for (int g = 0; g < G; g++) { s0[g] = 0.0; s1[g] = 0.0; }
+    for (int base = 0; base < nprod; base += ROWS * BATCH) {   // trip count uniform over the workgroup
+        const int b0 = base + row;
+        fl_u4 t[G][BATCH];
+        unsigned need = 0u;                                     // wave-uniform; bit g * BATCH + j
 #pragma unroll
-            for (int j = 0; j < BATCH; j++) need |= ((base + 4 * wave_u + j * ROWS) < nprod) ? (1u << j) : 0u;
-#pragma unroll
-            for (int j = 0; j < BATCH; j++) { t[j].x = 0u; t[j].y = 0u; t[j].z = 0u; t[j].w = 0u; }
-            // (tried in round 3 and removed: every wavefront first polling ONE load instruction's worth -- its four records of batch 0 --
-            // and starting the full sweep when those have arrived. Per-wave stamps: polling done 1.84-2.04 us after workgroup 0's
-            // publication against 1.72-1.84 us with the speculative sweeps: the sentinel's detection round trip costs what the wasted
-            // first sweep cost. Note for anyone who retries it: a loop around ONE buffer load with a loop-invariant address needs a
-            // compiler barrier, the load is hoisted otherwise.)
-            for (int spin = 0; need != 0u; spin++) {
-#ifdef FL_GATHER_STAMPS
-                if (tid == 0 && spin < 8) { g_fl_stamps[56 + spin] = (long long)wall_clock64(); g_fl_wall[2040 + spin] = (long long)__builtin_popcount(need); }
-#endif
-#pragma unroll
-                for (int j = 0; j < BATCH; j++) {
-                    if (need & (1u << j)) {
-                        const int b = b0 + j * ROWS;
-                        t[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (b * NV + g * 32 + kp * 2) * 8, 0, 16 /* sc1 */);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < BATCH; j++) {
-                    if (need & (1u << j)) {
-                        const int b = b0 + j * ROWS;
-                        const bool ok = (b >= nprod) || (((t[j].x & FL_TAG_MASK) == tag) && ((t[j].z & FL_TAG_MASK) == tag));
-                        if (__ballot(ok) == ~0ull) need &= ~(1u << j);
-                    }
-                }
-#ifdef FL_GATHER_STAMPS
-                if (tid == 0 && spin < 8) { g_fl_stamps[48 + spin] = (long long)wall_clock64(); g_fl_stamps[47] = spin + 1; g_fl_stamps[46] = (long long)__builtin_popcount(need); }
-#endif
-                if (need != 0u) {
-                    if (spin >= FL_GATHER_SPIN_LIMIT) { timeout = 1; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-#ifdef FL_GATHER_STAMPS
-            if ((tid & 63) == 0) g_fl_wall[2024 + wave_u] = (long long)wall_clock64();
-#endif
-            // this lane's records in ascending order, straight-line: batches beyond the grid were never loaded (t = 0) and a row beyond
-            // the grid inside a live batch read zeros (buffer bounds) -- both untag to +0.0. (This tail runs on ONE wavefront per SIMD:
-            // a compare + branch per record cost 0.7 us of every pass, a scalar branch per batch still 0.1 us.)
+        for (int g = 0; g < G; g++)
 #pragma unroll
             for (int j = 0; j < BATCH; j++) {
-                s0 += fl_untag(t[j].x, t[j].y);
-                s1 += fl_untag(t[j].z, t[j].w);
+                need |= ((base + 4 * wave_u + j * ROWS) < nprod) ? (1u << (g * BATCH + j)) : 0u;
+                t[g][j].x = 0u; t[g][j].y = 0u; t[g][j].z = 0u; t[g][j].w = 0u;
+            }
+        for (int spin = 0; need != 0u; spin++) {
+#ifdef FL_GATHER_STAMPS
+            if (tid == 0 && spin < 8) { g_fl_stamps[56 + spin] = (long long)wall_clock64(); g_fl_wall[2040 + spin] = (long long)__builtin_popcount(need); }
+#endif
+#pragma unroll
+            for (int g = 0; g < G; g++)
+#pragma unroll
+                for (int j = 0; j < BATCH; j++) {
+                    if (need & (1u << (g * BATCH + j))) {
+                        const int b = b0 + j * ROWS;
+                        t[g][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (b * NV + g * 32 + kp * 2) * 8, 0, 16 /* sc1 */);
+                    }
+                }
+#pragma unroll
+            for (int g = 0; g < G; g++)
+#pragma unroll
+                for (int j = 0; j < BATCH; j++) {
+                    if (need & (1u << (g * BATCH + j))) {
+                        const int b = b0 + j * ROWS;
+                        const bool ok = (b >= nprod) || (((t[g][j].x & FL_TAG_MASK) == tag) && ((t[g][j].z & FL_TAG_MASK) == tag));
+                        if (__ballot(ok) == ~0ull) need &= ~(1u << (g * BATCH + j));
+                    }
+                }
+#ifdef FL_GATHER_STAMPS
+            if (tid == 0 && spin < 8) { g_fl_stamps[48 + spin] = (long long)wall_clock64(); g_fl_stamps[47] = spin + 1; g_fl_stamps[46] = (long long)__builtin_popcount(need); }
+#endif
+            if (need != 0u) {
+                if (spin >= FL_GATHER_SPIN_LIMIT) { timeout = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
             }
         }
-        // the four 16-lane rows of a wavefront hold four different records' share of value pair kp: rows first (two lane swaps, no
-        // LDS), then the NT/64 wavefronts through LDS. Fixed order: (row 0 + row 1) + (row 2 + row 3), then wavefronts ascending.
-        swap16_f64(s0, s1);
-        double c = s0 + s1;                                         // even rows: value 2 kp, odd rows: value 2 kp + 1
-        {
-            double c2 = c;
-            swap32_f64(c, c2);
-            c = c + c2;
-        }
+#ifdef FL_GATHER_STAMPS
+        if ((tid & 63) == 0) g_fl_wall[2024 + wave_u] = (long long)wall_clock64();
+#endif
+        // this lane's records in ascending order, straight-line: batches beyond the grid were never loaded (t = 0) and a row beyond
+        // the grid inside a live batch read zeros (buffer bounds) -- both untag to +0.0. (This tail runs on ONE wavefront per SIMD:
+        // a compare + branch per record cost 0.7 us of every pass, a scalar branch per batch still 0.1 us.)
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int j = 0; j < BATCH; j++) {
+                s0[g] += fl_untag(t[g][j].x, t[g][j].y);
+                s1[g] += fl_untag(t[g][j].z, t[g][j].w);
+            }
+        if (timeout) break;
+    }
+    // the four 16-lane rows of a wavefront hold four different records' share of value pair kp: rows first (two lane swaps, no
+    // LDS), then the NT/64 wavefronts through LDS. Fixed order: (row 0 + row 1) + (row 2 + row 3), then wavefronts ascending.
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        double a = s0[g], b = s1[g];
+        swap16_f64(a, b);
+        double c = a + b;                                           // even rows: value 2 kp, odd rows: value 2 kp + 1
+        double c2 = c;
+        swap32_f64(c, c2);
+        c = c + c2;
         if ((tid & 63) < 32) lds[(g * (NT / 64) + wave_u) * 32 + 2 * kp + ((tid & 63) >> 4)] = c;
     }
     // ONE barrier: the time-out flags ride through it (__syncthreads_or is a workgroup reduction of its own), and behind it EVERY
     // wavefront adds the NT/64 partials up itself (same order, same bits) and writes all of out_lds -- identical values from every
     // wavefront, so whoever reads out_lds next reads what its own wavefront wrote and no second barrier is needed.
-    int *lds_to = reinterpret_cast<int *>(lds + (NV / 32) * (NT / 64) * 32);
+    int *lds_to = reinterpret_cast<int *>(lds + G * (NT / 64) * 32);
     if ((tid & 63) == 32) lds_to[wave_u] = timeout;
     __syncthreads();
     timeout = 0;
@@ -176,7 +191,7 @@ __device__ __forceinline__ int gather_records(const void *records, int nprod, un
     for (int w = 0; w < NT / 64; w++) timeout |= lds_to[w];
     if ((tid & 63) < 32) {
 #pragma unroll
-        for (int g = 0; g < NV / 32; g++) {
+        for (int g = 0; g < G; g++) {
             double t2 = lds[(g * (NT / 64)) * 32 + (tid & 63)];
 #pragma unroll
             for (int w = 1; w < NT / 64; w++) t2 += lds[(g * (NT / 64) + w) * 32 + (tid & 63)];
@@ -192,93 +207,6 @@ __device__ __forceinline__ int gather_records(const void *records, int nprod, un
     return timeout ? FL_NUM_TIMEOUT : 0;
 }
 
-
-// The 96-double records of Mode-23, up to 128 producers. gather_records walks the three 32-value groups one after the other (three
-// sweeps of a memory round trip each, 7 us measured). Here every wavefront of the workgroup takes its share of the RECORDS, all three
-// groups of each, every load in flight at once: a wavefront's sweep costs ~0.1 us per 16-byte load instruction (32 per lane took
-// 3.3 us when three wavefronts each swept one group of all 128 records), so the loads are spread over all NT / 64 wavefronts --
-// 24 per lane with 4 wavefronts, 12 with 8.  Same fixed summation order for every launch: per lane the wavefront's records
-// 4 j + row in ascending j, then the wavefronts in order, then the four rows.  lds >= (NT / 64) * 3 * 128 doubles.
-template <int NT>
-__device__ __forceinline__ int gather_records96(const void *records, int nprod /* <= 128 */, unsigned epoch, double *lds, double *out_lds /* 96 */)
-{
-    constexpr int NV = 96, W = NT / 64;
-    constexpr int RPW = ((128 + W - 1) / W + 3) & ~3;        // records per wavefront (a multiple of the 4 rows of a load)
-    constexpr int SLOTS = RPW / 4;                           // per group
-    static_assert(SLOTS * 3 <= 32, "the missing-mask is 32 bits");
-    const int tid = threadIdx.x;
-    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, kp = lane & 15, row = lane >> 4;
-    const unsigned tag = fl_epoch_tag(epoch);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)records, 0, nprod * NV * 8, 0x00020000);
-    int timeout = 0;
-    {
-        const int rec0 = wave_u * RPW;
-        fl_u4 t[3][SLOTS];
-        unsigned need = 0u;                                  // wave-uniform: bit g * SLOTS + j covers group g of records rec0 + 4 j .. + 3
-#pragma unroll
-        for (int g = 0; g < 3; g++)
-#pragma unroll
-            for (int j = 0; j < SLOTS; j++) {
-                need |= (rec0 + 4 * j < nprod) ? (1u << (g * SLOTS + j)) : 0u;
-                t[g][j].x = 0u; t[g][j].y = 0u; t[g][j].z = 0u; t[g][j].w = 0u;
-            }
-        for (int spin = 0; need != 0u; spin++) {
-#pragma unroll
-            for (int g = 0; g < 3; g++)
-#pragma unroll
-                for (int j = 0; j < SLOTS; j++) {
-                    if (need & (1u << (g * SLOTS + j))) {
-                        const int b = rec0 + 4 * j + row;
-                        t[g][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (b * NV + g * 32 + kp * 2) * 8, 0, 16 /* sc1 */);
-                    }
-                }
-#pragma unroll
-            for (int g = 0; g < 3; g++)
-#pragma unroll
-                for (int j = 0; j < SLOTS; j++) {
-                    if (need & (1u << (g * SLOTS + j))) {
-                        const int b = rec0 + 4 * j + row;
-                        const bool ok = (b >= nprod) || (((t[g][j].x & FL_TAG_MASK) == tag) && ((t[g][j].z & FL_TAG_MASK) == tag));
-                        if (__ballot(ok) == ~0ull) need &= ~(1u << (g * SLOTS + j));
-                    }
-                }
-#ifdef FL_IK_STAMPS
-            if (wave_u == 0 && lane == 0 && spin < 6) { g_fl_stamps[48 + spin] = (long long)wall_clock64(); g_fl_stamps[56 + spin] = (long long)__popc(need); }
-#endif
-            if (need != 0u) {
-                if (spin >= FL_GATHER_SPIN_LIMIT) { timeout = 1; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < 3; g++) {
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int j = 0; j < SLOTS; j++) {
-                const int b = rec0 + 4 * j + row;
-                if (b < nprod) {
-                    s0 += fl_untag(t[g][j].x, t[g][j].y);
-                    s1 += fl_untag(t[g][j].z, t[g][j].w);
-                }
-            }
-            lds[((wave_u * 3 + g) * 64 + lane) * 2] = s0;
-            lds[((wave_u * 3 + g) * 64 + lane) * 2 + 1] = s1;
-        }
-    }
-    __syncthreads();
-    if (tid < NV) {
-        const int g = tid >> 5, k = tid & 31;                // value g*32 + k lives in lane kp = k / 2, component k & 1, of the four rows
-        double a = 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-            for (int w = 0; w < W; w++) a += lds[((w * 3 + g) * 64 + r * 16 + (k >> 1)) * 2 + (k & 1)];
-        out_lds[tid] = a;
-    }
-    __syncthreads();
-    return __syncthreads_or(timeout) ? FL_NUM_TIMEOUT : 0;
-}
 
 // ---- state broadcast of the multi-pass kernels: solver workgroup -> every producer workgroup, inside one launch.
 // The new pose (12 doubles) + a control word travel as 25 self-validating 8-byte words: high 32 bits = payload (one
@@ -454,13 +382,12 @@ __device__ __forceinline__ int peer_allreduce32(const FlPeerView &P, unsigned xe
     return __syncthreads_or(timeout) ? FL_NUM_TIMEOUT : 0;
 }
 
-// The 96-double record of Mode-23 as three exchanges of 32 (epochs xe, xe + 1, xe + 2: the buffer keeps two parities, and an exchange
-// is left only when every peer's words of it have arrived, so consecutive exchanges cannot overtake each other). Three cross-rank
-// round trips instead of one wider one: the price of sharing the buffer layout with the 18-state filters.
-__device__ __forceinline__ int peer_allreduce96(const FlPeerView &P, unsigned xe, double *sums96, double *tmp)
+// The 64-double record of Mode-23 as two exchanges of 32 (epochs xe, xe + 1: the buffer keeps two parities, and an exchange is left
+// only when every peer's words of it have arrived, so consecutive exchanges cannot overtake each other).
+__device__ __forceinline__ int peer_allreduce64(const FlPeerView &P, unsigned xe, double *sums64, double *tmp)
 {
     int st = 0;
 #pragma unroll
-    for (int g = 0; g < 3; g++) st |= peer_allreduce32(P, xe + (unsigned)g, sums96 + 32 * g, tmp);
+    for (int g = 0; g < 2; g++) st |= peer_allreduce32(P, xe + (unsigned)g, sums64 + 32 * g, tmp);
     return st;
 }

@@ -68,9 +68,9 @@ __device__ __forceinline__ void ikfom_produce(const float4 *__restrict__ body4, 
                                               double *s_red, unsigned epoch, void *__restrict__ records)
 {
     constexpr int NT = FL_IK_NT;
-    double v[FL_SUMS23];
+    double v[FL_SUMS23I];
 #pragma unroll
-    for (int k = 0; k < FL_SUMS23; k++) v[k] = 0.0;
+    for (int k = 0; k < FL_SUMS23I; k++) v[k] = 0.0;
 #ifdef FL_IK_STAMPS
     if (threadIdx.x == 0 && blockIdx.x == 0) g_fl_stamps[41] = (long long)wall_clock64();
 #endif
@@ -92,17 +92,17 @@ __device__ __forceinline__ void ikfom_produce(const float4 *__restrict__ body4, 
         if (eff) {
             double row[12], z;
             fl_row23(x, pb, p_i, pl, pd2, row, &z);
-            fl_accum12(v, row, z);
-            v[FL_S23_NEFF] += 1.0;
-            v[FL_S23_RES] += (double)fabsf(pd2);
-            v[FL_S23_RES2] += (double)pd2 * (double)pd2;
+            fl_accum9(v, row, z);                       // the [n, A, B] block only: the C block follows from it (fl_ikfom_math.h)
+            v[FL_S23I_NEFF] += 1.0;
+            v[FL_S23I_RES] += (double)fabsf(pd2);
+            v[FL_S23I_RES2] += (double)pd2 * (double)pd2;
         }
     }
 #ifdef FL_IK_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x == 0) { asm volatile("" ::"v"(v[0] + v[95])); g_fl_stamps[42] = (long long)wall_clock64(); }
+    if (threadIdx.x == 0 && blockIdx.x == 0) { asm volatile("" ::"v"(v[0] + v[63])); g_fl_stamps[42] = (long long)wall_clock64(); }
 #endif
-    const double mine = block_reduce_record<NT, FL_SUMS23>(v, s_red);
-    publish_record<FL_SUMS23>(mine, epoch, records);
+    const double mine = block_reduce_record<NT, FL_SUMS23I>(v, s_red);
+    publish_record<FL_SUMS23I>(mine, epoch, records);
 #ifdef FL_IK_STAMPS
     if (threadIdx.x == 0 && blockIdx.x == 0) g_fl_stamps[43] = (long long)wall_clock64();
 #endif
@@ -121,8 +121,8 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float4 *__re
     const unsigned epoch = *epoch_ptr;
 
     if (blockIdx.x == nprod) {
-        __shared__ double s_fin[(NT / 64) * 3 * 128];          // gather_records96 (>= 2 NT of gather_records)
-        __shared__ double s_sums[FL_SUMS23];
+        __shared__ double s_fin[2 * NT];
+        __shared__ double s_sums[FL_SUMS23I];                  // the internal 64-double record (fl_ikfom_math.h)
         __shared__ FlIkLds s_ik;
 #ifdef FL_IK_STAMPS
         if (threadIdx.x == 0) g_fl_stamps[32] = (long long)wall_clock64();
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float4 *__re
 #ifdef FL_IK_STAMPS
         if (threadIdx.x == 0) g_fl_stamps[34] = (long long)wall_clock64();
 #endif
-        int gst = ((nprod <= 128) ? gather_records96<NT>(records, nprod, epoch, s_fin, s_sums) : gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums));
+        int gst = gather_records<NT, FL_SUMS23I>(records, nprod, epoch, s_fin, s_sums);
 #ifdef FL_IK_STAMPS
         if (threadIdx.x == 0) g_fl_stamps[35] = (long long)wall_clock64();
 #endif
@@ -144,8 +144,8 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float4 *__re
             __shared__ double s_xchg[FL_MAX_PEERS * 32];
             const FlPeerView PV = fl_peer_view(D);
             const unsigned xe = *D->xchg_epoch;
-            gst |= peer_allreduce96(PV, xe, s_sums, s_xchg);
-            if (threadIdx.x == 0) *D->xchg_epoch = xe + 3u;
+            gst |= peer_allreduce64(PV, xe, s_sums, s_xchg);
+            if (threadIdx.x == 0) *D->xchg_epoch = xe + 2u;
         }
         if (MODE == 0) {
             ikfom_post(D, s_sums, s_ik, gst);
@@ -153,12 +153,16 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float4 *__re
             if (threadIdx.x == 0) g_fl_stamps[40] = (long long)wall_clock64();
 #endif
         } else {
-            if (threadIdx.x < FL_SUMS23) sums_out[threadIdx.x] = s_sums[threadIdx.x];
+            // accumulate only: the PUBLIC 96-double record (78 + 12 + 3) leaves the kernel, the C block rebuilt from the state's rotation
+            __shared__ double s_Rm[9];
+            if (threadIdx.x == 0) { double q[4] = {D->x[FL_X23_ROT], D->x[FL_X23_ROT + 1], D->x[FL_X23_ROT + 2], D->x[FL_X23_ROT + 3]}, Rm[9]; flq_to_R(q, Rm); for (int k = 0; k < 9; k++) s_Rm[k] = Rm[k]; }
+            __syncthreads();
+            if (threadIdx.x < FL_SUMS23) sums_out[threadIdx.x] = ikfom_public_value(s_sums, s_Rm, (int)threadIdx.x);
         }
         return;
     }
 
-    __shared__ double s_red[(NT / 64) * FL_SUMS23];
+    __shared__ double s_red[(NT / 64) * FL_SUMS23I];
     double x[FL_X23_LEN];
 #pragma unroll
     for (int i = 0; i < FL_X23_LEN; i++) x[i] = D->x[i];
@@ -186,8 +190,8 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_multipass_kernel(const float4 
     const unsigned epoch0 = *epoch_ptr;
 
     if (blockIdx.x == nprod) {
-        __shared__ double s_fin[(NT / 64) * 3 * 128];          // gather_records96 (>= 2 NT of gather_records)
-        __shared__ double s_sums[FL_SUMS23];
+        __shared__ double s_fin[2 * NT];
+        __shared__ double s_sums[FL_SUMS23I];                  // the internal 64-double record (fl_ikfom_math.h)
         __shared__ FlIkLds s_ik;
         ikfom_stage_once(D, s_ik);
         __shared__ double s_xchg[FL_MAX_PEERS * 32];
@@ -199,8 +203,8 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_multipass_kernel(const float4 
         for (int p = 0; p < count; p++) {
             const unsigned epoch = epoch0 + (unsigned)p;
             ikfom_pre(s_ik);                                      // state-only half of the iteration, while the producers work
-            int gst = ((nprod <= 128) ? gather_records96<NT>(records, nprod, epoch, s_fin, s_sums) : gather_records<NT, FL_SUMS23>(records, nprod, epoch, s_fin, s_sums));
-            if (PV.world > 1) gst |= peer_allreduce96(PV, xe0 + 3u * (unsigned)p, s_sums, s_xchg);      // sharded form: totals over the ranks
+            int gst = gather_records<NT, FL_SUMS23I>(records, nprod, epoch, s_fin, s_sums);
+            if (PV.world > 1) gst |= peer_allreduce64(PV, xe0 + 2u * (unsigned)p, s_sums, s_xchg);      // sharded form: totals over the ranks
             ikfom_post(D, s_sums, s_ik, gst, bcast, epoch + 1u, false);
             __syncthreads();
             done = p + 1;
@@ -216,14 +220,14 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_multipass_kernel(const float4 
         }
         if (threadIdx.x == 0) {
             *epoch_ptr = epoch0 + (unsigned)done;
-            if (PV.world > 1) *D->xchg_epoch = xe0 + 3u * (unsigned)done;
+            if (PV.world > 1) *D->xchg_epoch = xe0 + 2u * (unsigned)done;
         }
         fl_mp_done(done_word, done_seq, true);
         return;
     }
 
     const int spin_limit = D->xchg_world > 1 ? FL_XCHG_SPIN_LIMIT : FL_GATHER_SPIN_LIMIT;   // the solver may be waiting for another process
-    __shared__ double s_red[(NT / 64) * FL_SUMS23];
+    __shared__ double s_red[(NT / 64) * FL_SUMS23I];
     __shared__ double s_state[FL_X23_LEN];
     __shared__ int s_ctrl;
     double x[FL_X23_LEN];
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_solve_kernel(FlDev23 *__restri
     if (threadIdx.x < FL_SUMS23) s_sums[threadIdx.x] = sums_in[threadIdx.x];
     ikfom_stage_once(D, s_ik);
     ikfom_pre(s_ik);
-    ikfom_post(D, s_sums, s_ik, 0);
+    ikfom_post<false>(D, s_sums, s_ik, 0);          // (the record arrives in the public 96-double form)
 }
 
 __global__ void ikfom_resume_kernel(FlDev23 *__restrict__ D)

@@ -38,7 +38,28 @@ struct FlIkLds {
     int cnt[4];          // t_count, iter_i, max_iter, iters_run: kept current across the passes of a multi-pass launch
     int sticky;          // status bits accumulated since fl_ikfom_begin
     double R;
+    double Jw[23][3];    // row r of the block-diagonal projection Jacobian Jf as three weights on the states jb[r] .. jb[r] + 2 (identity rows:
+    int jb[24];          //   (1, 0, 0) on r itself): P = Jf Pprop Jf^T becomes a branch-free 9-term sum per element (ikfom_pre)
+    double Rm[9];        // rotation matrix of x.rot (ikfom_pre): rebuilds the C block of h_x^T h_x from the internal record
+    double htz[12];      // h_x^T h
+    double scal[4];      // n_eff, sum |pd2|, sum pd2^2
 };
+
+// value `idx` of the PUBLIC 96-double record (78 upper-triangle entries of the 12 x 12, 12 x h_x^T h, n_eff, sum |pd2|, sum pd2^2)
+// out of the internal 64-double one
+__device__ __forceinline__ double ikfom_public_value(const double *s64, const double *Rm, int idx)
+{
+    if (idx < 78) {
+        int k = idx, i = 0, rowlen = 12;
+        while (k >= rowlen) { k -= rowlen; rowlen--; i++; }
+        return fl_s12_from_s9(s64, Rm, i, i + k);
+    }
+    if (idx < 90) return fl_htz12_from_s9(s64, Rm, idx - 78);
+    if (idx == FL_S23_NEFF) return s64[FL_S23I_NEFF];
+    if (idx == FL_S23_RES) return s64[FL_S23I_RES];
+    if (idx == FL_S23_RES2) return s64[FL_S23I_RES2];
+    return 0.0;
+}
 
 // block-diagonal Jf: element (r, a); blk = start index of r's block, bs = its size
 __device__ __forceinline__ void ik_blk(int r, int &blk, int &bs, int &which)
@@ -177,6 +198,14 @@ __device__ __forceinline__ void ikfom_stage_once(const FlDev23 *__restrict__ D, 
     if (tid < FL_X23_LEN) { L.x[tid] = D->x[tid]; L.xp[tid] = D->xprop[tid]; }
     for (int e = tid; e < n * n; e += NTH) L.Pp[e] = D->Pprop[e];
     if (tid >= 64 && tid < 64 + 23) L.limit[tid - 64] = D->limit[tid - 64];
+    if (tid >= 128 && tid < 128 + 23) {          // the weight table's constant part (identity rows) and every row's first state
+        const int r = tid - 128;
+        int rb, rs, rw;
+        ik_blk(r, rb, rs, rw);
+        L.jb[r] = rb;
+        if (rw < 0) { L.Jw[r][0] = 1.0; L.Jw[r][1] = 0.0; L.Jw[r][2] = 0.0; }
+        else if (rs == 2) L.Jw[r][2] = 0.0;
+    }
     if (tid == 96) { L.cnt[0] = D->t_count; L.cnt[1] = D->iter_i; L.cnt[2] = D->max_iter; L.cnt[3] = D->iters_run; L.sticky = D->status; L.R = D->meas_cov; }
     __syncthreads();
 }
@@ -187,6 +216,11 @@ __device__ __forceinline__ void ikfom_pre(FlIkLds &L)
     const int tid = threadIdx.x, NTH = blockDim.x, n = FL_N23;
     // dx = x (-) x_prop and the projection Jacobians at dx. The three manifold segments (SO3 rot, SO3 offset_R, S2 grav -- each a Log
     // with acos/atan2 and a Jacobian with sin/cos) are independent: one lane of three different waves each
+    if (tid == 192) {
+        double q[4] = {L.x[FL_X23_ROT], L.x[FL_X23_ROT + 1], L.x[FL_X23_ROT + 2], L.x[FL_X23_ROT + 3]}, Rm[9];
+        flq_to_R(q, Rm);
+        for (int k = 0; k < 9; k++) L.Rm[k] = Rm[k];
+    }
     if (tid == 0 || tid == 64 || tid == 128) {
         const double *x = L.x, *o = L.xp;
         double oc[4], r[4], d3[3];
@@ -197,6 +231,7 @@ __device__ __forceinline__ void ikfom_pre(FlIkLds &L)
             fl_so3_log(r, d3);
             for (int i = 0; i < 3; i++) { L.dx[3 + i] = d3[i]; L.dxn[3 + i] = d3[i]; }
             fl_ikfom_J_so3(d3, L.J[0]);
+            for (int i = 0; i < 9; i++) L.Jw[3 + i / 3][i % 3] = L.J[0][i];
         } else if (tid == 64) {
             oc[0] = -o[FL_X23_ORLI]; oc[1] = -o[FL_X23_ORLI + 1]; oc[2] = -o[FL_X23_ORLI + 2]; oc[3] = o[FL_X23_ORLI + 3];
             flq_mul(oc, x + FL_X23_ORLI, r);
@@ -206,6 +241,7 @@ __device__ __forceinline__ void ikfom_pre(FlIkLds &L)
                 const double v = x[FL_X23_OTLI + i] - o[FL_X23_OTLI + i]; L.dx[9 + i] = v; L.dxn[9 + i] = v;
             }
             fl_ikfom_J_so3(d3, L.J[1]);
+            for (int i = 0; i < 9; i++) L.Jw[6 + i / 3][i % 3] = L.J[1][i];
         } else {
             for (int i = 0; i < 3; i++) {
                 const double v = x[FL_X23_VEL + i] - o[FL_X23_VEL + i], g = x[FL_X23_BG + i] - o[FL_X23_BG + i], a = x[FL_X23_BA + i] - o[FL_X23_BA + i];
@@ -217,33 +253,46 @@ __device__ __forceinline__ void ikfom_pre(FlIkLds &L)
             double seg[23];
             seg[21] = d2[0]; seg[22] = d2[1];
             fl_ikfom_J_s2(L.x + FL_X23_GRAV, L.xp + FL_X23_GRAV, seg + 21, L.J[2]);
+            L.Jw[21][0] = L.J[2][0]; L.Jw[21][1] = L.J[2][1]; L.Jw[22][0] = L.J[2][2]; L.Jw[22][1] = L.J[2][3];
         }
     }
     __syncthreads();
-    // P = Jf Pprop Jf^T ; dx_new = Jf dx
-    for (int e = tid; e < n * n; e += NTH) {
-        const int r = e / n, c = e % n;
-        int rb, rs, rw, cb, cs, cw;
-        ik_blk(r, rb, rs, rw);
-        ik_blk(c, cb, cs, cw);
-        double s = 0.0;
-        for (int a = 0; a < rs; a++) {
-            const double jr = ik_J(L, rw, rs, r - rb, a);
-            for (int b = 0; b < cs; b++) s += jr * L.Pp[(rb + a) * n + (cb + b)] * ik_J(L, cw, cs, c - cb, b);
+#ifdef FL_IK_STAMPS
+    if (tid == 0) g_fl_stamps[44] = (long long)wall_clock64();
+#endif
+    // P = Jf Pprop Jf^T ; dx_new = Jf dx ; A12 = sym(P[0:12,0:12]) / R -- every element a branch-free 9-term sum over the weight table
+    // (round 3: the generic block loops with their run-time trip counts made this phase 3 us of a 5 us ikfom_pre, LONGER than the
+    // producers' pass and therefore on the critical path)
+    auto pelem = [&](int r, int c) -> double {
+        const int rb = L.jb[r], cb = L.jb[c];
+        double s2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const int ra = (rb + a < n) ? rb + a : n - 1;
+            double t = 0.0;
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                const int cbb = (cb + b < n) ? cb + b : n - 1;
+                t += L.Pp[ra * n + cbb] * L.Jw[c][b];
+            }
+            s2 += L.Jw[r][a] * t;
         }
-        L.P[e] = s;
-    }
+        return s2;
+    };
+    for (int e = tid; e < n * n; e += NTH) L.P[e] = pelem(e / n, e % n);
+#ifdef FL_IK_STAMPS
+    if (tid == 0) g_fl_stamps[45] = (long long)wall_clock64();
+#endif
     if (tid < n) {
-        int rb, rs, rw;
-        ik_blk(tid, rb, rs, rw);
-        double s = 0.0;
-        for (int a = 0; a < rs; a++) s += ik_J(L, rw, rs, tid - rb, a) * L.dx[rb + a];
-        L.dxn[tid] = s;
+        const int rb = L.jb[tid];
+        double s2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) s2 += L.Jw[tid][a] * L.dx[(rb + a < n) ? rb + a : n - 1];
+        L.dxn[tid] = s2;
     }
-    __syncthreads();
     if (tid < 144) {
         const int i = tid / 12, j = tid % 12;
-        L.A12[tid] = 0.5 * (L.P[i * n + j] + L.P[j * n + i]) / L.R;
+        L.A12[tid] = 0.5 * (pelem(i, j) + pelem(j, i)) / L.R;
     }
     __syncthreads();
 }
@@ -253,6 +302,8 @@ __device__ __forceinline__ void ikfom_pre(FlIkLds &L)
 
 // after the gather. All threads call it; on return (after the caller's barrier) L.ctl is valid for everybody.
 // bcast != nullptr (multi-pass kernel): the new state and the control word are published for the producers' next pass.
+// INTERNAL: s_sums is the 64-double record of the pass kernels (the C block is rebuilt here); else the public 96-double record.
+template <bool INTERNAL = true>
 __device__ __forceinline__ void ikfom_post(FlDev23 *__restrict__ D, const double *s_sums, FlIkLds &L, int gst,
                                            unsigned long long *bcast = nullptr, unsigned bepoch = 0u, bool write_P = true)
 {
@@ -269,13 +320,20 @@ __device__ __forceinline__ void ikfom_post(FlDev23 *__restrict__ D, const double
         }
         return;
     }
-    if (tid >= 64 && tid < 64 + 78) {   // unpack S (upper triangle, row-major)
-        int k = tid - 64, i = 0, rowlen = 12;
-        while (k >= rowlen) { k -= rowlen; rowlen--; i++; }
-        const int j = i + k;
-        const double v = s_sums[tid - 64];
-        L.S[i * 12 + j] = v;
-        L.S[j * 12 + i] = v;
+    if (INTERNAL) {                     // S = h_x^T h_x (12 x 12), h_x^T h and the scalars out of the internal record
+        if (tid < 144) L.S[tid] = fl_s12_from_s9(s_sums, L.Rm, tid / 12, tid % 12);
+        else if (tid >= 160 && tid < 172) L.htz[tid - 160] = fl_htz12_from_s9(s_sums, L.Rm, tid - 160);
+        else if (tid >= 192 && tid < 195) L.scal[tid - 192] = s_sums[FL_S23I_NEFF + (tid - 192)];
+    } else {
+        if (tid >= 64 && tid < 64 + 78) {   // unpack S (upper triangle, row-major)
+            int k = tid - 64, i = 0, rowlen = 12;
+            while (k >= rowlen) { k -= rowlen; rowlen--; i++; }
+            const int j = i + k;
+            const double v = s_sums[tid - 64];
+            L.S[i * 12 + j] = v;
+            L.S[j * 12 + i] = v;
+        } else if (tid >= 160 && tid < 172) L.htz[tid - 160] = s_sums[FL_S23_HTZ + (tid - 160)];
+        else if (tid >= 192 && tid < 195) L.scal[tid - 192] = s_sums[FL_S23_NEFF + (tid - 192)];
     }
     __syncthreads();
     if (tid < 144) {
@@ -286,7 +344,7 @@ __device__ __forceinline__ void ikfom_post(FlDev23 *__restrict__ D, const double
         L.SA[tid] = s;
     } else if (tid >= 160 && tid < 172) {          // rhs = HTh + S dx_new12
         const int i = tid - 160;
-        double s = s_sums[FL_S23_HTZ + i];
+        double s = L.htz[i];
 #pragma unroll
         for (int k = 0; k < 12; k++) s += L.S[i * 12 + k] * L.dxn[k];
         L.rhs[i] = s;
@@ -350,13 +408,15 @@ __device__ __forceinline__ void ikfom_post(FlDev23 *__restrict__ D, const double
             fl_s2_boxplus(gv, L.dxo + 21);
             for (int i = 0; i < 3; i++) L.x[FL_X23_GRAV + i] = gv[i];
         }
-    } else if (tid == 192) {
-        int converge = 1, st = bad;
-        for (int i = 0; i < n; i++) {
-            if (fabs(L.dxo[i]) > L.limit[i]) { converge = 0; break; }
-        }
-        for (int i = 0; i < n; i++)
-            if (!(fabs(L.dxo[i]) <= DBL_MAX)) st |= 2;
+    } else if (tid >= 192) {                 // wavefront 3 judges: lane i < 23 looks at dx_[i], lane 0 decides
+        const int ln = tid - 192;
+        const double di = (ln < n) ? L.dxo[ln] : 0.0;
+        const bool over = (ln < n) && (fabs(di) > L.limit[ln < n ? ln : 0]);
+        const bool nonfin = (ln < n) && !(fabs(di) <= DBL_MAX);
+        const unsigned long long m_over = __ballot(over), m_nf = __ballot(nonfin);
+        if (ln == 0) {
+        int converge = (m_over == 0ull) ? 1 : 0, st = bad;
+        if (m_nf != 0ull) st |= 2;
         int t = L.cnt[0];
         const int i_loop = L.cnt[1], max_iter = L.cnt[2];
         if (converge) t++;
@@ -370,15 +430,22 @@ __device__ __forceinline__ void ikfom_post(FlDev23 *__restrict__ D, const double
         D->converged = converge;
         D->iter_i = i_loop + 1;
         D->stop = stop;
-        D->neff = (int)s_sums[FL_S23_NEFF];
-        D->total_residual = s_sums[FL_S23_RES];
+        D->neff = (int)L.scal[0];
+        D->total_residual = L.scal[1];
         L.sticky |= st;
         D->status = L.sticky;
         D->iters_run = L.cnt[3];
-    } else if (tid >= 200 && tid < 223) {
-        D->solution[tid - 200] = L.dxo[tid - 200];
+        }
     }
-    if (tid >= 64 && tid < 64 + FL_SUMS23) D->sums[tid - 64] = s_sums[tid - 64];
+    if (tid >= 96 && tid < 96 + 23) D->solution[tid - 96] = L.dxo[tid - 96];
+    if (tid >= 64 && tid < 64 + FL_SUMS23) {      // the public record for the host
+        const int idx = tid - 64;
+        double v = 0.0;
+        if (idx < 78) { int k = idx, i = 0, rowlen = 12; while (k >= rowlen) { k -= rowlen; rowlen--; i++; } v = L.S[i * 12 + i + k]; }
+        else if (idx < 90) v = L.htz[idx - 78];
+        else if (idx < 93) v = L.scal[idx - 90];
+        D->sums[idx] = v;
+    }
     __syncthreads();
 #ifdef FL_IK_STAMPS
     if (tid == 0) g_fl_stamps[38] = (long long)wall_clock64();
@@ -457,5 +524,5 @@ __device__ __forceinline__ void ikfom_post(FlDev23 *__restrict__ D, const double
 // one whole pass for a single launch (per-pass kernel, solve kernel): stage + pre + post
 __device__ __forceinline__ void ikfom_solver_block(FlDev23 *__restrict__ D, const double *s_sums, FlIkLds &L, int gst)
 {
-    ikfom_post(D, s_sums, L, gst);
+    ikfom_post<true>(D, s_sums, L, gst);
 }

@@ -10,7 +10,7 @@ nbr, valid = synth.knn5(scene, fr.world_at(fr.R_prior, fr.p_prior))
 h = capi.Handle(capi.config_from_frames(fr), debug=True)
 x23 = capi.state23_from_frame(fr)
 h.lio_set_points(fr.body_xyz); h.ikfom_begin(x23, fr.cov23.copy()); h.lio_set_neighbours(nbr, valid)
-names = {32: "solver start", 33: "staged (x, Pprop)", 34: "pre done (dx, J, P, A12)", 35: "gather done", 36: "S, SA, M, rhs, y0", 37: "LDL^T + dx_", 38: "boxplus + judge",
+names = {32: "solver start", 33: "staged (x, Pprop)", 44: "pre: dx, J (three lanes) done", 45: "pre: P done", 34: "pre done (dx, J, P, A12)", 35: "gather done", 36: "S, SA, M, rhs, y0", 37: "LDL^T + dx_", 38: "boxplus + judge",
          40: "post returned", 41: "producer0 loop start", 42: "producer0 loop end", 43: "producer0 published"}
 for _ in range(5): h.ikfom_iterate(1, capi.FL_ITER_FORCE, want_info=False)
 for _ in range(3):
