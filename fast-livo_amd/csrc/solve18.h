@@ -383,9 +383,12 @@ __device__ __forceinline__ void vio_exact_decide(const FlVioExact ex, FlSolveLds
     if (ex.world <= 1) {     // single rank: the auditor workgroup has been adding this pass's chain up since its words arrived
         if (tid == 0) {
             float fc = 0.f, fl = 0.f;
-            // an auditor that has not reached this pass yet (many patches: its chain takes longer than a pass) is not waited for
+            // An auditor that is on this pass or finishing the previous one is waited for: its remaining chain (<= ~7 us, resp. two of
+            // them) is shorter than the two chains the workgroup would replay itself (~20 us: round 3 time line of ComputeJ -- on the
+            // coarse pyramid levels the auditor was one pass late on every fragile pass and never waited for). One that is further
+            // behind (many patches: its chain takes longer than a pass) is not.
             const unsigned at = (unsigned)__hip_atomic_load(audit + FL_AUDIT_RING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bool ok = (int)(at - ex.epoch) >= 0 && vio_audit_read(audit, ex.epoch, 1 << 12, &fc);
+            bool ok = (int)(at + 1u - ex.epoch) >= 0 && vio_audit_read(audit, ex.epoch, 1 << 12, &fc);
             if (ok && !L.last_exact_valid) {
                 ok = vio_audit_read(audit, L.acc_epoch, 64, &fl);     // (a pass long finished: there, or never audited)
                 if (ok) { L.last_exact = fl / n_all; L.last_exact_valid = 1; }

@@ -734,16 +734,16 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
         __shared__ int s_actrl;
         for (int ps = 0; ps < count; ps++) {
             const unsigned epoch = epoch0 + (unsigned)ps;
-            FL_AUDIT_STAMP(16 * ps + 0, wall_clock64());
+            FL_AUDIT_STAMP(16 * (epoch & 15) + 0, wall_clock64());
             if (ps > 0) {
                 bcast_wait(bcast, epoch, s_apose, &s_actrl, FL_GATHER_SPIN_LIMIT);
                 __syncthreads();
                 if (s_actrl & 7) break;
             }
-            FL_AUDIT_STAMP(16 * ps + 1, wall_clock64());
+            FL_AUDIT_STAMP(16 * (epoch & 15) + 1, wall_clock64());
             const int to = vio_audit_pass(err_base, err_cap, (pass0 + ps) & 1, m, epoch);
-            FL_AUDIT_STAMP(16 * ps + 2, wall_clock64());
-            FL_AUDIT_STAMP(16 * ps + 3, to);
+            FL_AUDIT_STAMP(16 * (epoch & 15) + 2, wall_clock64());
+            FL_AUDIT_STAMP(16 * (epoch & 15) + 3, to);
         }
 #endif
         return;
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
             FL_INSTR(if (p == 5) fl_stamp(flags, 16);)
             int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
             if (PV.world > 1) gst |= peer_allreduce32(PV, xe0 + (unsigned)p, s_sums, s_xchg);      // sharded form: totals over the ranks
-            FL_AUDIT_STAMP(16 * p + 8, wall_clock64());
+            FL_AUDIT_STAMP(16 * (epoch & 15) + 8, wall_clock64()); FL_AUDIT_STAMP(16 * (epoch & 15) + 11, epoch); FL_AUDIT_STAMP(16 * (epoch & 15) + 12, level);
             FL_INSTR(if (p == 5) fl_stamp(flags, 17);)
             FlVioExact ex;
             ex.words = err_base; ex.m = m; ex.cap = err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !force;
@@ -787,8 +787,8 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
             eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, gst, bcast, epoch + 1u, ex, VC, (p == 5) ? (flags & FL_ITER_STAMP) : 0);
             FL_INSTR(if (p == 5) fl_stamp(flags, 35);)
             __syncthreads();
-            FL_AUDIT_STAMP(16 * p + 9, wall_clock64());
-            FL_AUDIT_STAMP(16 * p + 10, s_solve.fragile + 2 * s_solve.audited + 4 * s_solve.exact_timeout);
+            FL_AUDIT_STAMP(16 * (epoch & 15) + 9, wall_clock64());
+            FL_AUDIT_STAMP(16 * (epoch & 15) + 10, s_solve.fragile + 2 * s_solve.audited + 4 * s_solve.exact_timeout + 8 * s_solve.accept);
             FL_INSTR(if (p == 5) fl_stamp(flags, 18);)
             done = p + 1;
             const int ctrl = s_solve.ctrl;

@@ -15,16 +15,16 @@ h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
 for rep in range(5):
     infos = h.vio_compute_j(capi.state18_from_frame(fr), capi.state18_from_frame(fr))
 w = np.array(h.debug_wall(), dtype=np.int64)
-t0 = w[0]
 print("levels:", [(int(i.iterations), int(i.accepted), int(i.status)) for i in infos])
-for p in range(int(infos[0].iterations) if False else 6):
-    a = w[16 * p: 16 * p + 16]
-    us = lambda v: (v - t0) / 100.0
-    print(f"pass {p}: auditor loop {us(a[0]):8.2f} bcast {us(a[1]):8.2f} chain done {us(a[2]):8.2f} to={a[3]} | solver gathered {us(a[8]):8.2f} "
-          f"pass done {us(a[9]):8.2f} flags(fragile16,audited2,timeout4)={a[10]}")
-
-c = w[1024:1024 + 256].reshape(64, 4)
-rows = sorted((r for r in c if r[0] > 0), key=lambda r: r[0])[-6:]
-for r in rows:
-    print("chain: entry %8.2f staged %8.2f (+%.2f) added %8.2f (+%.2f)" % ((r[0] - t0) / 100.0, (r[1] - t0) / 100.0, (r[1] - r[0]) / 100.0,
-                                                                          (r[2] - t0) / 100.0, (r[2] - r[1]) / 100.0))
+rows = []
+for k in range(16):
+    a = w[16 * k: 16 * k + 16]
+    if a[8] > 0:
+        rows.append(a)
+rows.sort(key=lambda a: a[11])
+rows = rows[-10:]                      # the passes of the last ComputeJ call, by epoch
+t0 = rows[0][8]
+us = lambda v: round((int(v) - int(t0)) / 100.0, 2)
+for a in rows:
+    print(f"epoch {int(a[11])} level {int(a[12])}: solver gathered {us(a[8]):8.2f}  pass done {us(a[9]):8.2f} (+{(int(a[9]) - int(a[8])) / 100.0:5.2f})  "
+          f"flags(fragile 16, audited 2, timeout 4, accept 8) = {int(a[10]):2d} | auditor: loop top {us(a[0]):8.2f} pose seen {us(a[1]):8.2f} chain done {us(a[2]):8.2f}")
