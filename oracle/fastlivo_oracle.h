@@ -232,6 +232,9 @@ int orc_ikfom_update_iterated(orc_state23 *x, double *P, const float *body_xyz, 
 /* bench.py's "generous" CPU baseline: threads for the VIO patch loop / column sums (1 = the reference's single thread; results
  * are bit-identical for any value, see orc_vio.c). */
 void orc_vio_set_threads(int n);
+/* sensitivity study only: alternative operation orders of the unpinned radtan projection (orc_vio.c); 0 = the restatement */
+void orc_vio_set_radtan_mode(int mode);
+void orc_vio_cam_pose(const orc_vio_config *cfg, const orc_state18 *x, double *Rcw, double *Pcw);
 
 /* The same update around ANY measurement callback of the reference's shape -- measurementModel_dyn_share, esekfom.hpp:129:
  * `void (state &, dyn_share_datastruct<scalar_type> &)`, registered by init_dyn_share (:238-254), invoked at :1636.  The callback

@@ -25,6 +25,14 @@
 int orc_solve18(orc_state18 *x, const orc_state18 *x_prop, const double *HTH6, const double *HTz6,
                 double meas_cov, double sign, double *G, double *solution);
 
+/* Sensitivity study only (tests/test_radtan_sensitivity_cpu.py): vikit is absent from this image, so the operation order of its radtan
+ * branch cannot be pinned. g_radtan_mode selects plausible alternatives of the SAME formula: bit 0 = Horner form of the radial
+ * polynomial (1 + r2 (k1 + r2 (k2 + r2 k3))) instead of the powers r2, r4, r6; bit 1 = the final `xd * fx + cx` contracted into a
+ * fused multiply-add (what -march=native / -ffp-contract=fast would do); bit 2 = the tangential terms associated the other way
+ * (x cdist + (p1 a1 + p2 a2)). Mode 0 is the restatement every parity test uses. */
+static int g_radtan_mode = 0;
+void orc_vio_set_radtan_mode(int mode) { g_radtan_mode = mode; }
+
 void orc_world2cam(const orc_vio_config *cfg, const double *xyz_c, double *px)
 {
     double u = xyz_c[0] / xyz_c[2], v = xyz_c[1] / xyz_c[2];
@@ -36,10 +44,19 @@ void orc_world2cam(const orc_vio_config *cfg, const double *xyz_c, double *px)
         double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
         double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
         double cdist = 1 + cfg->d[0] * r2 + cfg->d[1] * r4 + cfg->d[4] * r6;
+        if (g_radtan_mode & 1) cdist = 1 + r2 * (cfg->d[0] + r2 * (cfg->d[1] + r2 * cfg->d[4]));
         double xd = x * cdist + cfg->d[2] * a1 + cfg->d[3] * a2;
         double yd = y * cdist + cfg->d[3] * a1 + cfg->d[2] * a3;
+        if (g_radtan_mode & 4) {
+            xd = x * cdist + (cfg->d[2] * a1 + cfg->d[3] * a2);
+            yd = y * cdist + (cfg->d[3] * a1 + cfg->d[2] * a3);
+        }
         px[0] = xd * cfg->fx + cfg->cx;
         px[1] = yd * cfg->fy + cfg->cy;
+        if (g_radtan_mode & 2) {
+            px[0] = fma(xd, cfg->fx, cfg->cx);
+            px[1] = fma(yd, cfg->fy, cfg->cy);
+        }
     }
 }
 
@@ -104,6 +121,20 @@ static void vio_init_extr(const orc_vio_config *cfg, vio_extr *e)
  * H^T H / H^T z entry is still one sequential sum. 1 = the reference. */
 static int g_vio_threads = 1;
 void orc_vio_set_threads(int n) { g_vio_threads = n > 1 ? n : 1; }
+
+/* camera pose of state x (lidar_selection.cpp:780-784), for the sensitivity study of tests/test_radtan_sensitivity_cpu.py */
+void orc_vio_cam_pose(const orc_vio_config *cfg, const orc_state18 *x, double *Rcw, double *Pcw)
+{
+    vio_extr ex;
+    vio_init_extr(cfg, &ex);
+    double Rwit[9], nRci[9], T[9], t3[3];
+    m3_tr(x->rot, Rwit);
+    m3_mul(ex.Rci, Rwit, Rcw);
+    for (int i = 0; i < 9; i++) nRci[i] = -ex.Rci[i];
+    m3_mul(nRci, Rwit, T);
+    m3_vec(T, x->pos, t3);
+    for (int i = 0; i < 3; i++) Pcw[i] = t3[i] + ex.Pci[i];
+}
 
 float orc_vio_update_state(const orc_vio_config *cfg, orc_state18 *x, const orc_state18 *x_prop,
                            const uint8_t *img, const float *ref_patch, const double *pos,
