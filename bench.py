@@ -32,6 +32,12 @@ import sys
 import time
 
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # CPU baselines: idle OpenMP threads must not spin against the working ones
+if os.environ.get("FL_BENCH_SINGLE_DEVICE") == "1":
+    # test aid (all ranks on ONE device): the ranks wait for each other inside their kernels, so every rank's queue must be resident at
+    # once -- with HIP's default of 4 hardware queues per process, 8 processes oversubscribe the device's queue slots and the runlist is
+    # time-sliced (a pass then takes 11 ms instead of 14 us). Must be set before the HIP runtime initialises; irrelevant on a real
+    # multi-GPU node, where every process has a device of its own.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 import numpy as np
 
@@ -585,6 +591,11 @@ def main():
     hv = capi.Handle(cfg)   # VIO filter
     hl.set_stream(stream)
     hv.set_stream(stream)
+    if single_device and world > 1:
+        # test aid: the multi-pass kernels of ALL ranks must be resident on the one device together (on a real node every rank has a
+        # GPU of its own and the library's admission check sees the whole picture): cap this rank's producers at its share of the slots
+        share = hl.diagnostics()["capacity"] // world
+        hl.set_option(capi.FL_OPT_MAX_PRODUCERS, max(8, share - 4))
 
     def begin():
         hl.lio_set_points(body)

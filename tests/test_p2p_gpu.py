@@ -267,3 +267,25 @@ def test_bench_n2_path_on_one_device(gpu_lib):
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["scaling"] == "weak" and d["config"]["frame_points"] == 100000 and d["config"]["points_per_gpu"] == 50000
     assert abs(d["shard_iterations_per_s"] - 2 * d["value"]) < 1e-6 * d["value"]
+
+
+@pytest.mark.parametrize("points,config", [(50000, "3"), (200000, "4")])
+def test_bench_n8_path_on_one_device(gpu_lib, points, config):
+    """BASELINE configs 3 and 4 are defined at 8 GPUs: bench.py --gpus 8 exactly as the driver launches it (torch.distributed.run, one
+    process per rank, hipIpc-mapped exchange buffers, the in-kernel exchange with 7 peers: two polling rounds and the full store
+    fan-out of peer_allreduce32), all eight ranks on device 0 and the control plane on gloo -- so that the first real 8-GPU lease
+    measures instead of debugging. No time-out bit, all ranks bitwise equal (the bench's self-test), finite states."""
+    import json
+    env = dict(os.environ, FL_BENCH_BACKEND="gloo", FL_BENCH_SINGLE_DEVICE="1")
+    env.pop("GPU_MAX_HW_QUEUES", None)          # (conftest raises it for the in-process ranks; 8 PROCESSES need few queues each: bench.py)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                          "--master-port", "29571" if config == "3" else "29573", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "100",
+                          "--warmup", "20", "--points", str(points)], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["state_finite"] and d["scaling"] == "strong"
+    assert d["config"]["frame_points"] == points and d["config"]["points_per_gpu"] == points // 8 and d["config"]["patches_per_gpu"] == 250
+    assert f"BASELINE config {config}" in d["config"]["workload"]
+    assert d["exchange"]["used"] == "in-kernel p2p" and d["exchange"]["p2p_selftest"] == "passed" and d["exchange"]["ranks_on_distinct_devices"] is False
+    assert 1.0 < d["roofline"]["lio_pass_us"] < 200 and 1.0 < d["roofline"]["vio_pass_us"] < 200      # neither skipped (abandoned) nor timed out
+    print(f"\n[n8 on one device] config {config}: {d['value']:.0f} it/s, LIO pass {d['roofline']['lio_pass_us']:.1f} us, VIO pass {d['roofline']['vio_pass_us']:.1f} us")
