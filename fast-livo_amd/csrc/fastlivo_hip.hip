@@ -65,6 +65,7 @@ struct fl_context {
 #define FL_UP_SLOTS 12
     void *h_small = nullptr;        // page-locked scratch: 4 KB for the small per-call read-backs (counts, control blocks) + FL_UP_SLOTS x 1 KB for parameter uploads
     unsigned up_slot = 0;
+    unsigned up_pending = 0;        // uploads through the slot ring since the last stream synchronisation this code knows of (upload_small)
     bool hdev_busy = false, hdev23_busy = false;   // an async copy from the pinned mirror may still be in flight (begin without a read-back since)
     void *d_records = nullptr;      // tagged per-workgroup records (handoff.h)
     size_t rec_fresh_bytes = 0;     // bytes of d_records the previous pass launch covered (records_for)
@@ -242,21 +243,8 @@ static std::mutex g_mp_mu;
 static std::vector<fl_context *> g_mp_handles;      // live handles of this process
 // in flight = launched and its completion word not written yet (one store by the launch's last action; no events, no
 // extra commands in the stream -- an event per launch cost ~0.5 us per pass of GPU time)
-static bool mp_admit(fl_handle h, int grid, int capacity)
+static int mp_busy_locked(fl_handle h)
 {
-    std::lock_guard<std::mutex> lk(g_mp_mu);
-    int busy = 0;
-    for (fl_context *o : g_mp_handles) {
-        if (o == h || o->cfg.device != h->cfg.device || o->stream == h->stream) continue;
-        if (o->mp_seq != __atomic_load_n(o->h_mp_done, __ATOMIC_RELAXED)) busy += o->mp_last_grid;
-    }
-    if (busy + grid > capacity) { h->mp_fallbacks++; return false; }
-    return true;
-}
-// workgroup slots (two per CU) of this process' other streams still on the device
-static int mp_busy(fl_handle h)
-{
-    std::lock_guard<std::mutex> lk(g_mp_mu);
     int busy = 0;
     for (fl_context *o : g_mp_handles) {
         if (o == h || o->cfg.device != h->cfg.device || o->stream == h->stream) continue;
@@ -264,12 +252,27 @@ static int mp_busy(fl_handle h)
     }
     return busy;
 }
-// right before a multi-pass launch: the sequence number it carries (and writes to h_mp_done when it ends)
-static unsigned mp_begin(fl_handle h, int grid)
+// non-binding look (the frame drivers choose their launch plan with it; the launches themselves reserve)
+static bool mp_would_admit(fl_handle h, int slots, int capacity)
 {
     std::lock_guard<std::mutex> lk(g_mp_mu);
-    h->mp_last_grid = grid;
-    return ++h->mp_seq;
+    return mp_busy_locked(h) + slots <= capacity;
+}
+// Check AND reserve in one critical section (two host threads on different handles could both pass a separate check and
+// oversubscribe the device): on success the handle counts as in flight with `slots` workgroup slots from this moment, and the returned
+// sequence number is the one the launch carries and writes to h_mp_done when it ends. 0 = refused (the caller launches per pass).
+// need_idle: only if nothing else of the process is on the device (the whole-CU VIO variant).
+static unsigned mp_reserve(fl_handle h, int slots, int capacity, bool need_idle = false)
+{
+    std::lock_guard<std::mutex> lk(g_mp_mu);
+    const int busy = mp_busy_locked(h);
+    if (need_idle ? (busy != 0 || slots > capacity) : (busy + slots > capacity)) {
+        if (!need_idle) h->mp_fallbacks++;
+        return 0u;
+    }
+    h->mp_last_grid = slots;
+    if (++h->mp_seq == 0u) ++h->mp_seq;          // (0 is "refused")
+    return h->mp_seq;
 }
 // FL_NUM_TIMEOUT handling: clears the abandoned mark so that the enqueued per-pass chain runs (solve18.h, fl_pass_skipped)
 __global__ void eskf18_resume_kernel(FlDev18 *__restrict__ D)
@@ -412,6 +415,7 @@ int32_t fl_sync(fl_handle h)
 {
     if (!h) return fail_arg(nullptr, "null handle");
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->up_pending = 0;
     return FL_OK;
 }
 
@@ -633,6 +637,7 @@ static int32_t read_small(fl_handle h, void *dst, const void *d_src, size_t byte
     if (bytes > 4096) return fail_arg(h, "read_small: block too large");
     HIPCHK(h, hipMemcpyAsync(h->h_small, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->up_pending = 0;
     memcpy(dst, h->h_small, bytes);
     return FL_OK;
 }
@@ -643,6 +648,13 @@ static int32_t read_small(fl_handle h, void *dst, const void *d_src, size_t byte
 static int32_t upload_small(fl_handle h, void *d_dst, const void *src, size_t bytes)
 {
     if (bytes > 1024) return fail_arg(h, "upload_small: block too large");
+    // a slot is reused FL_UP_SLOTS uploads later: its asynchronous copy must have left the page-locked scratch by then --
+    // a synchronisation the code knows of resets the count, otherwise the ring waits here before it wraps
+    if (h->up_pending >= FL_UP_SLOTS) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->up_pending = 0;
+    }
+    h->up_pending++;
     char *slot = (char *)h->h_small + 4096 + (size_t)(h->up_slot++ % FL_UP_SLOTS) * 1024;
     memcpy(slot, src, bytes);
     HIPCHK(h, hipMemcpyAsync(d_dst, slot, bytes, hipMemcpyHostToDevice, h->stream));
@@ -703,7 +715,7 @@ static int32_t read_info18(fl_handle h, fl_iter_info *info)
 {
     HIPCHK(h, hipMemcpyAsync(h->h_dev, h->d_dev, sizeof(FlDev18) + FL_DEV18_TAIL, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->hdev_busy = false; h->hdev23_busy = false;
+    h->hdev_busy = false; h->hdev23_busy = false; h->up_pending = 0;
     if (!info) return FL_OK;
     const FlDev18 *D = h->h_dev;
     memset(info, 0, sizeof *info);
@@ -729,17 +741,23 @@ static void ensure_gates(fl_handle h)
     h->gate_valid = true;
 }
 // may this handle use the multi-pass form for a grid of `grid` workgroups right now?
-static bool multipass_ok(fl_handle h, int grid, bool mode23 = false)
+static bool multipass_ok(fl_handle h, int grid, bool mode23 = false)          // a look, not a reservation
 {
-    return grid <= h->num_cus && h->opt_multipass && mp_admit(h, grid, mode23 ? h->mp_capacity_ik : h->mp_capacity);
+    return grid <= h->num_cus && h->opt_multipass && mp_would_admit(h, grid, mode23 ? h->mp_capacity_ik : h->mp_capacity);
+}
+// the reservation of a multi-pass launch of `grid` workgroups: its sequence number, or 0 (launch per pass)
+static unsigned multipass_reserve(fl_handle h, int grid, bool mode23 = false)
+{
+    if (!(grid <= h->num_cus && h->opt_multipass)) return 0u;
+    return mp_reserve(h, grid, mode23 ? h->mp_capacity_ik : h->mp_capacity);
 }
 static void launch_lio_passes(fl_handle h, int grid, int count, int flags, bool allow_multi = true)
 {
     if (flags & FL_ITER_KEEP_NORMVEC) h->normvec_valid = true;
     ensure_gates(h);
-    if (allow_multi && count > 1 && multipass_ok(h, grid)) {
+    if (const unsigned seq = (allow_multi && count > 1) ? multipass_reserve(h, grid) : 0u) {
         hipLaunchKernelGGL(lio18_multipass_kernel, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_gate, h->d_plane, h->d_sel, h->d_normvec,
-                           h->n, h->d_dev, records_lio(h), h->d_epoch, h->d_bcast, (int)count, (int)flags, h->d_mp_done, mp_begin(h, grid));
+                           h->n, h->d_dev, records_lio(h), h->d_epoch, h->d_bcast, (int)count, (int)flags, h->d_mp_done, seq);
         return;
     }
     for (int i = 0; i < count; i++)
