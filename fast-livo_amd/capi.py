@@ -85,6 +85,11 @@ class Diagnostics(C.Structure):
                 ("compute_units", C.c_int32)]
 
 
+class FrameTiming(C.Structure):
+    """fl_frame_timing"""
+    _fields_ = [("match_ms", C.c_float), ("solve_ms", C.c_float), ("total_ms", C.c_float), ("searches", C.c_int32)]
+
+
 class ImuSample(C.Structure):
     _fields_ = [("t", C.c_double), ("gyr", C.c_double * 3), ("acc", C.c_double * 3)]
 
@@ -179,6 +184,7 @@ SYMBOLS = {
     "fl_host_free": (C.c_int32, [_H, C.c_void_p]),
     "fl_set_timing": (C.c_int32, [_H, C.c_int32]),
     "fl_get_last_kernel_ms": (C.c_int32, [_H, _fp]),
+    "fl_get_frame_timing": (C.c_int32, [_H, C.POINTER(FrameTiming)]),
     "fl_set_option": (C.c_int32, [_H, C.c_int32, C.c_int32]),
     "fl_get_diagnostics": (C.c_int32, [_H, C.POINTER(Diagnostics)]),
     "fl_lio_set_points": (C.c_int32, [_H, _fp, C.c_int32]),
@@ -577,6 +583,11 @@ class Handle:
 
     def set_timing(self, on):
         self._chk(self.L.fl_set_timing(self.h, 1 if on else 0), "fl_set_timing")
+
+    def frame_timing(self):
+        t = FrameTiming()
+        self._chk(self.L.fl_get_frame_timing(self.h, C.byref(t)), "fl_get_frame_timing")
+        return dict(match_ms=t.match_ms, solve_ms=t.solve_ms, total_ms=t.total_ms, searches=t.searches)
 
     def last_kernel_ms(self):
         ms = C.c_float()

@@ -166,6 +166,9 @@ struct fl_context {
     int comm_world = 0, comm_rank = 0;
     // misc
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_frame[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // fl_get_frame_timing
+    int ev_frame_n = 0;            // events recorded by the last frame driver: start, then (search end, passes end) per segment, covariance end
+    int ev_frame_kind[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // what ended at event i: 1 search + plane fit, 2 passes, 3 covariance update
     bool timing = false;
     bool dbg_knn_stamp = false;   // FL_INSTRUMENT build only
     float last_ms = 0.f;
@@ -394,6 +397,7 @@ int32_t fl_destroy(fl_handle h)
     if (h->h_mp_done) hipHostFree(h->h_mp_done);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
+    for (int i = 0; i < 8; i++) if (h->ev_frame[i]) hipEventDestroy(h->ev_frame[i]);
     if (h->aux_event) hipEventDestroy(h->aux_event);
     if (h->aux_stream) hipStreamDestroy(h->aux_stream);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -472,6 +476,34 @@ int32_t fl_set_timing(fl_handle h, int32_t enable)
 {
     if (!h) return fail_arg(nullptr, "null handle");
     h->timing = enable != 0;
+    return FL_OK;
+}
+
+// frame drivers under fl_set_timing: one event behind each stage (created on first use; ~0.5 us of GPU time each, only when timing is on)
+static void frame_mark(fl_handle h, int kind)
+{
+    if (!h->timing) return;
+    if (kind == 0) h->ev_frame_n = 0;
+    if (h->ev_frame_n >= 8) return;
+    hipEvent_t &e = h->ev_frame[h->ev_frame_n];
+    if (!e && hipEventCreate(&e) != hipSuccess) return;
+    if (hipEventRecord(e, h->stream) != hipSuccess) return;
+    h->ev_frame_kind[h->ev_frame_n++] = kind;
+}
+
+int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out)
+{
+    if (!h || !out) return fail_arg(h, "fl_get_frame_timing: null argument");
+    memset(out, 0, sizeof *out);
+    if (h->ev_frame_n < 2) return fail_arg(h, "fl_get_frame_timing: no frame was timed (fl_set_timing, then fl_lio_frame18_dev)");
+    HIPCHK(h, hipEventSynchronize(h->ev_frame[h->ev_frame_n - 1]));
+    for (int i = 1; i < h->ev_frame_n; i++) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev_frame[i - 1], h->ev_frame[i]));
+        if (h->ev_frame_kind[i] == 1) { out->match_ms += ms; out->searches++; }
+        else out->solve_ms += ms;
+        out->total_ms += ms;
+    }
     return FL_OK;
 }
 

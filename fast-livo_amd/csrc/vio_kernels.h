@@ -390,11 +390,14 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
         float t[PPL][4][4];
         // taps span [anchor - 5*scale, anchor + 5*scale]: no clamping needed inside the image
         const bool inside = (g.v_i - 5 * scale >= 0) && (g.v_i + 5 * scale <= Hm1) && (g.u_i - 5 * scale >= 0) && (g.u_i + 5 * scale <= Wm1);
-        // Finest level, every patch of the wavefront inside the image (the common case): a lane's four pixels sit two rows apart in
-        // one column, so their 4 x 4 tap windows are 10 image rows x 4 consecutive bytes. Ten aligned 8-byte loads + v_alignbyte
-        // instead of 48 single-byte loads (each a 64-address instruction for the texture addresser).
-        const bool fast_taps = (LPP == 16) && (__ballot(inside && scale == 1) == ~0ull);
-        if (fast_taps) {
+        // Every patch of the wavefront inside the image and at the same pyramid scale (the common case): a lane's four pixels sit
+        // two rows apart in one column, so at the finest level their 4 x 4 tap windows are 10 image rows x 4 consecutive bytes: ten
+        // aligned 8-byte loads + v_alignbyte instead of 48 single-byte loads (each a 64-address instruction for the texture addresser).
+        // Coarser pyramid levels (scale 2, 4: the first two levels of ComputeJ) read the same 10 rows at stride scale: the four
+        // taps of a row are bytes 0, s, 2s, 3s of a 7- / 13-byte span -- three / four aligned dwords per row and byte shifts.
+        const int scale_u = __builtin_amdgcn_readfirstlane(scale);
+        const bool fast_taps = (LPP == 16) && (scale_u == 1 || scale_u == 2 || scale_u == 4) && (__ballot(inside && scale == scale_u) == ~0ull);
+        if (fast_taps && scale_u == 1) {          // (one straight-line path per scale: a branch per row cost the finest level 1.3 us)
             const uint8_t *q = img + (g.v_i + xr - 5) * W + (col0 - 1);
             unsigned rowv[10];
 #pragma unroll
@@ -412,6 +415,48 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
                     for (int c = 0; c < 4; c++) {
                         const bool used = !((r == 0 && (c == 0 || c == 3)) || (r == 3 && (c == 0 || c == 3)));
                         t[px][r][c] = used ? (float)((rowv[2 * px + r] >> (8 * c)) & 0xffu) : 0.f;
+                    }
+        } else if (fast_taps && scale_u == 2) {
+            const uint8_t *q = img + (g.v_i + (xr - 5) * 2) * W + (col0 - 2);
+            unsigned lo[10], hi[10];               // bytes 0, 2 of lo: taps 0, 1; of hi: taps 2, 3
+#pragma unroll
+            for (int m2 = 0; m2 < 10; m2++) {
+                typedef unsigned int fl_u3 __attribute__((ext_vector_type(3)));
+                const uint8_t *a = q + m2 * 2 * W;
+                const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(a) & 3u);
+                const fl_u3 w3 = *reinterpret_cast<const fl_u3 *>(reinterpret_cast<uintptr_t>(a) & ~(uintptr_t)3);
+                lo[m2] = __builtin_amdgcn_alignbyte(w3.y, w3.x, sh);
+                hi[m2] = __builtin_amdgcn_alignbyte(w3.z, w3.y, sh);
+            }
+#pragma unroll
+            for (int px = 0; px < PPL; px++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const bool used = !((r == 0 && (c == 0 || c == 3)) || (r == 3 && (c == 0 || c == 3)));
+                        const unsigned wv = (c < 2) ? lo[2 * px + r] : hi[2 * px + r];
+                        t[px][r][c] = used ? (float)((wv >> (16 * (c & 1))) & 0xffu) : 0.f;
+                    }
+        } else if (fast_taps) {                   // scale 4
+            const uint8_t *q = img + (g.v_i + (xr - 5) * 4) * W + (col0 - 4);
+            unsigned tv[10][4];
+#pragma unroll
+            for (int m2 = 0; m2 < 10; m2++) {
+                const uint8_t *a = q + m2 * 4 * W;
+                const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(a) & 3u);
+                const fl_u4 w4 = *reinterpret_cast<const fl_u4 *>(reinterpret_cast<uintptr_t>(a) & ~(uintptr_t)3);
+                tv[m2][0] = __builtin_amdgcn_alignbyte(w4.y, w4.x, sh); tv[m2][1] = __builtin_amdgcn_alignbyte(w4.z, w4.y, sh);
+                tv[m2][2] = __builtin_amdgcn_alignbyte(w4.w, w4.z, sh); tv[m2][3] = w4.w >> (8 * sh);
+            }
+#pragma unroll
+            for (int px = 0; px < PPL; px++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const bool used = !((r == 0 && (c == 0 || c == 3)) || (r == 3 && (c == 0 || c == 3)));
+                        t[px][r][c] = used ? (float)(tv[2 * px + r][c] & 0xffu) : 0.f;
                     }
         } else {
 #pragma unroll

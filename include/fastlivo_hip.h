@@ -129,6 +129,16 @@ int32_t fl_host_free(fl_handle h, void *p);
 /* Times the last fl_lio_iterate18 / fl_vio_iterate batch with HIP events on the handle's stream. */
 int32_t fl_set_timing(fl_handle h, int32_t enable);
 int32_t fl_get_last_kernel_ms(fl_handle h, float *ms);
+/* The reference's per-frame timers (match_time / solve_time, src/laserMapping.cpp:1604,1729, printed at :1805) for the last
+ * fl_lio_frame18_dev run under fl_set_timing(h, 1): GPU time of the search + plane-fit launches (match) and of the pass launches +
+ * covariance update (solve), from HIP events behind each stage of the frame. */
+typedef struct fl_frame_timing {
+    float match_ms;      /* k-NN searches + plane fits */
+    float solve_ms;      /* passes (residuals, rows, normal equations, gain solve, state update) + covariance update */
+    float total_ms;
+    int32_t searches;    /* search launches that were enqueued (a search that was not asked for is a no-op launch) */
+} fl_frame_timing;
+int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out);
 /* Per-handle options (all have working defaults; none is read from the environment):
  *   FL_OPT_MULTIPASS      1 (default): fl_*_iterate(count > 1) and the frame drivers run the passes of a frame segment as ONE multi-pass
  *                         launch when its workgroups fit the device; 0: always one launch per pass.

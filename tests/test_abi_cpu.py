@@ -58,7 +58,7 @@ def test_struct_layouts_match_a_c_compiler(tmp_path):
     import subprocess
     pairs = {"fl_config": capi.Config, "fl_state18": capi.State18, "fl_state23": capi.State23, "fl_iter_info": capi.IterInfo,
              "fl_map_info": capi.MapInfo, "fl_imu_sample": capi.ImuSample, "fl_pose6d": capi.Pose6d, "fl_imu_proc": capi.ImuProc,
-             "fl_patch_candidate": capi.PatchCandidate, "fl_vmap_obs": capi.VmapObs, "fl_diagnostics": capi.Diagnostics}
+             "fl_patch_candidate": capi.PatchCandidate, "fl_vmap_obs": capi.VmapObs, "fl_diagnostics": capi.Diagnostics, "fl_frame_timing": capi.FrameTiming}
     hdr = open(os.path.join(REPO_ROOT, "include", "fastlivo_hip.h")).read()
     declared = set(re.findall(r"}\s*(fl_[a-z0-9_]+);", hdr))
     assert declared == set(pairs), declared ^ set(pairs)

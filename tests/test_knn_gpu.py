@@ -167,3 +167,21 @@ def test_frame_without_any_valid_neighbour(gpu_lib, oracle_lib, scene):
     mask, _ = h.lio_get_selection(fr.n)
     assert mask.sum() == 0
     h.close()
+
+
+def test_frame_timing_hook_splits_match_and_solve(gpu_lib, scene):
+    """fl_get_frame_timing: the reference's match_time / solve_time (laserMapping.cpp:1604,1729) for the all-device frame."""
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    fr = synth.make_lio_frame(30000, scene=scene)
+    h = capi.Handle(capi.config_from_frames(fr, max_iterations=10))
+    h.map_set_points(scene.map_xyz, 0.5)
+    h.set_timing(True)
+    for _ in range(3):
+        x = capi.state18_from_frame(fr)
+        info = h.lio_frame18_dev(x, fr.body_xyz)
+    t = h.frame_timing()
+    assert info.status == 0 and t["searches"] == 2
+    assert 0.0 < t["match_ms"] < 1.0 and 0.0 < t["solve_ms"] < 1.0 and abs(t["total_ms"] - t["match_ms"] - t["solve_ms"]) < 1e-3
+    print(f"\n[frame timing] match {t['match_ms'] * 1e3:.1f} us, solve {t['solve_ms'] * 1e3:.1f} us")
+    h.close()
