@@ -693,7 +693,7 @@ static int32_t upload_small(fl_handle h, void *d_dst, const void *src, size_t by
     return FL_OK;
 }
 
-static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_state18 *prop, double meas_cov, bool vio = false)
+static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_state18 *prop, double meas_cov, bool vio = false, bool prepare_in_search = false)
 {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     // h_dev is reused: wait only if a copy out of it can still be in flight. (A frame driver's begin follows the previous frame's
@@ -726,7 +726,8 @@ static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_sta
     HIPCHK(h, hipMemcpyAsync(h->d_dev, D, sizeof(FlDev18), hipMemcpyHostToDevice, h->stream));
     h->hdev_busy = true;
     if (vio) hipLaunchKernelGGL(vio_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev, (const FlVioConst *)h->d_vc);   // + the camera pose
-    else hipLaunchKernelGGL(eskf18_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev);
+    else if (!prepare_in_search) hipLaunchKernelGGL(eskf18_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev);
+    // (prepare_in_search: fl_lio_frame18_dev -- the first search launch of the frame carries the prepare workgroup, api_knn.inc)
     HIPCHK(h, hipGetLastError());
     h->begun18 = true;
     h->last_state_mode = 18;
@@ -783,18 +784,20 @@ static unsigned multipass_reserve(fl_handle h, int grid, bool mode23 = false)
     if (!(grid <= h->num_cus && h->opt_multipass)) return 0u;
     return mp_reserve(h, grid, mode23 ? h->mp_capacity_ik : h->mp_capacity);
 }
-static void launch_lio_passes(fl_handle h, int grid, int count, int flags, bool allow_multi = true)
+// returns true if the launch carried `extra` (FL_LIO_DO_COV: the covariance update at the end of the launch), i.e. it was a multi-pass one
+static bool launch_lio_passes(fl_handle h, int grid, int count, int flags, bool allow_multi = true, int extra = 0)
 {
     if (flags & FL_ITER_KEEP_NORMVEC) h->normvec_valid = true;
     ensure_gates(h);
     if (const unsigned seq = (allow_multi && count > 1) ? multipass_reserve(h, grid) : 0u) {
         hipLaunchKernelGGL(lio18_multipass_kernel, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_gate, h->d_plane, h->d_sel, h->d_normvec,
-                           h->n, h->d_dev, records_lio(h), h->d_epoch, h->d_bcast, (int)count, (int)flags, h->d_mp_done, seq);
-        return;
+                           h->n, h->d_dev, records_lio(h), h->d_epoch, h->d_bcast, (int)count, (int)flags, h->d_mp_done, seq, (int)extra);
+        return extra != 0;
     }
     for (int i = 0; i < count; i++)
         hipLaunchKernelGGL(lio18_pass_kernel<0>, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_gate, h->d_plane, h->d_sel,
                            h->d_normvec, h->n, h->d_dev, records_lio(h), h->d_epoch, (double *)nullptr, (int)flags);
+    return false;
 }
 // A pass of the enqueued chain was abandoned after a hand-off time-out (status bit FL_NUM_TIMEOUT, state untouched, everything
 // behind it skipped): clear the mark and run what is left with one launch per pass. `enqueue(remaining)` re-enqueues the tail

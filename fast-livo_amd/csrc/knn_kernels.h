@@ -257,12 +257,28 @@ __device__ __forceinline__ unsigned fl_cell_lookup(const FlMapGrid &G, unsigned 
 // min-reduction over (distance, index) keys merge them. Farther rings (sparse regions only) are scanned
 // cell-round-robin. Phase 2: one lane per query gathers the 5 neighbours and fits the plane (K0 fused) on
 // full waves.
+template <typename DEV> __device__ __forceinline__ void fl_search_prepare(DEV *D) {}
+// (inline: as a `noinline` function it is compiled for 180 VGPRs, which the kernel inherits -- occupancy 2 instead of 4, the frame
+// 13 us slower; inlined the kernel needs 106)
+template <> __device__ __forceinline__ void fl_search_prepare<FlDev18>(FlDev18 *D)
+{
+    if (threadIdx.x < 128) eskf18_prepare_body(D);      // (threads 128.. leave: the body's barriers count arrivals of live wavefronts only)
+}
 template <int MODE, typename DEV>
 __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *__restrict__ body, int n, FlMapGrid G, DEV *__restrict__ D,
                                                                   float4 *__restrict__ plane, uint8_t *__restrict__ sel,
                                                                   float *__restrict__ nbr_out /* nullable n x 15 */,
-                                                                  uint8_t *__restrict__ valid_out /* nullable */, int cond)
+                                                                  uint8_t *__restrict__ valid_out /* nullable */, int cond,
+                                                                  float4 *__restrict__ gate_out /* nullable */)
 {
+    // cond & 4 (the FIRST search of an 18-state frame, fl_lio_frame18_dev): the launch has one workgroup more than the scan needs,
+    // and that workgroup forms the gain-solve constants of the state block (what eskf18_prepare_kernel does) beside the search;
+    // gate_out != nullptr (same launch): every point's gate threshold (what lio_gate_kernel does) is written with its plane. Two
+    // launches and two kernel boundaries less per frame; the first search of a frame always runs (begin raises need_search).
+    if (MODE == 18 && (cond & 4) && blockIdx.x == gridDim.x - 1) {
+        fl_search_prepare<DEV>(D);
+        return;
+    }
     if ((cond & 1) && (!D->need_search || D->stop || (D->status & 8 /* FL_NUM_TIMEOUT: abandoned chain */))) return;
     const bool stamp = (cond & 2) && threadIdx.x == 0 && blockIdx.x < 512;
     FL_INSTR(if (stamp) g_fl_wall[blockIdx.x] = (long long)wall_clock64();)
@@ -433,6 +449,10 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
     const bool keep = valid && ok && (pl[0] == pl[0]);
     plane[iq] = keep ? make_float4(pl[0], pl[1], pl[2], pl[3]) : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);   // see lio_fit_planes_kernel
     sel[iq] = (uint8_t)keep;
+    if (gate_out) {
+        const float pb[3] = {body[(size_t)iq * 3], body[(size_t)iq * 3 + 1], body[(size_t)iq * 3 + 2]};
+        gate_out[iq] = make_float4(pb[0], pb[1], pb[2], fl_gate_threshold(pb));
+    }
     if (nbr_out) {
 #pragma unroll
         for (int k = 0; k < 15; k++) nbr_out[(size_t)iq * 15 + k] = nb[k];

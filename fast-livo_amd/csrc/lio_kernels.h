@@ -235,6 +235,8 @@ __global__ __launch_bounds__(FL_LIO_NT, FL_LIO_PASS_WAVES) void lio18_pass_kerne
     FL_INSTR(if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();)
 }
 
+#define FL_LIO_DO_COV 1
+__device__ __attribute__((noinline)) void eskf18_cov_outofline(FlDev18 *D);      // (out of line: its LDS and registers stay out of the pass loop)
 // -------------------------------------------------------------------------------------------- K1m
 // Up to `count` passes in ONE launch (the LIO block of a frame between two searches): the kernel boundary (~1.5 us), the
 // launch prologue and the no-op launches after stop/need_search disappear. Per pass the producers wait for the pose of the
@@ -248,12 +250,17 @@ __global__ __launch_bounds__(FL_LIO_NT, 2) void lio18_multipass_kernel(const flo
                                                                    uint8_t *__restrict__ sel, float4 *__restrict__ normvec, int n,
                                                                    FlDev18 *__restrict__ D, void *__restrict__ records,
                                                                    unsigned *__restrict__ epoch_ptr, unsigned long long *__restrict__ bcast,
-                                                                   int count, int flags, unsigned *__restrict__ done_word, unsigned done_seq)
+                                                                   int count, int flags, unsigned *__restrict__ done_word, unsigned done_seq,
+                                                                   int extra)
 {
+    // extra & FL_LIO_DO_COV (the LAST pass launch of fl_lio_frame18_dev): the solver workgroup ends with the covariance update
+    // P <- (I - G) P of eskf18_cov_update_kernel -- also when the launch has no pass left to run (the filter stopped in the first
+    // segment), not when the chain was abandoned (the host resumes and enqueues the kernel).
     constexpr int NT = FL_LIO_NT;
     const int nprod = gridDim.x - 1;
     const bool force = (flags & FL_ITER_FORCE) != 0;
     if (fl_pass_skipped(D, flags, count, blockIdx.x == nprod && threadIdx.x == 0)) {
+        if ((extra & FL_LIO_DO_COV) && blockIdx.x == nprod) eskf18_cov_outofline(D);
         fl_mp_done(done_word, done_seq, blockIdx.x == nprod);
         return;
     }
@@ -294,6 +301,10 @@ __global__ __launch_bounds__(FL_LIO_NT, 2) void lio18_multipass_kernel(const flo
         if (threadIdx.x == 0) {
             *epoch_ptr = epoch0 + (unsigned)done;
             if (PV.world > 1) *D->xchg_epoch = xe0 + (unsigned)done;
+        }
+        if (extra & FL_LIO_DO_COV) {
+            __syncthreads();
+            eskf18_cov_outofline(D);
         }
         fl_mp_done(done_word, done_seq, true);     // the solver leaves last: every producer has left its last wait by now
         return;
@@ -415,22 +426,25 @@ __device__ __forceinline__ void eskf18_gain_block(FlDev18 *__restrict__ D, doubl
     __syncthreads();
 }
 
-__global__ __launch_bounds__(384) void eskf18_cov_update_kernel(FlDev18 *__restrict__ D)
+// any workgroup of >= 128 threads, barriers inside
+__device__ __forceinline__ void eskf18_cov_update_body(FlDev18 *__restrict__ D)
 {
     __shared__ double sP[324];
     __shared__ double sG[108];
-    const int t = threadIdx.x;
-    if (D->status & FL_NUM_TIMEOUT) return;          // abandoned frame: the host resumes it and enqueues this kernel again
-    if (t < 324) sP[t] = D->P[t];
+    const int t = threadIdx.x, nt = blockDim.x;
+    if (D->status & FL_NUM_TIMEOUT) return;          // abandoned frame: the host resumes it and enqueues this kernel again (uniform)
+    for (int e = t; e < 324; e += nt) sP[e] = D->P[e];
     eskf18_gain_block(D, sG);
-    if (t < 324) {
-        const int r = t / 18, c = t % 18;
+    for (int e = t; e < 324; e += nt) {
+        const int r = e / 18, c = e % 18;
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < 6; k++) s += sG[r * 6 + k] * sP[k * 18 + c];
-        D->P[t] = sP[t] - s;
+        D->P[e] = sP[e] - s;
     }
 }
+__global__ __launch_bounds__(384) void eskf18_cov_update_kernel(FlDev18 *__restrict__ D) { eskf18_cov_update_body(D); }
+__device__ __attribute__((noinline)) void eskf18_cov_outofline(FlDev18 *D) { eskf18_cov_update_body(D); }
 
 // world points at the current device state (pointBodyToWorld) for the host kNN on rematch passes
 __global__ __launch_bounds__(FL_BLOCK) void lio_world_points_kernel(const float *__restrict__ body, float *__restrict__ world, int n,
