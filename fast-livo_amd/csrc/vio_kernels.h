@@ -207,6 +207,7 @@ __global__ __launch_bounds__(128) void vio_prepare_kernel(FlDev18 *__restrict__ 
 #define FL_VIO_SOLVER_BLOCK(nprod) (nprod)
 #define FL_VIO_AUDITOR_BLOCK(nprod) ((nprod) + 1)
 #define FL_VIO_PPL (64 / FL_VIO_LPP)          /* pixels per lane */
+#define FL_VIO_CHAIN_BATCH 4                 /* iterations whose per-patch float chains run together (vio_produce) */
 #define FL_VIO_GPW (64 / FL_VIO_LPP)          /* patches (lane groups) per wavefront */
 
 // grid = producers + 2 (the auditor workgroup, then the solver workgroup) ; MODE 0: fused pass ; MODE 1: accumulate only (sums -> sums_out).
@@ -242,10 +243,10 @@ __device__ __forceinline__ FlVioFirst vio_prefetch_first(const float *__restrict
 }
 
 // float patch_error of one patch from its 64 residuals in LDS (pixel order x*8+y), by the first lane of the patch's lane group
-__device__ __forceinline__ void vio_patch_error(const float *r, int hl, bool active, int i, float *__restrict__ errors,
+__device__ __forceinline__ void vio_patch_error(const float *r, bool mine, int i, float *__restrict__ errors,
                                                 unsigned long long *__restrict__ err_words, unsigned epoch)
 {
-    if (hl != 0 || !active) return;
+    if (!mine) return;
     float pe = 0.0f;
 #pragma unroll
     for (int k = 0; k < 64; k += 16) {               // operands from LDS sixteen at a time: the chain waits for the adder only
@@ -343,11 +344,15 @@ __device__ __forceinline__ void fl_vio_lane_role_pose(FlVioLaneRole &R, int hl, 
 }
 
 // One producer workgroup's share of a pass: residuals, rows, 6x6 update for its patches, reduced to one record and published.
+// CB: iterations whose per-patch float chains run together (FL_VIO_CHAIN_BATCH in the per-pass kernels, which iterate over many
+// patches at scale; 1 in the multi-pass kernels, whose wavefronts have one iteration each -- the bookkeeping cost them 0.3 us per pass).
+template <int CB>
 __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, const float *__restrict__ ref, const double *__restrict__ pos,
                                             const int32_t *__restrict__ slevel, float *__restrict__ errors, int m, int level_arg, int level,
                                             const FlVioConst &vc, const double (&Rcw)[9], const double (&Pcw)[3], const FlVioFirst &pf,
                                             int nprod, double *s_red, unsigned epoch, void *__restrict__ records, int flags,
-                                            unsigned long long *__restrict__ err_words /* this pass's half, nullable */, float *s_res /* LDS */,
+                                            unsigned long long *__restrict__ err_words /* this pass's half, nullable */,
+                                            float *s_res /* LDS: GPW * WPB * CB * 64 */, int *s_pidx /* LDS: GPW * WPB * CB */,
                                             const FlVioLaneRole &role /* fl_vio_lane_role + fl_vio_lane_role_pose of this pass */)
 {
     constexpr int WPB = FL_VIO_NT / 64;
@@ -372,8 +377,11 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
     FL_INSTR(if (blockIdx.x == 0) fl_stamp(flags, 0);)
     // trip count uniform over the wave: all lane groups iterate together, an inactive group (m not a multiple of GPW) computes
     // on patch 0 and contributes nothing
-    int def_i = 0;
-    bool def_active = false;
+    // The per-patch float chains (vio_patch_error: 64 dependent steps, ~250 instructions) run on ONE lane per patch, i.e. with 4 of
+    // the 64 lanes when they follow every iteration -- a third of the loop's instructions at 1 M patches. They are batched: the
+    // residuals of up to CB iterations wait in LDS and lanes hl < batch of every row each take one of them, so a
+    // chain pass serves 16 patches. The last batch is deferred until the record is published (off the hand-off's critical path).
+    int bslot = 0;                                   // iterations waiting in the batch
     for (int ib = (blockIdx.x * WPB + wave) * GPW; ib < m; ib += nprod * WPB * GPW) {
         const int i = ib + grp;
         const bool active = i < m;
@@ -531,8 +539,8 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
             const fl_f2 dv2 = half * ((wtl * tt[2][1] + wtr * tt[2][2] + wbl * tt[3][1] + wbr * tt[3][2])
                                     - (wtl * tt[0][1] + wtr * tt[0][2] + wbl * tt[1][1] + wbr * tt[1][2]));
             const fl_f2 rs2 = wtl * tt[1][1] + wtr * tt[1][2] + wbl * tt[2][1] + wbr * tt[2][2] - rf;
-            s_res[slot * 64 + LPP * px + hl] = rs2.x;                       // pixel order of the reference: x * 8 + y
-            s_res[slot * 64 + LPP * (px + 1) + hl] = rs2.y;
+            s_res[(slot * CB + bslot) * 64 + LPP * px + hl] = rs2.x;       // pixel order of the reference: x * 8 + y
+            s_res[(slot * CB + bslot) * 64 + LPP * (px + 1) + hl] = rs2.y;
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 const double dud = (double)(e ? du2.y : du2.x), dvd = (double)(e ? dv2.y : dv2.x), res = (double)(e ? rs2.y : rs2.x);
@@ -562,11 +570,14 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
             if (active) { acc1 += out1; acc2 += out2; }
         }
         FL_INSTR(if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(acc1 + acc2)); fl_stamp(flags, 45); })
-        if (last_iter) { def_i = i; def_active = active; }
-        else {
+        if (hl == 0) s_pidx[slot * CB + bslot] = active ? i : -1;
+        bslot++;
+        if (bslot == CB && !last_iter) {
             __builtin_amdgcn_wave_barrier();
-            vio_patch_error(s_res + slot * 64, hl, active, i, errors, err_words, epoch);
+            const int pi = s_pidx[slot * CB + (hl < CB ? hl : 0)];
+            vio_patch_error(s_res + (slot * CB + hl) * 64, hl < CB && pi >= 0, pi, errors, err_words, epoch);
             __builtin_amdgcn_wave_barrier();
+            bslot = 0;
         }
     }
     FL_INSTR(if (blockIdx.x == 0) fl_stamp(flags, 1);)
@@ -591,7 +602,10 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
     FL_INSTR(if (blockIdx.x == 0) fl_stamp(flags, 3);)
     FL_INSTR(if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();)   // every producer's publish time
     __builtin_amdgcn_wave_barrier();
-    vio_patch_error(s_res + slot * 64, hl, def_active, def_i, errors, err_words, epoch);
+    {
+        const int pi = s_pidx[slot * CB + (hl < bslot ? hl : 0)];
+        vio_patch_error(s_res + (slot * CB + hl) * 64, hl < bslot && pi >= 0, pi, errors, err_words, epoch);
+    }
 }
 
 // The AUDITOR workgroup (block `nprod`): the reference's float running sum `error += patch_error` over the patches in order
@@ -697,11 +711,12 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     for (int i = 0; i < 9; i++) Rcw[i] = D->Rcw[i];
 #pragma unroll
     for (int i = 0; i < 3; i++) Pcw[i] = D->Pcw[i];
-    __shared__ __attribute__((aligned(16))) float s_res[FL_VIO_GPW * WPB * 64];
+    __shared__ __attribute__((aligned(16))) float s_res[FL_VIO_GPW * WPB * FL_VIO_CHAIN_BATCH * 64];
+    __shared__ int s_pidx[FL_VIO_GPW * WPB * FL_VIO_CHAIN_BATCH];
     unsigned long long *ew = D->err_words ? D->err_words + (size_t)(D->iters_run & 1) * D->err_cap : nullptr;
     FlVioLaneRole role = fl_vio_lane_role((int)(threadIdx.x & 15), VC);
     fl_vio_lane_role_pose(role, (int)(threadIdx.x & 15), D->Rcw);
-    vio_produce(img, ref, pos, slevel, errors, m, level_arg, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags, ew, s_res, role);
+    vio_produce<FL_VIO_CHAIN_BATCH>(img, ref, pos, slevel, errors, m, level_arg, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags, ew, s_res, s_pidx, role);
     FL_INSTR(if (blockIdx.x == 0) fl_stamp(flags, 2);)
     FL_INSTR(if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();)
 }
@@ -864,6 +879,7 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
     __shared__ double s_pose[12];
     __shared__ int s_ctrl;
     __shared__ __attribute__((aligned(16))) float s_res[FL_VIO_GPW * WPB * 64];
+    __shared__ int s_pidx[FL_VIO_GPW * WPB];
     const int spin_limit = D->xchg_world > 1 ? FL_XCHG_SPIN_LIMIT : FL_GATHER_SPIN_LIMIT;   // the solver may be waiting for another process
     const FlVioConst vc = *VC;
     double Rcw[9], Pcw[3];
@@ -889,8 +905,8 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
             for (int i = 0; i < 3; i++) Pcw[i] = s_pose[9 + i];
             fl_vio_lane_role_pose(role, (int)(threadIdx.x & 15), s_pose);
         }
-        vio_produce(img, ref, pos, slevel, errors, m, level, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records,
-                    (ps == 5) ? flags : (flags & ~FL_ITER_STAMP), err_base ? err_base + (size_t)((pass0 + ps) & 1) * err_cap : nullptr, s_res, role);
+        vio_produce<1>(img, ref, pos, slevel, errors, m, level, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records,
+                    (ps == 5) ? flags : (flags & ~FL_ITER_STAMP), err_base ? err_base + (size_t)((pass0 + ps) & 1) * err_cap : nullptr, s_res, s_pidx, role);
         FL_INSTR(if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 23 + 4 * (ps - 5));)
         __syncthreads();
     }
