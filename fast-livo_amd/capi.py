@@ -891,12 +891,14 @@ def _knn_methods():
     def debug_hog(self, blocks, lds_bytes, usec):
         self._chk(self.L.fl_debug_hog(self.h, int(blocks), int(lds_bytes), int(usec)), "fl_debug_hog")
 
-    def debug_chain(self, e, init=0.0):
-        """(lane-parallel, one-lane) float running sums of init + e[0] + e[1] + ... on the device (csrc/exact_chain.h)"""
+    def debug_chain(self, e, init=0.0, full=False):
+        """(workgroup form, one-lane) float running sums of init + e[0] + e[1] + ... on the device (csrc/exact_chain.h);
+        full: (workgroup form, one-lane, wavefront form, chunks in which the workgroup form fell back)"""
         e = np.ascontiguousarray(e, dtype=np.float32)
-        out = np.zeros(2, dtype=np.float32)
+        out = np.zeros(16, dtype=np.float32)
         self._chk(self.L.fl_debug_chain(self.h, _p(e, C.c_float), len(e), C.c_float(init), _p(out, C.c_float)), "fl_debug_chain")
-        return out[0], out[1]
+        self.chain_profile = out[4:].copy()     # shader-clock offsets of the last chunk's phases (tools/chain_profile.py)
+        return (out[0], out[1], out[2], int(out[3])) if full else (out[0], out[1])
 
     def debug_drop_record(self, passes_ahead=0):
         self._chk(self.L.fl_debug_drop_record(self.h, int(passes_ahead)), "fl_debug_drop_record")

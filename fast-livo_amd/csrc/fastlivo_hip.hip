@@ -926,17 +926,17 @@ int32_t fl_debug_hog(fl_handle h, int32_t blocks, int32_t lds_bytes, int32_t use
     HIPCHK(h, hipGetLastError());
     return FL_OK;
 }
-// Debug / test: init + e[0] + ... + e[n-1] as one chain of float additions, by exact_chain.h's lane-parallel form (out2[0]) and
-// by one lane adding one by one (out2[1]); e is a host array.
-int32_t fl_debug_chain(fl_handle h, const float *e, int32_t n, float init, float *out2)
+// Debug / test: init + e[0] + ... + e[n-1] as one chain of float additions, by exact_chain.h's workgroup form (out4[0]), by one lane
+// adding one by one (out4[1]), by the wavefront form (out4[2]); out4[3] = chunks in which the workgroup form fell back. e is a host array.
+int32_t fl_debug_chain(fl_handle h, const float *e, int32_t n, float init, float *out4)
 {
-    if (!h || n < 0 || (n > 0 && !e) || !out2) return fail_arg(h, "fl_debug_chain: bad argument");
+    if (!h || n < 0 || (n > 0 && !e) || !out4) return fail_arg(h, "fl_debug_chain: bad argument");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     float *d = nullptr;
-    HIPCHK(h, hipMalloc(&d, sizeof(float) * ((size_t)n + 2)));
-    if (n > 0) HIPCHK(h, hipMemcpyAsync(d + 2, e, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(fl_chain_debug_kernel, dim3(1), dim3(256), 0, h->stream, (const float *)(d + 2), (int)n, init, d);
-    hipError_t err = hipMemcpyAsync(out2, d, sizeof(float) * 2, hipMemcpyDeviceToHost, h->stream);
+    HIPCHK(h, hipMalloc(&d, sizeof(float) * ((size_t)n + 16)));
+    if (n > 0) HIPCHK(h, hipMemcpyAsync(d + 16, e, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(fl_chain_debug_kernel, dim3(1), dim3(256), 0, h->stream, (const float *)(d + 16), (int)n, init, d);
+    hipError_t err = hipMemcpyAsync(out4, d, sizeof(float) * 16, hipMemcpyDeviceToHost, h->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(h->stream);
     hipFree(d);
     HIPCHK(h, err);

@@ -141,9 +141,8 @@ __device__ __forceinline__ float vio_exact_sum_inl(const unsigned long long *w, 
         for (int k = cnt + tid; k < cnt + FL_CHAIN_STEP; k += nt) scr[k] = 0.0f;       // the zero padding the chain's steps read into
         const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;
         FL_CHAIN_STAMP(tag, 1);
-        if (tid < 64) f = fl_chain_f32_wave(scr, cnt, f, any_bad);
+        f = fl_chain_f32_block(scr, cnt, f, any_bad);       // (ends with a barrier; the result is in every thread)
         FL_CHAIN_STAMP(tag, 2);
-        __syncthreads();
     }
     return f;
 }

@@ -722,25 +722,33 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
 }
 
 #ifdef FL_INSTRUMENT
-// Debug / test: exact_chain.h's lane-parallel chain beside the plain one-lane chain over the same floats
-__global__ __launch_bounds__(256) void fl_chain_debug_kernel(const float *__restrict__ e, int n, float init, float *__restrict__ out2)
+// Debug / test: exact_chain.h's workgroup chain (out4[0]) and wavefront chain (out4[2]) beside the plain one-lane chain (out4[1]) over
+// the same floats; out4[3] = number of chunks in which the workgroup form's checks failed (it then ran the wavefront form)
+__global__ __launch_bounds__(256) void fl_chain_debug_kernel(const float *__restrict__ e, int n, float init, float *__restrict__ out4)
 {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) float scr[FL_EXACT_LDS];
-    float f = init, g = init;
+    float f = init, g = init, w = init;
+    int fell = 0;
     for (int base = 0; base < n; base += FL_EXACT_CHUNK) {
         const int cnt = min(FL_EXACT_CHUNK, n - base);
         bool bad = false;
         for (int k = threadIdx.x; k < cnt; k += blockDim.x) { const float v = e[base + k]; scr[k] = v; bad |= !(v >= 0.0f); }
         for (int k = cnt + threadIdx.x; k < cnt + FL_CHAIN_STEP; k += blockDim.x) scr[k] = 0.0f;
         const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;
-        if (threadIdx.x < 64) f = fl_chain_f32_wave(scr, cnt, f, any_bad);
+        int fb = 0;
+        __shared__ long long s_prof[12];
+        f = fl_chain_f32_block(scr, cnt, f, any_bad, &fb, s_prof);
+        fell += fb;
+        if (threadIdx.x == 0) s_prof[10] = (long long)clock64();
+        if (threadIdx.x < 64) w = fl_chain_f32_wave(scr, cnt, w, any_bad);
+        if (threadIdx.x == 0) { s_prof[11] = (long long)clock64(); for (int i = 0; i < 12; i++) out4[4 + i] = (float)(s_prof[i] - s_prof[0]); }
         if (threadIdx.x == 64)
             for (int k = 0; k < cnt; k++) g = g + scr[k];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out2[0] = f;
-    if (threadIdx.x == 64) out2[1] = g;
+    if (threadIdx.x == 0) { out4[0] = f; out4[2] = w; out4[3] = (float)fell; }
+    if (threadIdx.x == 64) out4[1] = g;
 }
 #endif
 

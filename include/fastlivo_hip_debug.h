@@ -26,9 +26,11 @@ int32_t fl_debug_knn_stamp(fl_handle h, int32_t enable);
  * of its own: what another process on the same GPU looks like to the multi-pass kernels (tests/test_coresidency_gpu.py). */
 int32_t fl_debug_hog(fl_handle h, int32_t blocks, int32_t lds_bytes, int32_t usec);
 /* init + e[0] + ... + e[n-1] (host array) as ONE chain of float additions, as the reference's `error += patch_error`
- * (lidar_selection.cpp:857) rounds it: out2[0] by the lane-parallel form the kernels use (csrc/exact_chain.h), out2[1] by one lane
- * adding one by one. They must be the same bits. */
-int32_t fl_debug_chain(fl_handle h, const float *e, int32_t n, float init, float *out2);
+ * (lidar_selection.cpp:857) rounds it: out4[0] by the workgroup form the kernels use (csrc/exact_chain.h), out4[1] by one lane adding
+ * one by one, out4[2] by the wavefront form (the workgroup form's fallback). They must be the same bits. out4[3] = number of
+ * 2048-element chunks in which the workgroup form's checks failed and it fell back; out4[4..15]: shader-clock offsets of the phases
+ * of the last chunk (out4 holds 16 floats). */
+int32_t fl_debug_chain(fl_handle h, const float *e, int32_t n, float init, float *out4);
 /* Fault injection: producer workgroup 0 of the pass launched `passes_ahead` passes from now (0 = the next one) does not publish its
  * record, so that pass's bounded gather expires and the pass is ABANDONED (FL_NUM_TIMEOUT): exercises the resume paths. */
 int32_t fl_debug_drop_record(fl_handle h, int32_t passes_ahead);

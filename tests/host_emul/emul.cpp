@@ -180,6 +180,57 @@ float emul_chain_f32(const float *in, int cnt, float init, int *steps_out)
     if (steps_out) *steps_out = steps;
     return s;
 }
+// the workgroup form (fl_chain_f32_block): the product's per-element / per-event functions, the 256 threads and their scans run one
+// after the other. *fellback: a check failed (the device then runs the wavefront form); *nev: events walked.
+float emul_chain_f32_spec(const float *in, int cnt, float init, int *fellback, int *nev_out)
+{
+    *fellback = 0; if (nev_out) *nev_out = 0;
+    bool bad = false;
+    for (int i = 0; i < cnt; i++) if (!(in[i] >= 0.0f)) bad = true;
+    if (bad || cnt > 256 * FL_SPEC_EPT || fl_chain_plain_only(init)) { *fellback = 1; return emul_chain_f32(in, cnt, init, nullptr); }
+    static double evA[FL_SPEC_MAX_EVENTS + 1]; static unsigned evE[FL_SPEC_MAX_EVENTS + 1]; static int evB[FL_SPEC_MAX_EVENTS + 1];
+    const int lead = cnt < FL_SPEC_LEAD ? cnt : FL_SPEC_LEAD;
+    volatile float init2 = init;
+    for (int k = 0; k < lead; k++) init2 = init2 + in[k];
+    int nev = 0, fail = fl_chain_plain_only(init2) ? 1 : 0;
+    double incl_prev = (double)init2, A = 0.0;
+    for (int t = 0; t < 256; t++) {
+        float e[FL_SPEC_EPT]; double d[FL_SPEC_EPT]; double run = 0.0;
+        for (int j = 0; j < FL_SPEC_EPT; j++) { const int k = FL_SPEC_EPT * t + j; e[j] = (k >= lead && k < cnt) ? in[k] : 0.0f; run += (double)e[j]; d[j] = run; }
+        const double excl = incl_prev, incl = incl_prev + run;
+        int Eb[FL_SPEC_EPT + 1];
+        Eb[0] = fl_spec_binade(excl);
+        for (int j = 1; j < FL_SPEC_EPT; j++) Eb[j] = fl_spec_binade(excl + d[j - 1]);
+        Eb[FL_SPEC_EPT] = fl_spec_binade(incl);
+        for (int j = 0; j < FL_SPEC_EPT; j++) {
+            int q, tf;
+            const int kind = fl_spec_elem(e[j], Eb[j], Eb[j + 1], &q, &tf);
+            if (kind) {
+                union { float f; unsigned u; } b; b.f = e[j];
+                if (nev < FL_SPEC_MAX_EVENTS) { evA[nev] = A; evE[nev] = kind == 2 ? (unsigned)tf : b.u; evB[nev] = kind == 2 ? FL_SPEC_TIE : Eb[j + 1]; } else fail = 1;
+                nev++;
+            }
+            A += (double)q;
+        }
+        incl_prev = incl;
+    }
+    if (nev_out) *nev_out = nev;
+    if (!fail) {
+        evA[nev] = A; evE[nev] = 0u; evB[nev] = FL_SPEC_TAIL;
+        int S, Eb;
+        fl_chain_split(init2, &S, &Eb);
+        double Ap = 0.0;
+        for (int i = 0; i <= nev; i++) {
+            const double dq = evA[i] - Ap;
+            const int Q = dq < 16777216.0 ? (int)dq : FL_CHAIN_LIMIT;
+            fail |= fl_spec_event(&S, &Eb, Q, evE[i], evB[i]);
+            Ap = evA[i];
+        }
+        if (!fail) return fl_chain_from_units(S, Eb);
+    }
+    *fellback = 1;
+    return emul_chain_f32(in, cnt, init, nullptr);
+}
 float emul_chain_f32_plain(const float *scr, int cnt, float init)
 {
     volatile float s = init;

@@ -96,3 +96,79 @@ def test_random_bit_patterns(emul_lib, seed):
         e = bits.view(np.float32)
         a, b, _ = _run(emul_lib, e, 0.0)
         assert _same(a, b), (seed, m, a, b)
+
+
+# ---- the workgroup form (fl_chain_f32_block): binades guessed from a double prefix sum, every guess checked, wavefront form on a
+# failed check
+def _run_spec(E, e, init=0.0):
+    e = np.ascontiguousarray(e, dtype=np.float32)
+    E.emul_chain_f32_spec.restype = C.c_float
+    E.emul_chain_f32_plain.restype = C.c_float
+    fb, nev = C.c_int(0), C.c_int(0)
+    pe = e.ctypes.data_as(C.POINTER(C.c_float))
+    a = E.emul_chain_f32_spec(pe, len(e), C.c_float(init), C.byref(fb), C.byref(nev))
+    b = E.emul_chain_f32_plain(pe, len(e), C.c_float(init))
+    return np.float32(a), np.float32(b), fb.value, nev.value
+
+
+def test_workgroup_chain_equals_the_plain_chain(emul_lib):
+    rng = np.random.default_rng(20240924)
+    n = fell = 0
+    for name, e, init in chain_cases(rng, 600):
+        if len(e) > 2048:
+            continue
+        a, b, fb, nev = _run_spec(emul_lib, e, init)
+        assert _same(a, b), (name, a, b, fb, nev)
+        n += 1
+        fell += fb
+    assert n > 400 and fell < n          # (the corner cases fall back often; the point is the bits)
+
+
+def test_workgroup_chain_on_patch_errors_rarely_falls_back(emul_lib):
+    """the data the kernels see: 2 k sums of 64 squared grey-level residuals, near-converged passes"""
+    rng = np.random.default_rng(77)
+    fell = 0
+    worst_events = 0
+    trials = 400
+    for _ in range(trials):
+        m = int(rng.choice([500, 1000, 2000, 2048]))
+        e = ((rng.standard_normal((m, 64)).astype(np.float32) * rng.uniform(0.5, 30)) ** 2).sum(axis=1, dtype=np.float32)
+        a, b, fb, nev = _run_spec(emul_lib, e, 0.0)
+        assert _same(a, b), (m, a, b, fb, nev)
+        fell += fb
+        if not fb:
+            worst_events = max(worst_events, nev)
+    print(f"\n[workgroup chain] {fell} of {trials} chains fell back to the wavefront form; at most {worst_events} events walked")
+    assert fell <= trials // 10
+    assert 0 < worst_events <= 63
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_workgroup_chain_random_bit_patterns(emul_lib, seed):
+    rng = np.random.default_rng(300 + seed)
+    for _ in range(300):
+        m = int(rng.integers(1, 2049))
+        lo, hi = sorted(rng.integers(0, 250, 2))
+        bits = (rng.integers(0, 1 << 23, m).astype(np.uint32)) | (rng.integers(lo, hi + 1, m).astype(np.uint32) << np.uint32(23))
+        init = float(np.float32(rng.choice([0.0, 1.0, 2.0 ** 24, 1e-40, 3.0e38])))
+        with np.errstate(over="ignore"):
+            a, b, fb, nev = _run_spec(emul_lib, bits.view(np.float32), init)
+        assert _same(a, b), (seed, m, a, b, fb, nev)
+
+
+def test_workgroup_chain_binade_edges(emul_lib):
+    """running sums that land exactly on / one ulp beside powers of two, where the double prefix and the float chain may disagree about
+    the binade: the checks must catch every such case (result still the plain chain's)"""
+    rng = np.random.default_rng(9)
+    for trial in range(400):
+        m = int(rng.integers(2, 1500))
+        k = int(rng.integers(-20, 40))
+        e = rng.uniform(0, 1, m).astype(np.float64)
+        e *= (2.0 ** k) / e.sum()                         # the exact sum is (about) 2^k
+        j = int(rng.integers(1, m))
+        e[:j] *= (2.0 ** (k - 1)) / e[:j].sum()           # ... and a prefix is (about) 2^(k-1)
+        e = e.astype(np.float32)
+        if trial % 3 == 0:
+            e = np.concatenate([e, e[: m // 2]])[:2048]
+        a, b, fb, nev = _run_spec(emul_lib, e, 0.0)
+        assert _same(a, b), (trial, a, b, fb, nev)

@@ -28,3 +28,5 @@ us = lambda v: round((int(v) - int(t0)) / 100.0, 2)
 for a in rows:
     print(f"epoch {int(a[11])} level {int(a[12])}: solver gathered {us(a[8]):8.2f}  pass done {us(a[9]):8.2f} (+{(int(a[9]) - int(a[8])) / 100.0:5.2f})  "
           f"flags(fragile 16, audited 2, timeout 4, accept 8) = {int(a[10]):2d} | auditor: loop top {us(a[0]):8.2f} pose seen {us(a[1]):8.2f} chain done {us(a[2]):8.2f}")
+    c = w[1024 + 4 * (int(a[11]) & 63): 1024 + 4 * (int(a[11]) & 63) + 3]
+    print(f"          auditor chain stamps: entry {us(c[0]):8.2f} staged {us(c[1]):8.2f} (+{(int(c[1]) - int(c[0])) / 100.0:5.2f}) added {us(c[2]):8.2f} (+{(int(c[2]) - int(c[1])) / 100.0:5.2f})")
