@@ -26,6 +26,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -57,11 +58,17 @@ struct fl_context {
     int mp_last_grid = 0;
     int mp_fallbacks = 0, mp_resumes = 0;   // diagnostics: launches sent down the per-pass path by the admission check / frames resumed
     // fl_set_option (include/fastlivo_hip.h)
-    int opt_multipass = 1, opt_max_producers = 0, opt_ik_producers = 0, opt_vio_whole_cu = 1;
+    int opt_multipass = 1, opt_max_producers = 0, opt_ik_producers = 0, opt_vio_whole_cu = 1, opt_vio_one_launch = 1;
     bool normvec_valid = false;   // a pass with FL_ITER_KEEP_NORMVEC has run on the staged scan
     // 18-state block, reduction scratch
     FlDev18 *d_dev = nullptr;
     FlDev18 *h_dev = nullptr;      // pinned mirror
+    // result mailbox of the frame drivers (fl_device.h fl_publish_state): the word the frame's last kernel writes, its device address,
+    // the device address of the mirror, the sequence number of the last published frame
+    unsigned long long *h_pub = nullptr, *d_pub = nullptr;
+    void *d_hdev = nullptr;
+    unsigned long long pub_seq = 0;
+    int opt_mailbox = 2;            // bit 0: fl_vio_compute_j, bit 1: fl_lio_frame18_dev
 #define FL_UP_SLOTS 12
     void *h_small = nullptr;        // page-locked scratch: 4 KB for the small per-call read-backs (counts, control blocks) + FL_UP_SLOTS x 1 KB for parameter uploads
     unsigned up_slot = 0;
@@ -280,7 +287,7 @@ static unsigned mp_reserve(fl_handle h, int slots, int capacity, bool need_idle 
 // FL_NUM_TIMEOUT handling: clears the abandoned mark so that the enqueued per-pass chain runs (solve18.h, fl_pass_skipped)
 __global__ void eskf18_resume_kernel(FlDev18 *__restrict__ D)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { D->status &= ~FL_NUM_TIMEOUT; D->resume_count = 0; }
+    if (threadIdx.x == 0 && blockIdx.x == 0) { D->status &= ~FL_NUM_TIMEOUT; D->resume_count = 0; D->pub_flag = nullptr; }    // (a resumed frame is read back with a copy)
 }
 #ifdef FL_INSTRUMENT
 // debug / test aid: occupies `blocks` workgroup slots for ~`usec` microseconds (tests/test_coresidency_gpu.py)
@@ -317,6 +324,10 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
     // three FlVioLevelInfo)
     HIPCHK(h, hipMalloc(&h->d_dev, sizeof(FlDev18) + FL_DEV18_TAIL));
     HIPCHK(h, hipHostMalloc(&h->h_dev, sizeof(FlDev18) + FL_DEV18_TAIL));
+    HIPCHK(h, hipHostMalloc(&h->h_pub, 64));
+    memset(h->h_pub, 0, 64);
+    HIPCHK(h, hipHostGetDevicePointer((void **)&h->d_pub, h->h_pub, 0));
+    HIPCHK(h, hipHostGetDevicePointer(&h->d_hdev, h->h_dev, 0));
     HIPCHK(h, hipMalloc(&h->d_dev23, sizeof(FlDev23)));
     HIPCHK(h, hipHostMalloc(&h->h_dev23, sizeof(FlDev23)));
     HIPCHK(h, hipHostMalloc(&h->h_small, 4096 + FL_UP_SLOTS * 1024));
@@ -387,6 +398,7 @@ int32_t fl_destroy(fl_handle h)
     fl_comm_destroy(h);
     fl_p2p_disconnect(h);
     if (h->h_dev) hipHostFree(h->h_dev);
+    if (h->h_pub) hipHostFree(h->h_pub);
     if (h->h_dev23) hipHostFree(h->h_dev23);
     if (h->h_small) hipHostFree(h->h_small);
     {
@@ -459,6 +471,8 @@ int32_t fl_set_option(fl_handle h, int32_t option, int32_t value)
         else { h->mp_capacity = h->mp_capacity_q; h->mp_capacity_ik = h->mp_capacity_ik_q; }
         break;
     case FL_OPT_VIO_WHOLE_CU: h->opt_vio_whole_cu = value != 0; break;
+    case FL_OPT_VIO_ONE_LAUNCH: h->opt_vio_one_launch = value != 0; break;
+    case FL_OPT_MAILBOX: h->opt_mailbox = value & 3; break;
     default: return fail_arg(h, "fl_set_option: unknown option");
     }
     return FL_OK;
@@ -693,7 +707,8 @@ static int32_t upload_small(fl_handle h, void *d_dst, const void *src, size_t by
     return FL_OK;
 }
 
-static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_state18 *prop, double meas_cov, bool vio = false, bool prepare_in_search = false)
+static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_state18 *prop, double meas_cov, bool vio = false, bool prepare_in_search = false,
+                              bool publish = false)
 {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     // h_dev is reused: wait only if a copy out of it can still be in flight. (A frame driver's begin follows the previous frame's
@@ -723,6 +738,9 @@ static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_sta
     D->xchg_epoch = h->d_xepoch;
     D->xchg_rank = h->xchg_rank;
     D->xchg_world = h->xchg_world;
+    if (publish && (h->opt_mailbox & (vio ? 1 : 2))) {      // frame drivers: the frame's last kernel publishes the block (read_info18 polls)
+        D->pub_flag = h->d_pub; D->pub_dst = h->d_hdev; D->pub_seq = ++h->pub_seq;
+    }
     HIPCHK(h, hipMemcpyAsync(h->d_dev, D, sizeof(FlDev18), hipMemcpyHostToDevice, h->stream));
     h->hdev_busy = true;
     if (vio) hipLaunchKernelGGL(vio_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev, (const FlVioConst *)h->d_vc);   // + the camera pose
@@ -744,10 +762,31 @@ int32_t fl_lio_begin18(fl_handle h, const fl_state18 *state, const fl_state18 *p
     return FL_OK;
 }
 
-static int32_t read_info18(fl_handle h, fl_iter_info *info)
+// The frame's last kernel publishes the state block into the pinned mirror and raises h_pub (fl_publish_state): wait for it. False:
+// the stream ran dry without the word (abandoned chain: nothing behind the abandoned pass ran) -- the caller reads the block back.
+static bool wait_published(fl_handle h, unsigned long long seq)
 {
-    HIPCHK(h, hipMemcpyAsync(h->h_dev, h->d_dev, sizeof(FlDev18) + FL_DEV18_TAIL, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned n = 1;; n++) {
+        if (__atomic_load_n(h->h_pub, __ATOMIC_ACQUIRE) == seq) return true;
+        if ((n & 1023u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) {
+            // well past a frame: look at the stream now and then (a query costs microseconds)
+            if (hipStreamQuery(h->stream) != hipErrorNotReady) return __atomic_load_n(h->h_pub, __ATOMIC_ACQUIRE) == seq;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
+
+static int32_t read_info18(fl_handle h, fl_iter_info *info, bool published = false)
+{
+    // published: the block was uploaded with a mailbox request (begin18_common) and the chain ends in a kernel that serves it
+    if (!(published && h->h_dev->pub_flag && wait_published(h, h->pub_seq))) {
+        HIPCHK(h, hipMemcpyAsync(h->h_dev, h->d_dev, sizeof(FlDev18) + FL_DEV18_TAIL, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    // (either way everything enqueued before is complete: the stream is in order and the publishing kernel is its last command)
     h->hdev_busy = false; h->hdev23_busy = false; h->up_pending = 0;
     if (!info) return FL_OK;
     const FlDev18 *D = h->h_dev;

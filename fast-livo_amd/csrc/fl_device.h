@@ -71,6 +71,12 @@ struct FlDev18 {
     unsigned long long *xchg_peer[8];
     unsigned *xchg_epoch;            // device word: epoch of the next exchange (same value on every rank)
     int32_t xchg_rank, xchg_world;   // world <= 1: no exchange
+    // result mailbox of the frame drivers (fl_publish_state below): the frame's last kernel copies this block (+ its tail) into the
+    // page-locked host mirror and then writes pub_seq to the host word pub_flag -- the host polls that word instead of enqueueing a
+    // copy and synchronising the stream. nullptr: nobody polls (every other call reads the block back with a copy).
+    unsigned long long *pub_flag;
+    void *pub_dst;
+    unsigned long long pub_seq;
 };
 
 // VIO constants (lidar_selection.cpp:35-59 + camera), computed on the host once per handle.
@@ -180,6 +186,25 @@ __device__ __forceinline__ void fl_sin_omc(double x, double *s, double *omc)
 }
 
 #define FL_DEV18_TAIL 512                  /* bytes behind FlDev18 in its device and pinned-host allocations (fastlivo_hip.hip) */
+
+// The result mailbox (FlDev18::pub_flag): called by ALL threads of ONE workgroup as the last action of a frame's last kernel. The
+// block was last written by this workgroup or by earlier kernels; it travels as 8-byte words over the host link (~7 KB: well under a
+// microsecond), every thread makes its words visible to the system, then one thread raises the flag. The host (read_info18) sees the
+// flag ~1 us after the kernel's last store -- a device-to-host copy command plus a stream synchronisation cost 15-20 us per frame.
+__device__ __forceinline__ void fl_publish_state(FlDev18 *__restrict__ D)
+{
+    __syncthreads();
+    unsigned long long *flag = D->pub_flag;
+    if (!flag) return;                                   // (uniform)
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(D);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(D->pub_dst);
+    const unsigned long long seq = D->pub_seq;
+    constexpr int WORDS = (int)((sizeof(FlDev18) + FL_DEV18_TAIL) / 8);
+    for (int i = threadIdx.x; i < WORDS; i += blockDim.x) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // ---- instrumentation: compiled ONLY into the -DFL_INSTRUMENT build (libfastlivo_hip_debug.so, include/fastlivo_hip_debug.h).
 // The release library carries no stamp, no debug global, no run-time branch on FL_ITER_STAMP: every site is FL_INSTR(...).

@@ -426,22 +426,25 @@ __device__ __forceinline__ void eskf18_gain_block(FlDev18 *__restrict__ D, doubl
     __syncthreads();
 }
 
-// any workgroup of >= 128 threads, barriers inside
+// any workgroup of >= 128 threads, barriers inside; ends with the frame's result mailbox (fl_publish_state: a no-op unless a frame
+// driver asked for it)
 __device__ __forceinline__ void eskf18_cov_update_body(FlDev18 *__restrict__ D)
 {
     __shared__ double sP[324];
     __shared__ double sG[108];
     const int t = threadIdx.x, nt = blockDim.x;
-    if (D->status & FL_NUM_TIMEOUT) return;          // abandoned frame: the host resumes it and enqueues this kernel again (uniform)
-    for (int e = t; e < 324; e += nt) sP[e] = D->P[e];
-    eskf18_gain_block(D, sG);
-    for (int e = t; e < 324; e += nt) {
-        const int r = e / 18, c = e % 18;
-        double s = 0.0;
+    if (!(D->status & FL_NUM_TIMEOUT)) {             // abandoned frame: the host resumes it and enqueues this kernel again (uniform)
+        for (int e = t; e < 324; e += nt) sP[e] = D->P[e];
+        eskf18_gain_block(D, sG);
+        for (int e = t; e < 324; e += nt) {
+            const int r = e / 18, c = e % 18;
+            double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < 6; k++) s += sG[r * 6 + k] * sP[k * 18 + c];
-        D->P[e] = sP[e] - s;
+            for (int k = 0; k < 6; k++) s += sG[r * 6 + k] * sP[k * 18 + c];
+            D->P[e] = sP[e] - s;
+        }
     }
+    fl_publish_state(D);
 }
 __global__ __launch_bounds__(384) void eskf18_cov_update_kernel(FlDev18 *__restrict__ D) { eskf18_cov_update_body(D); }
 __device__ __attribute__((noinline)) void eskf18_cov_outofline(FlDev18 *D) { eskf18_cov_update_body(D); }

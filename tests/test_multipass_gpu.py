@@ -154,22 +154,57 @@ def test_non_finite_state_is_reported_not_hung(gpu_lib, scene):
 
 def test_vio_kernel_variants_give_the_same_bits(gpu_lib):
     """The VIO multi-pass kernel exists in two register budgets (a CU per workgroup / two workgroups per CU, api_vio.inc
-    vio_mp_variant) besides the one-launch-per-pass form: ComputeJ must not depend on which one a launch gets (the concurrent and
-    sharded uses get the co-resident one). Fused multiply-adds are written out (fma()) wherever the two instantiations could contract
+    vio_mp_variant) besides the one-launch-per-pass form, and ComputeJ runs its three levels in one launch or one launch per level:
+    the result must not depend on which form a launch gets (the concurrent and sharded uses get the co-resident one). Fused multiply-adds are written out (fma()) wherever the two instantiations could contract
     differently."""
     capi = gpu_lib
     from fast_livo_amd import synth
     lio = synth.make_lio_frame(2000)
     vf = synth.make_vio_frame(1800, lio)
     outs = []
-    for opts in ({}, {capi.FL_OPT_VIO_WHOLE_CU: 0}, {capi.FL_OPT_MULTIPASS: 0}):
+    for opts in ({}, {capi.FL_OPT_VIO_WHOLE_CU: 0}, {capi.FL_OPT_VIO_ONE_LAUNCH: 0}, {capi.FL_OPT_VIO_ONE_LAUNCH: 0, capi.FL_OPT_VIO_WHOLE_CU: 0},
+                 {capi.FL_OPT_MULTIPASS: 0}):
         h = capi.Handle(capi.config_from_frames(lio, vf, max_iterations=10))
         for k, v in opts.items():
             h.set_option(k, v)
         h.vio_set_frame(vf.img); h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
         x = capi.state18_from_frame(lio)
         infos = h.vio_compute_j(x, capi.state18_from_frame(lio))
-        outs.append((x.vec().copy(), x.cov_np().copy(), h.vio_get_errors(vf.m).view(np.uint32).copy(), [(i.iterations, i.accepted) for i in infos]))
+        outs.append((x.vec().copy(), x.cov_np().copy(), h.vio_get_errors(vf.m).view(np.uint32).copy(),
+                     [(i.iterations, i.accepted, i.status, i.total_residual, tuple(i.solution)) for i in infos]))
         h.close()
     for o in outs[1:]:
         assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2]) and o[3] == outs[0][3]
+
+
+def test_result_mailbox_gives_the_same_frame(gpu_lib, scene):
+    """The frame drivers get their results through a host word the frame's last kernel writes (fl_publish_state, FL_OPT_MAILBOX) or
+    through a copy + stream synchronisation: the same state, covariance, counters, level results -- also over repeated frames on one
+    handle and for a frame whose chain is resumed."""
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    fr = synth.make_lio_frame(20000, scene=scene)
+    vf = synth.make_vio_frame(1500, fr)
+    outs = []
+    for mailbox in (3, 0, 2):
+        h = capi.Handle(capi.config_from_frames(fr, vf, max_iterations=10))
+        h.set_option(capi.FL_OPT_MAILBOX, mailbox)
+        h.map_set_points(scene.map_xyz, 0.5)
+        h.vio_set_frame(vf.img); h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+        rec = []
+        for rep in range(4):
+            x = capi.state18_from_frame(fr)
+            info = h.lio_frame18_dev(x, fr.body_xyz)
+            xv = capi.state18_from_frame(fr)
+            infos = h.vio_compute_j(xv, capi.state18_from_frame(fr))
+            rec.append((x.vec().copy(), x.cov_np().copy(), info.status, info.iterations, info.effct_feat_num, xv.vec().copy(), xv.cov_np().copy(),
+                        [(i.iterations, i.accepted, i.status, i.total_residual, tuple(i.solution)) for i in infos]))
+        outs.append(rec)
+        h.close()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:5] == b[2:5]
+            assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6]) and a[7] == b[7]
+    for rec in outs:                    # and frame after frame on one handle
+        for r in rec[1:]:
+            assert np.array_equal(r[0], rec[0][0]) and np.array_equal(r[5], rec[0][5])
