@@ -68,7 +68,11 @@ struct fl_context {
     unsigned long long *h_pub = nullptr, *d_pub = nullptr;
     void *d_hdev = nullptr;
     unsigned long long pub_seq = 0;
-    int opt_mailbox = 2;            // bit 0: fl_vio_compute_j, bit 1: fl_lio_frame18_dev
+    int opt_scan_pull = 1;
+    struct PinnedRange { void *host; size_t bytes; void *dev; };
+    std::vector<PinnedRange> pinned;   // allocations of fl_host_alloc (kernels read scans in them in place)
+    std::mutex pinned_mu;
+    int opt_mailbox = 3;            // bit 0: fl_vio_compute_j, bit 1: fl_lio_frame18_dev
 #define FL_UP_SLOTS 12
     void *h_small = nullptr;        // page-locked scratch: 4 KB for the small per-call read-backs (counts, control blocks) + FL_UP_SLOTS x 1 KB for parameter uploads
     unsigned up_slot = 0;
@@ -440,13 +444,26 @@ int32_t fl_host_alloc(fl_handle h, size_t bytes, void **out)
     if (!h || !out || bytes == 0) return fail_arg(h, "fl_host_alloc: bad argument");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipHostMalloc(out, bytes, hipHostMallocDefault));
+    void *dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, *out, 0) == hipSuccess && dev) {      // (kernels may read it in place: fl_lio_frame18_dev)
+        std::lock_guard<std::mutex> lk(h->pinned_mu);
+        h->pinned.push_back({*out, bytes, dev});
+    }
     return FL_OK;
 }
 
 int32_t fl_host_free(fl_handle h, void *p)
 {
     if (!h) return fail_arg(nullptr, "null handle");
-    if (p) HIPCHK(h, hipHostFree(p));
+    if (p) {
+        {
+            std::lock_guard<std::mutex> lk(h->pinned_mu);
+            for (size_t k = 0; k < h->pinned.size(); k++)
+                if (h->pinned[k].host == p) { h->pinned.erase(h->pinned.begin() + (long)k); break; }
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));       // (a kernel may still be reading it)
+        HIPCHK(h, hipHostFree(p));
+    }
     return FL_OK;
 }
 
@@ -473,6 +490,7 @@ int32_t fl_set_option(fl_handle h, int32_t option, int32_t value)
     case FL_OPT_VIO_WHOLE_CU: h->opt_vio_whole_cu = value != 0; break;
     case FL_OPT_VIO_ONE_LAUNCH: h->opt_vio_one_launch = value != 0; break;
     case FL_OPT_MAILBOX: h->opt_mailbox = value & 3; break;
+    case FL_OPT_SCAN_PULL: h->opt_scan_pull = value != 0; break;
     default: return fail_arg(h, "fl_set_option: unknown option");
     }
     return FL_OK;
@@ -588,9 +606,10 @@ static inline void *records_lio(fl_handle h) { return records_for(h, (size_t)lio
 static inline void *records_vio(fl_handle h) { return records_for(h, (size_t)vio_grid(h->m) * FL_SUMS18 * 8); }
 static inline void *records_ik(fl_handle h) { return records_for(h, (size_t)ik_grid(h, h->n) * FL_SUMS23I * 8); }
 
-int32_t fl_lio_set_points(fl_handle h, const float *body_xyz, int32_t n)
+// everything fl_lio_set_points does except moving the points (and clearing the selection flags, which the search + fit kernel
+// writes for every point)
+static int32_t stage_points_meta(fl_handle h, int32_t n)
 {
-    if (!h || !body_xyz || n <= 0) return fail_arg(h, "fl_lio_set_points: bad argument");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int32_t st = ensure_points(h, n);
     if (st) return st;
@@ -600,6 +619,23 @@ int32_t fl_lio_set_points(fl_handle h, const float *body_xyz, int32_t n)
     h->have_nbr = false;
     h->normvec_valid = false;
     h->gate_valid = false;
+    return FL_OK;
+}
+// the device address of [p, p + bytes) if it lies inside an allocation of fl_host_alloc, else nullptr
+static const void *pinned_device_ptr(fl_handle h, const void *p, size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(h->pinned_mu);
+    for (const auto &a : h->pinned)
+        if ((const char *)p >= (const char *)a.host && (const char *)p + bytes <= (const char *)a.host + a.bytes)
+            return (const char *)a.dev + ((const char *)p - (const char *)a.host);
+    return nullptr;
+}
+
+int32_t fl_lio_set_points(fl_handle h, const float *body_xyz, int32_t n)
+{
+    if (!h || !body_xyz || n <= 0) return fail_arg(h, "fl_lio_set_points: bad argument");
+    int32_t st = stage_points_meta(h, n);
+    if (st) return st;
     HIPCHK(h, hipMemcpyAsync(h->d_body, body_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_sel, 0, (size_t)n, h->stream));
     return FL_OK;

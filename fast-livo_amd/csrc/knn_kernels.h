@@ -269,8 +269,14 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
                                                                   float4 *__restrict__ plane, uint8_t *__restrict__ sel,
                                                                   float *__restrict__ nbr_out /* nullable n x 15 */,
                                                                   uint8_t *__restrict__ valid_out /* nullable */, int cond,
-                                                                  float4 *__restrict__ gate_out /* nullable */)
+                                                                  float4 *__restrict__ gate_out /* nullable */,
+                                                                  float *__restrict__ body_keep /* nullable */)
 {
+    // body_keep != nullptr (fl_lio_frame18_dev with the scan in page-locked host memory): `body` is that HOST buffer as the device
+    // addresses it -- every workgroup fetches its 64 points over the host link itself (768 B, each byte once, through LDS) and leaves
+    // them in body_keep (the device copy the second search and later calls read). The fetches of the workgroups that are served
+    // later overlap the searches of those served first: the scan's copy command (20 us at 50 k points) and the 8 us between a DMA
+    // copy and the first kernel behind it are gone from the frame.
     // cond & 4 (the FIRST search of an 18-state frame, fl_lio_frame18_dev): the launch has one workgroup more than the scan needs,
     // and that workgroup forms the gain-solve constants of the state block (what eskf18_prepare_kernel does) beside the search;
     // gate_out != nullptr (same launch): every point's gate threshold (what lio_gate_kernel does) is written with its plane. Two
@@ -290,7 +296,19 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
     const int q0 = blockIdx.x * FL_KNN_QPB;
     const int i = min(q0 + ql, n - 1);                // tail quads repeat the last query (results unused)
 
-    const float pb[3] = {body[i * 3], body[i * 3 + 1], body[i * 3 + 2]};
+    __shared__ float s_body[FL_KNN_QPB * 3];
+    if (body_keep) {
+        const int cnt = min(FL_KNN_QPB, n - q0) * 3;
+        if ((int)threadIdx.x < cnt) {
+            const float v = __builtin_nontemporal_load(body + (size_t)q0 * 3 + threadIdx.x);
+            s_body[threadIdx.x] = v;
+            body_keep[(size_t)q0 * 3 + threadIdx.x] = v;
+        }
+        __syncthreads();
+    }
+    const int il = i - q0;
+    const float pb[3] = {body_keep ? s_body[il * 3] : body[i * 3], body_keep ? s_body[il * 3 + 1] : body[i * 3 + 1],
+                         body_keep ? s_body[il * 3 + 2] : body[i * 3 + 2]};
     float pw[3];
     if constexpr (MODE == 18) {
         const FlDev18 *D18 = D;
@@ -450,8 +468,9 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
     plane[iq] = keep ? make_float4(pl[0], pl[1], pl[2], pl[3]) : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);   // see lio_fit_planes_kernel
     sel[iq] = (uint8_t)keep;
     if (gate_out) {
-        const float pb[3] = {body[(size_t)iq * 3], body[(size_t)iq * 3 + 1], body[(size_t)iq * 3 + 2]};
-        gate_out[iq] = make_float4(pb[0], pb[1], pb[2], fl_gate_threshold(pb));
+        const float pg[3] = {body_keep ? s_body[qf * 3] : body[(size_t)iq * 3], body_keep ? s_body[qf * 3 + 1] : body[(size_t)iq * 3 + 1],
+                             body_keep ? s_body[qf * 3 + 2] : body[(size_t)iq * 3 + 2]};
+        gate_out[iq] = make_float4(pg[0], pg[1], pg[2], fl_gate_threshold(pg));
     }
     if (nbr_out) {
 #pragma unroll

@@ -150,10 +150,13 @@ int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out);
  *                         budget; 0: always the co-resident form. Results are bit-identical either way.
  *   FL_OPT_VIO_ONE_LAUNCH 1 (default): fl_vio_compute_j runs its three pyramid levels in ONE multi-pass launch; 0: one launch per level.
  *                         Results are bit-identical either way.
- *   FL_OPT_MAILBOX        bit 1 (2, default): fl_lio_frame18_dev gets its results through a word the frame's last kernel writes into
- *                         page-locked host memory, polled by the calling thread, instead of a device-to-host
- *                         copy and a stream synchronisation (-4 us per frame); bit 0 (1): fl_vio_compute_j too (-5 us for the call,
- *                         but a large upload enqueued right behind it -- the next scan -- then starts ~6 us later: off by default).
+ *   FL_OPT_MAILBOX        bit 0 (1): fl_vio_compute_j, bit 1 (2): fl_lio_frame18_dev get their results through a word the frame's last
+ *                         kernel writes into page-locked host memory, polled by the calling thread, instead
+ *                         of a device-to-host copy and a stream synchronisation (-4 .. -5 us per call). Default 3. (A large copy
+ *                         command enqueued right behind a call that ended this way starts ~6 us later than behind a synchronised
+ *                         stream: callers that upload scans with copy commands may prefer 2.) Results are bit-identical either way.
+ *   FL_OPT_SCAN_PULL      1 (default): fl_lio_frame18_dev does not copy a scan that lies in memory of fl_host_alloc -- the frame's first
+ *                         search kernel fetches it over the host link (and leaves the device copy behind); 0: always a copy command.
  *                         Results are bit-identical either way. */
 #define FL_OPT_MULTIPASS 1
 #define FL_OPT_MAX_PRODUCERS 2
@@ -162,6 +165,7 @@ int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out);
 #define FL_OPT_VIO_WHOLE_CU 5
 #define FL_OPT_VIO_ONE_LAUNCH 6
 #define FL_OPT_MAILBOX 7
+#define FL_OPT_SCAN_PULL 8
 int32_t fl_set_option(fl_handle h, int32_t option, int32_t value);
 /* Counters of the resident-grid machinery of the multi-pass kernels. */
 typedef struct fl_diagnostics {

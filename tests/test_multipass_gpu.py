@@ -208,3 +208,42 @@ def test_result_mailbox_gives_the_same_frame(gpu_lib, scene):
     for rec in outs:                    # and frame after frame on one handle
         for r in rec[1:]:
             assert np.array_equal(r[0], rec[0][0]) and np.array_equal(r[5], rec[0][5])
+
+
+def test_scan_fetched_by_the_search_kernel_gives_the_same_frame(gpu_lib, scene):
+    """A scan in fl_host_alloc memory is fetched by the frame's first search kernel over the host link (FL_OPT_SCAN_PULL) instead of
+    a copy command: same frame as from pageable memory and as with the option off; the device copy it leaves behind serves a
+    following frame on the staged scan (body None); odd sizes (a last workgroup with fewer than 64 points)."""
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    for n in (20000, 12345, 65):
+        fr = synth.make_lio_frame(n, scene=scene)
+        ref = None
+        for pull, pinned in ((1, True), (0, True), (1, False)):
+            h = capi.Handle(capi.config_from_frames(fr, max_iterations=10))
+            h.set_option(capi.FL_OPT_SCAN_PULL, pull)
+            h.map_set_points(scene.map_xyz, 0.5)
+            scan = fr.body_xyz
+            if pinned:
+                scan = h.host_alloc(fr.body_xyz.shape, np.float32)
+                scan[:] = fr.body_xyz
+            out = []
+            for rep in range(2):
+                x = capi.state18_from_frame(fr)
+                info = h.lio_frame18_dev(x, scan)
+                out.append((x.vec().copy(), x.cov_np().copy(), info.status, info.iterations, info.effct_feat_num))
+            x = capi.state18_from_frame(fr)
+            info = h.lio_frame18_dev(x, None)                  # the scan as the last frame left it on the device
+            out.append((x.vec().copy(), x.cov_np().copy(), info.status, info.iterations, info.effct_feat_num))
+            mask, normvec = h.lio_get_selection(n)
+            out.append((mask.copy(), normvec.view(np.uint32).copy()))
+            if pinned:
+                h.host_free(scan)
+            h.close()
+            if ref is None:
+                ref = out
+            else:
+                for a, b in zip(ref[:3], out[:3]):
+                    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:], (n, pull, pinned)
+                assert np.array_equal(ref[3][0], out[3][0]) and np.array_equal(ref[3][1], out[3][1])
+            assert out[0][2] == 0 and np.array_equal(out[0][0], out[2][0])
