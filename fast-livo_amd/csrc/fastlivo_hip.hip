@@ -58,7 +58,7 @@ struct fl_context {
     int mp_last_grid = 0;
     int mp_fallbacks = 0, mp_resumes = 0;   // diagnostics: launches sent down the per-pass path by the admission check / frames resumed
     // fl_set_option (include/fastlivo_hip.h)
-    int opt_multipass = 1, opt_max_producers = 0, opt_ik_producers = 0, opt_vio_whole_cu = 1, opt_vio_one_launch = 1;
+    int opt_multipass = 1, opt_max_producers = 0, opt_ik_producers = 0, opt_vio_whole_cu = 1;
     bool normvec_valid = false;   // a pass with FL_ITER_KEEP_NORMVEC has run on the staged scan
     // 18-state block, reduction scratch
     FlDev18 *d_dev = nullptr;
@@ -488,7 +488,6 @@ int32_t fl_set_option(fl_handle h, int32_t option, int32_t value)
         else { h->mp_capacity = h->mp_capacity_q; h->mp_capacity_ik = h->mp_capacity_ik_q; }
         break;
     case FL_OPT_VIO_WHOLE_CU: h->opt_vio_whole_cu = value != 0; break;
-    case FL_OPT_VIO_ONE_LAUNCH: h->opt_vio_one_launch = value != 0; break;
     case FL_OPT_MAILBOX: h->opt_mailbox = value & 3; break;
     case FL_OPT_SCAN_PULL: h->opt_scan_pull = value != 0; break;
     default: return fail_arg(h, "fl_set_option: unknown option");

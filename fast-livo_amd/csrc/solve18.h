@@ -41,7 +41,6 @@ struct FlSolveLds {
     int sticky;         // status bits accumulated since fl_*_begin (mirror of D->status)
     // VIO exact accept test (see eskf18_solve_block): mirrors of the FlDev18 fields, kept across the passes of a multi-pass launch
     int need_exact, acc_buf, last_exact_valid, exact_timeout;
-    int buf_base;                      // parity offset of the per-patch error halves (vio_multipass_kernel with several levels; else 0)
     unsigned acc_epoch;
     float last_exact, exact_cur;
     // loop counters of the judgement, staged with the solve inputs so that the judging lane does not wait for global loads
@@ -258,7 +257,7 @@ __device__ __forceinline__ void eskf18_prefetch_commit(double v, FlSolveLds &L)
     else if (tid == 200) L.acc_epoch = (unsigned)v;
     else if (tid == 201) L.last_exact_valid = (int)v;
     else if (tid == 202) L.last_exact = (float)v;
-    else if (tid == 203) { L.jpass = 0; L.jflag = 0; L.buf_base = 0; }
+    else if (tid == 203) { L.jpass = 0; L.jflag = 0; }
     __syncthreads();
     eskf18_form_vec(L);
     __syncthreads();
@@ -377,7 +376,7 @@ __device__ __forceinline__ void vio_exact_decide(const FlVioExact ex, FlSolveLds
     FlSolveLds &L = *Lp;
     const int tid = threadIdx.x;
     __syncthreads();
-    const int cur_buf = (L.iters_run + L.buf_base) & 1;
+    const int cur_buf = L.iters_run & 1;
     bool audited = false;
     const unsigned long long *audit = ex.words + 2 * (size_t)ex.cap;
     if (ex.world <= 1) {     // single rank: the auditor workgroup has been adding this pass's chain up since its words arrived
@@ -572,7 +571,7 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
             L.accept = accept;
             if (accept) {
                 L.last_error = error;
-                L.acc_buf = (L.iters_run + L.buf_base) & 1; L.acc_epoch = ex.epoch;
+                L.acc_buf = L.iters_run & 1; L.acc_epoch = ex.epoch;
                 L.last_exact_valid = vio_exact; L.last_exact = error;
             }
         }

@@ -761,17 +761,13 @@ struct FlVioLevelInfo {
 // Up to `count` passes of one pyramid level in ONE launch (see lio18_multipass_kernel): the solver broadcasts the derived camera
 // pose (Rcw, Pcw: what the producers consume) and the stop bit; a rejected solve (error went up, lidar_selection.cpp:888-892)
 // reverts and stops like the reference. Bit-identical to `count` launches of vio_pass_kernel<0>.
-// nlev > 1 (ComputeJ, begin_residual >= 0): the levels level, level-1, ... one behind the other in the SAME launch, each with the
-// level prologue / epilogue -- the pose the solver publishes with a level's stop bit is the pose of the next level's first pass, so a
-// level change costs one hand-off instead of a kernel boundary and a cold first pass (frame: -10 us). The per-patch error halves
-// alternate over the launch's passes (not per level), so an auditor that is a pass behind never meets a half being rewritten.
 // WAVES = the register budget (launch bound): 2 = two workgroups per CU (256 VGPRs), the form every concurrent or sharded use needs;
 // 1 = a CU's registers to one workgroup (256 VGPRs + AGPRs, no scratch): 8.5 instead of 9.2 us per pass, taken when the launch has the
 // device to itself (api_vio.inc vio_mp_variant). Same code, same arithmetic, same bits.
 template <int WAVES>
 __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const uint8_t *__restrict__ img, const float *__restrict__ ref,
                                                                  const double *__restrict__ pos, const int32_t *__restrict__ slevel,
-                                                                 float *__restrict__ errors, int m, int level, int nlev,
+                                                                 float *__restrict__ errors, int m, int level,
                                                                  const FlVioConst *__restrict__ VC, FlDev18 *__restrict__ D,
                                                                  void *__restrict__ records, unsigned *__restrict__ epoch_ptr,
                                                                  unsigned long long *__restrict__ bcast, int count, int flags,
@@ -779,15 +775,14 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
                                                                  unsigned *__restrict__ done_word, unsigned done_seq)
 {
     // begin_residual >= 0: the launch starts a pyramid level, i.e. it first does what vio_level_begin_kernel does (UpdateState
-    // prologue, lidar_selection.cpp:747,756); level_info != nullptr (the entry of `level`; finer levels at lower addresses): it ends
-    // with what vio_level_end_kernel does. ComputeJ then needs one launch instead of nine.
+    // prologue, lidar_selection.cpp:747,756); level_info != nullptr: it ends with what vio_level_end_kernel does. ComputeJ then
+    // needs one launch per level instead of three.
     constexpr int NT = FL_VIO_NT;
     constexpr int WPB = NT / 64;
     const int nprod = gridDim.x - 2;              // then the solver and the auditor (FL_VIO_SOLVER_BLOCK / FL_VIO_AUDITOR_BLOCK)
     const int solver_block = FL_VIO_SOLVER_BLOCK(nprod), auditor_block = FL_VIO_AUDITOR_BLOCK(nprod);
     const bool force = (flags & FL_ITER_FORCE) != 0;
     const bool begin = begin_residual >= 0.f;
-    const int last_level = level - (nlev > 1 ? nlev - 1 : 0);
     if (D->status & FL_NUM_TIMEOUT) {             // an earlier pass of the chain was abandoned: nothing runs until the host has resumed
         if (blockIdx.x == solver_block && threadIdx.x == 0) D->resume_count += count;  // (the solver workgroup is the only writer)
         fl_mp_done(done_word, done_seq, blockIdx.x == solver_block);
@@ -805,21 +800,16 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
 #ifndef FL_AB_NO_AUDITOR
         __shared__ double s_apose[12];
         __shared__ int s_actrl;
-        int lv = level, ps = 0;
-        for (unsigned epoch = epoch0;; epoch++) {
+        for (int ps = 0; ps < count; ps++) {
+            const unsigned epoch = epoch0 + (unsigned)ps;
             FL_AUDIT_STAMP(16 * (epoch & 15) + 0, wall_clock64());
-            if (epoch != epoch0) {
+            if (ps > 0) {
                 bcast_wait(bcast, epoch, s_apose, &s_actrl, FL_GATHER_SPIN_LIMIT);
                 __syncthreads();
-                const int ctrl = s_actrl;
-                if (ctrl & 4) break;
-                if ((ctrl & 3) || ps + 1 >= count) {         // the level is over: pass `epoch` is the first of the next one, if any
-                    if (lv == last_level) break;
-                    lv--; ps = 0;
-                } else ps++;
+                if (s_actrl & 7) break;
             }
             FL_AUDIT_STAMP(16 * (epoch & 15) + 1, wall_clock64());
-            const int to = vio_audit_pass(err_base, err_cap, (pass0 + (int)(epoch - epoch0)) & 1, m, epoch);
+            const int to = vio_audit_pass(err_base, err_cap, (pass0 + ps) & 1, m, epoch);
             FL_AUDIT_STAMP(16 * (epoch & 15) + 2, wall_clock64());
             FL_AUDIT_STAMP(16 * (epoch & 15) + 3, to);
         }
@@ -831,72 +821,63 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
         __shared__ double s_sums[FL_SUMS18];
         __shared__ FlSolveLds s_solve;
         __shared__ __attribute__((aligned(16))) float s_ex[FL_EXACT_LDS];
+        eskf18_prefetch(D, s_solve);
+        if (begin) {
+            __syncthreads();
+            if (threadIdx.x < 24) D->xold[threadIdx.x] = s_solve.x[threadIdx.x];      // old_state = *state
+            if (threadIdx.x == 32) {
+                s_solve.last_error = begin_residual; s_solve.iters_run = 0; s_solve.accepted = 0; s_solve.fragile = 0; s_solve.sticky = 0;
+                s_solve.last_exact = begin_residual; s_solve.last_exact_valid = 1; s_solve.acc_buf = 0; s_solve.acc_epoch = 0u;
+                D->last_exact = begin_residual; D->last_exact_valid = 1; D->err_acc_buf = 0; D->err_acc_epoch = 0u;
+                D->last_error = begin_residual; D->level = level; D->stop = 0; D->converged = 0; D->iters_run = 0; D->accepted = 0;
+                D->status = 0;
+            }
+            __syncthreads();
+        }
         __shared__ double s_xchg[FL_MAX_PEERS * 32];
         __shared__ unsigned long long *s_peers[FL_MAX_PEERS];
-        eskf18_prefetch(D, s_solve);
         const FlPeerView PV = fl_peer_view_lds(D, s_peers);
-        unsigned e0 = epoch0, xe0 = PV.world > 1 ? *D->xchg_epoch : 0u;
-        bool abandoned = false;
-        for (int lv = level; lv >= last_level; lv--) {
-            if (begin) {
-                __syncthreads();
-                if (threadIdx.x < 24) D->xold[threadIdx.x] = s_solve.x[threadIdx.x];      // old_state = *state
-                if (threadIdx.x == 32) {
-                    s_solve.last_error = begin_residual; s_solve.iters_run = 0; s_solve.accepted = 0; s_solve.fragile = 0; s_solve.sticky = 0;
-                    s_solve.last_exact = begin_residual; s_solve.last_exact_valid = 1; s_solve.acc_buf = 0; s_solve.acc_epoch = 0u;
-                    s_solve.buf_base = (int)((e0 - epoch0) & 1u);
-                    D->last_exact = begin_residual; D->last_exact_valid = 1; D->err_acc_buf = 0; D->err_acc_epoch = 0u;
-                    D->last_error = begin_residual; D->level = lv; D->stop = 0; D->converged = 0; D->iters_run = 0; D->accepted = 0;
-                    D->status = 0;
-                }
-                __syncthreads();
+        const unsigned xe0 = PV.world > 1 ? *D->xchg_epoch : 0u;
+        int done = 0;
+        for (int p = 0; p < count; p++) {
+            const unsigned epoch = epoch0 + (unsigned)p;
+            FlSolveRegs G;
+            eskf18_load_regs(s_solve, G, VC);                    // solve operands into wave 0's registers while the producers work
+            FL_INSTR(if (p == 5) fl_stamp(flags, 16);)
+            int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
+            if (PV.world > 1) gst |= peer_allreduce32(PV, xe0 + (unsigned)p, s_sums, s_xchg);      // sharded form: totals over the ranks
+            FL_AUDIT_STAMP(16 * (epoch & 15) + 8, wall_clock64()); FL_AUDIT_STAMP(16 * (epoch & 15) + 11, epoch); FL_AUDIT_STAMP(16 * (epoch & 15) + 12, level);
+            FL_INSTR(if (p == 5) fl_stamp(flags, 17);)
+            FlVioExact ex;
+            ex.words = err_base; ex.m = m; ex.cap = err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !force;
+            ex.own = PV.own; ex.peer = PV.peer; ex.rank = PV.rank; ex.world = PV.world; ex.xe = xe0 + (unsigned)p;
+            // wave 0 solves, derives the camera pose of the new state and publishes it (+ the control word) for the producers
+            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, gst, bcast, epoch + 1u, ex, VC, (p == 5) ? (flags & FL_ITER_STAMP) : 0);
+            FL_INSTR(if (p == 5) fl_stamp(flags, 35);)
+            __syncthreads();
+            FL_AUDIT_STAMP(16 * (epoch & 15) + 9, wall_clock64());
+            FL_AUDIT_STAMP(16 * (epoch & 15) + 10, s_solve.fragile + 2 * s_solve.audited + 4 * s_solve.exact_timeout + 8 * s_solve.accept);
+            FL_INSTR(if (p == 5) fl_stamp(flags, 18);)
+            done = p + 1;
+            const int ctrl = s_solve.ctrl;
+            if (ctrl & 4) {                                      // abandoned (hand-off time-out): this pass and the rest are still to do
+                if (threadIdx.x == 0) D->resume_count = count - p;
+                break;
             }
-            int done = 0;
-            for (int p = 0; p < count; p++) {
-                const unsigned epoch = e0 + (unsigned)p;
-                FlSolveRegs G;
-                eskf18_load_regs(s_solve, G, VC);                    // solve operands into wave 0's registers while the producers work
-                FL_INSTR(if (p == 5) fl_stamp(flags, 16);)
-                int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
-                if (PV.world > 1) gst |= peer_allreduce32(PV, xe0 + (unsigned)p, s_sums, s_xchg);      // sharded form: totals over the ranks
-                FL_AUDIT_STAMP(16 * (epoch & 15) + 8, wall_clock64()); FL_AUDIT_STAMP(16 * (epoch & 15) + 11, epoch); FL_AUDIT_STAMP(16 * (epoch & 15) + 12, lv);
-                FL_INSTR(if (p == 5) fl_stamp(flags, 17);)
-                FlVioExact ex;
-                ex.words = err_base; ex.m = m; ex.cap = err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !force;
-                ex.own = PV.own; ex.peer = PV.peer; ex.rank = PV.rank; ex.world = PV.world; ex.xe = xe0 + (unsigned)p;
-                // wave 0 solves, derives the camera pose of the new state and publishes it (+ the control word) for the producers
-                eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, gst, bcast, epoch + 1u, ex, VC, (p == 5) ? (flags & FL_ITER_STAMP) : 0);
-                FL_INSTR(if (p == 5) fl_stamp(flags, 35);)
-                __syncthreads();
-                FL_AUDIT_STAMP(16 * (epoch & 15) + 9, wall_clock64());
-                FL_AUDIT_STAMP(16 * (epoch & 15) + 10, s_solve.fragile + 2 * s_solve.audited + 4 * s_solve.exact_timeout + 8 * s_solve.accept);
-                FL_INSTR(if (p == 5) fl_stamp(flags, 18);)
-                done = p + 1;
-                const int ctrl = s_solve.ctrl;
-                if (ctrl & 4) {                                      // abandoned (hand-off time-out): this pass and the rest are still to do
-                    if (threadIdx.x == 0) D->resume_count = count - p;
-                    abandoned = true;
-                    break;
-                }
-                if (!force && (ctrl & 3)) break;
-                if (p + 1 < count) eskf18_restage(s_solve);
-            }
-            e0 += (unsigned)done; xe0 += (unsigned)done;
-            if (level_info) {
-                FlVioLevelInfo *li = level_info - (level - lv);
-                __syncthreads();
-                if (threadIdx.x < 18) li->solution[threadIdx.x] = D->solution[threadIdx.x];
-                if (threadIdx.x == 32) {
-                    li->error = D->last_error; li->iterations = D->iters_run; li->n_meas = D->neff;
-                    li->accepted = D->accepted; li->status = D->status; li->converged = D->converged;
-                }
-            }
-            if (abandoned) break;
-            if (lv > last_level) eskf18_restage(s_solve);         // the state the level ended with is the next level's start
+            if (!force && (ctrl & 3)) break;
+            if (p + 1 < count) eskf18_restage(s_solve);
         }
         if (threadIdx.x == 0) {
-            *epoch_ptr = e0;
-            if (PV.world > 1) *D->xchg_epoch = xe0;
+            *epoch_ptr = epoch0 + (unsigned)done;
+            if (PV.world > 1) *D->xchg_epoch = xe0 + (unsigned)done;
+        }
+        if (level_info) {
+            __syncthreads();
+            if (threadIdx.x < 18) level_info->solution[threadIdx.x] = D->solution[threadIdx.x];
+            if (threadIdx.x == 32) {
+                level_info->error = D->last_error; level_info->iterations = D->iters_run; level_info->n_meas = D->neff;
+                level_info->accepted = D->accepted; level_info->status = D->status; level_info->converged = D->converged;
+            }
         }
         fl_mp_done(done_word, done_seq, true);
         return;
@@ -916,32 +897,26 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
     for (int i = 0; i < 3; i++) Pcw[i] = D->Pcw[i];
     FlVioLaneRole role = fl_vio_lane_role((int)(threadIdx.x & 15), VC);
     fl_vio_lane_role_pose(role, (int)(threadIdx.x & 15), D->Rcw);
-    int lv = level, ps = 0;
-    for (unsigned epoch = epoch0;; epoch++) {
-        const FlVioFirst pf = vio_prefetch_first(ref, pos, slevel, m, lv, nprod);
-        if (epoch != epoch0) {
-            FL_INSTR(if (blockIdx.x == 0 && (ps == 4 || ps == 5)) fl_stamp(flags, 20 + 4 * (ps - 4));)
+    for (int ps = 0; ps < count; ps++) {
+        const unsigned epoch = epoch0 + (unsigned)ps;
+        const FlVioFirst pf = vio_prefetch_first(ref, pos, slevel, m, level, nprod);
+        if (ps > 0) {
+            FL_INSTR(if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 20 + 4 * (ps - 5));)
             bcast_wait(bcast, epoch, s_pose, &s_ctrl, spin_limit);
             __syncthreads();
-            FL_INSTR(if (blockIdx.x == 0 && (ps == 4 || ps == 5)) fl_stamp(flags, 21 + 4 * (ps - 4));)
-            const int ctrl = s_ctrl;
-            if (ctrl & 4) break;
-            if ((!force && (ctrl & 3)) || ps + 1 >= count) {   // the level is over: this pose starts the next one, if any
-                if (lv == last_level) break;
-                lv--; ps = 0;
-            } else ps++;
+            FL_INSTR(if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 21 + 4 * (ps - 5));)
+            if (!force && (s_ctrl & 3)) break;
+            if (s_ctrl & 4) break;
 #pragma unroll
             for (int i = 0; i < 9; i++) Rcw[i] = s_pose[i];
 #pragma unroll
             for (int i = 0; i < 3; i++) Pcw[i] = s_pose[9 + i];
             fl_vio_lane_role_pose(role, (int)(threadIdx.x & 15), s_pose);
         }
-        const FlVioFirst pf2 = (epoch != epoch0 && ps == 0) ? vio_prefetch_first(ref, pos, slevel, m, lv, nprod) : pf;   // (a new level)
-        vio_produce<1>(img, ref, pos, slevel, errors, m, lv, lv, vc, Rcw, Pcw, pf2, nprod, s_red, epoch, records,
-                    (ps == 5) ? flags : (flags & ~FL_ITER_STAMP), err_base ? err_base + (size_t)((pass0 + (int)(epoch - epoch0)) & 1) * err_cap : nullptr, s_res, s_pidx, role);
+        vio_produce<1>(img, ref, pos, slevel, errors, m, level, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records,
+                    (ps == 5) ? flags : (flags & ~FL_ITER_STAMP), err_base ? err_base + (size_t)((pass0 + ps) & 1) * err_cap : nullptr, s_res, s_pidx, role);
         FL_INSTR(if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 23 + 4 * (ps - 5));)
         __syncthreads();
-        if (nlev <= 1 && ps + 1 >= count) break;               // one level: nobody needs the pose the last pass ends with
     }
 }
 

@@ -148,8 +148,6 @@ int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out);
  *                         lowering it sends concurrent launches down the per-pass path earlier.
  *   FL_OPT_VIO_WHOLE_CU   1 (default): a VIO multi-pass launch that has the device to itself uses the one-workgroup-per-CU register
  *                         budget; 0: always the co-resident form. Results are bit-identical either way.
- *   FL_OPT_VIO_ONE_LAUNCH 1 (default): fl_vio_compute_j runs its three pyramid levels in ONE multi-pass launch; 0: one launch per level.
- *                         Results are bit-identical either way.
  *   FL_OPT_MAILBOX        bit 0 (1): fl_vio_compute_j, bit 1 (2): fl_lio_frame18_dev get their results through a word the frame's last
  *                         kernel writes into page-locked host memory, polled by the calling thread, instead
  *                         of a device-to-host copy and a stream synchronisation (-4 .. -5 us per call). Default 3. (A large copy
@@ -163,9 +161,8 @@ int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out);
 #define FL_OPT_IK_PRODUCERS 3
 #define FL_OPT_MP_CAPACITY 4
 #define FL_OPT_VIO_WHOLE_CU 5
-#define FL_OPT_VIO_ONE_LAUNCH 6
-#define FL_OPT_MAILBOX 7
-#define FL_OPT_SCAN_PULL 8
+#define FL_OPT_MAILBOX 6
+#define FL_OPT_SCAN_PULL 7
 int32_t fl_set_option(fl_handle h, int32_t option, int32_t value);
 /* Counters of the resident-grid machinery of the multi-pass kernels. */
 typedef struct fl_diagnostics {

@@ -154,16 +154,15 @@ def test_non_finite_state_is_reported_not_hung(gpu_lib, scene):
 
 def test_vio_kernel_variants_give_the_same_bits(gpu_lib):
     """The VIO multi-pass kernel exists in two register budgets (a CU per workgroup / two workgroups per CU, api_vio.inc
-    vio_mp_variant) besides the one-launch-per-pass form, and ComputeJ runs its three levels in one launch or one launch per level:
-    the result must not depend on which form a launch gets (the concurrent and sharded uses get the co-resident one). Fused multiply-adds are written out (fma()) wherever the two instantiations could contract
+    vio_mp_variant) besides the one-launch-per-pass form: ComputeJ must not depend on which one a launch gets (the concurrent and
+    sharded uses get the co-resident one). Fused multiply-adds are written out (fma()) wherever the two instantiations could contract
     differently."""
     capi = gpu_lib
     from fast_livo_amd import synth
     lio = synth.make_lio_frame(2000)
     vf = synth.make_vio_frame(1800, lio)
     outs = []
-    for opts in ({}, {capi.FL_OPT_VIO_WHOLE_CU: 0}, {capi.FL_OPT_VIO_ONE_LAUNCH: 0}, {capi.FL_OPT_VIO_ONE_LAUNCH: 0, capi.FL_OPT_VIO_WHOLE_CU: 0},
-                 {capi.FL_OPT_MULTIPASS: 0}):
+    for opts in ({}, {capi.FL_OPT_VIO_WHOLE_CU: 0}, {capi.FL_OPT_MULTIPASS: 0}):
         h = capi.Handle(capi.config_from_frames(lio, vf, max_iterations=10))
         for k, v in opts.items():
             h.set_option(k, v)
