@@ -13,6 +13,7 @@ stats() {   # name, bench args...
   [ -n "$f" ] && cp $f $OUT/${TAG}_${name}_kernel_stats.csv
 }
 stats bench --no-cpu-baseline --no-extras
+stats bench_steps20 --steps 20 --warmup 5 --no-cpu-baseline --no-extras      # the driver's round-end command line
 stats at_scale_8M --only at_scale --at-scale-points 8000000
 stats at_scale_32M --only at_scale --at-scale-points 32000000
 stats vio_sweep_2k --only vio_sweep --vio-sweep-patches 2000
@@ -21,7 +22,22 @@ stats vio_sweep_1M --only vio_sweep --vio-sweep-patches 1000000
 stats mode23 --only mode23
 stats frame --only frame
 stats restage --only restage
+stats config4 --only config4
+stats config5 --only config5
 cd $R
 bash tools/pmc_traffic.sh gpurun_out/${TAG}_pmc_hbm_traffic.json > /dev/null 2>&1
 python bench.py > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err
+python bench.py --steps 20 --warmup 5 --no-extras > gpurun_out/${TAG}_bench_n1_steps20.json 2> /dev/null
+# the micro-benchmarks the design decisions of the round quote (DESIGN.md / NOTES.md)
+{
+  echo "== tools/hop_bench.bin"; timeout 120 tools/hop_bench.bin 2>&1 | tail -30
+  echo "== tools/clock_bench.bin"; timeout 120 tools/clock_bench.bin 2>&1 | tail -20
+  echo "== tools/chain_profile.py"; timeout 120 python tools/chain_profile.py 2>&1 | tail -14
+  echo "== tools/mailbox_ab.py"; timeout 120 python tools/mailbox_ab.py 2>&1 | tail -8
+  echo "== tools/vio_pass_bench.py"; timeout 120 python tools/vio_pass_bench.py 2>&1 | tail -1
+  echo "== tools/multipass_bench.py"; timeout 120 python tools/multipass_bench.py 2>&1 | tail -1
+  echo "== tools/ikfom_pass_bench.py"; timeout 120 python tools/ikfom_pass_bench.py 2>&1 | tail -1
+  echo "== tools/computej_breakdown.py"; timeout 120 python tools/computej_breakdown.py 2>&1 | tail -2
+  echo "== tools/lioframe_breakdown.py"; timeout 120 python tools/lioframe_breakdown.py 2>&1 | tail -2
+} > gpurun_out/${TAG}_microbench.txt 2>&1
 ls -la gpurun_out/${TAG}_* | head -40
