@@ -225,14 +225,17 @@ def section_mode23(capi, synth, scene, fr, cfg, nbr, valid):
     F = capi.FL_ITER_FORCE
     # (a)
     tf, passes = [], 0
+    scan_a = h.host_alloc(fr.body_xyz.shape, np.float32)  # page-locked (fetched by the first search kernel), in the order
+    scan_a[...] = synth.in_voxel_order(fr, 0.15).body_xyz # pcl::VoxelGrid emits feats_down_body in (SCAN_ORDER_NOTE)
     for rep in range(25):
         x23 = capi.state23_from_frame(fr)
         P = fr.cov23.copy()
         t0 = time.perf_counter()
-        info = h.ikfom_update_iterated_dev(x23, P, fr.body_xyz, 0.001)
+        info = h.ikfom_update_iterated_dev(x23, P, scan_a, 0.001)
         if rep >= 5:
             tf.append(time.perf_counter() - t0)
         passes = int(info.iterations)
+    h.host_free(scan_a)
     # (b)
     x23 = capi.state23_from_frame(fr)
     h.lio_set_points(fr.body_xyz)
@@ -275,15 +278,21 @@ def section_mode23(capi, synth, scene, fr, cfg, nbr, valid):
             "status": int(info.status), "effct_feat_num": int(info.effct_feat_num)}
 
 
-def section_frame(capi, synth, scene, fr, vf, cfg):
+SCAN_ORDER_NOTE = ("scan points in the order pcl::VoxelGrid emits them (ascending voxel index, leaf = filter_size_surf of the camera/LiDAR "
+                   "YAML: what feats_down_body is in the reference, laserMapping.cpp:1398-1399); *_unordered_scan: the same points in "
+                   "the random order the generator samples them in (costs the k-NN search its cache locality)")
+
+
+def section_frame(capi, synth, scene, fr_in, vf, cfg):
     """The whole frame as a running system does it, everything on the device: fl_lio_frame18_dev = scan H2D + [k-NN search + plane fit when
     asked, passes until converged] + covariance update + read-back, then fl_vio_compute_j = 3 pyramid levels until the reference's stop
     rule + covariance update + read-back. Host wall time (median), nothing excluded."""
+    fr = synth.in_voxel_order(fr_in, 0.15)            # avia.yaml: filter_size_surf 0.15
     h = capi.Handle(cfg)
     h.map_set_points(scene.map_xyz, 0.5)
     h.vio_set_frame(vf.img)
     h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
-    tl, tv, tlp, its, acc = [], [], [], 0, 0
+    tl, tv, tlp, tlu, its, acc = [], [], [], [], 0, 0
     scan_pinned = h.host_alloc(fr.body_xyz.shape, np.float32)     # fl_host_alloc: the caller's PointCloud -> float xyz loop writes here
     scan_pinned[...] = fr.body_xyz
     for rep in range(40):
@@ -304,11 +313,20 @@ def section_frame(capi, synth, scene, fr, vf, cfg):
         h.lio_frame18_dev(x, fr.body_xyz)
         if rep >= 5:
             tlp.append(time.perf_counter() - t0)
+    scan_pinned[...] = fr_in.body_xyz                 # the same points as the generator emits them (random order)
+    for rep in range(25):
+        x = capi.state18_from_frame(fr)
+        t0 = time.perf_counter()
+        h.lio_frame18_dev(x, scan_pinned)
+        if rep >= 5:
+            tlu.append(time.perf_counter() - t0)
     h.host_free(scan_pinned)
     h.close()
     lio_ms, vio_ms = float(np.median(tl)) * 1e3, float(np.median(tv)) * 1e3
     return {"lio_frame_ms": lio_ms, "vio_computej_ms": vio_ms, "frame_ms": lio_ms + vio_ms, "lio_passes": its, "vio_passes_3_levels": acc,
             "lio_frame_ms_pageable_scan": float(np.median(tlp)) * 1e3,
+            "lio_frame_ms_unordered_scan": float(np.median(tlu)) * 1e3, "frame_ms_unordered_scan": float(np.median(tlu)) * 1e3 + vio_ms,
+            "scan_order": SCAN_ORDER_NOTE,
             "frame_iterations_per_s": (its + acc) / ((lio_ms + vio_ms) * 1e-3),
             "what": f"fl_lio_frame18_dev ({fr.n} pts in a page-locked buffer of fl_host_alloc, {len(scene.map_xyz)} map points: H2D, searches + plane fits, passes, covariance) + "
                     f"fl_vio_compute_j ({vf.m} patches, levels 2-1-0); host wall time incl. every synchronisation"}
@@ -386,20 +404,22 @@ def section_config4(capi, synth, scene):
     h = capi.Handle(cfg)
     h.map_set_points(scene.map_xyz, 0.5)
     scan = h.host_alloc(fr.body_xyz.shape, np.float32)
-    scan[...] = fr.body_xyz
-    ts, its = [], 0
-    for rep in range(25):
-        x = capi.state18_from_frame(fr)
-        t0 = time.perf_counter()
-        info = h.lio_frame18_dev(x, scan)
-        if rep >= 5:
-            ts.append(time.perf_counter() - t0)
-        its = int(info.iterations)
+    ts, tsu, its = [], [], 0
+    for ordered, acc_t in ((True, ts), (False, tsu)):
+        scan[...] = synth.in_voxel_order(fr, 0.15).body_xyz if ordered else fr.body_xyz
+        for rep in range(25):
+            x = capi.state18_from_frame(fr)
+            t0 = time.perf_counter()
+            info = h.lio_frame18_dev(x, scan)
+            if rep >= 5:
+                acc_t.append(time.perf_counter() - t0)
+            its = int(info.iterations)
     h.host_free(scan); h.close()
     return {"workload": f"BASELINE config 4 at N = 1: one frame of {fr.n} points + {vf.m} patches on ONE GPU (the 8-GPU form shards it 8 x 25 000)",
             "lio_pass_us": lio_us, "vio_pass_us": vio_us, "iterations_per_s": 1e6 / (lio_us + vio_us),
-            "lio_frame_ms": float(np.median(ts)) * 1e3, "lio_frame_passes": its,
-            "what": "forced passes: multi-pass launches, HIP events; lio_frame_ms: fl_lio_frame18_dev (H2D, searches, plane fits, passes, covariance), host wall time"}
+            "lio_frame_ms": float(np.median(ts)) * 1e3, "lio_frame_passes": its, "lio_frame_ms_unordered_scan": float(np.median(tsu)) * 1e3,
+            "scan_order": SCAN_ORDER_NOTE,
+            "what": "forced passes: multi-pass launches, HIP events; lio_frame_ms: fl_lio_frame18_dev (scan fetch, searches, plane fits, passes, covariance), host wall time"}
 
 
 def section_config5(capi, synth, scene):
@@ -423,8 +443,8 @@ def section_config5(capi, synth, scene):
     h.map_set_points(scene.map_xyz, 0.5)
     h.vio_set_frame(vf.img); h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
     scan = h.host_alloc(fr.body_xyz.shape, np.float32)
-    scan[...] = fr.body_xyz
-    tl, tv, its, acc = [], [], 0, 0
+    scan[...] = synth.in_voxel_order(fr, 0.5).body_xyz            # NTU_VIRAL.yaml: filter_size_surf 0.5
+    tl, tv, tlu, its, acc = [], [], [], 0, 0
     for rep in range(25):
         x = capi.state18_from_frame(fr)
         t0 = time.perf_counter()
@@ -436,12 +456,20 @@ def section_config5(capi, synth, scene):
         if rep >= 5:
             tl.append(t1 - t0); tv.append(t2 - t1)
         its, acc = int(info.iterations), int(sum(i.iterations for i in infos))
+    scan[...] = fr.body_xyz
+    for rep in range(15):
+        x = capi.state18_from_frame(fr)
+        t0 = time.perf_counter()
+        h.lio_frame18_dev(x, scan)
+        if rep >= 5:
+            tlu.append(time.perf_counter() - t0)
     h.host_free(scan); h.close()
     lio_ms, vio_ms = float(np.median(tl)) * 1e3, float(np.median(tv)) * 1e3
     return {"workload": f"BASELINE config 5 at N = 1: NTU_VIRAL camera and extrinsics, {fr.n} points + {vf.m} patches, max_iteration 10, full LIVO frame on ONE GPU",
             "lio_pass_us": lio_us, "vio_pass_us": vio_us, "iterations_per_s": 1e6 / (lio_us + vio_us),
             "lio_frame_ms": lio_ms, "vio_computej_ms": vio_ms, "frame_ms": lio_ms + vio_ms, "lio_passes": its, "vio_passes_3_levels": acc,
             "frame_iterations_per_s": (its + acc) / ((lio_ms + vio_ms) * 1e-3),
+            "lio_frame_ms_unordered_scan": float(np.median(tlu)) * 1e3, "scan_order": SCAN_ORDER_NOTE,
             "what": "forced passes: multi-pass launches, HIP events; frame: fl_lio_frame18_dev + fl_vio_compute_j, host wall time incl. every synchronisation"}
 
 
@@ -454,6 +482,7 @@ def section_cpu_frame(synth, scene, fr, vf, budget_s):
     from oracle import oracle as orc, ikdref
     if not ikdref.available():
         return {"skipped": "oracle/_ref/libikdtree_ref.so not present"}
+    fr = synth.in_voxel_order(fr, 0.15)               # the same scan order as `frame` (SCAN_ORDER_NOTE)
     tree = ikdref.IkdTree(0.5)
     t0 = time.perf_counter()
     tree.build(scene.map_xyz)

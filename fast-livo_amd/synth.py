@@ -160,6 +160,22 @@ class LioFrame:
         return (pi @ R.T + p).astype(np.float32)
 
 
+def voxel_order(body_xyz, leaf):
+    """Permutation that puts scan points into the order pcl::VoxelGrid emits its centroids in: ascending voxel index
+    idx = i + j * dx + k * dx * dy over the leaf grid (PCL voxel_grid.hpp, applyFilter: the index vector is sorted by idx). That is what
+    `feats_down_body` looks like when the reference's ESKF loop gets it (laserMapping.cpp:1398-1399, leaf = filter_size_surf) -- a
+    synthetic scan sampled plane by plane in random order is not."""
+    ijk = np.floor(np.asarray(body_xyz, dtype=np.float64) / leaf).astype(np.int64)
+    ijk -= ijk.min(axis=0)
+    d = ijk.max(axis=0) + 1
+    return np.argsort(ijk[:, 0] + ijk[:, 1] * d[0] + ijk[:, 2] * d[0] * d[1], kind="stable")
+
+
+def in_voxel_order(fr, leaf):
+    """the same frame with its scan points in pcl::VoxelGrid's output order (see voxel_order)"""
+    return dataclasses.replace(fr, body_xyz=np.ascontiguousarray(fr.body_xyz[voxel_order(fr.body_xyz, leaf)]))
+
+
 def _spd(rng, n, base, pert):
     A = rng.normal(size=(n, n))
     return base * np.eye(n) + pert * (A @ A.T) / n

@@ -246,3 +246,32 @@ def test_scan_fetched_by_the_search_kernel_gives_the_same_frame(gpu_lib, scene):
                     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:], (n, pull, pinned)
                 assert np.array_equal(ref[3][0], out[3][0]) and np.array_equal(ref[3][1], out[3][1])
             assert out[0][2] == 0 and np.array_equal(out[0][0], out[2][0])
+
+
+def test_mode23_update_with_the_scan_fetched_by_the_search_kernel(gpu_lib, scene):
+    """fl_ikfom_update_iterated_dev with the scan in fl_host_alloc memory (fetched by the first search kernel) against the same update
+    from pageable memory (copy command): the same state, covariance and counters."""
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    fr = synth.make_lio_frame(12345, scene=scene)
+    outs = []
+    for pinned in (True, False):
+        h = capi.Handle(capi.config_from_frames(fr, max_iterations=10))
+        h.map_set_points(scene.map_xyz, 0.5)
+        scan = fr.body_xyz
+        if pinned:
+            scan = h.host_alloc(fr.body_xyz.shape, np.float32)
+            scan[:] = fr.body_xyz
+        rec = []
+        for rep in range(2):
+            x23 = capi.state23_from_frame(fr)
+            P = fr.cov23.copy()
+            info = h.ikfom_update_iterated_dev(x23, P, scan, 0.001)
+            rec.append((x23.vec().copy(), P.copy(), info.status, info.iterations, info.effct_feat_num))
+        outs.append(rec)
+        if pinned:
+            h.host_free(scan)
+        h.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+    assert outs[0][0][2] == 0

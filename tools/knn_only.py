@@ -9,8 +9,18 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--points", type=int, default=50000)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--cell", type=float, default=0.5)
+ap.add_argument("--order", choices=("as_is", "voxel", "random"), default="as_is", help="order of the scan points: as synth makes them, sorted by voxel index as pcl::VoxelGrid emits its centroids, shuffled")
+ap.add_argument("--leaf", type=float, default=0.5)
 a = ap.parse_args()
 fr = synth.make_lio_frame(a.points)
+if a.order != "as_is":
+    b = fr.body_xyz
+    if a.order == "random":
+        perm = np.random.default_rng(1).permutation(len(b))
+    else:      # pcl::VoxelGrid: idx = ijk0 + ijk1 * dx + ijk2 * dx * dy, points emitted in ascending idx
+        ijk = np.floor(b / a.leaf).astype(np.int64); ijk -= ijk.min(axis=0); d = ijk.max(axis=0) + 1
+        perm = np.argsort(ijk[:, 0] + ijk[:, 1] * d[0] + ijk[:, 2] * d[0] * d[1], kind="stable")
+    fr.body_xyz = np.ascontiguousarray(b[perm])
 h = capi.Handle(capi.config_from_frames(fr, max_iterations=10))
 h.map_set_points(fr.scene.map_xyz, a.cell)
 x = capi.state18_from_frame(fr); h.lio_set_points(fr.body_xyz); h.lio_begin18(x, x)
