@@ -743,7 +743,7 @@ static int32_t upload_small(fl_handle h, void *d_dst, const void *src, size_t by
 }
 
 static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_state18 *prop, double meas_cov, bool vio = false, bool prepare_in_search = false,
-                              bool publish = false)
+                              bool publish = false, bool leave_in_mirror = false)
 {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     // h_dev is reused: wait only if a copy out of it can still be in flight. (A frame driver's begin follows the previous frame's
@@ -776,7 +776,10 @@ static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_sta
     if (publish && (h->opt_mailbox & (vio ? 1 : 2))) {      // frame drivers: the frame's last kernel publishes the block (read_info18 polls)
         D->pub_flag = h->d_pub; D->pub_dst = h->d_hdev; D->pub_seq = ++h->pub_seq;
     }
-    HIPCHK(h, hipMemcpyAsync(h->d_dev, D, sizeof(FlDev18), hipMemcpyHostToDevice, h->stream));
+    // leave_in_mirror (fl_lio_frame18_dev, prepare_in_search): no copy command -- the frame's first search kernel fetches the block
+    // from the mirror (knn_kernels.h host_state); it arrives as that search would leave it (searched_at = iters_run = 0)
+    if (leave_in_mirror && prepare_in_search) D->searched_at = 0;
+    else HIPCHK(h, hipMemcpyAsync(h->d_dev, D, sizeof(FlDev18), hipMemcpyHostToDevice, h->stream));
     h->hdev_busy = true;
     if (vio) hipLaunchKernelGGL(vio_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev, (const FlVioConst *)h->d_vc);   // + the camera pose
     else if (!prepare_in_search) hipLaunchKernelGGL(eskf18_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev);

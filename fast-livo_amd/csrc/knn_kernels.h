@@ -270,8 +270,13 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
                                                                   float *__restrict__ nbr_out /* nullable n x 15 */,
                                                                   uint8_t *__restrict__ valid_out /* nullable */, int cond,
                                                                   float4 *__restrict__ gate_out /* nullable */,
-                                                                  float *__restrict__ body_keep /* nullable */)
+                                                                  float *__restrict__ body_keep /* nullable */,
+                                                                  const DEV *__restrict__ host_state /* nullable */)
 {
+    // host_state != nullptr (same launch as cond & 4): the state block has NOT been copied to the device -- it is still in the
+    // caller's page-locked mirror (this is its device address). The prepare workgroup copies it into D (7 KB over the host link)
+    // before it forms the constants; the search workgroups read the pose and the extrinsics (36 doubles) from the mirror directly,
+    // next to their scan bytes. The copy command of the state block and the gap behind it (3.5 + 4.6 us) leave the frame.
     // body_keep != nullptr (fl_lio_frame18_dev with the scan in page-locked host memory): `body` is that HOST buffer as the device
     // addresses it -- every workgroup fetches its 64 points over the host link itself (768 B, each byte once, through LDS) and leaves
     // them in body_keep (the device copy the second search and later calls read). The fetches of the workgroups that are served
@@ -282,10 +287,23 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
     // gate_out != nullptr (same launch): every point's gate threshold (what lio_gate_kernel does) is written with its plane. Two
     // launches and two kernel boundaries less per frame; the first search of a frame always runs (begin raises need_search).
     if (MODE == 18 && (cond & 4) && blockIdx.x == gridDim.x - 1) {
+        if (host_state) {
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(host_state);
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(D);
+            constexpr int WORDS = (int)(sizeof(DEV) / 8), PER = (WORDS + FL_KNN_NT - 1) / FL_KNN_NT;
+            unsigned long long v[PER];
+#pragma unroll
+            for (int k = 0; k < PER; k++) { const int w = (int)threadIdx.x + FL_KNN_NT * k; v[k] = w < WORDS ? __builtin_nontemporal_load(src + w) : 0ull; }
+#pragma unroll
+            for (int k = 0; k < PER; k++) { const int w = (int)threadIdx.x + FL_KNN_NT * k; if (w < WORDS) dst[w] = v[k]; }
+            __threadfence();
+            __syncthreads();
+        }
         fl_search_prepare<DEV>(D);
         return;
     }
-    if ((cond & 1) && (!D->need_search || D->stop || (D->status & 8 /* FL_NUM_TIMEOUT: abandoned chain */))) return;
+    // (the first search of a frame always runs: begin raises need_search; with host_state the block is not on the device yet)
+    if (!host_state && (cond & 1) && (!D->need_search || D->stop || (D->status & 8 /* FL_NUM_TIMEOUT: abandoned chain */))) return;
     const bool stamp = (cond & 2) && threadIdx.x == 0 && blockIdx.x < 512;
     FL_INSTR(if (stamp) g_fl_wall[blockIdx.x] = (long long)wall_clock64();)
     __shared__ int s_at[FL_KNN_QPB][5];
@@ -311,7 +329,7 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
                          body_keep ? s_body[il * 3 + 2] : body[i * 3 + 2]};
     float pw[3];
     if constexpr (MODE == 18) {
-        const FlDev18 *D18 = D;
+        const FlDev18 *D18 = host_state ? host_state : D;
         const double b0 = (double)pb[0], b1 = (double)pb[1], b2 = (double)pb[2];
         const double u0 = (D18->R_LI[0] * b0 + D18->R_LI[1] * b1 + D18->R_LI[2] * b2) + D18->t_LI[0];
         const double u1 = (D18->R_LI[3] * b0 + D18->R_LI[4] * b1 + D18->R_LI[5] * b2) + D18->t_LI[1];
@@ -446,7 +464,7 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
 
     // "the search for pass iters_run has been made": the pass kernels run when need_search is down or
     // searched_at == iters_run. No workgroup of this kernel reads searched_at, so one of them may write it.
-    if (blockIdx.x == 0 && threadIdx.x == 0) D->searched_at = D->iters_run;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !host_state) D->searched_at = D->iters_run;      // (host_state: the block arrives with it set)
     const int qf = (int)threadIdx.x;
     const int iq = q0 + qf;
     if (qf >= FL_KNN_QPB || iq >= n) return;
