@@ -193,3 +193,22 @@ def test_cpp_local_map_window_follows_the_oracle(tmp_path):
         assert np.array_equal(np.array(vals[1:], dtype=np.float32), win), ln
         moved += len(boxes) > 0
     assert moved > 10
+
+
+def test_voxel_order_is_pcl_voxelgrid_output_order():
+    """synth.voxel_order: ascending idx = i + j*dx + k*dx*dy over the leaf grid, stable inside a voxel (what pcl::VoxelGrid's sorted index
+    vector gives; bench.py feeds the frame drivers scans in this order)"""
+    import importlib
+    synth = importlib.import_module("fast-livo_amd.synth")
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-5, 7, (4000, 3)).astype(np.float32)
+    leaf = 0.5
+    perm = synth.voxel_order(pts, leaf)
+    assert sorted(perm.tolist()) == list(range(len(pts)))
+    ijk = np.floor(pts.astype(np.float64) / leaf).astype(np.int64)
+    mn = ijk.min(axis=0); d = ijk.max(axis=0) - mn + 1
+    idx = (ijk[:, 0] - mn[0]) + (ijk[:, 1] - mn[1]) * d[0] + (ijk[:, 2] - mn[2]) * d[0] * d[1]
+    si = idx[perm]
+    assert np.all(np.diff(si) >= 0)
+    same = np.diff(si) == 0
+    assert np.all(np.diff(perm)[same] > 0)          # stable: equal voxels keep their input order

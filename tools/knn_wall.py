@@ -6,6 +6,8 @@ import fastlivo  # noqa
 from fast_livo_amd import capi, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 fr = synth.make_lio_frame(n)
+if os.environ.get("FL_ORDER", "voxel") == "voxel":      # as pcl::VoxelGrid emits feats_down_body (bench.py SCAN_ORDER_NOTE)
+    fr = synth.in_voxel_order(fr, 0.15)
 h = capi.Handle(capi.config_from_frames(fr, max_iterations=10), debug=True)
 L = capi.lib(debug=True); h.debug_knn_stamp(True)
 h.map_set_points(fr.scene.map_xyz, 0.5)
