@@ -24,6 +24,8 @@
 
 struct FlIkLds {
     double P[529];       // projected P_ (then the final P_ on the finishing pass)
+    double Pd[276];      // P_[:, 0:12] / R (23 x 12), formed once per pass by the threads the record unpacking leaves idle: the
+                         // twelve IEEE divisions per row sat on wavefront 0's path behind the LDL^T (0.75 us) and again in the final block
     double Pc[529];      // P_ with columns re-projected (final block)
     double L[529];       // L_ (final block)
     double Pp[529];      // P_propagated, staged once per launch
@@ -320,6 +322,9 @@ __device__ __forceinline__ void ikfom_post(FlDev23 *__restrict__ D, const double
         }
         return;
     }
+    if (tid >= 144) {                   // (same quotients, same products as before: bit-identical)
+        for (int e = tid - 144; e < n * 12; e += NTH - 144) L.Pd[e] = L.P[(e / 12) * n + (e % 12)] / R;
+    }
     if (INTERNAL) {                     // S = h_x^T h_x (12 x 12), h_x^T h and the scalars out of the internal record
         if (tid < 144) L.S[tid] = fl_s12_from_s9(s_sums, L.Rm, tid / 12, tid % 12);
         else if (tid >= 160 && tid < 172) L.htz[tid - 160] = fl_htz12_from_s9(s_sums, L.Rm, tid - 160);
@@ -376,7 +381,7 @@ __device__ __forceinline__ void ikfom_post(FlDev23 *__restrict__ D, const double
         if (tid < n) {                          // dx_ = A[:,0:12] y - dx_new
             double s2 = 0.0;
 #pragma unroll
-            for (int cc = 0; cc < 12; cc++) s2 += (L.P[tid * n + cc] / R) * y[cc];
+            for (int cc = 0; cc < 12; cc++) s2 += L.Pd[tid * 12 + cc] * y[cc];
             L.dxo[tid] = s2 - L.dxn[tid];
         }
     }
@@ -484,7 +489,7 @@ __device__ __forceinline__ void ikfom_post(FlDev23 *__restrict__ D, const double
     for (int e = tid; e < n * 12; e += NTH) {   // Kx = A[:,0:12] X
         const int r = e / 12, c = e % 12;
         double s = 0.0;
-        for (int k = 0; k < 12; k++) s += (L.P[r * n + k] / R) * L.M[k * 12 + c];
+        for (int k = 0; k < 12; k++) s += L.Pd[r * 12 + k] * L.M[k * 12 + c];
         L.Kx[e] = s;
     }
     for (int e = tid; e < n * n; e += NTH) {    // Pc = P Jf^T (columns)
