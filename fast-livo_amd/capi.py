@@ -329,6 +329,22 @@ def _p(a, ty):
     return a.ctypes.data_as(C.POINTER(ty))
 
 
+_hot_ptr = {}
+_DEFAULT_LIMIT23 = np.full(23, 0.001)      # esekfom's epsi (laserMapping.cpp:1140)
+
+
+def _p_hot(a, ty):
+    """_p for the arrays a frame driver gets again and again (the caller's scan buffer): `a.ctypes.data_as` costs 4 us per call --
+    of a 0.11 ms frame --, a look-up 0.2 us. Keyed by the array object (kept alive by the entry), a handful of entries at most."""
+    e = _hot_ptr.get(id(a))
+    if e is None or e[0] is not a or e[2] is not ty:
+        if len(_hot_ptr) > 16:
+            _hot_ptr.clear()
+        e = (a, a.ctypes.data_as(C.POINTER(ty)), ty)
+        _hot_ptr[id(a)] = e
+    return e[1]
+
+
 def make_config(R_LI, t_LI, Rcl, Pcl, cam, max_iterations=10, laser_point_cov=0.001, img_point_cov=100.0, device=0):
     c = Config()
     c.device = device
@@ -922,17 +938,19 @@ def _knn_methods():
         if body is None:
             self._chk(self.L.fl_lio_frame18_dev(self.h, C.byref(state), None, 0, C.byref(info)), "fl_lio_frame18_dev")
             return info
-        body = np.ascontiguousarray(body, dtype=np.float32)
-        self._chk(self.L.fl_lio_frame18_dev(self.h, C.byref(state), _p(body, C.c_float), body.shape[0], C.byref(info)),
+        if not (isinstance(body, np.ndarray) and body.dtype == np.float32 and body.flags["C_CONTIGUOUS"]):
+            body = np.ascontiguousarray(body, dtype=np.float32)
+        self._chk(self.L.fl_lio_frame18_dev(self.h, C.byref(state), _p_hot(body, C.c_float), body.shape[0], C.byref(info)),
                   "fl_lio_frame18_dev")
         return info
 
     def ikfom_update_iterated_dev(self, x23, P, body, R, limit=None):
-        body = np.ascontiguousarray(body, dtype=np.float32)
-        limit = np.full(23, 0.001) if limit is None else np.ascontiguousarray(limit, dtype=np.float64)
+        if not (isinstance(body, np.ndarray) and body.dtype == np.float32 and body.flags["C_CONTIGUOUS"]):
+            body = np.ascontiguousarray(body, dtype=np.float32)
+        limit = _DEFAULT_LIMIT23 if limit is None else np.ascontiguousarray(limit, dtype=np.float64)
         info = IterInfo()
-        self._chk(self.L.fl_ikfom_update_iterated_dev(self.h, C.byref(x23), _p(P, C.c_double), _p(body, C.c_float), body.shape[0], R,
-                                                      _p(limit, C.c_double), C.byref(info)), "fl_ikfom_update_iterated_dev")
+        self._chk(self.L.fl_ikfom_update_iterated_dev(self.h, C.byref(x23), _p(P, C.c_double), _p_hot(body, C.c_float), body.shape[0], R,
+                                                      _p_hot(limit, C.c_double), C.byref(info)), "fl_ikfom_update_iterated_dev")
         return info
 
     for f in (map_set_points, map_clear, map_add_points, map_delete_boxes, map_get_points, lio_search18, ikfom_search, lio_frame18_dev, ikfom_update_iterated_dev,
