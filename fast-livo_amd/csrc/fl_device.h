@@ -190,7 +190,8 @@ __device__ __forceinline__ void fl_sin_omc(double x, double *s, double *omc)
 // The result mailbox (FlDev18::pub_flag): called by ALL threads of ONE workgroup as the last action of a frame's last kernel. The
 // block was last written by this workgroup or by earlier kernels; it travels as 8-byte words over the host link (~7 KB: well under a
 // microsecond), every thread makes its words visible to the system, then one thread raises the flag. The host (read_info18) sees the
-// flag ~1 us after the kernel's last store -- a device-to-host copy command plus a stream synchronisation cost 15-20 us per frame.
+// flag ~1 us after the kernel's last store; against a device-to-host copy command plus a stream synchronisation that is 4-5 us less
+// per frame driver call (tools/mailbox_ab.py).
 __device__ __forceinline__ void fl_publish_state(FlDev18 *__restrict__ D)
 {
     __syncthreads();
