@@ -248,6 +248,14 @@ int orc_ikfom_update_dyn_share(orc_state23 *x, double *P, double R, int maximum_
 void orc_state23_boxplus(orc_state23 *x, const double *dx /*23*/);
 void orc_state23_boxminus(const orc_state23 *x, const orc_state23 *other, double *dx /*23*/);
 
+/* Unit entry points (one restated reference function each) for the cross-oracle and Eigen-pinning tests:
+ * esti_plane<float> common_lib.h:448-493 ; StatesGroup += / - common_lib.h:343-365 ; Exp / Log so3_math.h:54-81. */
+int orc_unit_esti_plane(const float *near /*5x3*/, float threshold, float *pabcd /*4*/);
+void orc_unit_state18_plus(orc_state18 *x, const double *d /*18*/);
+void orc_unit_state18_minus(const orc_state18 *a, const orc_state18 *b, double *out /*18*/);
+void orc_unit_so3_exp(const double *v /*3*/, double *R /*9 row-major*/);
+void orc_unit_so3_log(const double *R /*9 row-major*/, double *out /*3*/);
+
 #ifdef __cplusplus
 }
 #endif

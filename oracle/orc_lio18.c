@@ -273,3 +273,11 @@ int orc_plane_sensitivity(const float *nbr_xyz /* n x 5 x 3 */, const float *wor
     }
     return 0;
 }
+
+/* ---- unit entry points for tests/test_cross_oracle_cpu.py and tests/test_ref_eigen_cpu.py (oracle/ref_eigen pins these four to the
+ * reference's own headers wherever Eigen exists): the restatements above, one call each. */
+int orc_unit_esti_plane(const float *near /*5x3*/, float threshold, float *pabcd /*4*/) { return orc_esti_plane(near, threshold, pabcd); }
+void orc_unit_state18_plus(orc_state18 *x, const double *d /*18*/) { state18_plus(x, d); }
+void orc_unit_state18_minus(const orc_state18 *a, const orc_state18 *b, double *out /*18*/) { state18_minus(a, b, out); }
+void orc_unit_so3_exp(const double *v /*3*/, double *R /*9 row-major*/) { so3_Exp(v[0], v[1], v[2], R); }
+void orc_unit_so3_log(const double *R /*9 row-major*/, double *out /*3*/) { so3_Log(R, out); }

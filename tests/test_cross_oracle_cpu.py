@@ -44,3 +44,219 @@ def test_vio_iteration_c_vs_numpy(oracle_lib, scene):
         assert np.abs(HTH - HTH_c).max() <= 1e-9 * np.abs(HTH_c).max()
         assert np.abs(HTz - np.array(r["out"].HTz)).max() <= 1e-9 * np.abs(HTz).max()
         assert np.abs(sol - np.array(r["out"].solution)).max() <= 1e-9
+
+
+# ----------------------------------------------------------------------------------------------------------------- Mode-23
+# oracle/np_ikfom.py was written from the reference headers alone (esekfom.hpp:1619-1928, S2.hpp, SOn.hpp, mtkmath.hpp), with
+# numpy.linalg.inv and whole-block products; oracle/orc_ikfom.c is the loop-level C restatement the HIP path is held to.  Both
+# run around the SAME measurement callback here, so the only thing compared is the updater's own arithmetic.
+def _c_rows_callback(orc, fr, scene_map):
+    """h_share_model of the C oracle as a dyn_share callback taking the C state struct"""
+    import ctypes as C
+    from helpers import p
+    n = fr.n
+    st = dict(nbr=np.zeros((n, 5, 3), np.float32), sel=np.zeros(n, np.uint8))
+    normvec = np.zeros((n, 4), np.float32); res = np.zeros(n); world = np.zeros((n, 3), np.float32)
+
+    def cb(xs, valid, converge):
+        hx = np.zeros((n, 12)); hv = np.zeros(n); tr = C.c_double()
+        if converge:
+            scratch = np.zeros(n, np.uint8)
+            orc.lib().orc_h_share_model(C.byref(xs), p(fr.body_xyz, C.c_float), p(st["nbr"], C.c_float), p(scratch, C.c_uint8), n, 1,
+                                        p(world, C.c_float), p(normvec, C.c_float), p(res, C.c_double), p(hx, C.c_double), p(hv, C.c_double),
+                                        C.byref(tr))
+            nb, _, va, _ = orc.knn5_bruteforce(scene_map, world)
+            st["nbr"][:] = nb
+            st["sel"][:] = va
+        neff = orc.lib().orc_h_share_model(C.byref(xs), p(fr.body_xyz, C.c_float), p(st["nbr"], C.c_float), p(st["sel"], C.c_uint8), n, 2,
+                                           None, p(normvec, C.c_float), p(res, C.c_double), p(hx, C.c_double), p(hv, C.c_double), C.byref(tr))
+        return True, hx[:neff].copy(), hv[:neff].copy()
+    return cb, st
+
+
+def _np_view(orc, cb_c):
+    """the same callback for the numpy updater (its state class -> the C struct)"""
+    def cb(x, valid, converge):
+        xs = orc.State23()
+        x.to_c(xs)
+        return cb_c(xs, valid, converge)
+    return cb
+
+
+def _counting(cb, cnt):
+    def w(xs, valid, converge):
+        cnt["calls"] += 1
+        cnt["searches"] += int(bool(converge))
+        return cb(xs, valid, converge)
+    return w
+
+
+def _run_both(orc, fr, scene, P0, max_iter, R, wrap=lambda cb: cb, limit=None):
+    from fast_livo_amd import synth
+    from oracle import np_ikfom as npi
+    limit = np.full(23, 0.001) if limit is None else limit
+    x_c = orc.state23_from_frame(fr, synth.quat_from_R)
+    P_c = P0.copy()
+    cb_c, _ = _c_rows_callback(orc, fr, scene.map_xyz)
+    cnt = dict(calls=0, searches=0)
+    r_c = orc.ikfom_update_dyn_share(x_c, P_c, R, max_iter, _counting(wrap(cb_c), cnt), limit=limit)
+    r_c["cnt"] = cnt
+    x_n = npi.State.from_c(orc.state23_from_frame(fr, synth.quat_from_R))
+    P_n = P0.copy()
+    cb_c2, _ = _c_rows_callback(orc, fr, scene.map_xyz)
+    r_n = npi.update_iterated_dyn_share_modified(x_n, P_n, R, max_iter, limit, wrap(_np_view(orc, cb_c2)))
+    return x_c, P_c, r_c, x_n, P_n, r_n
+
+
+def _spd23(seed, scale):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((23, 23))
+    return scale * (A @ A.T / 23 + 0.5 * np.eye(23))
+
+
+def test_ikfom_update_c_vs_numpy(oracle_lib, scene):
+    """esekfom.hpp:1619-1928, rows >= 23 branch (:1779-1806): state <= 1e-9, covariance <= 1e-10 (relative to max |P|)."""
+    from fast_livo_amd import synth
+    orc = oracle_lib
+    for n, max_iter, P0 in ((3000, 4, None), (3000, 10, _spd23(1, 1e-3)), (400, 3, _spd23(2, 1e-2))):
+        fr = synth.make_lio_frame(n, scene=scene)
+        P0 = fr.cov23.copy() if P0 is None else P0
+        x_c, P_c, r_c, x_n, P_n, r_n = _run_both(orc, fr, scene, P0, max_iter, 0.001)
+        assert r_c["cnt"]["calls"] == r_c["out"].iterations == r_n["iterations"] and r_c["cnt"]["searches"] == r_n["searches"] >= 2
+        assert r_n["finished"]
+        assert np.abs(x_c.vec() - x_n.vec()).max() <= 1e-9
+        assert np.abs(P_c - P_n).max() <= 1e-10 * max(1.0, np.abs(P_n).max())
+        assert np.abs(np.array(r_c["out"].dx) - r_n["dx"]).max() <= 1e-9
+        # the update moved the gravity direction, so the S2 blocks (Nx_yy * Mx with the `scalar(1/2) == 0` quirk, S2.hpp:277) were live
+        assert np.abs(x_n.grav - orc.state23_from_frame(fr, synth.quat_from_R).vec()[20:23]).max() > 1e-9
+
+
+def test_ikfom_update_c_vs_numpy_few_rows_branch(oracle_lib, scene):
+    """n > dof_Measurement (:1712-1741): K = P H^T (H P H^T / R + I)^-1 / R with fewer than 23 rows."""
+    from fast_livo_amd import synth
+    orc = oracle_lib
+    fr = synth.make_lio_frame(3000, scene=scene)
+
+    def few(cb):
+        def w(xs, valid, converge):
+            v, hx, hv = cb(xs, valid, converge)
+            return v, hx[:15].copy(), hv[:15].copy()
+        return w
+    x_c, P_c, r_c, x_n, P_n, r_n = _run_both(orc, fr, scene, _spd23(3, 1e-3), 4, 0.001, wrap=few)
+    assert r_c["out"].iterations == r_n["iterations"]
+    assert np.abs(x_c.vec() - x_n.vec()).max() <= 1e-9
+    assert np.abs(P_c - P_n).max() <= 1e-10 * max(1.0, np.abs(P_n).max())
+
+
+def test_ikfom_update_c_vs_numpy_invalid_pass_and_forced_rematch(oracle_lib, scene):
+    """`if(!dyn_share.valid) continue;` (:1651-1654) keeps the converge flag and the working covariance of the pass before; limits so
+    tight that t stays 0 exercise the forced `converge = true` at i == maximum_iter - 2 (:1826-1829) and the exit at the last pass."""
+    from fast_livo_amd import synth
+    orc = oracle_lib
+    fr = synth.make_lio_frame(2000, scene=scene)
+
+    def flaky(cb):
+        k = dict(i=0)
+
+        def w(xs, valid, converge):
+            k["i"] += 1
+            v, hx, hv = cb(xs, valid, converge)
+            return (k["i"] != 2), hx, hv
+        return w
+    x_c, P_c, r_c, x_n, P_n, r_n = _run_both(orc, fr, scene, _spd23(4, 1e-3), 5, 0.001, wrap=flaky, limit=np.full(23, 1e-30))
+    assert r_c["out"].iterations == r_n["iterations"] == 6 and r_c["cnt"]["searches"] == r_n["searches"]
+    assert np.abs(x_c.vec() - x_n.vec()).max() <= 1e-9
+    assert np.abs(P_c - P_n).max() <= 1e-10 * max(1.0, np.abs(P_n).max())
+
+
+def test_state23_box_ops_c_vs_numpy(oracle_lib):
+    """build_manifold.hpp:192-200 over SOn.hpp:233-239 / S2.hpp:136-167 / vect: boxplus, boxminus, incl. the small-angle series
+    (cos_sinc_sqrt below sqrt(sqrt(eps)), mtkmath.hpp:147-171), the log's tolerance clamp (:273-283) and S2's aligned / opposed branches."""
+    import ctypes as C
+    from oracle import np_ikfom as npi
+    orc = oracle_lib
+    rng = np.random.default_rng(7)
+
+    def rand_state():
+        s = orc.State23()
+        for f, _ in s._fields_:
+            a = getattr(s, f)
+            a[:] = rng.standard_normal(len(a))
+        for f in ("rot", "offset_R_L_I"):
+            q = np.array(getattr(s, f)); getattr(s, f)[:] = q / np.linalg.norm(q)
+        g = np.array(s.grav); s.grav[:] = g / np.linalg.norm(g) * 9.809
+        return s
+    worst_p = worst_m = 0.0
+    for k in range(300):
+        a = rand_state()
+        mag = [1.0, 1e-2, 1e-3, 1e-6, 1e-13, 0.0][k % 6]
+        d = rng.standard_normal(23) * mag
+        b = a.copy()
+        orc.lib().orc_state23_boxplus(C.byref(b), d.ctypes.data_as(C.POINTER(C.c_double)))
+        nb = npi.State.from_c(a); nb.boxplus(d)
+        worst_p = max(worst_p, np.abs(b.vec() - nb.vec()).max())
+        out = np.zeros(23)
+        orc.lib().orc_state23_boxminus(C.byref(b), C.byref(a), out.ctypes.data_as(C.POINTER(C.c_double)))
+        nm = npi.State.from_c(b).boxminus(npi.State.from_c(a))
+        worst_m = max(worst_m, np.abs(out - nm).max())
+        if mag == 0.0:
+            assert np.array_equal(nm, np.zeros(23)) or np.abs(nm).max() < 1e-15
+    assert worst_p <= 1e-13 and worst_m <= 1e-11, (worst_p, worst_m)
+    # S2 boxminus, opposed vectors (v_sin < tol, |theta| > tol): the reference returns (3.1415926, 0)
+    a = rand_state(); b = a.copy(); b.grav[:] = [-v for v in a.grav]
+    out = np.zeros(23)
+    orc.lib().orc_state23_boxminus(C.byref(b), C.byref(a), out.ctypes.data_as(C.POINTER(C.c_double)))
+    nm = npi.State.from_c(b).boxminus(npi.State.from_c(a))
+    assert out[21] == nm[21] == 3.1415926 and out[22] == nm[22] == 0.0
+    # S2_Bx's fallback chart (vec[0] + length <= tol): gravity along -x
+    a.grav[:] = [-9.809, 0.0, 0.0]
+    d = np.zeros(23); d[21:23] = [0.01, -0.02]
+    b = a.copy()
+    orc.lib().orc_state23_boxplus(C.byref(b), d.ctypes.data_as(C.POINTER(C.c_double)))
+    nb = npi.State.from_c(a); nb.boxplus(d)
+    assert np.abs(b.vec() - nb.vec()).max() <= 1e-13
+
+
+def test_h_share_model_rows_c_vs_numpy(oracle_lib, scene):
+    """laserMapping.cpp:961-1093: with the plane fit taken from the C oracle (its float QR order is what the two restatements do not
+    share), the selection, the N_eff x 12 rows and h agree to rounding; with scipy's float QR they agree to the fit's conditioning."""
+    import ctypes as C
+    from helpers import p
+    from fast_livo_amd import synth
+    from oracle import np_ikfom as npi, np_oracle as npo
+    orc = oracle_lib
+    n = 1500
+    fr = synth.make_lio_frame(n, scene=scene)
+    xs = orc.state23_from_frame(fr, synth.quat_from_R)
+    cb, st = _c_rows_callback(orc, fr, scene.map_xyz)
+    _, hx_c, hv_c = cb(xs, True, True)
+    sel_after_c = st["sel"].copy()          # orc_h_share_model overwrites sel in place (the reference's point_selected_surf)
+    nb, _, va, _ = orc.knn5_bruteforce(scene.map_xyz, synth_world(orc, fr, xs, n))
+    x = npi.State.from_c(xs)
+
+    def c_plane(near):
+        out = np.zeros(4, np.float32)
+        near = np.ascontiguousarray(near, dtype=np.float32)
+        ok = orc.lib().orc_unit_esti_plane(p(near, C.c_float), C.c_float(0.1), p(out, C.c_float))
+        return out, bool(ok)
+    hx_n, hv_n, new_sel, eff = npi.h_share_model_rows(x, fr.body_xyz, nb, va, c_plane)
+    assert np.array_equal(new_sel, sel_after_c != 0)
+    assert hx_n.shape == hx_c.shape and hx_c.shape[0] > n // 3
+    assert np.abs(hx_n - hx_c).max() <= 1e-12 * max(1.0, np.abs(hx_c).max())
+    assert np.array_equal(hv_n, hv_c)
+    hx_s, hv_s, sel_s, eff_s = npi.h_share_model_rows(x, fr.body_xyz, nb, va, npo.esti_plane)
+    assert int((eff_s != eff).sum()) <= 2
+    both = eff_s & eff
+    a = hx_s[both[eff_s]]; b = hx_n[both[eff]]
+    assert np.abs(a - b).max() <= 2e-2 * max(1.0, np.abs(b).max())          # rows scale with the lever arm (~10 m) x 1e-3 of normal
+
+
+def synth_world(orc, fr, xs, n):
+    import ctypes as C
+    from helpers import p
+    world = np.zeros((n, 3), np.float32)
+    normvec = np.zeros((n, 4), np.float32); res = np.zeros(n); hx = np.zeros((n, 12)); hv = np.zeros(n); tr = C.c_double()
+    scratch = np.zeros(n, np.uint8); nbr = np.zeros((n, 5, 3), np.float32)
+    orc.lib().orc_h_share_model(C.byref(xs), p(fr.body_xyz, C.c_float), p(nbr, C.c_float), p(scratch, C.c_uint8), n, 1,
+                                p(world, C.c_float), p(normvec, C.c_float), p(res, C.c_double), p(hx, C.c_double), p(hv, C.c_double), C.byref(tr))
+    return world
