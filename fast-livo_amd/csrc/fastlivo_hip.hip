@@ -43,6 +43,10 @@ struct fl_context {
     float4 *d_gate = nullptr;     // staged scan as (x, y, z, T), T = per-point selection threshold (fl_math.h: fl_gate_threshold); valid when gate_valid
     bool gate_valid = false;
     uint8_t *d_valid = nullptr, *d_sel = nullptr;
+    float4 *d_knn_ids = nullptr;        // the 5 winners of every scan point's last search (position + map index, 5 x float4 per point)
+    bool knn_ids_valid = false;         // ... filled for the staged scan and the staged map by a search that certainly ran
+    bool search_certain = false;        // the next conditional search will run (a begin raised need_search)
+    bool opt_incr_search = true;        // FL_OPT_INCR_SEARCH
     float4 *d_plane = nullptr, *d_normvec = nullptr;
     int cap_points = 0, n = 0;
     bool have_nbr = false;
@@ -389,7 +393,7 @@ int32_t fl_destroy(fl_handle h)
     if (!h) return FL_OK;
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
-    hipFree(h->d_body); hipFree(h->d_nbr); hipFree(h->d_world); hipFree(h->d_valid); hipFree(h->d_sel); hipFree(h->d_gate);
+    hipFree(h->d_body); hipFree(h->d_nbr); hipFree(h->d_world); hipFree(h->d_valid); hipFree(h->d_sel); hipFree(h->d_gate); hipFree(h->d_knn_ids);
     hipFree(h->d_plane); hipFree(h->d_normvec); hipFree(h->d_dev); hipFree(h->d_dev23); hipFree(h->d_records);
     hipFree(h->d_epoch); hipFree(h->d_sums_tmp); hipFree(h->d_bcast); hipFree(h->d_vc); hipFree(h->d_img); hipFree(h->d_ref);
     hipFree(h->d_errors); hipFree(h->d_err_words); hipFree(h->d_pos); hipFree(h->d_slevel);
@@ -490,6 +494,7 @@ int32_t fl_set_option(fl_handle h, int32_t option, int32_t value)
     case FL_OPT_VIO_WHOLE_CU: h->opt_vio_whole_cu = value != 0; break;
     case FL_OPT_MAILBOX: h->opt_mailbox = value & 3; break;
     case FL_OPT_SCAN_PULL: h->opt_scan_pull = value != 0; break;
+    case FL_OPT_INCR_SEARCH: h->opt_incr_search = value != 0; break;
     default: return fail_arg(h, "fl_set_option: unknown option");
     }
     return FL_OK;
@@ -555,7 +560,8 @@ static int32_t ensure_points(fl_handle h, int n)
     while (cap < n) cap *= 2;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     hipFree(h->d_body); hipFree(h->d_nbr); hipFree(h->d_world); hipFree(h->d_valid); hipFree(h->d_sel);
-    hipFree(h->d_plane); hipFree(h->d_normvec); hipFree(h->d_gate);
+    hipFree(h->d_plane); hipFree(h->d_normvec); hipFree(h->d_gate); hipFree(h->d_knn_ids);
+    h->d_knn_ids = nullptr; h->knn_ids_valid = false;
     h->d_body = h->d_nbr = h->d_world = nullptr; h->d_valid = h->d_sel = nullptr; h->d_plane = h->d_normvec = nullptr; h->d_gate = nullptr;
     h->cap_points = 0; h->gate_valid = false;
     HIPCHK(h, hipMalloc(&h->d_body, sizeof(float) * 3 * (size_t)cap));
@@ -566,6 +572,7 @@ static int32_t ensure_points(fl_handle h, int n)
     HIPCHK(h, hipMalloc(&h->d_gate, sizeof(float4) * (size_t)cap));
     HIPCHK(h, hipMalloc(&h->d_plane, sizeof(float4) * (size_t)cap));
     HIPCHK(h, hipMalloc(&h->d_normvec, sizeof(float4) * (size_t)cap));
+    HIPCHK(h, hipMalloc(&h->d_knn_ids, sizeof(float4) * 5 * (size_t)cap));
     h->cap_points = cap;
     return FL_OK;
 }
@@ -618,6 +625,7 @@ static int32_t stage_points_meta(fl_handle h, int32_t n)
     h->have_nbr = false;
     h->normvec_valid = false;
     h->gate_valid = false;
+    h->knn_ids_valid = false;          // another scan: the kept winners belong to the old one
     return FL_OK;
 }
 // the device address of [p, p + bytes) if it lies inside an allocation of fl_host_alloc, else nullptr
@@ -761,6 +769,7 @@ static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_sta
     D->iterCount = -1;
     D->rematch_num = 0;
     D->need_search = 1;
+    h->search_certain = true;          // the next conditional search runs (launch_search)
     D->searched_at = -1;
     D->stop = 0;
     D->max_iter = h->cfg.max_iterations;

@@ -271,8 +271,16 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
                                                                   uint8_t *__restrict__ valid_out /* nullable */, int cond,
                                                                   float4 *__restrict__ gate_out /* nullable */,
                                                                   float *__restrict__ body_keep /* nullable */,
-                                                                  const DEV *__restrict__ host_state /* nullable */)
+                                                                  const DEV *__restrict__ host_state /* nullable */,
+                                                                  float4 *ids /* nullable n x 5: the 5 winners of every query (position, map index), kept between searches */,
+                                                                  int incremental)
 {
+    // ids / incremental (the SECOND search of a frame, and every later one over the same scan and map): the winners of the search
+    // before (kept with their positions, so the bound needs no second trip through the map) are 5 distinct map points, so the largest of their distances to the query's NEW world point bounds the new 5th-best
+    // distance from above (B2) whatever the pose did in between. Only cells whose box lies within sqrt(B2) of the query can hold a
+    // point that enters the best 5 (or ties with its 5th): the quad looks up and walks those cells -- typically 3-6 of the 27 --
+    // and the result is the full search's, key for key (same float distances, same index tie rule). Where the old winners are
+    // farther than one cell edge (sparse map) or fewer than 5, the query falls back to the full walk.
     // host_state != nullptr (same launch as cond & 4): the state block has NOT been copied to the device -- it is still in the
     // caller's page-locked mirror (this is its device address). The prepare workgroup copies it into D (7 KB over the host link)
     // before it forms the constants; the search workgroups read the pose and the extrinsics (36 doubles) from the mirror directly,
@@ -313,6 +321,9 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
     const int ql = (int)(threadIdx.x >> 2), j = (int)(threadIdx.x & 3u);
     const int q0 = blockIdx.x * FL_KNN_QPB;
     const int i = min(q0 + ql, n - 1);                // tail quads repeat the last query (results unused)
+    // previous winners of this query (incremental): position + map index, 5 x float4 per point
+    float4 rec_mine = make_float4(0.f, 0.f, 0.f, 0.f), rec_4th = rec_mine;
+    if (incremental) { rec_mine = ids[(size_t)i * 5 + j]; rec_4th = ids[(size_t)i * 5 + 4]; }
 
     __shared__ float s_body[FL_KNN_QPB * 3];
     if (body_keep) {
@@ -345,6 +356,24 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
     }
     const int cx = (int)floorf(pw[0] * G.inv_cell), cy = (int)floorf(pw[1] * G.inv_cell), cz = (int)floorf(pw[2] * G.inv_cell);
 
+    // ---- incremental bound: B2 = largest new distance of the previous winners (lane j takes winner j, lane 0 also winner 4)
+    float B2s = INFINITY;                             // prune threshold, INFINITY = full search
+    if (incremental) {
+        const float4 wa = rec_mine, wb = rec_4th;     // (loaded at the top: the addresses depend on the query index alone)
+        float dm = INFINITY;
+        if (__float_as_int(wa.w) != FL_KNN_NO_ID && __float_as_int(wb.w) != FL_KNN_NO_ID) {
+            const float d0x = pw[0] - wa.x, d0y = pw[1] - wa.y, d0z = pw[2] - wa.z;
+            const float d1x = pw[0] - wb.x, d1y = pw[1] - wb.y, d1z = pw[2] - wb.z;
+            dm = fmaxf(d0x * d0x + d0y * d0y + d0z * d0z, d1x * d1x + d1y * d1y + d1z * d1z);
+        }
+        dm = fmaxf(dm, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dm), FL_DPP_QUAD_XOR1, 0xf, 0xf, false)));
+        dm = fmaxf(dm, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dm), FL_DPP_QUAD_XOR2, 0xf, 0xf, false)));
+        const float reach1 = G.cell - 1e-3f;
+        // inside ring 1 only (farther winners: the full path with its ring logic); 1e-5 relative slack covers the float rounding of
+        // the box distance below, the 1 mm margin the float cell assignment (floorf(x * inv_cell)) -- as the stop rule of the full walk
+        if (dm <= reach1 * reach1) B2s = dm * (1.0f + 1e-5f);
+    }
+
     // ---- phase 1a: rings 0..1, cells c = j, j+4, ... < 27 ; c = (dz+1)*9 + (dy+1)*3 + (dx+1)
     {
         unsigned long long key[7];
@@ -353,9 +382,16 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
 #pragma unroll
         for (int m = 0; m < 7; m++) {
             const int c = min(j + 4 * m, 26);
-            key[m] = fl_cell_key(cx + (c % 3) - 1, cy + ((c / 3) % 3) - 1, cz + (c / 9) - 1);
+            const int ox = (c % 3) - 1, oy = ((c / 3) % 3) - 1, oz = (c / 9) - 1;
+            key[m] = fl_cell_key(cx + ox, cy + oy, cz + oz);
             hs[m] = fl_hash64(key[m]) & G.hmask;
-            first[m] = *reinterpret_cast<const uint4 *>(&G.htab[hs[m]]);
+            // squared distance from the query to the cell's box (0 inside), each face pushed out by the 1 mm margin
+            const float lx = (float)(cx + ox) * G.cell, ly = (float)(cy + oy) * G.cell, lz = (float)(cz + oz) * G.cell;
+            const float gx = fmaxf(fmaxf(lx - pw[0], pw[0] - (lx + G.cell)) - 1e-3f, 0.f);
+            const float gy = fmaxf(fmaxf(ly - pw[1], pw[1] - (ly + G.cell)) - 1e-3f, 0.f);
+            const float gz = fmaxf(fmaxf(lz - pw[2], pw[2] - (lz + G.cell)) - 1e-3f, 0.f);
+            const bool look = !(gx * gx + gy * gy + gz * gz > B2s);
+            first[m] = look ? *reinterpret_cast<const uint4 *>(&G.htab[hs[m]]) : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);   // (pruned: reads as an empty slot)
         }
         // compact the occupied cells (a plane crosses ~9 of the 27) into the quad's LDS list, in cell order:
         // rank = occupied cells of the earlier rows m + occupied cells of the lower lanes in this row
@@ -479,6 +515,10 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
         } else {
             nb[k * 3] = 0.f; nb[k * 3 + 1] = 0.f; nb[k * 3 + 2] = 0.f;
         }
+    }
+    if (ids) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) ids[(size_t)iq * 5 + k] = make_float4(nb[k * 3], nb[k * 3 + 1], nb[k * 3 + 2], __int_as_float(s_at[qf][k]));
     }
     float pl[4];
     const int ok = fl_esti_plane(nb, pl);

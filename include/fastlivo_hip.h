@@ -155,7 +155,10 @@ int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out);
  *                         stream: callers that upload scans with copy commands may prefer 2.) Results are bit-identical either way.
  *   FL_OPT_SCAN_PULL      1 (default): fl_lio_frame18_dev does not copy a scan that lies in memory of fl_host_alloc -- the frame's first
  *                         search kernel fetches it over the host link (and leaves the device copy behind); 0: always a copy command.
- *                         Results are bit-identical either way. */
+ *                         Results are bit-identical either way.
+ *   FL_OPT_INCR_SEARCH    1 (default): a k-NN search over a scan and a map that an earlier search already covered (the rematch of a
+ *                         frame, KD_TREE::Nearest_Search at laserMapping.cpp:1543 for the second time) walks only the map cells within
+ *                         reach of the earlier winners' new distances; 0: every search walks all 27 cells. Results are identical either way. */
 #define FL_OPT_MULTIPASS 1
 #define FL_OPT_MAX_PRODUCERS 2
 #define FL_OPT_IK_PRODUCERS 3
@@ -163,6 +166,7 @@ int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out);
 #define FL_OPT_VIO_WHOLE_CU 5
 #define FL_OPT_MAILBOX 6
 #define FL_OPT_SCAN_PULL 7
+#define FL_OPT_INCR_SEARCH 8
 int32_t fl_set_option(fl_handle h, int32_t option, int32_t value);
 /* Counters of the resident-grid machinery of the multi-pass kernels. */
 typedef struct fl_diagnostics {

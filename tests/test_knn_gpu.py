@@ -185,3 +185,65 @@ def test_frame_timing_hook_splits_match_and_solve(gpu_lib, scene):
     assert 0.0 < t["match_ms"] < 1.0 and 0.0 < t["solve_ms"] < 1.0 and abs(t["total_ms"] - t["match_ms"] - t["solve_ms"]) < 1e-3
     print(f"\n[frame timing] match {t['match_ms'] * 1e3:.1f} us, solve {t['solve_ms'] * 1e3:.1f} us")
     h.close()
+
+
+@pytest.mark.parametrize("cell", [0.5, 0.3, 1.2])
+def test_incremental_search_is_the_full_search(gpu_lib, oracle_lib, scene, cell):
+    """A search over a scan and a map an earlier search covered walks only the cells within reach of the earlier winners
+    (knn_kernels.h, FL_OPT_INCR_SEARCH): same neighbours, bit for bit, as the full walk and as the brute-force oracle --
+    for pose changes from a fraction of a millimetre (the rematch of a frame, laserMapping.cpp:1700-1705) to metres
+    (bound beyond one cell: the query falls back to the full walk)."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    from oracle import np_oracle as npo
+    n = 20000
+    fr = synth.make_lio_frame(n, scene=scene)
+    rng = np.random.default_rng(42)
+    h_inc = _handle(capi, synth, fr)
+    h_full = _handle(capi, synth, fr)
+    h_full.set_option(capi.FL_OPT_INCR_SEARCH, 0)
+    for h in (h_inc, h_full):
+        h.map_set_points(scene.map_xyz, cell)
+        h.lio_set_points(fr.body_xyz)
+    x0 = capi.state18_from_frame(fr)
+    for h in (h_inc, h_full):
+        h.lio_begin18(x0, x0)
+        h.lio_search18(n)                      # the first search of the scan: full in both, leaves the winners behind
+    for d_pos, d_rot in ((0.0, 0.0), (2e-4, 1e-5), (3e-3, 2e-4), (3e-2, 2e-3), (0.3, 2e-2), (3.0, 0.2), (1e-3, 1e-4)):
+        R = fr.R_prior @ npo.Exp(rng.standard_normal(3) * d_rot)
+        p = fr.p_prior + rng.standard_normal(3) * d_pos
+        x = capi.State18.make(R, p, fr.vel, fr.bg, fr.ba, fr.grav, fr.cov18)
+        out = []
+        for h in (h_inc, h_full):
+            h.lio_begin18(x, x)
+            nbr, valid = h.lio_search18(n)
+            out.append((nbr, valid, h.lio_get_world_points(n)))
+        (nbr_i, val_i, world), (nbr_f, val_f, world_f) = out
+        assert np.array_equal(world, world_f)
+        assert np.array_equal(val_i, val_f)
+        assert np.array_equal(nbr_i, nbr_f), f"d_pos {d_pos}: {int((nbr_i != nbr_f).any(axis=(1, 2)).sum())} queries differ from the full walk"
+        nbr_o, sq_o, valid_o, _ = orc.knn5_bruteforce(scene.map_xyz, world)
+        assert np.array_equal(val_i, valid_o)
+        ok = valid_o != 0
+        assert np.array_equal(nbr_i[ok], nbr_o[ok])
+    # another map under the same scan: the kept winners index the old map -- the next search must not use them
+    rng2 = np.random.default_rng(3)
+    thin = scene.map_xyz[rng2.choice(len(scene.map_xyz), len(scene.map_xyz) // 3, replace=False)]
+    h_inc.map_set_points(thin, cell)
+    nbr, valid = h_inc.lio_search18(n)
+    nbr_o, _, valid_o, _ = orc.knn5_bruteforce(thin, h_inc.lio_get_world_points(n))
+    assert np.array_equal(valid, valid_o) and np.array_equal(nbr[valid_o != 0], nbr_o[valid_o != 0])
+    # and incremental over the thin map (winners often farther than a cell: mixed pruned / full queries in one wave)
+    x = capi.State18.make(fr.R_prior, fr.p_prior + np.array([0.004, -0.003, 0.002]), fr.vel, fr.bg, fr.ba, fr.grav, fr.cov18)
+    h_inc.lio_begin18(x, x)
+    nbr, valid = h_inc.lio_search18(n)
+    nbr_o, _, valid_o, _ = orc.knn5_bruteforce(thin, h_inc.lio_get_world_points(n))
+    assert np.array_equal(valid, valid_o) and np.array_equal(nbr[valid_o != 0], nbr_o[valid_o != 0])
+    # another scan under the same map
+    fr2 = synth.make_lio_frame(n // 2, scene=scene, seed=9) if "seed" in synth.make_lio_frame.__code__.co_varnames else fr
+    h_inc.lio_set_points(fr2.body_xyz[: n // 2][::-1].copy())
+    h_inc.lio_begin18(x0, x0)
+    nbr, valid = h_inc.lio_search18(n // 2)
+    nbr_o, _, valid_o, _ = orc.knn5_bruteforce(thin, h_inc.lio_get_world_points(n // 2))
+    assert np.array_equal(valid, valid_o) and np.array_equal(nbr[valid_o != 0], nbr_o[valid_o != 0])
+    h_inc.close(); h_full.close()

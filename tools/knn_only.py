@@ -11,6 +11,7 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--cell", type=float, default=0.5)
 ap.add_argument("--order", choices=("as_is", "voxel", "random"), default="as_is", help="order of the scan points: as synth makes them, sorted by voxel index as pcl::VoxelGrid emits its centroids, shuffled")
 ap.add_argument("--leaf", type=float, default=0.5)
+ap.add_argument("--move", type=float, default=-1.0, help=">= 0: also time a second search after the pose moved by this many metres (incremental on / off)")
 a = ap.parse_args()
 fr = synth.make_lio_frame(a.points)
 if a.order != "as_is":
@@ -29,3 +30,16 @@ ks = []
 for _ in range(a.reps):
     h.lio_search18(fr.n, want=False); ks.append(h.last_kernel_ms() * 1e3)
 print("search_fit_us", ks)
+# the rematch search of a frame: same scan, same map, the pose moved by --move metres (and --move / 10 rad)
+if a.move >= 0:
+    from oracle import np_oracle as npo          # Exp only (tool, not product)
+    rng = np.random.default_rng(2)
+    for incr in (1, 0):
+        h.set_option(capi.FL_OPT_INCR_SEARCH, incr)
+        ks = []
+        for r in range(a.reps):
+            h.lio_begin18(x, x); h.lio_search18(fr.n, want=False)
+            R = fr.R_prior @ npo.Exp(rng.standard_normal(3) * a.move / 10)
+            x2 = capi.State18.make(R, fr.p_prior + rng.standard_normal(3) * a.move, fr.vel, fr.bg, fr.ba, fr.grav, fr.cov18)
+            h.lio_begin18(x2, x2); h.lio_search18(fr.n, want=False); ks.append(h.last_kernel_ms() * 1e3)
+        print("second_search_us incremental=%d move=%g" % (incr, a.move), ks)
