@@ -6,6 +6,7 @@ or no GPU is visible -- there is no CPU fallback anywhere in the product path.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import os
 import subprocess
 
@@ -333,16 +334,31 @@ _hot_ptr = {}
 _DEFAULT_LIMIT23 = np.full(23, 0.001)      # esekfom's epsi (laserMapping.cpp:1140)
 
 
-def _p_hot(a, ty):
+def _p_hot(a, ty, cache=True):
     """_p for the arrays a frame driver gets again and again (the caller's scan buffer): `a.ctypes.data_as` costs 4 us per call --
-    of a 0.11 ms frame --, a look-up 0.2 us. Keyed by the array object (kept alive by the entry), a handful of entries at most."""
-    e = _hot_ptr.get(id(a))
-    if e is None or e[0] is not a or e[2] is not ty:
+    of a 0.11 ms frame --, a look-up 0.2 us. Keyed by the array object through a weak reference (the cache keeps no scan alive, and a
+    recycled id() cannot alias: the entry's referent must be this very object); entries are dropped when their array dies and by
+    Handle.host_free for page-locked buffers. cache=False for temporaries the wrapper made itself (ascontiguousarray copies)."""
+    if not cache:
+        return a.ctypes.data_as(C.POINTER(ty))
+    k = id(a)
+    e = _hot_ptr.get(k)
+    if e is None or e[0]() is not a or e[2] is not ty:
+        ptr = a.ctypes.data_as(C.POINTER(ty))
+        try:
+            ref = weakref.ref(a, lambda _r, k=k, d=_hot_ptr: d.pop(k, None))      # (d bound now: module globals are gone at interpreter exit)
+        except TypeError:                      # not weak-referenceable: do not cache
+            return ptr
         if len(_hot_ptr) > 16:
             _hot_ptr.clear()
-        e = (a, a.ctypes.data_as(C.POINTER(ty)), ty)
-        _hot_ptr[id(a)] = e
+        e = (ref, ptr, ty, a.ctypes.data)
+        _hot_ptr[k] = e
     return e[1]
+
+
+def _hot_evict(address):
+    for k in [k for k, e in _hot_ptr.items() if e[3] == address]:
+        _hot_ptr.pop(k, None)
 
 
 def make_config(R_LI, t_LI, Rcl, Pcl, cam, max_iterations=10, laser_point_cov=0.001, img_point_cov=100.0, device=0):
@@ -594,6 +610,7 @@ class Handle:
         return arr
 
     def host_free(self, arr):
+        _hot_evict(arr.ctypes.data)            # a cached pointer into this buffer would dangle
         p = self._pinned.pop(arr.ctypes.data)
         self._chk(self.L.fl_host_free(self.h, C.c_void_p(p)), "fl_host_free")
 
@@ -938,19 +955,22 @@ def _knn_methods():
         if body is None:
             self._chk(self.L.fl_lio_frame18_dev(self.h, C.byref(state), None, 0, C.byref(info)), "fl_lio_frame18_dev")
             return info
-        if not (isinstance(body, np.ndarray) and body.dtype == np.float32 and body.flags["C_CONTIGUOUS"]):
+        own = isinstance(body, np.ndarray) and body.dtype == np.float32 and body.flags["C_CONTIGUOUS"]
+        if not own:
             body = np.ascontiguousarray(body, dtype=np.float32)
-        self._chk(self.L.fl_lio_frame18_dev(self.h, C.byref(state), _p_hot(body, C.c_float), body.shape[0], C.byref(info)),
+        self._chk(self.L.fl_lio_frame18_dev(self.h, C.byref(state), _p_hot(body, C.c_float, own), body.shape[0], C.byref(info)),
                   "fl_lio_frame18_dev")
         return info
 
     def ikfom_update_iterated_dev(self, x23, P, body, R, limit=None):
-        if not (isinstance(body, np.ndarray) and body.dtype == np.float32 and body.flags["C_CONTIGUOUS"]):
+        own = isinstance(body, np.ndarray) and body.dtype == np.float32 and body.flags["C_CONTIGUOUS"]
+        if not own:
             body = np.ascontiguousarray(body, dtype=np.float32)
+        own_l = limit is None
         limit = _DEFAULT_LIMIT23 if limit is None else np.ascontiguousarray(limit, dtype=np.float64)
         info = IterInfo()
-        self._chk(self.L.fl_ikfom_update_iterated_dev(self.h, C.byref(x23), _p(P, C.c_double), _p_hot(body, C.c_float), body.shape[0], R,
-                                                      _p_hot(limit, C.c_double), C.byref(info)), "fl_ikfom_update_iterated_dev")
+        self._chk(self.L.fl_ikfom_update_iterated_dev(self.h, C.byref(x23), _p(P, C.c_double), _p_hot(body, C.c_float, own), body.shape[0], R,
+                                                      _p_hot(limit, C.c_double, own_l), C.byref(info)), "fl_ikfom_update_iterated_dev")
         return info
 
     for f in (map_set_points, map_clear, map_add_points, map_delete_boxes, map_get_points, lio_search18, ikfom_search, lio_frame18_dev, ikfom_update_iterated_dev,

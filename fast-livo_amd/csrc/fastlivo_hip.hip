@@ -474,6 +474,8 @@ int32_t fl_host_free(fl_handle h, void *p)
 int32_t fl_set_option(fl_handle h, int32_t option, int32_t value)
 {
     if (!h) return fail_arg(nullptr, "null handle");
+    HIPCHK(h, hipSetDevice(h->cfg.device));            // (the record memsets below go to this handle's stream)
+    std::lock_guard<std::mutex> lk(g_mp_mu);           // mp_reserve of other threads reads opt_multipass / mp_capacity
     switch (option) {
     case FL_OPT_MULTIPASS: h->opt_multipass = value != 0; break;
     case FL_OPT_MAX_PRODUCERS:
@@ -782,7 +784,9 @@ static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_sta
     D->xchg_epoch = h->d_xepoch;
     D->xchg_rank = h->xchg_rank;
     D->xchg_world = h->xchg_world;
-    if (publish && (h->opt_mailbox & (vio ? 1 : 2))) {      // frame drivers: the frame's last kernel publishes the block (read_info18 polls)
+    // frame drivers: the frame's last kernel publishes the block (read_info18 polls). Not for a sharded handle: its chain waits for
+    // peers (seconds under FL_XCHG_SPIN_LIMIT if one is late) and the calling thread would spin on the word all that time
+    if (publish && (h->opt_mailbox & (vio ? 1 : 2)) && h->xchg_world <= 1) {
         D->pub_flag = h->d_pub; D->pub_dst = h->d_hdev; D->pub_seq = ++h->pub_seq;
     }
     // leave_in_mirror (fl_lio_frame18_dev, prepare_in_search): no copy command -- the frame's first search kernel fetches the block
@@ -813,12 +817,14 @@ int32_t fl_lio_begin18(fl_handle h, const fl_state18 *state, const fl_state18 *p
 // the stream ran dry without the word (abandoned chain: nothing behind the abandoned pass ran) -- the caller reads the block back.
 static bool wait_published(fl_handle h, unsigned long long seq)
 {
+    // Spin budget: a frame is 0.1-0.3 ms; past 1 ms the chain is slow for a reason (a large scan, another client on the device, a
+    // time-out being served) and the thread blocks in the runtime instead of burning a core.
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned n = 1;; n++) {
         if (__atomic_load_n(h->h_pub, __ATOMIC_ACQUIRE) == seq) return true;
-        if ((n & 1023u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) {
-            // well past a frame: look at the stream now and then (a query costs microseconds)
-            if (hipStreamQuery(h->stream) != hipErrorNotReady) return __atomic_load_n(h->h_pub, __ATOMIC_ACQUIRE) == seq;
+        if ((n & 1023u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1000)) {
+            if (hipStreamSynchronize(h->stream) != hipSuccess) return false;
+            return __atomic_load_n(h->h_pub, __ATOMIC_ACQUIRE) == seq;
         }
 #if defined(__x86_64__)
         __builtin_ia32_pause();

@@ -204,7 +204,12 @@ __device__ __forceinline__ void fl_publish_state(FlDev18 *__restrict__ D)
     for (int i = threadIdx.x; i < WORDS; i += blockDim.x) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // one-shot: a later kernel over this block that no begin preceded (fl_lio_finish18 behind a frame driver) must not publish
+        // again -- the host may be filling the mirror for the next frame by then (the copy above already carries the live value)
+        D->pub_flag = nullptr;
+    }
 }
 
 // ---- instrumentation: compiled ONLY into the -DFL_INSTRUMENT build (libfastlivo_hip_debug.so, include/fastlivo_hip_debug.h).
@@ -378,6 +383,10 @@ __device__ __forceinline__ double load_wt(const double *p)
 
 typedef unsigned int fl_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned int fl_u2 __attribute__((ext_vector_type(2)));
+// the same vectors at DWORD alignment: the VIO tap rows are fetched with 8- / 12- / 16-byte loads from addresses rounded down to 4
+// bytes (global_load_dwordxN needs no more); loading through the naturally aligned types would be undefined behaviour
+typedef unsigned int fl_u2_dw __attribute__((ext_vector_type(2), aligned(4)));
+typedef unsigned int fl_u4_dw __attribute__((ext_vector_type(4), aligned(4)));
 
 // Phase timestamps for tools/kstamps.py (FL_INSTRUMENT build only): slot i of workgroup 0 and of the last workgroup, under the
 // FL_ITER_STAMP flag. The release build ignores the flag.

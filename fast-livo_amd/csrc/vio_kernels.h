@@ -412,7 +412,7 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
             for (int m2 = 0; m2 < 10; m2++) {
                 const uint8_t *a = q + m2 * W;
                 const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(a) & 3u);
-                const fl_u2 w2 = *reinterpret_cast<const fl_u2 *>(reinterpret_cast<uintptr_t>(a) & ~(uintptr_t)3);   // (the frame buffer is padded: api_vio.inc)
+                const fl_u2 w2 = *reinterpret_cast<const fl_u2_dw *>(reinterpret_cast<uintptr_t>(a) & ~(uintptr_t)3);   // (dword-aligned 8-byte load; the frame buffer is padded: api_vio.inc)
                 rowv[m2] = __builtin_amdgcn_alignbyte(w2.y, w2.x, sh);
             }
 #pragma unroll
@@ -430,9 +430,10 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
 #pragma unroll
             for (int m2 = 0; m2 < 10; m2++) {
                 typedef unsigned int fl_u3 __attribute__((ext_vector_type(3)));
+                typedef unsigned int fl_u3_dw __attribute__((ext_vector_type(3), aligned(4)));
                 const uint8_t *a = q + m2 * 2 * W;
                 const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(a) & 3u);
-                const fl_u3 w3 = *reinterpret_cast<const fl_u3 *>(reinterpret_cast<uintptr_t>(a) & ~(uintptr_t)3);
+                const fl_u3 w3 = *reinterpret_cast<const fl_u3_dw *>(reinterpret_cast<uintptr_t>(a) & ~(uintptr_t)3);
                 lo[m2] = __builtin_amdgcn_alignbyte(w3.y, w3.x, sh);
                 hi[m2] = __builtin_amdgcn_alignbyte(w3.z, w3.y, sh);
             }
@@ -453,7 +454,7 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
             for (int m2 = 0; m2 < 10; m2++) {
                 const uint8_t *a = q + m2 * 4 * W;
                 const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(a) & 3u);
-                const fl_u4 w4 = *reinterpret_cast<const fl_u4 *>(reinterpret_cast<uintptr_t>(a) & ~(uintptr_t)3);
+                const fl_u4 w4 = *reinterpret_cast<const fl_u4_dw *>(reinterpret_cast<uintptr_t>(a) & ~(uintptr_t)3);
                 tv[m2][0] = __builtin_amdgcn_alignbyte(w4.y, w4.x, sh); tv[m2][1] = __builtin_amdgcn_alignbyte(w4.z, w4.y, sh);
                 tv[m2][2] = __builtin_amdgcn_alignbyte(w4.w, w4.z, sh); tv[m2][3] = w4.w >> (8 * sh);
             }

@@ -65,3 +65,39 @@ def test_border_patches_are_clamped_not_faulting(gpu_lib, scene):
     assert np.isfinite(h.vio_get_errors(vf.m)).all()
     assert all(infos[lv].iterations >= 1 for lv in (0, 1, 2))
     h.close()
+
+
+def test_mailbox_is_one_shot(gpu_lib, oracle_lib, scene):
+    """the result mailbox of a frame driver (fl_publish_state) must serve ONE frame. A covariance-update kernel launched
+    later without a new begin (fl_lio_finish18(h, NULL) behind fl_lio_frame18_dev) must not copy the block into the page-locked
+    mirror again -- the host may already be filling the mirror for the next frame. Frame, stray finish, frame: the second frame's
+    result equals a fresh handle's (and the oracle's)."""
+    import ctypes as C
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+
+    def knn(w):
+        nb, _, va, _ = orc.knn5_bruteforce(scene.map_xyz, w)
+        return nb, va
+    frames = [synth.make_lio_frame(6000, scene=scene, point_seed=300 + k) for k in range(3)]
+    h = capi.Handle(capi.config_from_frames(frames[0], max_iterations=4))
+    h.map_set_points(scene.map_xyz, 0.5)
+    scan = h.host_alloc(frames[0].body_xyz.shape, np.float32)      # the mirror-fed path: the search kernel reads the state from the mirror
+    for rep in range(20):
+        for fr in frames:
+            scan[:] = fr.body_xyz
+            xg = capi.state18_from_frame(fr)
+            info = h.lio_frame18_dev(xg, scan)
+            assert info.status == 0 and info.stop == 1
+            # a stray covariance update without begin, not synchronised: with a live mailbox it would republish asynchronously
+            assert h.L.fl_lio_finish18(h.h, None) == 0
+            if rep == 0:
+                xo = orc.state18_from_frame(fr)
+                ro = orc.lio18_frame(xo, fr.body_xyz, fr.R_LI, fr.t_LI, fr.laser_point_cov, 4, knn)
+                assert info.iterations == ro["out"].iterations
+                assert np.abs(xg.vec() - xo.vec()).max() <= 1e-9
+                fr._expect = xg.vec().copy()
+            else:
+                assert np.array_equal(xg.vec(), fr._expect), (rep,)
+    h.host_free(scan)
+    h.close()
