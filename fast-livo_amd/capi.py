@@ -208,6 +208,8 @@ SYMBOLS = {
     "fl_vio_iterate": (C.c_int32, [_H, C.c_int32, C.c_int32, C.c_int32, C.POINTER(IterInfo)]),
     "fl_vio_accumulate": (C.c_int32, [_H, C.c_int32, C.c_void_p]),
     "fl_vio_solve": (C.c_int32, [_H, C.c_void_p, C.c_int32, C.POINTER(IterInfo)]),
+    "fl_vio_errors_chunk": (C.c_int32, [_H, C.c_void_p, C.c_int32]),
+    "fl_vio_solve_exact": (C.c_int32, [_H, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(IterInfo)]),
     "fl_vio_get_state18": (C.c_int32, [_H, C.POINTER(State18)]),
     "fl_ikfom_begin": (C.c_int32, [_H, C.POINTER(State23), _dp, _dp]),
     "fl_h_share_model_sums": (C.c_int32, [_H, C.POINTER(State23), _dp, _dp, _i32p, _dp]),
@@ -748,6 +750,16 @@ class Handle:
         info = IterInfo()
         self._chk(self.L.fl_vio_solve(self.h, C.c_void_p(d_sums_ptr), flags, C.byref(info) if want_info else None),
                   "fl_vio_solve")
+        return info
+
+    def vio_errors_chunk(self, d_chunk_ptr, stride):
+        """this rank's per-patch floats as one chunk of the all-gather behind the exact accept test (device pointer, stride floats)"""
+        self._chk(self.L.fl_vio_errors_chunk(self.h, C.c_void_p(d_chunk_ptr), int(stride)), "fl_vio_errors_chunk")
+
+    def vio_solve_exact(self, d_sums_ptr, flags, d_all_chunks_ptr, stride, world, want_info=False):
+        info = IterInfo()
+        self._chk(self.L.fl_vio_solve_exact(self.h, C.c_void_p(d_sums_ptr), flags, C.c_void_p(d_all_chunks_ptr), int(stride), int(world),
+                                            C.byref(info) if want_info else None), "fl_vio_solve_exact")
         return info
 
     def vio_get_state18(self):

@@ -105,6 +105,8 @@ struct fl_context {
     int xchg_alloc_world = 0, xchg_world = 1, xchg_rank = 0;
     // VIO
     FlVioConst *d_vc = nullptr;
+    float *d_flat = nullptr;            // all-gathered per-patch floats of the sharded VIO pass (api_comm.inc), world + 1 chunks
+    size_t flat_cap = 0;
     FlVioConst h_vc;
     uint8_t *d_img = nullptr;
     size_t cap_img = 0;
@@ -393,7 +395,7 @@ int32_t fl_destroy(fl_handle h)
     if (!h) return FL_OK;
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
-    hipFree(h->d_body); hipFree(h->d_nbr); hipFree(h->d_world); hipFree(h->d_valid); hipFree(h->d_sel); hipFree(h->d_gate); hipFree(h->d_knn_ids);
+    hipFree(h->d_body); hipFree(h->d_nbr); hipFree(h->d_world); hipFree(h->d_valid); hipFree(h->d_sel); hipFree(h->d_gate); hipFree(h->d_knn_ids); hipFree(h->d_flat);
     hipFree(h->d_plane); hipFree(h->d_normvec); hipFree(h->d_dev); hipFree(h->d_dev23); hipFree(h->d_records);
     hipFree(h->d_epoch); hipFree(h->d_sums_tmp); hipFree(h->d_bcast); hipFree(h->d_vc); hipFree(h->d_img); hipFree(h->d_ref);
     hipFree(h->d_errors); hipFree(h->d_err_words); hipFree(h->d_pos); hipFree(h->d_slevel);

@@ -384,8 +384,11 @@ __global__ __launch_bounds__(FL_LIO_NT, 2) void lio18_multipass_kernel(const flo
 
 // -------------------------------------------------------------------------------------------- K3
 // Solve from an externally reduced record (sharded form). vio != 0 selects the VIO epilogue.
+// flat != nullptr (VIO): the ranks' all-gathered per-patch floats (FlVioExact::flat) -- the accept test is then decided on the
+// reference's float running sum over all patches, as in the fused and in-kernel-exchange forms.
 __global__ __launch_bounds__(FL_BLOCK) void eskf18_solve_kernel(FlDev18 *__restrict__ D, const double *__restrict__ sums_in,
-                                                               int vio, int flags, const FlVioConst *__restrict__ VC)
+                                                               int vio, int flags, const FlVioConst *__restrict__ VC,
+                                                               const float *__restrict__ flat = nullptr, int flat_stride = 0, int flat_world = 0)
 {
     if (D->status & FL_NUM_TIMEOUT) return;
     if (!(flags & FL_ITER_FORCE) && (D->stop || (!vio && D->need_search && D->searched_at != D->iters_run))) return;
@@ -395,8 +398,13 @@ __global__ __launch_bounds__(FL_BLOCK) void eskf18_solve_kernel(FlDev18 *__restr
     eskf18_prefetch(D, s_solve);
     FlSolveRegs G;
     eskf18_load_regs(s_solve, G, vio ? VC : nullptr);
-    if (vio) eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, 0, nullptr, 0u, FlVioExact{}, VC);   // incl. the derived camera pose
-    else eskf18_solve_block<FL_EPI_LIO>(D, s_sums, s_solve, G, 0);
+    if (vio) {
+        __shared__ __attribute__((aligned(16))) float s_ex[FL_EXACT_LDS];
+        FlVioExact ex{};
+        ex.words = nullptr; ex.scratch = s_ex; ex.enabled = !(flags & FL_ITER_FORCE);
+        ex.flat = flat; ex.flat_stride = flat_stride; ex.world = flat_world;
+        eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, 0, nullptr, 0u, ex, VC);   // incl. the derived camera pose
+    } else eskf18_solve_block<FL_EPI_LIO>(D, s_sums, s_solve, G, 0);
 }
 
 // -------------------------------------------------------------------------------------------- K4

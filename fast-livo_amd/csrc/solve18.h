@@ -71,6 +71,12 @@ struct FlVioExact {
     unsigned long long *const *peer;   // everybody's buffers
     int rank, world;
     unsigned xe;                       // exchange epoch of this pass = tag of the mail
+    // RCCL / torch.distributed form (fl_vio_iterate_sharded, fl_vio_solve_exact): the ranks have all-gathered their per-patch floats,
+    // `flat` holds `world` chunks of `flat_stride` floats in rank order, chunk = [patch count of the rank (int bits), its
+    // patch_error floats in patch order, zero padding]. Every rank then runs the reference's chain over ALL patches itself, on every
+    // pass -- the accept test is the reference's float comparison in this form too.
+    const float *flat = nullptr;
+    int flat_stride = 0;
 };
 // single rank: the auditor workgroup's ring of per-pass totals sits behind the words (vio_kernels.h vio_audit_pass), slot = epoch & 15
 // total of pass `tag` out of the auditor's ring (thread 0); false when it does not arrive within `spins` polls or the auditor gave
@@ -152,6 +158,33 @@ __device__ __forceinline__ float vio_exact_sum_inl(const unsigned long long *w, 
 __device__ __attribute__((noinline)) float vio_exact_sum(const unsigned long long *w, int m, unsigned tag, float *scr, int *timeout_flag, float init = 0.0f)
 {
     return vio_exact_sum_inl(w, m, tag, scr, timeout_flag, init);
+}
+
+// The running sum over the all-gathered per-patch floats of all ranks (FlVioExact::flat), rank after rank in patch order: the m
+// dependent float additions of lidar_selection.cpp:849-857, bit for bit (exact_chain.h). Whole workgroup (256 threads), barriers
+// inside, the result in every thread. Not inlined: its staging and the chain stay out of the solve's register allocation.
+__device__ __attribute__((noinline)) float vio_exact_flat_sum(const float *__restrict__ flat, int stride, int world, float *scr /* LDS, FL_EXACT_LDS */)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    float f = 0.0f;
+    for (int r = 0; r < world; r++) {
+        const float *seg = flat + (size_t)r * stride;
+        int m = __float_as_int(seg[0]);
+        m = m < 0 ? 0 : (m > stride - 1 ? stride - 1 : m);
+        for (int base = 0; base < m; base += FL_EXACT_CHUNK) {
+            const int cnt = min(FL_EXACT_CHUNK, m - base);
+            bool bad = false;
+            for (int k = tid; k < cnt; k += nt) {
+                const float e = seg[1 + base + k];
+                bad |= !(e >= 0.0f);
+                scr[k] = e;
+            }
+            for (int k = cnt + tid; k < cnt + FL_CHAIN_STEP; k += nt) scr[k] = 0.0f;
+            const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;
+            f = fl_chain_f32_block(scr, cnt, f, any_bad);       // (ends with a barrier; the result is in every thread)
+        }
+    }
+    return f;
 }
 
 // The running sum over the patches of ALL ranks (see FlVioExact): thread 0 waits for the carry of rank-1, the workgroup adds this
@@ -511,7 +544,8 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
         // (vio_kernels.h vio_audit_pass; exact_chain.h: bit-identical to the m dependent additions, lane-parallel) and the solver reads
         // its ring; if the auditor is not there yet or gave up, the workgroup replays the chain itself (vio_exact_decide).
         // With the patches spread over ranks (in-kernel exchange) the chain runs through the ranks (vio_exact_chain); without
-        // the per-patch words (solve kernel of the RCCL form: `ex.words` == nullptr) bit 16 means "may differ".
+        // the per-patch words AND without the all-gathered floats (`ex.flat`, the RCCL / torch form's exact path: vio_exact_flat_sum on every
+        // pass) -- i.e. only fl_vio_solve without the gather -- bit 16 means "may differ".
         // Every thread evaluates the trigger itself from pass-invariant inputs (G.last_error was read before the gather), so the
         // common case needs no barrier.
         bool can_replay = ex.words != nullptr && ex.enabled;     // (by value: a nullable pointer to it kept the struct in scratch)
@@ -530,6 +564,14 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
         if (slow) {      // uniform over the workgroup
             vio_exact_decide(ex, &L, (float)s_sums[FL_S_NEFF]);
             eskf18_load_regs(L, G, VC);      // the operands come back from LDS: nothing of them has to survive the call in registers
+        }
+        if (ex.flat != nullptr && ex.enabled) {      // all-gathered per-patch floats: the reference's chain on EVERY pass (uniform)
+            __syncthreads();
+            const float fc = vio_exact_flat_sum(ex.flat, ex.flat_stride, ex.world, ex.scratch);
+            if (tid == 0) { L.exact_cur = fc / n_meas; L.exact_timeout = 0; }
+            __syncthreads();
+            slow = true;                     // every accepted pass stores an exact last_error: last_exact_valid stays 1 from the begin on
+            eskf18_load_regs(L, G, VC);
         }
     }
     if (wave >= 2) return;

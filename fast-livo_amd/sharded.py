@@ -32,10 +32,33 @@ class ShardedPass:
 
     def step(self):
         rec = self.backend.accumulate()
-        if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
+        live = self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1
+        if live:
             self.dist.all_reduce(rec)          # default op = SUM
-        self.backend.solve(rec)
+        # VIO: the accept test is the reference's FLOAT running sum over the patches in order (lidar_selection.cpp:849-861). A backend
+        # that exports its per-patch floats (`chunk()`: [count, floats, padding], equal size on every rank) gets them all-gathered
+        # in rank order, and its solve replays the chain over all ranks' patches itself -- bit-identical decisions on all ranks.
+        chunk = self.backend.chunk() if hasattr(self.backend, "chunk") else None
+        if chunk is not None:
+            world = self.dist.get_world_size() if live else 1
+            gathered = self.backend.gather_buffer(world)
+            if live:
+                self.dist.all_gather_into_tensor(gathered, chunk)
+            else:
+                gathered.copy_(chunk)
+            self.backend.solve(rec, gathered, world)
+        else:
+            self.backend.solve(rec)
         return rec
+
+
+def agree_stride(count, dist=None, device="cpu"):
+    """Chunk size of the per-patch gather: the largest patch count of any rank + 1 (one max all-reduce, once per patch set)."""
+    import torch
+    t = torch.tensor([int(count) + 1], dtype=torch.int64, device=device)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
 
 
 class GpuLioBackend:
@@ -57,19 +80,39 @@ class GpuLioBackend:
 
 
 class GpuVioBackend:
-    """capi.Handle-backed VIO pass (one pyramid level) for ShardedPass."""
+    """capi.Handle-backed VIO pass (one pyramid level) for ShardedPass. stride (agree_stride over the ranks' patch counts): the pass
+    decides its accept test on the reference's float chain over all ranks' patches (fl_vio_solve_exact); None: the fp64 comparison
+    of fl_vio_solve (forced benchmark passes, which take no decision)."""
 
-    def __init__(self, handle, level, flags):
+    def __init__(self, handle, level, flags, stride=None):
         import torch
         from . import capi
         self.h = handle
         self.level = level
         self.flags = flags
+        self.stride = stride
         self.buf = torch.zeros(capi.FL_SUMS18, dtype=torch.float64, device="cuda")
+        self._chunk = torch.zeros(stride, dtype=torch.float32, device="cuda") if stride else None
+        self._all = None
 
     def accumulate(self):
         self.h.vio_accumulate(self.level, self.buf.data_ptr())
         return self.buf
 
-    def solve(self, rec):
-        self.h.vio_solve(rec.data_ptr(), self.flags)
+    def chunk(self):
+        if self._chunk is None:
+            return None
+        self.h.vio_errors_chunk(self._chunk.data_ptr(), self.stride)
+        return self._chunk
+
+    def gather_buffer(self, world):
+        import torch
+        if self._all is None or self._all.numel() != world * self.stride:
+            self._all = torch.zeros(world * self.stride, dtype=torch.float32, device="cuda")
+        return self._all
+
+    def solve(self, rec, gathered=None, world=1):
+        if gathered is None:
+            self.h.vio_solve(rec.data_ptr(), self.flags)
+        else:
+            self.h.vio_solve_exact(rec.data_ptr(), self.flags, gathered.data_ptr(), self.stride, world)

@@ -40,9 +40,10 @@ extern "C" {
 #define FL_NUM_FRAGILE 16     /* VIO: an accept test `error <= last_error` (lidar_selection.cpp:859) fell inside the rounding noise of the
                                  reference's float running sum of res^2 and was decided by replaying that sum in the reference's own
                                  arithmetic (informational; also with the patches spread over ranks by fl_p2p_*: the sum runs through the
-                                 ranks). Only where the per-patch errors are not available -- the collective forms fl_vio_solve /
-                                 fl_vio_iterate_sharded -- or under FL_ITER_FORCE it means "the reference may take the other
-                                 branch here". */
+                                 ranks; in the collective forms fl_vio_iterate_sharded / fl_vio_solve_exact every rank replays it over the
+                                 all-gathered per-patch floats on every pass). Only where the per-patch errors of the other ranks are
+                                 not available -- fl_vio_solve without the gather -- or under FL_ITER_FORCE it means "the reference may
+                                 take the other branch here". */
 
 #define FL_DIM18 18           /* DIM_STATE, include/common_lib.h:34 */
 #define FL_DIM23 23           /* state_ikfom::DOF, include/use-ikfom.hpp:12-21 */
@@ -251,6 +252,15 @@ int32_t fl_vio_get_errors(fl_handle h, float *errors);
 int32_t fl_vio_iterate(fl_handle h, int32_t level, int32_t count, int32_t flags, fl_iter_info *info);
 int32_t fl_vio_accumulate(fl_handle h, int32_t level, double *d_sums);
 int32_t fl_vio_solve(fl_handle h, const double *d_sums, int32_t flags, fl_iter_info *info);
+/* The collective form with the reference's accept test (lidar_selection.cpp:849-861: `error` is a FLOAT running sum over the patches
+ * in order): after fl_vio_accumulate every rank exports its per-patch floats as one chunk of `stride` floats
+ * [patch count (int bits), patch_error[0..m-1], zero padding] (stride >= the largest patch count of any rank + 1, equal on all
+ * ranks), the caller all-gathers the chunks in rank order with its transport (and all-reduces the sums), and fl_vio_solve_exact
+ * decides every pass on the float chain over ALL patches, replayed on every rank (bit-identical results on all ranks, equal to the
+ * single-GPU and to the in-kernel-exchange forms). fl_vio_iterate_sharded does exactly this with its RCCL communicator. */
+int32_t fl_vio_errors_chunk(fl_handle h, float *d_chunk /* device, stride floats */, int32_t stride);
+int32_t fl_vio_solve_exact(fl_handle h, const double *d_sums, int32_t flags, const float *d_all_chunks /* device, world x stride */,
+                           int32_t stride, int32_t world, fl_iter_info *info);
 int32_t fl_vio_get_state18(fl_handle h, fl_state18 *state_out);
 
 /* ------------------------------------------------------------------------------------------------
@@ -485,8 +495,9 @@ int32_t fl_ikfom_iterate_sharded(fl_handle h, int32_t count, int32_t flags, fl_i
  * same sequence of passes (it is a collective). State, covariance, configuration replicated; map / image replicated or sharded
  * by the caller. The VIO accept test stays the reference's: on the fragile passes the float running sum over the patches is handed
  * from rank to rank (rank r continues from the float rank r-1 ended with; the last rank sends the total back), so accept / revert
- * sequences equal the single-GPU ones. (Only the collective forms fl_vio_solve / fl_vio_iterate_sharded, which never see the other
- * ranks' patches, keep the fp64 comparison: FL_NUM_FRAGILE = "may differ" there.)
+ * sequences equal the single-GPU ones. (The collective forms fl_vio_iterate_sharded / fl_vio_solve_exact all-gather the per-patch
+ * floats and replay the chain on every rank: the same decisions. Only fl_vio_solve without the gather keeps the fp64 comparison:
+ * FL_NUM_FRAGILE = "may differ" there.)
  *   separate processes:  fl_p2p_export on every rank -> exchange the 64-byte handles (any transport) -> fl_p2p_connect
  *   one process:         fl_p2p_connect_local(h, rank, world, all_handles) on every handle
  * Connect before fl_*_begin of the frame, and put a barrier of the caller's transport between the connects and the first pass

@@ -42,9 +42,70 @@ class EmulLioBackend:
                                  p(s, C.c_double), C.c_double(1.0), p(G6, C.c_double), p(self.delta, C.c_double))
 
 
+class EmulVioChunkBackend:
+    """The VIO side of ShardedPass's protocol (accumulate / chunk / gather_buffer / solve(rec, gathered, world)) around the oracle's
+    per-patch errors: checks what the orchestration must deliver to fl_vio_solve_exact -- every rank's chunk, in rank order, at the
+    agreed stride -- and takes the accept decision on the reference's float chain over the gathered floats."""
+
+    def __init__(self, errors_mine, stride, errors_all, n_meas):
+        self.e, self.stride, self.all, self.n = errors_mine, stride, errors_all, n_meas
+        self.decision = None
+        self._all = None
+
+    def accumulate(self):
+        rec = np.zeros(32)
+        rec[28] = float(np.sum(self.e.astype(np.float64)))
+        rec[27] = 64.0 * len(self.e)
+        return torch.from_numpy(rec)
+
+    def chunk(self):
+        c = np.zeros(self.stride, np.float32)
+        c[:1].view(np.int32)[0] = len(self.e)
+        c[1:1 + len(self.e)] = self.e
+        return torch.from_numpy(c)
+
+    def gather_buffer(self, world):
+        if self._all is None:
+            self._all = torch.zeros(world * self.stride, dtype=torch.float32)
+        return self._all
+
+    def solve(self, rec, gathered, world):
+        g = gathered.numpy()
+        parts = []
+        for r in range(world):
+            seg = g[r * self.stride:(r + 1) * self.stride]
+            m = int(seg[:1].view(np.int32)[0])
+            parts.append(seg[1:1 + m])
+        flat = np.concatenate(parts)
+        assert np.array_equal(flat.view(np.uint32), self.all.view(np.uint32)), "gathered per-patch floats are not the frame's, in order"
+        f = np.float32(0.0)
+        for e in flat:                       # lidar_selection.cpp:851-852: error += patch_error, float
+            f = np.float32(f + e)
+        assert int(rec[27].item()) == self.n
+        self.decision = np.float32(f / np.float32(self.n))
+
+
+def vio_part(rank, world):
+    """the chunk protocol of the exact VIO accept test on gloo (sharded.py: agree_stride, all_gather_into_tensor in rank order)"""
+    from fast_livo_amd.sharded import agree_stride
+    scene = synth.make_scene()
+    fr = synth.make_lio_frame(400, scene=scene)
+    vf = synth.make_vio_frame(301, fr)               # odd: the ranks hold different patch counts
+    vf.max_iterations = 1
+    x = orc.state18_from_frame(fr)
+    r = orc.vio_update_state(vf, x, x.copy(), 1e10, 0)
+    lo, hi = shard_range(vf.m, rank, world)
+    stride = agree_stride(hi - lo, dist)
+    assert stride == max(shard_range(vf.m, q, world)[1] - shard_range(vf.m, q, world)[0] for q in range(world)) + 1
+    be = EmulVioChunkBackend(r["errors"][lo:hi].copy(), stride, r["errors"], 64 * vf.m)
+    ShardedPass(be, dist).step()
+    assert be.decision == np.float32(r["error"]), (be.decision, r["error"])       # the reference's `error`, bit for bit, on every rank
+
+
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    vio_part(rank, world)
     E = C.CDLL(os.path.join(ROOT, "tests", "host_emul", "libemul.so"))
     scene = synth.make_scene()
     n = 6000
