@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--only", choices=SECTIONS, default=None, help="run ONE extra section alone and print it (rocprofv3 runs)")
     ap.add_argument("--at-scale-points", type=int, nargs="*", default=None, help="sizes of the at_scale section (default 8 M and 32 M)")
     ap.add_argument("--vio-sweep-patches", type=int, nargs="*", default=None, help="sizes of the vio_sweep section (default 2 k, 200 k, 1 M)")
+    ap.add_argument("--vio-sweep-distinct", action="store_true", help="vio_sweep: a distinct position for EVERY patch (no cap; host generation ~36 s per million patches)")
     return ap.parse_args()
 
 
@@ -166,50 +167,80 @@ def lio_pass_at(capi, synth, scene, cfg, x0, n):
     torch.cuda.synchronize()
     us = ev0.elapsed_time(ev1) * 1e3 / K
     gbs = LIO_BYTES_PER_POINT * n / (us * 1e-6) / 1e9
+    # what the timed passes did (every at-scale figure stands on a checked pass): status bits, effective points, a finite state
+    li = h.lio_iterate18(0, capi.FL_ITER_FORCE)
+    check = {"status": int(li.status), "effct_feat_num": int(li.effct_feat_num), "points": n,
+             "state_finite": bool(np.isfinite(h.lio_get_state18().vec()).all())}
     h.close()
-    return us, gbs
+    if (check["status"] & ~16) != 0 or not check["state_finite"] or check["effct_feat_num"] < n // 2:
+        raise SystemExit(f"[bench] at-scale LIO pass over {n} points failed its check: {check}")
+    return us, gbs, check
 
 
 def section_at_scale(capi, synth, scene, cfg, x0):
     out = []
     for n in AT_SCALE_POINTS:
-        us, gbs = lio_pass_at(capi, synth, scene, cfg, x0, n)
+        us, gbs, check = lio_pass_at(capi, synth, scene, cfg, x0, n)
         out.append({"kernel": "lio18_pass_kernel", "points": n, "pass_us": us, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                    "algorithmic_bytes": LIO_BYTES_PER_POINT * n,
+                    "algorithmic_bytes": LIO_BYTES_PER_POINT * n, "check": check,
                     "note": "8 M points x 32 B read = 256 MB = the size of the Infinity Cache: part of it stays on chip between the passes of a "
                             "frame" if n <= 8000000 else "streams from HBM (32 B read per point and pass)"})
     return out
 
 
-def section_vio_sweep(capi, synth, fr, vf, cfg, x0):
-    """One forced VIO pass (level 0, one launch per pass) over m patches: m = 2 k (BASELINE), 200 k, 1 M (the 2 k patch set tiled)."""
+VIO_SWEEP_DISTINCT_CAP = 250000     # default run: distinct patch positions up to here (host generation 36 s per million), tiled beyond
+
+
+def section_vio_sweep(capi, synth, fr, vf, cfg, x0, distinct_cap=None):
+    """One forced VIO pass (level 0, one launch per pass) over m patches: m = 2 k (BASELINE), 200 k, 1 M. Two patch sets per size:
+    `tiled` = the frame's 2 k patch set repeated (every patch position occurs m / 2000 times) and `distinct` = m patches at m
+    different sub-pixel positions over the image (generated up to `distinct_cap` patches, that set tiled beyond -- --vio-sweep-distinct
+    lifts the cap). The image itself (0.3 MB) is L2-resident either way; what differs is the spread of the tap addresses."""
     import torch
+    distinct_cap = VIO_SWEEP_DISTINCT_CAP if distinct_cap is None else distinct_cap
     out = []
     for m in VIO_SWEEP:
-        reps = (m + vf.m - 1) // vf.m
-        ref = np.tile(vf.ref_patch, (reps, 1, 1))[:m]
-        pos = np.tile(vf.pos, (reps, 1))[:m]
-        sl = np.tile(vf.search_level, reps)[:m]
-        h = capi.Handle(cfg)
-        h.set_stream(torch.cuda.current_stream().cuda_stream)
-        h.vio_set_frame(vf.img)
-        h.vio_set_patches(ref, pos, sl)
-        h.vio_begin(x0, x0)
-        K = 100 if m <= 200000 else 20
-        ev0, ev1 = _events(torch)
-        for _ in range(5):
-            h.vio_iterate(VIO_LEVEL, 1, capi.FL_ITER_FORCE, want_info=False)
-        torch.cuda.synchronize()
-        ev0.record()
-        for _ in range(K):
-            h.vio_iterate(VIO_LEVEL, 1, capi.FL_ITER_FORCE, want_info=False)
-        ev1.record()
-        torch.cuda.synchronize()
-        us = ev0.elapsed_time(ev1) * 1e3 / K
-        gbs = VIO_BYTES_PER_PATCH * m / (us * 1e-6) / 1e9
-        out.append({"kernel": "vio_pass_kernel", "patches": m, "pass_us": us, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                    "algorithmic_bytes": VIO_BYTES_PER_PATCH * m, "ns_per_patch": us * 1e3 / m})
-        h.close()
+        row = {"kernel": "vio_pass_kernel", "patches": m, "algorithmic_bytes": VIO_BYTES_PER_PATCH * m}
+        for kind in ("tiled", "distinct"):
+            if kind == "distinct" and m <= vf.m:
+                continue                     # (the 2 k set IS distinct)
+            base = vf if kind == "tiled" else synth.make_vio_frame(min(m, distinct_cap), fr, patch_seed=synth.SEED + 977)
+            reps = (m + base.m - 1) // base.m
+            ref = np.tile(base.ref_patch, (reps, 1, 1))[:m]
+            pos = np.tile(base.pos, (reps, 1))[:m]
+            sl = np.tile(base.search_level, reps)[:m]
+            h = capi.Handle(cfg)
+            h.set_stream(torch.cuda.current_stream().cuda_stream)
+            h.vio_set_frame(vf.img)
+            h.vio_set_patches(ref, pos, sl)
+            del ref
+            h.vio_begin(x0, x0)
+            K = 100 if m <= 200000 else 20
+            ev0, ev1 = _events(torch)
+            for _ in range(5):
+                h.vio_iterate(VIO_LEVEL, 1, capi.FL_ITER_FORCE, want_info=False)
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(K):
+                h.vio_iterate(VIO_LEVEL, 1, capi.FL_ITER_FORCE, want_info=False)
+            ev1.record()
+            torch.cuda.synchronize()
+            us = ev0.elapsed_time(ev1) * 1e3 / K
+            gbs = VIO_BYTES_PER_PATCH * m / (us * 1e-6) / 1e9
+            # every figure stands on a checked pass: status bits, the pixel count of the last pass, a finite state
+            vi = h.vio_iterate(VIO_LEVEL, 0, capi.FL_ITER_FORCE)
+            check = {"status": int(vi.status), "n_meas": int(vi.effct_feat_num), "expected_n_meas": 64 * m,
+                     "state_finite": bool(np.isfinite(h.vio_get_state18().vec()).all())}
+            h.close()
+            if (check["status"] & ~16) != 0 or not check["state_finite"] or check["n_meas"] != 64 * m:
+                raise SystemExit(f"[bench] VIO pass over {m} patches ({kind}) failed its check: {check}")
+            key = "" if kind == "tiled" else "_distinct"
+            row.update({"pass_us" + key: us, "achieved" + key: gbs, "frac" + key: gbs / HBM_PEAK_GBS, "ns_per_patch" + key: us * 1e3 / m,
+                        "check" + key: check})
+            if kind == "distinct":
+                row["distinct_positions"] = int(base.m)
+        row["unit"] = "GB/s"
+        out.append(row)
     return out
 
 
@@ -606,7 +637,7 @@ def main():
 
     if args.only:           # one extra section alone (N = 1): what the rocprofv3 runs behind profiles/ execute
         sec = {"at_scale": lambda: section_at_scale(capi, synth, scene, cfg, x0),
-               "vio_sweep": lambda: section_vio_sweep(capi, synth, fr, vf, cfg, x0),
+               "vio_sweep": lambda: section_vio_sweep(capi, synth, fr, vf, cfg, x0, 1 << 30 if args.vio_sweep_distinct else None),
                "mode23": lambda: section_mode23(capi, synth, scene, fr, cfg, nbr, valid),
                "frame": lambda: section_frame(capi, synth, scene, fr, vf, cfg),
                "restage": lambda: section_restage(capi, synth, fr, cfg, x0, nbr, valid),
@@ -946,7 +977,7 @@ def main():
 def sweep(capi, synth, scene, cfg, x0, fh):
     """Kernel-only effective bandwidth of the LIO pass over a size sweep."""
     for n in (50000, 200000, 1000000, 4000000, 8000000):
-        us, gbs = lio_pass_at(capi, synth, scene, cfg, x0, n)
+        us, gbs, _ = lio_pass_at(capi, synth, scene, cfg, x0, n)
         print(json.dumps({"sweep_points": n, "lio_pass_us": us, "effective_GBps": gbs, "frac_of_8TBps": gbs / HBM_PEAK_GBS}),
               file=fh)
 

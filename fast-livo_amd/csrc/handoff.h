@@ -73,7 +73,11 @@ __device__ __forceinline__ void publish_record(double mine, unsigned epoch, void
     const int tid = threadIdx.x;
     FL_INSTR(if (blockIdx.x == 0 && epoch == g_fl_fault_epoch) return;)      // fault injection (debug build): this record never shows up
     if (tid < NV) {
-        unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
+        // The tag takes the low 6 bits of the mantissa: the partial travels with 46 of its 52 bits. Rounded to nearest (+ half of the
+        // dropped field, carries run into the exponent like any rounding), not truncated -- truncation biased every partial toward
+        // zero by up to 2^-46 and the bias of ~1000 like-signed partials (the diagonal of H^T H at millions of points) adds up
+        // instead of averaging out. (inf becomes NaN, NaN stays NaN: both still fail the finiteness check of the solve.)
+        unsigned long long bits = (unsigned long long)__double_as_longlong(mine) + (unsigned long long)((FL_TAG_MASK + 1u) >> 1);
         bits = (bits & ~(unsigned long long)FL_TAG_MASK) | fl_epoch_tag(epoch);
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(records) + (size_t)blockIdx.x * NV + tid, bits, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);   // sc1 write-through
