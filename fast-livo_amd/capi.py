@@ -83,7 +83,7 @@ class IterInfo(C.Structure):
 class Diagnostics(C.Structure):
     """fl_diagnostics"""
     _fields_ = [("multipass_fallbacks", C.c_int32), ("frames_resumed", C.c_int32), ("multipass_capacity", C.c_int32),
-                ("compute_units", C.c_int32)]
+                ("compute_units", C.c_int32), ("demotions", C.c_int32), ("demoted_calls_left", C.c_int32)]
 
 
 class FrameTiming(C.Structure):
@@ -253,6 +253,7 @@ DEBUG_SYMBOLS = {
     "fl_debug_drop_record": (C.c_int32, [_H, C.c_int32]),
 }
 FL_OPT_MULTIPASS, FL_OPT_MAX_PRODUCERS, FL_OPT_IK_PRODUCERS, FL_OPT_MP_CAPACITY, FL_OPT_VIO_WHOLE_CU, FL_OPT_MAILBOX, FL_OPT_SCAN_PULL, FL_OPT_INCR_SEARCH = 1, 2, 3, 4, 5, 6, 7, 8
+FL_OPT_DEMOTE_AFTER, FL_OPT_DEMOTE_CALLS = 9, 10
 DEBUG_LIB_PATH = os.path.join(PKG_DIR, "libfastlivo_hip_debug.so")
 
 _lib = None
@@ -959,7 +960,8 @@ def _knn_methods():
         abandoned pass, workgroups of a multi-pass kernel the device holds at once, compute units (fl_get_diagnostics)."""
         d = Diagnostics()
         self._chk(self.L.fl_get_diagnostics(self.h, C.byref(d)), "fl_get_diagnostics")
-        return dict(fallbacks=d.multipass_fallbacks, resumes=d.frames_resumed, capacity=d.multipass_capacity, cus=d.compute_units)
+        return dict(fallbacks=d.multipass_fallbacks, resumes=d.frames_resumed, capacity=d.multipass_capacity, cus=d.compute_units,
+                    demotions=d.demotions, demoted_calls_left=d.demoted_calls_left)
 
     def lio_frame18_dev(self, state, body):
         """body None: use the scan already staged on the device (lio_set_points / scan_voxel_filter)."""

@@ -61,6 +61,11 @@ struct fl_context {
     unsigned mp_seq = 0;             // sequence number of this handle's last multi-pass launch
     int mp_last_grid = 0;
     int mp_fallbacks = 0, mp_resumes = 0;   // diagnostics: launches sent down the per-pass path by the admission check / frames resumed
+    // Demotion (another compute client on the device that the admission check cannot see): a synchronous driver call whose chain ended
+    // in an abandoned pass costs a full FL_GATHER_SPIN_LIMIT stall before the resume. After `demote_after` such calls in a row the
+    // handle launches per pass for `demote_calls` calls (doubling on every relapse, up to 1024), then tries the multi-pass form again.
+    int opt_demote_after = 2, opt_demote_calls = 64;
+    int mp_consec_timeouts = 0, mp_demoted_left = 0, mp_demote_period = 0, mp_demotions = 0;
     // fl_set_option (include/fastlivo_hip.h)
     int opt_multipass = 1, opt_max_producers = 0, opt_ik_producers = 0, opt_vio_whole_cu = 1;
     bool normvec_valid = false;   // a pass with FL_ITER_KEEP_NORMVEC has run on the staged scan
@@ -499,6 +504,14 @@ int32_t fl_set_option(fl_handle h, int32_t option, int32_t value)
     case FL_OPT_MAILBOX: h->opt_mailbox = value & 3; break;
     case FL_OPT_SCAN_PULL: h->opt_scan_pull = value != 0; break;
     case FL_OPT_INCR_SEARCH: h->opt_incr_search = value != 0; break;
+    case FL_OPT_DEMOTE_AFTER:
+        if (value < 0) return fail_arg(h, "fl_set_option: FL_OPT_DEMOTE_AFTER out of range");
+        h->opt_demote_after = value; h->mp_consec_timeouts = 0;
+        if (value == 0) { h->mp_demoted_left = 0; h->mp_demote_period = 0; }
+        break;
+    case FL_OPT_DEMOTE_CALLS:
+        if (value < 1 || value > 1024) return fail_arg(h, "fl_set_option: FL_OPT_DEMOTE_CALLS out of range");
+        h->opt_demote_calls = value; break;
     default: return fail_arg(h, "fl_set_option: unknown option");
     }
     return FL_OK;
@@ -509,6 +522,7 @@ int32_t fl_get_diagnostics(fl_handle h, fl_diagnostics *out)
     if (!h || !out) return fail_arg(h, "fl_get_diagnostics: null argument");
     out->multipass_fallbacks = h->mp_fallbacks; out->frames_resumed = h->mp_resumes;
     out->multipass_capacity = h->mp_capacity; out->compute_units = h->num_cus;
+    out->demotions = h->mp_demotions; out->demoted_calls_left = h->mp_demoted_left;
     return FL_OK;
 }
 
@@ -870,12 +884,27 @@ static void ensure_gates(fl_handle h)
 // may this handle use the multi-pass form for a grid of `grid` workgroups right now?
 static bool multipass_ok(fl_handle h, int grid, bool mode23 = false)          // a look, not a reservation
 {
-    return grid <= h->num_cus && h->opt_multipass && mp_would_admit(h, grid, mode23 ? h->mp_capacity_ik : h->mp_capacity);
+    return grid <= h->num_cus && h->opt_multipass && h->mp_demoted_left <= 0 && mp_would_admit(h, grid, mode23 ? h->mp_capacity_ik : h->mp_capacity);
+}
+// the outcome of one synchronous driver call (resume_after_timeout / resume23_after_timeout call this exactly once per call)
+static void mp_note_outcome(fl_handle h, bool timed_out)
+{
+    if (h->mp_demoted_left > 0) {                       // serving a demotion: one call less (time-outs of per-pass launches do not extend it)
+        if (--h->mp_demoted_left == 0) h->mp_consec_timeouts = h->opt_demote_after > 0 ? h->opt_demote_after - 1 : 0;   // probation
+        return;
+    }
+    if (!timed_out) { h->mp_consec_timeouts = 0; h->mp_demote_period = 0; return; }
+    if (h->opt_demote_after <= 0 || !h->opt_multipass) return;
+    if (++h->mp_consec_timeouts >= h->opt_demote_after) {
+        h->mp_demote_period = h->mp_demote_period ? (h->mp_demote_period * 2 > 1024 ? 1024 : h->mp_demote_period * 2) : h->opt_demote_calls;
+        h->mp_demoted_left = h->mp_demote_period;
+        h->mp_demotions++;
+    }
 }
 // the reservation of a multi-pass launch of `grid` workgroups: its sequence number, or 0 (launch per pass)
 static unsigned multipass_reserve(fl_handle h, int grid, bool mode23 = false)
 {
-    if (!(grid <= h->num_cus && h->opt_multipass)) return 0u;
+    if (!(grid <= h->num_cus && h->opt_multipass) || h->mp_demoted_left > 0) return 0u;
     return mp_reserve(h, grid, mode23 ? h->mp_capacity_ik : h->mp_capacity);
 }
 // returns true if the launch carried `extra` (FL_LIO_DO_COV: the covariance update at the end of the launch), i.e. it was a multi-pass one
@@ -901,6 +930,7 @@ extern "C++" {
 template <class F>
 static int32_t resume_after_timeout(fl_handle h, fl_iter_info *li, F enqueue)
 {
+    mp_note_outcome(h, (li->status & FL_NUM_TIMEOUT) != 0 && h->xchg_world <= 1);
     for (int attempt = 0; attempt < 3 && (li->status & FL_NUM_TIMEOUT) && h->xchg_world <= 1; attempt++) {
         h->mp_resumes++;
         const int remaining = h->h_dev->resume_count;

@@ -159,7 +159,14 @@ int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out);
  *                         Results are bit-identical either way.
  *   FL_OPT_INCR_SEARCH    1 (default): a k-NN search over a scan and a map that an earlier search already covered (the rematch of a
  *                         frame, KD_TREE::Nearest_Search at laserMapping.cpp:1543 for the second time) walks only the map cells within
- *                         reach of the earlier winners' new distances; 0: every search walks all 27 cells. Results are identical either way. */
+ *                         reach of the earlier winners' new distances; 0: every search walks all 27 cells. Results are identical either way.
+ *   FL_OPT_DEMOTE_AFTER   2 (default): the multi-pass kernels wait for their own workgroups, which the library admits only when they fit
+ *                         beside its OWN launches; a foreign compute client on the device can still keep some of them off the chip, the
+ *                         bounded wait then abandons the pass (FL_NUM_TIMEOUT, resumed per pass by the synchronous entry points). After
+ *                         this many driver calls IN A ROW that ended so, the handle is demoted to one launch per pass for
+ *   FL_OPT_DEMOTE_CALLS   64 (default) driver calls (doubling on every relapse, at most 1024), then it tries the multi-pass form again.
+ *                         0 for FL_OPT_DEMOTE_AFTER: never demote. fl_get_diagnostics reports demotions / demoted_calls_left. Results
+ *                         are bit-identical in either launch form. */
 #define FL_OPT_MULTIPASS 1
 #define FL_OPT_MAX_PRODUCERS 2
 #define FL_OPT_IK_PRODUCERS 3
@@ -168,6 +175,8 @@ int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out);
 #define FL_OPT_MAILBOX 6
 #define FL_OPT_SCAN_PULL 7
 #define FL_OPT_INCR_SEARCH 8
+#define FL_OPT_DEMOTE_AFTER 9
+#define FL_OPT_DEMOTE_CALLS 10
 int32_t fl_set_option(fl_handle h, int32_t option, int32_t value);
 /* Counters of the resident-grid machinery of the multi-pass kernels. */
 typedef struct fl_diagnostics {
@@ -175,6 +184,8 @@ typedef struct fl_diagnostics {
     int32_t frames_resumed;        /* frames / iterate calls resumed per pass after an ABANDONED pass (FL_NUM_TIMEOUT) */
     int32_t multipass_capacity;    /* workgroups of a multi-pass kernel the device can hold at once */
     int32_t compute_units;
+    int32_t demotions;             /* times the handle was demoted to one launch per pass after repeated time-outs (FL_OPT_DEMOTE_AFTER) */
+    int32_t demoted_calls_left;    /* > 0: driver calls the handle still serves per pass before it tries the multi-pass form again */
 } fl_diagnostics;
 int32_t fl_get_diagnostics(fl_handle h, fl_diagnostics *out);
 /* Flag bit 4 of the iterate calls (FL_ITER_STAMP) is reserved for the instrumented build (include/fastlivo_hip_debug.h); this
