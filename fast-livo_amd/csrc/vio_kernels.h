@@ -24,6 +24,14 @@ struct FlPatchGeom {
     int u_i, v_i, scale;
 };
 
+// a patch's projection as the geometry batches of vio_produce stage it in LDS (96 bytes: six 16-byte reads per lane)
+struct __attribute__((aligned(16))) FlGeomLds {
+    double d[7];        // Jdpi[0], Jdpi[2], Jdpi[4], Jdpi[5], pf[0..2]
+    double pad;
+    float w[4];         // wtl, wtr, wbl, wbr
+    int q[4];           // u_i, v_i, scale, -
+};
+
 FL_HD void fl_world2cam(const FlVioConst &c, const double *pf, double *pc)
 {
     const double u = pf[0] / pf[2], v = pf[1] / pf[2];
@@ -382,17 +390,57 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
     // residuals of up to CB iterations wait in LDS and lanes hl < batch of every row each take one of them, so a
     // chain pass serves 16 patches. The last batch is deferred until the record is published (off the hand-off's critical path).
     int bslot = 0;                                   // iterations waiting in the batch
-    for (int ib = (blockIdx.x * WPB + wave) * GPW; ib < m; ib += nprod * WPB * GPW) {
+    // Geometry batches (GB > 1, the per-pass kernels that iterate over many patches): the projection of a patch -- three fp64
+    // divisions, the radtan polynomial, dpi, the sub-pixel weights: ~130 of the loop's ~610 vector instructions -- is the same for the
+    // 16 lanes of its row, i.e. it ran with 4 useful lanes out of 64. Every GB iterations the wavefront therefore projects the 64
+    // patches of its next GB iterations at once, one patch per lane (lane 4k + g: iteration k, lane group g), into LDS, and an
+    // iteration reads its patch's 96 bytes back (broadcast reads: the 16 lanes of a row ask for the same address). The arithmetic
+    // is fl_patch_geom's on another lane: the same bits. GB = 1 (multi-pass kernels: one iteration per wavefront and pass): as before.
+    constexpr int GB = (CB > 1) ? 16 : 1;
+    const int stride_it = nprod * WPB * GPW;
+    for (int ib0 = (blockIdx.x * WPB + wave) * GPW; ib0 < m; ib0 += stride_it * GB) {
+    FlGeomLds *geom_w = nullptr;
+    if constexpr (GB > 1) {
+        __shared__ __attribute__((aligned(16))) FlGeomLds s_geom[WPB][64];
+        geom_w = s_geom[wave];
+        const int gi = ib0 + (lane >> 2) * stride_it + (lane & 3);
+        const int gii = gi < m ? gi : 0;
+        const int gscale = 1 << (level + slevel[gii]);
+        const double gps[3] = {pos[gii * 3 + 0], pos[gii * 3 + 1], pos[gii * 3 + 2]};
+        FlPatchGeom gg;
+        fl_patch_geom(vc, Rcw, Pcw, gps, gscale, gg);
+        __builtin_amdgcn_wave_barrier();                       // the rows have read the previous batch
+        FlGeomLds o;
+        o.d[0] = gg.Jdpi[0]; o.d[1] = gg.Jdpi[2]; o.d[2] = gg.Jdpi[4]; o.d[3] = gg.Jdpi[5]; o.d[4] = gg.pf[0]; o.d[5] = gg.pf[1]; o.d[6] = gg.pf[2];
+        o.w[0] = gg.wtl; o.w[1] = gg.wtr; o.w[2] = gg.wbl; o.w[3] = gg.wbr;
+        o.q[0] = gg.u_i; o.q[1] = gg.v_i; o.q[2] = gg.scale; o.q[3] = 0;
+        o.pad = 0.0;
+        geom_w[lane] = o;
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int kk = 0; kk < GB; kk++) {
+        const int ib = ib0 + kk * stride_it;
+        if (ib >= m) break;                                    // (uniform over the wavefront)
         const int i = ib + grp;
         const bool active = i < m;
         const int ii = active ? i : 0;
         const bool first = (i == i_first) && have_first;
-        const int scale = 1 << (level + (first ? pf_slevel : slevel[ii]));
-        double ps[3];
-        if (first) { ps[0] = pf_pos0; ps[1] = pf_pos1; ps[2] = pf_pos2; }
-        else { ps[0] = pos[ii * 3 + 0]; ps[1] = pos[ii * 3 + 1]; ps[2] = pos[ii * 3 + 2]; }
         FlPatchGeom g;
-        fl_patch_geom(vc, Rcw, Pcw, ps, scale, g);
+        int scale;
+        if constexpr (GB > 1) {
+            const FlGeomLds gl = geom_w[kk * 4 + grp];
+            g.Jdpi[0] = gl.d[0]; g.Jdpi[1] = 0.0; g.Jdpi[2] = gl.d[1]; g.Jdpi[3] = 0.0; g.Jdpi[4] = gl.d[2]; g.Jdpi[5] = gl.d[3];
+            g.pf[0] = gl.d[4]; g.pf[1] = gl.d[5]; g.pf[2] = gl.d[6];
+            g.wtl = gl.w[0]; g.wtr = gl.w[1]; g.wbl = gl.w[2]; g.wbr = gl.w[3];
+            g.u_i = gl.q[0]; g.v_i = gl.q[1]; g.scale = gl.q[2];
+            scale = gl.q[2];
+        } else {
+            scale = 1 << (level + (first ? pf_slevel : slevel[ii]));
+            double ps[3];
+            if (first) { ps[0] = pf_pos0; ps[1] = pf_pos1; ps[2] = pf_pos2; }
+            else { ps[0] = pos[ii * 3 + 0]; ps[1] = pos[ii * 3 + 1]; ps[2] = pos[ii * 3 + 2]; }
+            fl_patch_geom(vc, Rcw, Pcw, ps, scale, g);
+        }
         FL_INSTR(if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(g.wbr), "v"(g.u_i)); fl_stamp(flags, 40); })
         const int col0 = g.u_i + (yc - 4) * scale;
         float t[PPL][4][4];
@@ -557,7 +605,7 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
         // double res): one lane per patch replays the 64 additions in pixel order (vio_patch_error). It feeds only the errors[]
         // output and the rare exact accept test, never the record: for the wave's LAST patch group it is deferred until the record is
         // published, off the hand-off's critical path (the residuals wait in LDS).
-        const bool last_iter = (ib + nprod * WPB * GPW >= m);
+        const bool last_iter = (ib + stride_it >= m);
         {   // this lane's two outputs of the patch (explicit fma(), see above)
             __builtin_amdgcn_wave_barrier();
             const double Ma1 = s_M[role.o1a], Mb1 = s_M[6 + role.o1a], Mc1 = s_M[role.o1b], Md1 = s_M[6 + role.o1b];
@@ -580,6 +628,7 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
             __builtin_amdgcn_wave_barrier();
             bslot = 0;
         }
+    }
     }
     FL_INSTR(if (blockIdx.x == 0) fl_stamp(flags, 1);)
     // lane hl of every row holds the row's outputs hl and hl + 16: the four rows of a wavefront with two lane swaps (even rows then

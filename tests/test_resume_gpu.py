@@ -119,6 +119,7 @@ def test_demotion_after_repeated_timeouts_and_recovery(gpu_lib, scene):
     h.set_option(capi.FL_OPT_DEMOTE_AFTER, 2)
     h.set_option(capi.FL_OPT_DEMOTE_CALLS, 3)
     h.lio_set_points(fr.body_xyz); h.lio_set_neighbours(nbr, valid)
+    h.debug_drop_record(1 << 30)                  # the injector's epoch is a global of the debug library: park what an earlier test left armed
 
     def call(drop):
         x0 = capi.state18_from_frame(fr)
