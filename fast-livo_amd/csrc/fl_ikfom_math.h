@@ -41,7 +41,7 @@
 // critical path (ikfom_pre 5 us, the three boxplus segments 1.6 us). Power series in the squared argument (truncation < 1e-17
 // relative inside the stated range, no cancellation) replace them on the device; larger arguments and the host build (the unit
 // tests against the oracle) keep the library form. The update is compared with the oracle by tolerance (1e-9), never bitwise.
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) || defined(FL_IK_SERIES_ON_HOST)      /* FL_IK_SERIES_ON_HOST: tests/host_emul builds the SHIPPED forms too */
 #define FL_IK_SERIES 1
 #else
 #define FL_IK_SERIES 0
@@ -228,7 +228,11 @@ FL_HD void fl_s2_Bx(const double *vec, double *Bx)
 #if FL_IK_SERIES
     if (vec[0] + L > FL_MTK_TOL) {       // device: one reciprocal (+ two Newton steps, ~1e-16) instead of nine IEEE divisions
         const double den = L + vec[0];
+#if defined(__HIP_DEVICE_COMPILE__)
         double r = __builtin_amdgcn_rcp(den);
+#else
+        double r = (double)(1.0f / (float)den);      // host build of the shipped form (tests): any 2^-20 seed, the two Newton steps below do the rest
+#endif
         double e = fma(-den, r, 1.0);
         r = fma(r, e, r);
         e = fma(-den, r, 1.0);

@@ -53,6 +53,20 @@ def emul_lib():
 
 
 @pytest.fixture(scope="session")
+def emul_series_lib():
+    """The same host build with -DFL_IK_SERIES_ON_HOST: the Mode-23 manifold operations in the power-series forms the DEVICE compiles
+    (fl_ikfom_math.h FL_IK_SERIES) -- what ships, run on the CPU."""
+    import ctypes
+    d = os.path.join(ROOT, "tests", "host_emul")
+    so = os.path.join(d, "libemul_series.so")
+    src = os.path.join(d, "emul.cpp")
+    hdrs = [os.path.join(ROOT, "fast-livo_amd", "csrc", h) for h in ("fl_math.h", "fl_ikfom_math.h", "exact_chain.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in [src] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-DFL_IK_SERIES_ON_HOST", "-fPIC", "-shared", "-o", so, src, "-lm"])
+    return ctypes.CDLL(so)
+
+
+@pytest.fixture(scope="session")
 def gpu_lib():
     if not _has_gpu():
         pytest.skip("no GPU in this container")

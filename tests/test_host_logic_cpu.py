@@ -142,6 +142,72 @@ def test_mode23_iteration_matches_oracle(oracle_lib, emul_lib, scene):
         assert np.abs(dx - np.array(ro["out"].dx)).max() <= 1e-9
 
 
+def test_mode23_shipped_series_forms_on_the_host(oracle_lib, emul_lib, emul_series_lib, scene):
+    """the device compiles power-series forms of the manifold exp / log / Jacobians (fl_ikfom_math.h FL_IK_SERIES),
+    the host emulation used the libm forms -- only GPU tests saw the shipped arithmetic. libemul_series.so is the same source with
+    the series forms selected: (1) the whole update, series build vs the C oracle (1e-9 / 1e-10) and vs the libm build (rounding
+    level); (2) boxplus / boxminus across the series range and beyond it (|delta| from 1e-13 to 2 rad: the forms hand over to libm
+    at x^2 = 0.25) against the oracle's MTK restatement."""
+    from fast_livo_amd import synth
+    orc, E, ES = oracle_lib, emul_lib, emul_series_lib
+    knn = lambda w: synth.knn5(scene, w)  # noqa: E731
+
+    def run(lib, fr, max_iter):
+        n = fr.n
+        x0 = orc.state23_from_frame(fr, synth.quat_from_R).vec().copy()
+        x = x0.copy()
+        Pw = np.zeros((23, 23)); Pprop = fr.cov23.copy(); limit = np.full(23, 0.001)
+        ctl = np.array([-1, 0, 1, 0, max_iter, 0], dtype=np.int32)
+        plane = np.zeros((n, 4), np.float32); ok = np.zeros(n, np.uint8); sel = np.zeros(n, np.uint8)
+        sums = np.zeros(96); dx = np.zeros(23)
+        iters = 0
+        while not ctl[3] and ctl[0] < max_iter:
+            if ctl[2]:
+                w = np.zeros((n, 3), np.float32)
+                lib.emul_world_points23(p(x, C.c_double), p(fr.body_xyz, C.c_float), n, p(w, C.c_float))
+                nbr, valid = knn(w)
+                nbr = np.ascontiguousarray(nbr)
+                lib.emul_fit_planes(p(nbr, C.c_float), n, p(plane, C.c_float), p(ok, C.c_uint8))
+                sel = (valid & ok).astype(np.uint8)
+            lib.emul_h_share_sums(p(x, C.c_double), p(fr.body_xyz, C.c_float), p(plane, C.c_float), p(sel, C.c_uint8), n, p(sums, C.c_double), None)
+            lib.emul_ikfom_iterate(p(x, C.c_double), p(x0, C.c_double), p(Pprop, C.c_double), p(Pw, C.c_double), p(limit, C.c_double),
+                                   C.c_double(0.001), p(sums, C.c_double), p(ctl, C.c_int32), p(dx, C.c_double))
+            iters += 1
+        return x, Pw, iters
+    for n, max_iter in ((15, 4), (3000, 4), (3000, 10)):
+        fr = synth.make_lio_frame(n, scene=scene)
+        x23 = orc.state23_from_frame(fr, synth.quat_from_R)
+        P = fr.cov23.copy()
+        ro = orc.ikfom_update(x23, P, fr.body_xyz, 0.001, max_iter, knn)
+        xs, Ps, its = run(ES, fr, max_iter)
+        xl, Pl, itl = run(E, fr, max_iter)
+        assert its == itl == ro["out"].iterations
+        assert np.abs(xs - x23.vec()).max() <= 1e-9 and np.abs(Ps - P).max() <= 1e-10
+        assert np.abs(xs - xl).max() <= 1e-13 and np.abs(Ps - Pl).max() <= 1e-13          # series vs libm: rounding level
+    rng = np.random.default_rng(17)
+    worst = 0.0
+    for k in range(600):
+        mag = [1e-13, 1e-9, 1e-5, 1e-3, 0.05, 0.3, 0.49, 0.51, 1.0, 2.0][k % 10]
+        s = orc.State23()
+        for f, _ in s._fields_:
+            getattr(s, f)[:] = rng.standard_normal(len(getattr(s, f)))
+        for f in ("rot", "offset_R_L_I"):
+            q = np.array(getattr(s, f)); getattr(s, f)[:] = q / np.linalg.norm(q)
+        g = np.array(s.grav); s.grav[:] = g / np.linalg.norm(g) * 9.809
+        d = rng.standard_normal(23); d *= mag / np.linalg.norm(d[3:6])
+        b = s.copy()
+        orc.lib().orc_state23_boxplus(C.byref(b), p(d, C.c_double))
+        xs = s.vec().copy()
+        ES.emul_x23_boxplus(p(xs, C.c_double), p(d, C.c_double))
+        worst = max(worst, np.abs(xs - b.vec()).max())
+        out_o = np.zeros(23); out_s = np.zeros(23)
+        orc.lib().orc_state23_boxminus(C.byref(b), C.byref(s), p(out_o, C.c_double))
+        bv, sv = b.vec().copy(), s.vec().copy()
+        ES.emul_x23_boxminus(p(bv, C.c_double), p(sv, C.c_double), p(out_s, C.c_double))
+        worst = max(worst, np.abs(out_s - out_o).max())
+    assert worst <= 1e-12, worst
+
+
 def test_shard_ranges_cover_everything():
     import fastlivo  # noqa: F401
     from fast_livo_amd.sharded import shard_range

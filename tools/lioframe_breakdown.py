@@ -12,6 +12,10 @@ fr = synth.make_lio_frame(n, scene=scene, point_seed=synth.SEED + 101)
 vf = synth.make_vio_frame(2000, fr, patch_seed=synth.SEED + 103)
 h = capi.Handle(capi.config_from_frames(fr, vf, max_iterations=10, device=0))
 h.map_set_points(scene.map_xyz, float(os.environ.get("FL_CELL", "0.5")))
+if os.environ.get("FL_INCR") is not None:
+    h.set_option(capi.FL_OPT_INCR_SEARCH, int(os.environ["FL_INCR"]))
+if os.environ.get("FL_ORDER") == "voxel":
+    fr = synth.in_voxel_order(fr, 0.15)
 scan = fr.body_xyz
 if os.environ.get("FL_PAGEABLE", "0") != "1":      # the scan in page-locked memory of the library (the frame's first search kernel fetches it)
     scan = h.host_alloc(fr.body_xyz.shape, np.float32)
