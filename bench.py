@@ -352,9 +352,21 @@ def section_frame(capi, synth, scene, fr_in, vf, cfg):
         if rep >= 5:
             tlu.append(time.perf_counter() - t0)
     h.host_free(scan_pinned)
+    # the scan already on the device, as the all-device pipeline leaves it (fl_scan_voxel_filter writes feats_down_body there, SURVEY 8f
+    # N3): staged outside the timed region, every frame anew (the kept k-NN winners of the frame before are dropped with it)
+    tld = []
+    for rep in range(25):
+        h.lio_set_points(fr.body_xyz)
+        h.sync()
+        x = capi.state18_from_frame(fr)
+        t0 = time.perf_counter()
+        h.lio_frame18_dev(x, None)
+        if rep >= 5:
+            tld.append(time.perf_counter() - t0)
     h.close()
     lio_ms, vio_ms = float(np.median(tl)) * 1e3, float(np.median(tv)) * 1e3
     return {"lio_frame_ms": lio_ms, "vio_computej_ms": vio_ms, "frame_ms": lio_ms + vio_ms, "lio_passes": its, "vio_passes_3_levels": acc,
+            "lio_frame_ms_device_scan": float(np.median(tld)) * 1e3,
             "lio_frame_ms_pageable_scan": float(np.median(tlp)) * 1e3,
             "lio_frame_ms_unordered_scan": float(np.median(tlu)) * 1e3, "frame_ms_unordered_scan": float(np.median(tlu)) * 1e3 + vio_ms,
             "scan_order": SCAN_ORDER_NOTE,
