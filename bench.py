@@ -285,6 +285,18 @@ def section_mode23(capi, synth, scene, fr, cfg, nbr, valid):
         if rep >= 5:
             tot += ev0.elapsed_time(ev1)
     us_first3 = tot * 1e3 / (K * C3)
+    tot1 = 0.0
+    for rep in range(K + 5):                  # the same bracket around ONE pass: (3 passes - 1 pass) / 2 = a pass without the launch's fixed cost
+        h.ikfom_begin(x23, fr.cov23.copy())
+        h.lio_set_neighbours(nbr, valid)
+        torch.cuda.synchronize()
+        ev0.record()
+        h.ikfom_iterate(1, F, want_info=False)
+        ev1.record()
+        torch.cuda.synchronize()
+        if rep >= 5:
+            tot1 += ev0.elapsed_time(ev1)
+    us_marginal = (tot - tot1) * 1e3 / (K * (C3 - 1))
     # (c)
     C = PASSES_PER_LAUNCH
     for _ in range(10):
@@ -305,6 +317,8 @@ def section_mode23(capi, synth, scene, fr, cfg, nbr, valid):
             "passes, final covariance, read-back; host wall time",
             "pass_us": us_first3, "pass_what": f"passes alone, neighbours/planes resident: the first {C3} passes after a begin in one multi-pass launch "
             "(launch overhead included)", "iterations_per_s": 1e6 / us_first3,
+            "marginal_pass_us": us_marginal, "marginal_pass_what": "(event bracket around 3 passes - bracket around 1 pass) / 2: a non-finishing pass inside a "
+            "multi-pass launch without the launch's fixed cost (per-pass launch kernel for 1 pass, multi-pass kernel for 3)",
             "forced_steady_state_pass_us": us, "forced_steady_state_note": "every forced pass after convergence also runs the final covariance block",
             "status": int(info.status), "effct_feat_num": int(info.effct_feat_num)}
 

@@ -202,10 +202,19 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_multipass_kernel(const float4 
         bool wrote_P = false;
         for (int p = 0; p < count; p++) {
             const unsigned epoch = epoch0 + (unsigned)p;
+#ifdef FL_IK_STAMPS
+#define FL_IK_MP_STAMP(slot) do { if (p == 2 && threadIdx.x == 0) g_fl_stamps[slot] = (long long)wall_clock64(); } while (0)
+#else
+#define FL_IK_MP_STAMP(slot) do { } while (0)
+#endif
+            FL_IK_MP_STAMP(20);
             ikfom_pre(s_ik);                                      // state-only half of the iteration, while the producers work
+            FL_IK_MP_STAMP(21);
             int gst = gather_records<NT, FL_SUMS23I>(records, nprod, epoch, s_fin, s_sums);
+            FL_IK_MP_STAMP(22);
             if (PV.world > 1) gst |= peer_allreduce64(PV, xe0 + 2u * (unsigned)p, s_sums, s_xchg);      // sharded form: totals over the ranks
             ikfom_post(D, s_sums, s_ik, gst, bcast, epoch + 1u, false);
+            FL_IK_MP_STAMP(23);
             __syncthreads();
             done = p + 1;
             if (s_ik.ctl[4]) {                                    // abandoned
@@ -235,15 +244,24 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_multipass_kernel(const float4 
     for (int i = 0; i < FL_X23_LEN; i++) x[i] = D->x[i];
     for (int ps = 0; ps < count; ps++) {
         const unsigned epoch = epoch0 + (unsigned)ps;
+#ifdef FL_IK_STAMPS
+        if (blockIdx.x == 0 && threadIdx.x == 0 && (ps == 2 || ps == 3)) g_fl_stamps[24 + 4 * (ps - 2)] = (long long)wall_clock64();
+#endif
         if (ps > 0) {
             bcast_wait<FL_IK_BCAST_WORDS>(bcast, epoch, s_state, &s_ctrl, spin_limit);
             __syncthreads();
+#ifdef FL_IK_STAMPS
+            if (blockIdx.x == 0 && threadIdx.x == 0 && (ps == 2 || ps == 3)) g_fl_stamps[25 + 4 * (ps - 2)] = (long long)wall_clock64();
+#endif
             if (s_ctrl & 4) break;
             if (!force && (s_ctrl & 3)) break;
 #pragma unroll
             for (int i = 0; i < FL_X23_LEN; i++) x[i] = s_state[i];
         }
         ikfom_produce(body4, plane, sel, normvec, n, x, nprod, flags, s_red, epoch, records);
+#ifdef FL_IK_STAMPS
+        if (blockIdx.x == 0 && threadIdx.x == 0 && (ps == 2 || ps == 3)) g_fl_stamps[26 + 4 * (ps - 2)] = (long long)wall_clock64();
+#endif
         __syncthreads();
     }
 }
