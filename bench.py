@@ -247,7 +247,8 @@ def section_vio_sweep(capi, synth, fr, vf, cfg, x0, distinct_cap=None):
 def section_mode23(capi, synth, scene, fr, cfg, nbr, valid):
     """BASELINE config 2 with the 23-state IKFoM filter (esekfom.hpp:1619-1928): 50 k points.
     (a) the whole update on the device (searches included) and its pass count; (b) the passes alone, neighbours pre-staged: the
-    first three passes after a begin (none of them finishes), one multi-pass launch; (c) forced steady-state passes -- after
+    first three FORCED passes after a begin in one multi-pass launch (launch overhead included; the third finishes under
+    FL_ITER_FORCE) and the marginal cost of a non-finishing pass (non-forced launches of 3 and 2 passes); (c) forced steady-state passes -- after
     convergence t > 1, so EVERY forced pass also runs the final covariance block of esekfom.hpp:1831-1924."""
     import torch
     h = capi.Handle(cfg)
@@ -285,18 +286,30 @@ def section_mode23(capi, synth, scene, fr, cfg, nbr, valid):
         if rep >= 5:
             tot += ev0.elapsed_time(ev1)
     us_first3 = tot * 1e3 / (K * C3)
-    tot1 = 0.0
-    for rep in range(K + 5):                  # the same bracket around ONE pass: (3 passes - 1 pass) / 2 = a pass without the launch's fixed cost
-        h.ikfom_begin(x23, fr.cov23.copy())
-        h.lio_set_neighbours(nbr, valid)
-        torch.cuda.synchronize()
-        ev0.record()
-        h.ikfom_iterate(1, F, want_info=False)
-        ev1.record()
-        torch.cuda.synchronize()
-        if rep >= 5:
-            tot1 += ev0.elapsed_time(ev1)
-    us_marginal = (tot - tot1) * 1e3 / (K * (C3 - 1))
+    # a pass inside the multi-pass launch without the launch's fixed cost: NON-forced launches of 2 and of 3 passes after a begin (the
+    # update's first segment: pass 3 converges and asks for the rematch search, none of the three finishes); their difference is pass 3
+    def first_segment(cnt):
+        acc_us, its = 0.0, 0
+        for rep in range(K + 5):
+            h.ikfom_begin(x23, fr.cov23.copy())
+            h.lio_set_neighbours(nbr, valid)
+            torch.cuda.synchronize()
+            ev0.record()
+            h.ikfom_iterate(cnt, 0, want_info=False)
+            ev1.record()
+            torch.cuda.synchronize()
+            if rep >= 5:
+                acc_us += ev0.elapsed_time(ev1) * 1e3
+            its = int(h.ikfom_iterate(0, 0).iterations)
+        return acc_us / K, its
+    _, seg = first_segment(10)               # how many passes the update's first segment has (until the rematch search is asked for)
+    us_marginal, marg_note = None, f"first segment of the update = {seg} pass(es)"
+    if seg >= 2:
+        ta, ita = first_segment(seg - 1)
+        tb, itb = first_segment(seg)
+        if ita == seg - 1 and itb == seg:
+            us_marginal = tb - ta
+            marg_note = f"pass {seg} of the update = bracket({seg} passes) - bracket({seg - 1} passes)"
     # (c)
     C = PASSES_PER_LAUNCH
     for _ in range(10):
@@ -315,10 +328,11 @@ def section_mode23(capi, synth, scene, fr, cfg, nbr, valid):
     return {"workload": f"BASELINE config 2: {fr.n} pts point-to-plane, 23-state IKFoM update (state_ikfom)",
             "update_ms": upd_ms, "update_passes": passes, "update_what": "fl_ikfom_update_iterated_dev: H2D of the scan, k-NN searches + plane fits, "
             "passes, final covariance, read-back; host wall time",
-            "pass_us": us_first3, "pass_what": f"passes alone, neighbours/planes resident: the first {C3} passes after a begin in one multi-pass launch "
-            "(launch overhead included)", "iterations_per_s": 1e6 / us_first3,
-            "marginal_pass_us": us_marginal, "marginal_pass_what": "(event bracket around 3 passes - bracket around 1 pass) / 2: a non-finishing pass inside a "
-            "multi-pass launch without the launch's fixed cost (per-pass launch kernel for 1 pass, multi-pass kernel for 3)",
+            "pass_us": us_first3, "pass_what": f"passes alone, neighbours/planes resident: the first {C3} FORCED passes after a begin in one multi-pass launch, "
+            "launch overhead included (under FL_ITER_FORCE the third already runs the final covariance block: see marginal_pass_us)", "iterations_per_s": 1e6 / us_first3,
+            "marginal_pass_us": us_marginal, "marginal_pass_what": "event bracket around a NON-forced multi-pass launch of the update's first segment (k passes after a begin, until the rematch "
+            "search is asked for) minus the same around k - 1 passes: a pass that does not finish, without the launch's fixed "
+            "cost; null if the update's first segment has a single pass", "marginal_pass_note": marg_note,
             "forced_steady_state_pass_us": us, "forced_steady_state_note": "every forced pass after convergence also runs the final covariance block",
             "status": int(info.status), "effct_feat_num": int(info.effct_feat_num)}
 

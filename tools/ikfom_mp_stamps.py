@@ -15,9 +15,12 @@ names = {20: "solver: loop top (pass 3)", 44: "solver: pre dx/J done", 45: "solv
          23: "solver: post returned (state broadcast)", 24: "producer0: waiting for pass 3's state", 25: "producer0: got it", 41: "producer0: loop start", 42: "producer0: loop end", 43: "producer0: published",
          26: "producer0: produce returned", 28: "producer0: waiting for pass 4's state", 29: "producer0: got pass 4's state", 30: "producer0: pass 4 produce returned"}
 F = capi.FL_ITER_FORCE
+fresh = len(sys.argv) > 1 and sys.argv[1] == "fresh"      # "fresh": begin before every launch -> pass 3 is the third pass after a begin (not finishing)
 for _ in range(3): h.ikfom_iterate(6, F, want_info=False)
 for _ in range(3):
-    h.ikfom_iterate(6, F, want_info=False); h.sync()
+    if fresh:
+        h.ikfom_begin(x23, fr.cov23.copy()); h.lio_set_neighbours(nbr, valid)
+    h.ikfom_iterate(4 if fresh else 6, F, want_info=False); h.sync()
     st = np.array(h.debug_stamps(), dtype=np.int64)
     t0 = st[20]
     print(json.dumps({names[k]: int(st[k] - t0) * 10 for k in sorted(names, key=lambda k: st[k])}))
