@@ -76,6 +76,7 @@ struct fl_context {
     // the device address of the mirror, the sequence number of the last published frame
     unsigned long long *h_pub = nullptr, *d_pub = nullptr;
     void *d_hdev = nullptr;
+    void *d_hdev23 = nullptr;           // device address of the page-locked FlDev23 mirror (state pull + result mailbox of the Mode-23 update)
     unsigned long long pub_seq = 0;
     int opt_scan_pull = 1;
     struct PinnedRange { void *host; size_t bytes; void *dev; };
@@ -345,6 +346,7 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
     HIPCHK(h, hipHostGetDevicePointer(&h->d_hdev, h->h_dev, 0));
     HIPCHK(h, hipMalloc(&h->d_dev23, sizeof(FlDev23)));
     HIPCHK(h, hipHostMalloc(&h->h_dev23, sizeof(FlDev23)));
+    HIPCHK(h, hipHostGetDevicePointer(&h->d_hdev23, h->h_dev23, 0));
     HIPCHK(h, hipHostMalloc(&h->h_small, 4096 + FL_UP_SLOTS * 1024));
     HIPCHK(h, hipMalloc(&h->d_records, (size_t)16 * FL_MAX_BLOCKS * FL_SUMS23));
     HIPCHK(h, hipMalloc(&h->d_epoch, 64));

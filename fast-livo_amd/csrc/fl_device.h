@@ -202,8 +202,14 @@ __device__ __forceinline__ void fl_publish_state(FlDev18 *__restrict__ D)
     const unsigned long long seq = D->pub_seq;
     constexpr int WORDS = (int)((sizeof(FlDev18) + FL_DEV18_TAIL) / 8);
     for (int i = threadIdx.x; i < WORDS; i += blockDim.x) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
+    // Every wavefront waits for its own stores (workgroup-scope release: the counters only), then ONE wavefront pays the system-scope
+    // release -- an L2 write-back of a few microseconds whoever issues it: with every wavefront of the workgroup issuing its own the
+    // publishing kernel ran 2.5-4.5 us longer (round 4, rocprofv3 time line of the Mode-23 update).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
+    if (threadIdx.x >= 64) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __threadfence_system();
     if (threadIdx.x == 0) {
         __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         // one-shot: a later kernel over this block that no begin preceded (fl_lio_finish18 behind a frame driver) must not publish

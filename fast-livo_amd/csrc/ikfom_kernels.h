@@ -42,7 +42,43 @@ struct FlDev23 {
     unsigned long long *xchg_peer[8];
     unsigned *xchg_epoch;
     int32_t xchg_rank, xchg_world;
+    // result mailbox of fl_ikfom_update_iterated_dev (as FlDev18::pub_flag, fl_device.h): the update's last launch copies the block into
+    // the page-locked mirror and raises a host word the calling thread polls -- no copy command, no stream synchronisation
+    unsigned long long *pub_flag;
+    void *pub_dst;
+    unsigned long long pub_seq;
 };
+
+#define FL_IK_PUBLISH 0x100            /* launch flag (internal): this launch is the update's last one -- serve the mailbox at its end */
+
+// see fl_publish_state (fl_device.h): all threads of ONE workgroup, as the last action of the update's last kernel; one-shot
+__device__ __forceinline__ void fl_publish_state23(FlDev23 *__restrict__ D)
+{
+    __syncthreads();
+    unsigned long long *flag = D->pub_flag;
+    if (!flag) return;                                   // (uniform)
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(D);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(D->pub_dst);
+    const unsigned long long seq = D->pub_seq;
+#ifdef FL_PUB_WORDS
+    constexpr int WORDS = FL_PUB_WORDS;
+#else
+    constexpr int WORDS = (int)(sizeof(FlDev23) / 8);
+#endif
+    for (int i = threadIdx.x; i < WORDS; i += blockDim.x) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every wavefront waits for its own stores (workgroup-scope release: counters only), then ONE wavefront pays the system-scope
+    // release (an L2 write-back, ~3 us whoever issues it: with all four wavefronts issuing their own the publication took 12.8 us)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __threadfence_system();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            D->pub_flag = nullptr;
+        }
+    }
+}
 
 #include "ikfom_solve_block.h"
 
@@ -184,6 +220,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_multipass_kernel(const float4 
     const int nprod = gridDim.x - 1;
     const bool force = (flags & FL_ITER_FORCE) != 0;
     if (ik_pass_skipped(D, flags, count, blockIdx.x == nprod && threadIdx.x == 0)) {
+        if ((flags & FL_IK_PUBLISH) && blockIdx.x == nprod) fl_publish_state23(D);      // (the update ended in an earlier launch)
         fl_mp_done(done_word, done_seq, blockIdx.x == nprod);
         return;
     }
@@ -231,6 +268,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_multipass_kernel(const float4 
             *epoch_ptr = epoch0 + (unsigned)done;
             if (PV.world > 1) *D->xchg_epoch = xe0 + 2u * (unsigned)done;
         }
+        if (flags & FL_IK_PUBLISH) { __threadfence(); fl_publish_state23(D); }      // (the barrier inside orders this workgroup's stores to D)
         fl_mp_done(done_word, done_seq, true);
         return;
     }
@@ -281,7 +319,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_solve_kernel(FlDev23 *__restri
 
 __global__ void ikfom_resume_kernel(FlDev23 *__restrict__ D)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { D->status &= ~FL_NUM_TIMEOUT; D->resume_count = 0; }
+    if (threadIdx.x == 0 && blockIdx.x == 0) { D->status &= ~FL_NUM_TIMEOUT; D->resume_count = 0; D->pub_flag = nullptr; }    // (a resumed update is read back with a copy)
 }
 
 // world points at the current state_ikfom (laserMapping.cpp:980-984) for the host kNN

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
     // and that workgroup forms the gain-solve constants of the state block (what eskf18_prepare_kernel does) beside the search;
     // gate_out != nullptr (same launch): every point's gate threshold (what lio_gate_kernel does) is written with its plane. Two
     // launches and two kernel boundaries less per frame; the first search of a frame always runs (begin raises need_search).
-    if (MODE == 18 && (cond & 4) && blockIdx.x == gridDim.x - 1) {
+    if ((cond & 4) && blockIdx.x == gridDim.x - 1) {      // (Mode-23: the copy only -- fl_search_prepare<FlDev23> is empty)
         if (host_state) {
             const unsigned long long *src = reinterpret_cast<const unsigned long long *>(host_state);
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(D);
@@ -349,9 +349,10 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
         pw[1] = (float)((D18->x[3] * u0 + D18->x[4] * u1 + D18->x[5] * u2) + D18->x[10]);
         pw[2] = (float)((D18->x[6] * u0 + D18->x[7] * u1 + D18->x[8] * u2) + D18->x[11]);
     } else {
+        const FlDev23 *D23 = host_state ? host_state : D;
         double xs[FL_X23_LEN], p_i[3];
 #pragma unroll
-        for (int k = 0; k < FL_X23_LEN; k++) xs[k] = D->x[k];
+        for (int k = 0; k < FL_X23_LEN; k++) xs[k] = D23->x[k];
         fl_world_point23(xs, pb, p_i, pw);
     }
     const int cx = (int)floorf(pw[0] * G.inv_cell), cy = (int)floorf(pw[1] * G.inv_cell), cz = (int)floorf(pw[2] * G.inv_cell);
