@@ -375,8 +375,25 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
         if (dm <= reach1 * reach1) B2s = dm * (1.0f + 1e-5f);
     }
 
-    // ---- phase 1a: rings 0..1, cells c = j, j+4, ... < 27 ; c = (dz+1)*9 + (dy+1)*3 + (dx+1)
-    {
+    // ---- phase 1: rings 0..1 in at most two rounds. Cells c = j, j+4, ... < 27 ; c = (dz+1)*9 + (dy+1)*3 + (dx+1).
+    // Round 0 takes the cells that must be looked at: with a bound from the previous winners (incremental) the cells within its
+    // reach; without one the 2 x 2 x 2 block of cells around the query's nearest cell corner -- every map point within
+    // dmin >= cell / 2 of the query lies in that block, so when the block's 5th-best distance is below dmin the search is over after
+    // 8 look-ups and ~30 candidates instead of 27 and ~100 (the usual case where the map is dense: the 5th neighbour of a scan point
+    // is a fraction of a cell away). Round 1 (only if some query of the wavefront needs it) takes the other 19 cells, pruned by
+    // the bound round 0 produced. The lane-local lists run through both rounds: the result is the best 5 of everything visited, key
+    // for key what one walk over all 27 cells gives.
+    FlTop5 t, g;
+    fl_top5_clear(t);
+    const float reach1 = G.cell - 1e-3f;
+    const float fx = pw[0] * G.inv_cell - (float)cx, fy = pw[1] * G.inv_cell - (float)cy, fz = pw[2] * G.inv_cell - (float)cz;
+    const int bx = fx < 0.5f ? -1 : 0, by = fy < 0.5f ? -1 : 0, bz = fz < 0.5f ? -1 : 0;      // the block: offsets {b, b + 1} per axis
+    const float dmin = G.cell * fminf(fminf(fx < 0.5f ? 1.0f - fx : fx, fy < 0.5f ? 1.0f - fy : fy), fz < 0.5f ? 1.0f - fz : fz) - 1e-3f;
+    const bool blockmode = !(B2s < INFINITY);
+    bool needB = false;
+    float B2r = INFINITY;
+    for (int round = 0; round < 2; round++) {
+        if (round == 1 && __ballot(needB) == 0ull) break;             // (uniform over the wavefront)
         unsigned long long key[7];
         unsigned hs[7];
         uint4 first[7];
@@ -391,8 +408,11 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
             const float gx = fmaxf(fmaxf(lx - pw[0], pw[0] - (lx + G.cell)) - 1e-3f, 0.f);
             const float gy = fmaxf(fmaxf(ly - pw[1], pw[1] - (ly + G.cell)) - 1e-3f, 0.f);
             const float gz = fmaxf(fmaxf(lz - pw[2], pw[2] - (lz + G.cell)) - 1e-3f, 0.f);
-            const bool look = !(gx * gx + gy * gy + gz * gz > B2s);
-            first[m] = look ? *reinterpret_cast<const uint4 *>(&G.htab[hs[m]]) : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);   // (pruned: reads as an empty slot)
+            const float box2 = gx * gx + gy * gy + gz * gz;
+            const bool inblock = (ox == bx || ox == bx + 1) && (oy == by || oy == by + 1) && (oz == bz || oz == bz + 1);
+            const bool look = (j + 4 * m < 27) &&
+                              (round == 0 ? (blockmode ? inblock : !(box2 > B2s)) : (needB && !inblock && !(box2 > B2r)));
+            first[m] = look ? *reinterpret_cast<const uint4 *>(&G.htab[hs[m]]) : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);   // (skipped: reads as an empty slot)
         }
         // compact the occupied cells (a plane crosses ~9 of the 27) into the quad's LDS list, in cell order:
         // rank = occupied cells of the earlier rows m + occupied cells of the lower lanes in this row
@@ -402,8 +422,7 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
 #pragma unroll
         for (int m = 0; m < 7; m++) {
             unsigned st = 0;
-            unsigned cn = fl_cell_lookup(G, key[m], first[m], hs[m], &st);
-            if (j + 4 * m >= 27) cn = 0;
+            const unsigned cn = fl_cell_lookup(G, key[m], first[m], hs[m], &st);
             const unsigned bits = (unsigned)(__ballot(cn != 0u) >> quad_shift) & 0xFu;
             const int r = nocc + __popc(bits & ((1u << j) - 1u));
             if (cn != 0u) { s_cstart[ql][r] = st; s_ccnt[ql][r] = cn; }
@@ -412,16 +431,18 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
         }
         if (j == 0) s_ccnt[ql][nocc] = 0x40000000u;      // terminator: the walk never advances past it
         const unsigned T = quad_sum_u32(mysum);
-        __syncthreads();
-        FL_INSTR(if (stamp) g_fl_wall[512 + blockIdx.x] = (long long)wall_clock64();)
-        // ---- phase 1b: the T candidates of the concatenated cell ranges are split evenly over the 4 lanes, lane j
+        // (the list of a query is written and read by its own quad only -- one wavefront: no workgroup barrier, which the
+        // wavefront-uniform `break` above could not pair up anyway)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        FL_INSTR(if (stamp && round == 0) g_fl_wall[512 + blockIdx.x] = (long long)wall_clock64();)
+        // ---- the walk: the T candidates of the concatenated cell ranges are split evenly over the 4 lanes, lane j
         // takes [j*T/4, (j+1)*T/4) -- balanced however unevenly the cells are filled. One flat loop over the
         // candidates (the 16 queries of a wave have their points in different cells: a loop over cells would run
         // every cell's longest range for the whole wave); every listed cell holds >= 1 point, so stepping to the
         // next candidate crosses at most one cell boundary (branch-free). Loads are issued FL_KNN_BATCH at a time.
         const unsigned seg_b = (T * (unsigned)j) >> 2, seg_e = (T * (unsigned)(j + 1)) >> 2;
-        FlTop5 t, g;
-        fl_top5_clear(t);
         int c = 0;
         unsigned cell_end = s_ccnt[ql][0], base = s_cstart[ql][0];
         while (seg_b >= cell_end) {                      // position on the cell of the first candidate
@@ -452,10 +473,22 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
                 fl_top5_insert(t, fl_knn_key(live ? d : INFINITY, live ? __float_as_int(p[u].w) : FL_KNN_NO_ID));
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the quad's list is rewritten by the next round)
+        __builtin_amdgcn_wave_barrier();
+        if (round == 0) {
+            if (blockmode) {
+                quad_merge_top5(t, g);
+                const float d5 = fl_knn_key_d(g.key[4]);
+                needB = !(d5 <= dmin * dmin);                                    // a 5th neighbour may lie outside the block
+                B2r = (d5 <= reach1 * reach1) ? d5 * (1.0f + 1e-5f) : INFINITY;   // (no bound inside ring 1: all of the other 19 cells)
+            }
+        }
+    }
+    {
         quad_merge_top5(t, g);
         // 1 mm safety margin: cell boundaries are evaluated in float (floorf(x * inv_cell)), exact to
         // well under a millimetre for maps of several kilometres
-        float reach = G.cell - 1e-3f;
+        float reach = reach1;
         if (!(fl_knn_key_d(g.key[4]) <= reach * reach)) {
             // ring 2 cell by cell (98 cells, round-robin over the quad): enough wherever the map is merely a little thin
             bool done = false;
