@@ -275,3 +275,45 @@ def test_mode23_update_with_the_scan_fetched_by_the_search_kernel(gpu_lib, scene
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
     assert outs[0][0][2] == 0
+
+
+@pytest.mark.parametrize("n", [63, 12345, 50000])
+def test_mode23_update_driver_variants_give_the_same_update(gpu_lib, oracle_lib, scene, n):
+    """Round 4: fl_ikfom_update_iterated_dev pulls the state block from the page-locked mirror in its first search kernel, lets that
+    kernel write the gate thresholds, runs two launch segments and gets its result through the mailbox. Every combination of
+    mailbox on / off, scan + state pulled / copied, multi-pass / one launch per pass, on consecutive updates of one handle (a
+    stale mailbox or a stale winner record would show in the second one): the same state, covariance and counters, bit for
+    bit -- and equal to the oracle's update."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    fr = synth.make_lio_frame(n, scene=scene)
+
+    def knn(w):
+        nb, _, va, _ = orc.knn5_bruteforce(scene.map_xyz, w)
+        return nb, va
+    xo = orc.state23_from_frame(fr, synth.quat_from_R)
+    Po = fr.cov23.copy()
+    ro = orc.ikfom_update(xo, Po, fr.body_xyz, 0.001, 10, knn)
+    ref = None
+    for mailbox in (3, 0):
+        for pull in (1, 0):
+            for multipass in (1, 0):
+                h = capi.Handle(capi.config_from_frames(fr, max_iterations=10))
+                h.set_option(capi.FL_OPT_MAILBOX, mailbox)
+                h.set_option(capi.FL_OPT_SCAN_PULL, pull)
+                h.set_option(capi.FL_OPT_MULTIPASS, multipass)
+                h.map_set_points(scene.map_xyz, 0.5)
+                scan = h.host_alloc(fr.body_xyz.shape, np.float32)
+                scan[:] = fr.body_xyz
+                for rep in range(3):
+                    x23 = capi.state23_from_frame(fr)
+                    P = fr.cov23.copy()
+                    info = h.ikfom_update_iterated_dev(x23, P, scan, 0.001)
+                    out = (x23.vec().copy(), P.copy(), int(info.status), int(info.iterations), int(info.effct_feat_num))
+                    if ref is None:
+                        ref = out
+                        assert out[2] == 0 and out[3] == ro["out"].iterations and out[4] == ro["out"].effct_feat_num
+                        assert np.abs(out[0] - xo.vec()).max() <= 1e-9 and np.abs(out[1] - Po).max() <= 1e-10
+                    assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1]) and out[2:] == ref[2:], (mailbox, pull, multipass, rep)
+                h.host_free(scan)
+                h.close()
