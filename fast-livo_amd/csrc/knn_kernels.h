@@ -369,7 +369,7 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
         }
         dm = fmaxf(dm, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dm), FL_DPP_QUAD_XOR1, 0xf, 0xf, false)));
         dm = fmaxf(dm, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dm), FL_DPP_QUAD_XOR2, 0xf, 0xf, false)));
-        const float reach1 = G.cell - 1e-3f;
+        const float reach1 = fmaxf(G.cell - 1e-3f, 0.f);
         // inside ring 1 only (farther winners: the full path with its ring logic); 1e-5 relative slack covers the float rounding of
         // the box distance below, the 1 mm margin the float cell assignment (floorf(x * inv_cell)) -- as the stop rule of the full walk
         if (dm <= reach1 * reach1) B2s = dm * (1.0f + 1e-5f);
@@ -385,10 +385,10 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
     // for key what one walk over all 27 cells gives.
     FlTop5 t, g;
     fl_top5_clear(t);
-    const float reach1 = G.cell - 1e-3f;
+    const float reach1 = fmaxf(G.cell - 1e-3f, 0.f);      // (a cell edge below the 1 mm margin: no bound ever holds, every query walks on)
     const float fx = pw[0] * G.inv_cell - (float)cx, fy = pw[1] * G.inv_cell - (float)cy, fz = pw[2] * G.inv_cell - (float)cz;
     const int bx = fx < 0.5f ? -1 : 0, by = fy < 0.5f ? -1 : 0, bz = fz < 0.5f ? -1 : 0;      // the block: offsets {b, b + 1} per axis
-    const float dmin = G.cell * fminf(fminf(fx < 0.5f ? 1.0f - fx : fx, fy < 0.5f ? 1.0f - fy : fy), fz < 0.5f ? 1.0f - fz : fz) - 1e-3f;
+    const float dmin = fmaxf(G.cell * fminf(fminf(fx < 0.5f ? 1.0f - fx : fx, fy < 0.5f ? 1.0f - fy : fy), fz < 0.5f ? 1.0f - fz : fz) - 1e-3f, 0.f);
     const bool blockmode = !(B2s < INFINITY);
     bool needB = false;
     float B2r = INFINITY;

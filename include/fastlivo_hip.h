@@ -315,7 +315,8 @@ int32_t fl_ikfom_solve(fl_handle h, const double *d_sums, int32_t flags, fl_iter
  * (:692-706) with the current map points (k x 3 floats). cell_size (m) is the voxel edge of the device
  * grid: 2-3x the map's point spacing. cell_size <= 0: automatic -- the library keeps the points per occupied cell
  * between 5 and 20 by moving the edge in steps of 1.5x whenever the map is (re)built; results do not depend on it
- * (the search is exact for any cell), its cost does (a 0.5 m cell on a map thinned to 0.5 m spacing: 10x slower). */
+ * (the search is exact for any cell), its cost does (a 0.5 m cell on a map thinned to 0.5 m spacing: 10x slower).
+ * An explicit edge below 0.02 m is raised to 0.02 m. */
 int32_t fl_map_set_points(fl_handle h, const float *map_xyz, int32_t k, float cell_size);
 /* The map kept ON the device between frames (the map side of rows N1/N3): instead of re-staging the host map after every
  * map_incremental, update the device copy in place. The array order is part of the contract (ties of the k-NN go to the lower

@@ -10,7 +10,7 @@ def _handle(capi, synth, fr, max_iter=10):
     return capi.Handle(capi.config_from_frames(fr, max_iterations=max_iter))
 
 
-@pytest.mark.parametrize("n,cell", [(1, 0.5), (777, 0.5), (20000, 0.5), (5000, 0.3), (5000, 1.2)])
+@pytest.mark.parametrize("n,cell", [(1, 0.5), (777, 0.5), (20000, 0.5), (5000, 0.3), (5000, 1.2), (300, 0.02), (300, 0.0008)])   # (the last two: the smallest cell edge the library uses, and one below it -- raised to 2 cm)
 def test_search_is_exact(gpu_lib, oracle_lib, scene, n, cell):
     capi, orc = gpu_lib, oracle_lib
     from fast_livo_amd import synth
