@@ -12,6 +12,7 @@ ap.add_argument("--cell", type=float, default=0.5)
 ap.add_argument("--order", choices=("as_is", "voxel", "random"), default="as_is", help="order of the scan points: as synth makes them, sorted by voxel index as pcl::VoxelGrid emits its centroids, shuffled")
 ap.add_argument("--leaf", type=float, default=0.5)
 ap.add_argument("--move", type=float, default=-1.0, help=">= 0: also time a second search after the pose moved by this many metres (incremental on / off)")
+ap.add_argument("--only-incremental", action="store_true", help="with --move: time the incremental form only (rocprofv3 --stats of this run = the rematch search kernel)")
 a = ap.parse_args()
 fr = synth.make_lio_frame(a.points)
 if a.order != "as_is":
@@ -34,7 +35,7 @@ print("search_fit_us", ks)
 if a.move >= 0:
     from oracle import np_oracle as npo          # Exp only (tool, not product)
     rng = np.random.default_rng(2)
-    for incr in (1, 0):
+    for incr in ((1,) if a.only_incremental else (1, 0)):
         h.set_option(capi.FL_OPT_INCR_SEARCH, incr)
         ks = []
         for r in range(a.reps):
