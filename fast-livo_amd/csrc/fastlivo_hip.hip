@@ -592,7 +592,8 @@ static int32_t ensure_points(fl_handle h, int n)
     HIPCHK(h, hipMalloc(&h->d_gate, sizeof(float4) * (size_t)cap));
     HIPCHK(h, hipMalloc(&h->d_plane, sizeof(float4) * (size_t)cap));
     HIPCHK(h, hipMalloc(&h->d_normvec, sizeof(float4) * (size_t)cap));
-    HIPCHK(h, hipMalloc(&h->d_knn_ids, sizeof(float4) * 5 * (size_t)cap));
+    // (d_knn_ids, 80 B per point, is allocated by the first device search: launch_search -- a handle that is fed neighbours by the host,
+    // like the 32 M-point passes of bench.py, never pays for it)
     h->cap_points = cap;
     return FL_OK;
 }
