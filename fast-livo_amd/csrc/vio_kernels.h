@@ -808,6 +808,33 @@ struct FlVioLevelInfo {
     int32_t iterations, n_meas, accepted, status, converged;
 };
 
+// ComputeJ tail: if (now_error < error) state->cov -= G*state->cov  (:978-981); then the frame's result mailbox (fl_publish_state).
+// Any workgroup of >= 128 threads, barriers inside.
+__device__ __forceinline__ void vio_cov_update_body(FlDev18 *__restrict__ D)
+{
+    __shared__ double sP[324];
+    __shared__ double sG[108];
+    const int t = threadIdx.x, nt = blockDim.x;
+    const bool apply = D->last_error < 1e10f;
+    if (!(D->status & FL_NUM_TIMEOUT)) {          // abandoned frame: enqueued again after the resume (uniform)
+        for (int e = t; e < 324; e += nt) sP[e] = D->P[e];
+        eskf18_gain_block(D, sG);     // G[:,0:6] of the last ACCEPTED iteration (G is only rewritten on acceptance, :877)
+        if (apply) {
+            for (int e = t; e < 324; e += nt) {
+                const int r = e / 18, c = e % 18;
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) s += sG[r * 6 + k] * sP[k * 18 + c];
+                D->P[e] = sP[e] - s;
+            }
+        }
+    }
+    fl_publish_state(D);
+}
+// (out of line: its registers and LDS addressing stay out of the pass loop's allocation, as eskf18_cov_outofline for the LIO kernel)
+__device__ __attribute__((noinline)) void vio_cov_outofline(FlDev18 *D) { vio_cov_update_body(D); }
+#define FL_VIO_DO_COV 0x200            /* launch flag (internal): the LAST level launch of fl_vio_compute_j ends with the covariance update */
+
 // Up to `count` passes of one pyramid level in ONE launch (see lio18_multipass_kernel): the solver broadcasts the derived camera
 // pose (Rcw, Pcw: what the producers consume) and the stop bit; a rejected solve (error went up, lidar_selection.cpp:888-892)
 // reverts and stops like the reference. Bit-identical to `count` launches of vio_pass_kernel<0>.
@@ -835,6 +862,7 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
     const bool begin = begin_residual >= 0.f;
     if (D->status & FL_NUM_TIMEOUT) {             // an earlier pass of the chain was abandoned: nothing runs until the host has resumed
         if (blockIdx.x == solver_block && threadIdx.x == 0) D->resume_count += count;  // (the solver workgroup is the only writer)
+        if ((flags & FL_VIO_DO_COV) && blockIdx.x == solver_block) { __syncthreads(); vio_cov_outofline(D); }    // (publishes the abandoned block)
         fl_mp_done(done_word, done_seq, blockIdx.x == solver_block);
         return;
     }
@@ -929,6 +957,11 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
                 level_info->accepted = D->accepted; level_info->status = D->status; level_info->converged = D->converged;
             }
         }
+        if (flags & FL_VIO_DO_COV) {                              // the frame's last launch: covariance update + result mailbox
+            __threadfence();
+            __syncthreads();
+            vio_cov_outofline(D);
+        }
         fl_mp_done(done_word, done_seq, true);
         return;
     }
@@ -998,23 +1031,4 @@ __global__ void vio_level_end_kernel(const FlDev18 *__restrict__ D, FlVioLevelIn
     out->converged = D->converged;
 }
 
-// ComputeJ tail: if (now_error < error) state->cov -= G*state->cov  (:978-981); then the frame's result mailbox (fl_publish_state)
-__global__ __launch_bounds__(384) void vio_cov_update_kernel(FlDev18 *__restrict__ D)
-{
-    __shared__ double sP[324];
-    __shared__ double sG[108];
-    const int t = threadIdx.x;
-    const bool apply = D->last_error < 1e10f;
-    if (!(D->status & FL_NUM_TIMEOUT)) {          // abandoned frame: enqueued again after the resume (uniform)
-        if (t < 324) sP[t] = D->P[t];
-        eskf18_gain_block(D, sG);     // G[:,0:6] of the last ACCEPTED iteration (G is only rewritten on acceptance, :877)
-        if (apply && t < 324) {
-            const int r = t / 18, c = t % 18;
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) s += sG[r * 6 + k] * sP[k * 18 + c];
-            D->P[t] = sP[t] - s;
-        }
-    }
-    fl_publish_state(D);
-}
+__global__ __launch_bounds__(384) void vio_cov_update_kernel(FlDev18 *__restrict__ D) { vio_cov_update_body(D); }
