@@ -42,6 +42,20 @@ NTU_CAM = dict(width=752, height=480, fx=4.250258563372763e+02, fy=4.26797626090
                d=(-0.288105327549552, 0.074578284234601, 7.784489598138802e-04,
                   -2.277853975035461e-04, 0.0))
 
+# /root/reference/config/MARS_LVIG.yaml:3,9,15-16,36-39,47-50 ; config/camera_MARS_LVIG.yaml:3-12 (HKisland / HKairport calibration)
+MARS_RCL = np.array([[0.00438814, -0.999807, -0.0191582],
+                     [-0.00978695, 0.0191145, -0.999769],
+                     [0.999942, 0.00457463, -0.00970118]])
+MARS_PCL = np.array([0.016069, 0.0871753, -0.0718021])
+MARS_CAM = dict(width=1224, height=1024, fx=722.215831395, fy=722.171768344, cx=588.900539701, cy=521.800513284,
+                d=(-0.05729528706141188, 0.1210407244166642, 0.001274128378760289, 0.0004389741530109464, 0.0))
+# /root/reference/config/mid360.yaml:3,32-35,43-46 (max_iteration 5; the camera intrinsics are camera_pinhole.yaml's)
+MID360_T_LI = np.array([-0.011, -0.02329, 0.04412])
+MID360_RCL = np.array([[0.0268125, -0.999465, 0.0187293],
+                       [-0.157156, -0.0227175, -0.987312],
+                       [0.98721, 0.0235289, -0.157681]])
+MID360_PCL = np.array([-0.112954, 0.0328782, -0.308706])
+
 LASER_POINT_COV = 0.001   # avia.yaml:16
 IMG_POINT_COV = 100.0     # avia.yaml:15
 INIT_COV = 0.001          # common_lib.h:38
