@@ -695,6 +695,14 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
 {
     constexpr int NT = FL_VIO_NT;
     constexpr int WPB = NT / 64;
+    // chain batch: 8 iterations in the fused kernel (16 KB more LDS than 4; the solver workgroup's gather and replay buffers live in the
+    // producers' arrays -- a workgroup has ONE role --, which keeps two workgroups per CU), 4 in the accumulate-only form (its third
+    // workgroup per CU is worth more than the longer batch)
+    constexpr int CB = (MODE == 0) ? 8 : FL_VIO_CHAIN_BATCH;
+    __shared__ double s_red[FL_VIO_GPW * WPB * FL_SUMS18];
+    __shared__ __attribute__((aligned(16))) float s_res[FL_VIO_GPW * WPB * CB * 64];
+    static_assert(sizeof(double) * FL_VIO_GPW * WPB * FL_SUMS18 >= sizeof(double) * 2 * NT, "the solver's gather buffer fits the producers' reduction buffer");
+    static_assert(MODE != 0 || sizeof(float) * FL_VIO_GPW * WPB * CB * 64 >= sizeof(float) * FL_EXACT_LDS, "the solver's replay buffer fits the producers' residual buffer");
     const int nprod = gridDim.x - 2;              // then the solver and the auditor (FL_VIO_SOLVER_BLOCK / FL_VIO_AUDITOR_BLOCK)
     const int solver_block = FL_VIO_SOLVER_BLOCK(nprod), auditor_block = FL_VIO_AUDITOR_BLOCK(nprod);
     FL_INSTR(if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();)
@@ -717,7 +725,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     }
     if (blockIdx.x == solver_block) {
         // ------------------------------------------------------------------ solver workgroup
-        __shared__ double s_fin[2 * NT];
+        double *s_fin = s_red;                               // (2 * NT doubles: see the static_assert above)
         __shared__ double s_sums[FL_SUMS18];
         __shared__ FlSolveLds s_solve;
         FL_INSTR(fl_stamp(flags, 8);)
@@ -738,7 +746,7 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
             if (threadIdx.x == 0) *D->xchg_epoch = xe + 1u;
         }
         if (MODE == 0) {
-            __shared__ __attribute__((aligned(16))) float s_ex[FL_EXACT_LDS];
+            float *s_ex = s_res;                             // (FL_EXACT_LDS floats)
             FlVioExact ex;
             ex.words = D->err_words; ex.m = m; ex.cap = D->err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !(flags & FL_ITER_FORCE);
             ex.own = (world > 1) ? D->xchg_peer[D->xchg_rank] : nullptr; ex.peer = D->xchg_peer; ex.rank = D->xchg_rank; ex.world = world;
@@ -752,7 +760,6 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     }
 
     // -------------------------------------------------------------------- producer workgroups
-    __shared__ double s_red[FL_VIO_GPW * WPB * FL_SUMS18];
     const int level = (level_arg >= 0) ? level_arg : D->level;
     // wave-uniform camera pose, derived from the state by the previous pass's solver (vio_derive_pose)
     const FlVioConst vc = *VC;
@@ -761,12 +768,11 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     for (int i = 0; i < 9; i++) Rcw[i] = D->Rcw[i];
 #pragma unroll
     for (int i = 0; i < 3; i++) Pcw[i] = D->Pcw[i];
-    __shared__ __attribute__((aligned(16))) float s_res[FL_VIO_GPW * WPB * FL_VIO_CHAIN_BATCH * 64];
-    __shared__ int s_pidx[FL_VIO_GPW * WPB * FL_VIO_CHAIN_BATCH];
+    __shared__ int s_pidx[FL_VIO_GPW * WPB * CB];
     unsigned long long *ew = D->err_words ? D->err_words + (size_t)(D->iters_run & 1) * D->err_cap : nullptr;
     FlVioLaneRole role = fl_vio_lane_role((int)(threadIdx.x & 15), VC);
     fl_vio_lane_role_pose(role, (int)(threadIdx.x & 15), D->Rcw);
-    vio_produce<FL_VIO_CHAIN_BATCH>(img, ref, pos, slevel, errors, m, level_arg, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags, ew, s_res, s_pidx, role);
+    vio_produce<CB>(img, ref, pos, slevel, errors, m, level_arg, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags, ew, s_res, s_pidx, role);
     FL_INSTR(if (blockIdx.x == 0) fl_stamp(flags, 2);)
     FL_INSTR(if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();)
 }
