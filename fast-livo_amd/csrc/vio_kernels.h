@@ -374,6 +374,11 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
     const double pf_pos0 = pf.pos0, pf_pos1 = pf.pos1, pf_pos2 = pf.pos2;
     const int xr = hl >> 3, yc = hl & 7;          // this lane's pixels: (xr + (LPP / 8) k, yc), k = 0 .. PPL-1
     const int W = vc.stride, Hm1 = vc.height - 1, Wm1 = vc.width - 1;
+    // the tap rows of the fast paths come through a buffer descriptor: per-lane byte offset (one VGPR) + a scalar row offset -- no
+    // 64-bit pointer arithmetic per row (10 rows x ~6 vector instructions per iteration before). Needs rows that keep the dword phase
+    // of a lane's first row (stride % 4 == 0: true for every shipped camera); other strides take the byte-tap path.
+    const __amdgpu_buffer_rsrc_t img_rs = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, W * vc.height + 16, 0x00020000);
+    const bool rows_dword_phase = (W & 3) == 0;
 
     static_assert(FL_VIO_LPP == 16, "the lane-distributed 6x6 update maps one patch to one 16-lane DPP row");
     double *s_M = s_red + slot * FL_VIO_MROW;                     // this lane group's M exchange (GPW * WPB * FL_VIO_MROW doubles)
@@ -452,15 +457,15 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
         // Coarser pyramid levels (scale 2, 4: the first two levels of ComputeJ) read the same 10 rows at stride scale: the four
         // taps of a row are bytes 0, s, 2s, 3s of a 7- / 13-byte span -- three / four aligned dwords per row and byte shifts.
         const int scale_u = __builtin_amdgcn_readfirstlane(scale);
-        const bool fast_taps = (LPP == 16) && (scale_u == 1 || scale_u == 2 || scale_u == 4) && (__ballot(inside && scale == scale_u) == ~0ull);
+        const bool fast_taps = (LPP == 16) && rows_dword_phase && (scale_u == 1 || scale_u == 2 || scale_u == 4) && (__ballot(inside && scale == scale_u) == ~0ull);
         if (fast_taps && scale_u == 1) {          // (one straight-line path per scale: a branch per row cost the finest level 1.3 us)
-            const uint8_t *q = img + (g.v_i + xr - 5) * W + (col0 - 1);
+            const int off0 = (g.v_i + xr - 5) * W + (col0 - 1);       // >= 0: the patch is inside the image
+            const unsigned sh = (unsigned)off0 & 3u;
+            const int voff = off0 & ~3;
             unsigned rowv[10];
 #pragma unroll
             for (int m2 = 0; m2 < 10; m2++) {
-                const uint8_t *a = q + m2 * W;
-                const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(a) & 3u);
-                const fl_u2 w2 = *reinterpret_cast<const fl_u2_dw *>(reinterpret_cast<uintptr_t>(a) & ~(uintptr_t)3);   // (dword-aligned 8-byte load; the frame buffer is padded: api_vio.inc)
+                const fl_u2 w2 = __builtin_bit_cast(fl_u2, __builtin_amdgcn_raw_buffer_load_b64(img_rs, voff, m2 * W, 0));   // (dword-aligned; the frame buffer is padded: api_vio.inc)
                 rowv[m2] = __builtin_amdgcn_alignbyte(w2.y, w2.x, sh);
             }
 #pragma unroll
@@ -473,15 +478,14 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
                         t[px][r][c] = used ? (float)((rowv[2 * px + r] >> (8 * c)) & 0xffu) : 0.f;
                     }
         } else if (fast_taps && scale_u == 2) {
-            const uint8_t *q = img + (g.v_i + (xr - 5) * 2) * W + (col0 - 2);
+            const int off0 = (g.v_i + (xr - 5) * 2) * W + (col0 - 2);
+            const unsigned sh = (unsigned)off0 & 3u;
+            const int voff = off0 & ~3;
             unsigned lo[10], hi[10];               // bytes 0, 2 of lo: taps 0, 1; of hi: taps 2, 3
 #pragma unroll
             for (int m2 = 0; m2 < 10; m2++) {
                 typedef unsigned int fl_u3 __attribute__((ext_vector_type(3)));
-                typedef unsigned int fl_u3_dw __attribute__((ext_vector_type(3), aligned(4)));
-                const uint8_t *a = q + m2 * 2 * W;
-                const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(a) & 3u);
-                const fl_u3 w3 = *reinterpret_cast<const fl_u3_dw *>(reinterpret_cast<uintptr_t>(a) & ~(uintptr_t)3);
+                const fl_u3 w3 = __builtin_bit_cast(fl_u3, __builtin_amdgcn_raw_buffer_load_b96(img_rs, voff, m2 * 2 * W, 0));
                 lo[m2] = __builtin_amdgcn_alignbyte(w3.y, w3.x, sh);
                 hi[m2] = __builtin_amdgcn_alignbyte(w3.z, w3.y, sh);
             }
@@ -496,13 +500,13 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
                         t[px][r][c] = used ? (float)((wv >> (16 * (c & 1))) & 0xffu) : 0.f;
                     }
         } else if (fast_taps) {                   // scale 4
-            const uint8_t *q = img + (g.v_i + (xr - 5) * 4) * W + (col0 - 4);
+            const int off0 = (g.v_i + (xr - 5) * 4) * W + (col0 - 4);
+            const unsigned sh = (unsigned)off0 & 3u;
+            const int voff = off0 & ~3;
             unsigned tv[10][4];
 #pragma unroll
             for (int m2 = 0; m2 < 10; m2++) {
-                const uint8_t *a = q + m2 * 4 * W;
-                const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(a) & 3u);
-                const fl_u4 w4 = *reinterpret_cast<const fl_u4_dw *>(reinterpret_cast<uintptr_t>(a) & ~(uintptr_t)3);
+                const fl_u4 w4 = __builtin_bit_cast(fl_u4, __builtin_amdgcn_raw_buffer_load_b128(img_rs, voff, m2 * 4 * W, 0));
                 tv[m2][0] = __builtin_amdgcn_alignbyte(w4.y, w4.x, sh); tv[m2][1] = __builtin_amdgcn_alignbyte(w4.z, w4.y, sh);
                 tv[m2][2] = __builtin_amdgcn_alignbyte(w4.w, w4.z, sh); tv[m2][3] = w4.w >> (8 * sh);
             }
