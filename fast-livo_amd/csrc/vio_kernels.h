@@ -32,6 +32,25 @@ struct __attribute__((aligned(16))) FlGeomLds {
     int q[4];           // u_i, v_i, scale, -
 };
 
+// 1 / scale for scale = 2^k (a pyramid scale, 1 ... 2^30): exact in both precisions, so building it from the exponent gives the very
+// bits of the IEEE divisions it replaces (~15 dependent instructions each in fp64 on the device) -- host build: the division itself
+FL_HD double fl_inv_pow2_f64(int scale)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hiloint2double((1023 - (__ffs(scale) - 1)) << 20, 0);
+#else
+    return 1.0 / (double)scale;
+#endif
+}
+FL_HD float fl_inv_pow2_f32(int scale)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __int_as_float((127 - (__ffs(scale) - 1)) << 23);
+#else
+    return 1.0f / (float)scale;
+#endif
+}
+
 FL_HD void fl_world2cam(const FlVioConst &c, const double *pf, double *pc)
 {
     const double u = pf[0] / pf[2], v = pf[1] / pf[2];
@@ -63,8 +82,8 @@ FL_HD void fl_patch_geom(const FlVioConst &c, const double *Rcw, const double *P
     g.scale = scale;
     // scale is a power of two: x / scale == x * (1 / scale) bit for bit (no rounding in either), one multiply instead of an IEEE
     // division sequence on the patch's critical path (lidar_selection.cpp:806-809 divides)
-    const double inv_sd = 1.0 / (double)scale;
-    const float inv_sf = 1.0f / (float)scale;
+    const double inv_sd = fl_inv_pow2_f64(scale);
+    const float inv_sf = fl_inv_pow2_f32(scale);
     g.u_i = (int)(floorf((float)(pc[0] * inv_sd)) * scale);
     g.v_i = (int)(floorf((float)(pc[1] * inv_sd)) * scale);
     const float su = (u_ref - g.u_i) * inv_sf;
@@ -85,7 +104,7 @@ FL_HD void fl_pixel_row(const FlPatchGeom &g, const float t[4][4], float ref, co
                            - (wtl * t[1][0] + wtr * t[1][1] + wbl * t[2][0] + wbr * t[2][1]));
     const float dv = 0.5f * ((wtl * t[2][1] + wtr * t[2][2] + wbl * t[3][1] + wbr * t[3][2])
                            - (wtl * t[0][1] + wtr * t[0][2] + wbl * t[1][1] + wbr * t[1][2]));
-    const double inv_s = 1.0 / g.scale;
+    const double inv_s = fl_inv_pow2_f64(g.scale);
     const double J0 = (double)du * inv_s, J1 = (double)dv * inv_s;
     double JJ[3], Jdphi[3], Jdp[3];
 #pragma unroll
@@ -126,7 +145,7 @@ FL_HD void fl_patch_M(const FlPatchGeom &g, const double *Jdphi_dR, const double
 #pragma unroll
         for (int j = 0; j < 3; j++)
             B[i * 3 + j] = (ph[i * 3 + 0] * Jdphi_dR[0 * 3 + j] + ph[i * 3 + 1] * Jdphi_dR[1 * 3 + j] + ph[i * 3 + 2] * Jdphi_dR[2 * 3 + j]) - Jdp_dR[i * 3 + j];
-    const double inv_s = 1.0 / g.scale;
+    const double inv_s = fl_inv_pow2_f64(g.scale);
     const double a = g.Jdpi[0] * inv_s, c = g.Jdpi[2] * inv_s, b = g.Jdpi[4] * inv_s, d = g.Jdpi[5] * inv_s;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -563,7 +582,7 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
         FL_INSTR(if ((flags & FL_ITER_STAMP) && blockIdx.x == 0) { asm volatile("" ::"v"(t[0][1][1] + t[PPL - 1][2][2] + refv[PPL - 1])); fl_stamp(flags, 41); })
         {   // this lane's entry of M (lanes 0..11), overlaps the tap loads. Explicit fma() in a fixed form: the kernel variants (launch
             // bounds) must produce the same bits, and a contraction left to the compiler differs between instantiations.
-            const double inv_s = 1.0 / g.scale;
+            const double inv_s = fl_inv_pow2_f64(g.scale);
             const double s1 = (role.r ? g.Jdpi[4] : g.Jdpi[0]) * inv_s, s2 = (role.r ? g.Jdpi[5] : g.Jdpi[2]) * inv_s;
             const double q1 = role.r ? g.pf[2] : -g.pf[2], q2 = role.r ? -g.pf[0] : g.pf[1];
             const double Br = fma(q1, role.X1, fma(q2, role.X2, -role.X3));
