@@ -1,9 +1,12 @@
-"""ctypes binding of oracle/_ref/libeigen_ref.so: the REFERENCE's own Eigen-dependent headers (common_lib.h, so3_math.h and, with
-Boost, use-ikfom.hpp + the IKFoM toolkit) behind a C driver.  TEST INFRASTRUCTURE ONLY; only tests/ may import this module.
+"""ctypes binding of oracle/_ref/libeigen_ref.so: the REFERENCE's own sources behind a C driver -- include/common_lib.h and
+include/so3_math.h, the text of the Mode-18 loop (laserMapping.cpp:1506-1732), of LidarSelector::UpdateState / ComputeJ and of
+ImuProcess::UndistortPcl, all over the reference's own ikd-Tree; with Boost + a real Eigen also use-ikfom.hpp and the IKFoM toolkit.
+TEST INFRASTRUCTURE ONLY; only tests/ may import this module.
 
-Recipe: oracle/ref_eigen/ (Makefile, stubs/, eigen_driver.cpp).  It needs Eigen 3, which this image does not have: `build()` runs the
-recipe when /root/reference is present, the recipe skips itself (successfully, saying why) when it finds no Eigen, and `why_not()`
-returns the reason the tests print when they skip.
+Recipe: oracle/ref_eigen/ (Makefile, ref_text.sh, text/, stubs/, eigen_driver.cpp, shim/).  `build()` runs it when /root/reference is
+present; elsewhere the prebuilt library that travelled in oracle/_ref/ is used.  No Eigen is installed here: the recipe then compiles
+against oracle/ref_eigen/shim (NOT Eigen; `linalg_kind()` returns "shim"), which pins the reference's logic and leaves Eigen's own
+arithmetic unpinned.  `why_not()` returns the reason the tests print when they have to skip.
 """
 from __future__ import annotations
 
@@ -62,6 +65,13 @@ def lib():
         L.ref_so3_exp.argtypes = [dp, dp]
         L.ref_so3_exp_dt.argtypes = [dp, C.c_double, dp]
         L.ref_so3_log.argtypes = [dp, dp]
+        L.ref_linalg_kind.restype = C.c_int
+        vp = C.c_void_p
+        L.ref_lio18_frame.argtypes = [vp, vp, C.c_int, vp, C.c_int, dp, dp, C.c_double, C.c_int, vp, vp, vp, vp]
+        L.ref_vio_update_state.restype = C.c_float
+        L.ref_vio_update_state.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]
+        L.ref_vio_compute_j.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]
+        L.ref_imu_undistort.argtypes = [vp, vp, vp, C.c_int, C.c_double, vp, C.c_int, vp, vp, vp, vp]
         if L.ref_have_mtk():
             L.ref_state23_boxplus.argtypes = [dp, dp]
             L.ref_state23_boxminus.argtypes = [dp, dp, dp]
@@ -115,6 +125,71 @@ def so3_log(R):
     out = np.zeros(3)
     lib().ref_so3_log(_d(R), _d(out))
     return out
+
+
+def linalg_kind():
+    """'eigen' = the library was compiled against a real Eigen; 'shim' = against oracle/ref_eigen/shim (NOT Eigen: the reference's
+    text runs, Eigen's own arithmetic does not)."""
+    return "shim" if lib().ref_linalg_kind() else "eigen"
+
+
+def lio18_frame(x, body, map_xyz, R_LI, t_LI, cov, max_iter):
+    """The reference's Mode-18 loop text (laserMapping.cpp:1506-1732) over its own ikd-Tree built from map_xyz.  Mutates x
+    (oracle.State18); returns the oracle's frame outputs."""
+    from . import oracle as orc
+    body = np.ascontiguousarray(body, dtype=np.float32)
+    map_xyz = np.ascontiguousarray(map_xyz, dtype=np.float32)
+    n = body.shape[0]
+    out = orc.LioFrameOut()
+    sel = np.zeros(n, dtype=np.uint8)
+    normvec = np.zeros((n, 4), dtype=np.float32)
+    world = np.zeros((n, 3), dtype=np.float32)
+    R_LI = np.ascontiguousarray(R_LI, dtype=np.float64)
+    t_LI = np.ascontiguousarray(t_LI, dtype=np.float64)
+    st = lib().ref_lio18_frame(C.addressof(x), body.ctypes.data, n, map_xyz.ctypes.data, len(map_xyz), _d(R_LI), _d(t_LI), cov, max_iter,
+                               sel.ctypes.data, normvec.ctypes.data, world.ctypes.data, C.addressof(out))
+    return dict(status=st, out=out, sel=sel, normvec=normvec, world=world)
+
+
+def vio_update_state(vf, x, x_prop, total_residual, level, G=None):
+    """LidarSelector::UpdateState, the reference's text (lidar_selection.cpp:743-902).  Mutates x and G."""
+    from . import oracle as orc
+    cfg = orc.vio_config(vf)
+    G = np.zeros((18, 18)) if G is None else G
+    errors = np.zeros(vf.m, dtype=np.float32)
+    HTH = np.zeros((6, 6))
+    err = lib().ref_vio_update_state(C.addressof(cfg), C.addressof(x), C.addressof(x_prop), vf.img.ctypes.data, vf.ref_patch.ctypes.data,
+                                     vf.pos.ctypes.data, vf.search_level.ctypes.data, vf.m, total_residual, level, errors.ctypes.data,
+                                     G.ctypes.data, HTH.ctypes.data)
+    return dict(error=err, errors=errors, G=G, HTH=HTH)
+
+
+def vio_compute_j(vf, x, x_prop):
+    """LidarSelector::ComputeJ, the reference's text (lidar_selection.cpp:967-983 over :743-911).  Mutates x."""
+    from . import oracle as orc
+    cfg = orc.vio_config(vf)
+    errors = np.zeros(vf.m, dtype=np.float32)
+    Tcw = np.zeros(12)
+    st = lib().ref_vio_compute_j(C.addressof(cfg), C.addressof(x), C.addressof(x_prop), vf.img.ctypes.data, vf.ref_patch.ctypes.data,
+                                 vf.pos.ctypes.data, vf.search_level.ctypes.data, vf.m, errors.ctypes.data, Tcw.ctypes.data)
+    return dict(status=st, errors=errors, Tcw=Tcw)
+
+
+def imu_undistort(proc, state, imu, pcl_beg_time, pts_xyzt):
+    """ImuProcess::UndistortPcl, the reference's text (IMU_Processing.cpp:611-809), on one whole scan (is_lidar_end).  Mutates proc
+    (oracle.ImuProc) and state (oracle.State18).  Returns (compensated cloud of the KEPT points (k, 4), poses, pcl_end_time): the
+    reference derives pcl_end_time from the last point and may leave the last point(s) out (see text/imu_2.inc)."""
+    from . import oracle as orc
+    samples = imu if not isinstance(imu, np.ndarray) else orc.imu_samples(imu)
+    k = len(samples)
+    pts = np.array(pts_xyzt, dtype=np.float32, order="C", copy=True)
+    poses = (orc.Pose6d * (k + 1))()
+    npz, kept, t_end = C.c_int32(0), C.c_int32(0), C.c_double(0.0)
+    rc = lib().ref_imu_undistort(C.addressof(proc), C.addressof(state), C.addressof(samples), k, pcl_beg_time, pts.ctypes.data, pts.shape[0],
+                                 C.addressof(poses), C.addressof(npz), C.addressof(kept), C.addressof(t_end))
+    if rc != 0:
+        raise RuntimeError("ref_imu_undistort failed")
+    return pts[:kept.value], [poses[i] for i in range(npz.value)], t_end.value
 
 
 def have_mtk():

@@ -57,18 +57,22 @@ static inline void skew3(const double *v, double *K) /* so3_math.h:9 */
 }
 static inline double norm3(const double *v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
-/* so3_math.h:54-72 : Rodrigues with threshold 1e-5 on the norm. */
+/* so3_math.h:54-72 : Rodrigues with threshold 1e-5 on the norm.  The reference writes `Eye3 + std::sin(norm) * K + (1.0 - std::cos(norm)) * K * K`,
+ * which C++ groups as (Eye3 + s*K) + ((c*K)*K): the scalar goes into the LEFT factor before the product (for 3x3 fixed-size operands
+ * Eigen evaluates exactly that, coefficient by coefficient).  Until round 4 this function computed c*(K*K) instead -- one unit in the last place
+ * away in 14 % of random rotations, found by running the reference's own text (oracle/ref_eigen, tests/test_ref_eigen_cpu.py). */
 static inline void so3_Exp(double v1, double v2, double v3, double *R)
 {
     double nrm = sqrt(v1 * v1 + v2 * v2 + v3 * v3);
     for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
     if (nrm > 0.00001) {
         double r[3] = {v1 / nrm, v2 / nrm, v3 / nrm};
-        double K[9], KK[9];
+        double K[9], cK[9], cKK[9];
         skew3(r, K);
-        m3_mul(K, K, KK);
         double s = sin(nrm), c = 1.0 - cos(nrm);
-        for (int i = 0; i < 9; i++) R[i] = R[i] + s * K[i] + c * KK[i];
+        for (int i = 0; i < 9; i++) cK[i] = c * K[i];
+        m3_mul(cK, K, cKK);
+        for (int i = 0; i < 9; i++) R[i] = (R[i] + s * K[i]) + cKK[i];
     }
 }
 /* so3_math.h:75-81 */

@@ -12,11 +12,11 @@
 // The entry points take the same flat layouts as the oracle's (oracle/fastlivo_oracle.h: orc_state18 fields, orc_state23 = 26
 // doubles, row-major matrices) so that tests/test_ref_eigen_cpu.py can hold oracle/orc_*.c to them value for value.
 //
-// Status (round 4): no Eigen exists in the build container or on the GPU box, so this file has never been compiled against Eigen.
-// The part outside REF_HAVE_MTK -- together with the reference's common_lib.h / so3_math.h and every stub header -- WAS compiled,
-// linked and run against a throwaway 150-line stand-in for the Eigen API (fixed / dynamic Matrix, blocks, comma initialiser, a
-// least-squares solve; not Eigen, not committed): it builds without a diagnostic and all eight entry points run, so the stubs are
-// sufficient and the driver is syntactically sound. The REF_HAVE_MTK part needs Boost.Preprocessor and has not met a compiler.
+// Status (round 4): no Eigen exists in the build container or on the GPU box.  The recipe therefore falls back to shim/ (this
+// repository's own small dense-matrix library behind the part of Eigen's API these sources use -- NOT Eigen, see shim/Eigen/Core):
+// the part of this file outside REF_HAVE_MTK, the reference's common_lib.h / so3_math.h and the text units of ref_text.sh compile
+// and RUN against it here (ref_linalg_kind() == 1), which pins the reference's own logic but not Eigen's arithmetic.  Against a real
+// Eigen this file has never been compiled; the REF_HAVE_MTK part additionally needs Boost.Preprocessor and has not met a compiler.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -76,6 +76,17 @@ extern "C" {
 int ref_have_mtk(void)
 {
 #ifdef REF_HAVE_MTK
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+// 0 = compiled against a real Eigen, 1 = against oracle/ref_eigen/shim (this repository's stand-in behind Eigen's API: the
+// reference's text runs, Eigen's own arithmetic does not)
+int ref_linalg_kind(void)
+{
+#ifdef REF_LINALG_SHIM
     return 1;
 #else
     return 0;

@@ -1,0 +1,84 @@
+#!/bin/bash
+# oracle/ref_eigen/ref_text.sh -- TEST INFRASTRUCTURE ONLY.
+# Writes ONE translation unit to stdout: hand-written pieces from text/ with line ranges of the REFERENCE's sources between them,
+# read from $REF at build time and piped straight into the compiler by the Makefile (no reference text is stored in this repository
+# or in oracle/_ref).  The ranges are functions / statements the reference only has inside main() or inside a class whose header
+# needs OpenCV, PCL, vikit and Sophus; taking the text is the only way to get THOSE LINES through a compiler here.
+#   ref_text.sh lio   -> pointBodyToWorld (laserMapping.cpp:272-286), `rematch_num` / `nearest_search_en` (:1472-1473),
+#                        the Mode-18 loop (:1506-1732)
+#   ref_text.sh vio   -> LidarSelector::set_extrinsic (lidar_selection.cpp:35-39), the Jacobian part of init (:41-52, :58-59),
+#                        dpi (:92-103), UpdateState (:743-902), updateFrameState (:904-911), ComputeJ (:967-983)
+#   ref_text.sh imu   -> ImuProcess::UndistortPcl (IMU_Processing.cpp:611-809)
+# Every range is anchored: the first and the last line must look as they did in the snapshot the line numbers were taken from
+# (reference of 2024-11-08), otherwise the script fails and nothing is built.
+set -e
+REF=${REF:-/root/reference}
+HERE=$(cd "$(dirname "$0")" && pwd)
+LM=$REF/src/laserMapping.cpp
+LS=$REF/src/lidar_selection.cpp
+IP=$REF/src/IMU_Processing.cpp
+
+anchor() {   # file line regex
+    sed -n "$2p" "$1" | grep -Eq "$3" || { echo "ref_text.sh: $1:$2 does not match /$3/ -- the reference differs from the snapshot" >&2; exit 1; }
+}
+range() {    # file first last
+    echo "// ---- reference text $(basename "$1"):$2-$3 (not stored; read at build time)"
+    echo "#line $2 \"$1\""
+    sed -n "$2,$3p" "$1"
+    echo "// ---- end of reference text"
+}
+
+case "$1" in
+lio)
+    anchor "$LM" 272 '^void pointBodyToWorld\(PointType const'
+    anchor "$LM" 286 '^\}'
+    anchor "$LM" 1472 'int +rematch_num = 0;'
+    anchor "$LM" 1473 'bool nearest_search_en = true;'
+    anchor "$LM" 1506 'for \(iterCount = -1; iterCount < NUM_MAX_ITERATIONS && flg_EKF_inited; iterCount\+\+\)'
+    anchor "$LM" 1731 'if \(EKF_stop_flg\) +break;'
+    anchor "$LM" 1732 '^ {12}\}'
+    cat "$HERE/text/lio_1.inc"
+    range "$LM" 272 286
+    cat "$HERE/text/lio_2.inc"
+    range "$LM" 1472 1473
+    cat "$HERE/text/lio_3.inc"
+    range "$LM" 1506 1732
+    cat "$HERE/text/lio_4.inc"
+    ;;
+vio)
+    anchor "$LS" 35 '^void LidarSelector::set_extrinsic\('
+    anchor "$LS" 39 '^\}'
+    anchor "$LS" 41 '^void LidarSelector::init\(\)'
+    anchor "$LS" 52 'Jdp_dR = -Rci \* tmp;'
+    anchor "$LS" 58 'fx = cam->errorMultiplier2\(\);'
+    anchor "$LS" 59 'fy = cam->errorMultiplier\(\) / \(4\. \* fx\);'
+    anchor "$LS" 92 '^void LidarSelector::dpi\('
+    anchor "$LS" 103 '^\}'
+    anchor "$LS" 743 '^float LidarSelector::UpdateState\('
+    anchor "$LS" 902 '^\}'
+    anchor "$LS" 904 '^void LidarSelector::updateFrameState\('
+    anchor "$LS" 911 '^\}'
+    anchor "$LS" 967 '^void LidarSelector::ComputeJ\('
+    anchor "$LS" 983 '^\}'
+    cat "$HERE/text/vio_1.inc"
+    range "$LS" 35 39
+    range "$LS" 41 52
+    range "$LS" 58 59
+    cat "$HERE/text/vio_2.inc"
+    range "$LS" 92 103
+    range "$LS" 743 902
+    range "$LS" 904 911
+    range "$LS" 967 983
+    cat "$HERE/text/vio_3.inc"
+    ;;
+imu)
+    anchor "$IP" 611 '^void ImuProcess::UndistortPcl\(LidarMeasureGroup &lidar_meas, StatesGroup &state_inout, PointCloudXYZI &pcl_out\)'
+    anchor "$IP" 809 '^\}'
+    anchor "$IP" 811 '^void ImuProcess::Process2\('
+    cat "$HERE/text/imu_1.inc"
+    range "$IP" 611 809
+    cat "$HERE/text/imu_2.inc"
+    ;;
+*)
+    echo "usage: ref_text.sh lio|vio|imu" >&2; exit 2;;
+esac

@@ -147,9 +147,13 @@ int ikdref_delete_boxes(void *h, const float *boxes /* nb x 6: min xyz, max xyz 
 }
 
 // live points in the tree's traversal order; returns their number (writes at most cap)
+// Waits for the rebuild thread first: while it swaps a rebuilt subtree in, a traversal from Root_Node from another thread can come
+// back short (seen once in ~40 runs of the CPU suite as an EMPTY list right behind Delete_Point_Boxes); the reference itself only
+// flattens under its own locks.
 int ikdref_flatten(void *h, float *out_xyz, int cap)
 {
     KD_TREE *t = ((Ref *)h)->tree;
+    ikdref_wait_rebuild(h, 60000);
     PointVector v;
     t->flatten(t->Root_Node, v, NOT_RECORD);
     const int n = (int)v.size();
