@@ -72,6 +72,8 @@ def lib():
         L.ref_vio_update_state.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]
         L.ref_vio_compute_j.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]
         L.ref_imu_undistort.argtypes = [vp, vp, vp, C.c_int, C.c_double, vp, C.c_int, vp, vp, vp, vp]
+        L.ref_vio_select.argtypes = [vp, dp, dp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, vp, vp, vp, vp, vp]
+        L.ref_ikfom_update_text.argtypes = [dp, dp, C.c_double, C.c_int, dp, H_FN, C.c_void_p]
         if L.ref_have_mtk():
             L.ref_state23_boxplus.argtypes = [dp, dp]
             L.ref_state23_boxminus.argtypes = [dp, dp, dp]
@@ -192,6 +194,28 @@ def imu_undistort(proc, state, imu, pcl_beg_time, pts_xyzt):
     return pts[:kept.value], [poses[i] for i in range(npz.value)], t_end.value
 
 
+def vio_select(cfg, Rcw, Pcw, cur_img, keyframes, depth, cand, ncc_en=False, ncc_thre=0.0, outlier_threshold=300.0):
+    """The pixel-level part of LidarSelector::addFromSparseMap, the reference's text (lidar_selection.cpp:476-582 over getpatch,
+    getWarpMatrixAffine, warpAffine, NCC, getBestSearchLevel).  Same inputs and outputs as oracle.vio_select (without `reason`)."""
+    Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(9)
+    Pcw = np.ascontiguousarray(Pcw, np.float64)
+    cur = np.ascontiguousarray(cur_img, np.uint8)
+    kfs = [np.ascontiguousarray(k, np.uint8) for k in keyframes]
+    ptrs = (C.c_void_p * len(kfs))(*[k.ctypes.data for k in kfs])
+    depth = np.ascontiguousarray(depth, np.float32)
+    m = len(cand)
+    idx = np.zeros(max(m, 1), np.int32); err = np.zeros(max(m, 1), np.float32); lvl = np.zeros(max(m, 1), np.int32)
+    patches = np.zeros((max(m, 1), 192), np.float32)
+    na = C.c_int32(0)
+    rc = lib().ref_vio_select(C.addressof(cfg), _d(Rcw), _d(Pcw), cur.ctypes.data, C.addressof(ptrs), depth.ctypes.data, C.addressof(cand), m,
+                              1 if ncc_en else 0, ncc_thre, outlier_threshold, idx.ctypes.data, patches.ctypes.data, err.ctypes.data,
+                              lvl.ctypes.data, C.addressof(na))
+    if rc != 0:
+        raise RuntimeError("ref_vio_select failed: %d" % rc)
+    k = na.value
+    return dict(idx=idx[:k].copy(), errors=err[:k].copy(), levels=lvl[:k].copy(), patches=patches[:k].copy())
+
+
 def have_mtk():
     return bool(lib().ref_have_mtk())
 
@@ -211,9 +235,21 @@ def state23_boxminus(s26, o26):
     return out
 
 
+def ikfom_update_text(s26, P, R, max_iter, h_dyn_share, limit=None):
+    """The TEXT of esekf::update_iterated_dyn_share_modified (esekfom.hpp:1619-1928) around a Python callback, with the oracle's manifold
+    operations as the stand-in for the Boost-generated state type (oracle/ref_eigen/text/ikf_1.inc).  Same contract as
+    ikfom_update_dyn_share below; needs neither Boost nor a real Eigen."""
+    return _ikfom_update(lib().ref_ikfom_update_text, s26, P, R, max_iter, h_dyn_share, limit)
+
+
 def ikfom_update_dyn_share(s26, P, R, max_iter, h_dyn_share, limit=None, state_cls=None):
-    """The reference's unmodified update_iterated_dyn_share_modified around a Python callback of the oracle's shape:
-    h_dyn_share(state (oracle.State23), valid, converge) -> (valid, h_x (rows, 12), h (rows,)).  Returns (state26, P, calls)."""
+    """The reference's unmodified update_iterated_dyn_share_modified (its own MTK state type; needs Boost + Eigen) around a Python callback
+    of the oracle's shape: h_dyn_share(state (oracle.State23), valid, converge) -> (valid, h_x (rows, 12), h (rows,)).
+    Returns (state26, P, calls)."""
+    return _ikfom_update(lib().ref_ikfom_update_dyn_share, s26, P, R, max_iter, h_dyn_share, limit)
+
+
+def _ikfom_update(entry, s26, P, R, max_iter, h_dyn_share, limit):
     from . import oracle as orc
     limit = np.full(23, 0.001) if limit is None else np.ascontiguousarray(limit, dtype=np.float64)
     s = np.array(s26, dtype=np.float64).copy()
@@ -230,5 +266,5 @@ def ikfom_update_dyn_share(s26, P, R, max_iter, h_dyn_share, limit=None, state_c
         rows[0] = hx.shape[0]
         hx_out[0] = _d(hx) if hx.size else None
         h_out[0] = _d(hv) if hv.size else None
-    calls = lib().ref_ikfom_update_dyn_share(_d(s), _d(P), R, max_iter, _d(limit), H_FN(cb), None)
+    calls = entry(_d(s), _d(P), R, max_iter, _d(limit), H_FN(cb), None)
     return s, P, calls

@@ -248,6 +248,11 @@ int orc_ikfom_update_dyn_share(orc_state23 *x, double *P, double R, int maximum_
 void orc_state23_boxplus(orc_state23 *x, const double *dx /*23*/);
 void orc_state23_boxminus(const orc_state23 *x, const orc_state23 *other, double *dx /*23*/);
 
+/* MTK::A_matrix (mtkmath.hpp:236-247), S2::S2_Nx_yy / S2_Mx (S2.hpp:259-280); matrices row-major. */
+void orc_unit_A_matrix(const double *v /*3*/, double *res /*3x3*/);
+void orc_unit_s2_Nx_yy(const double *vec /*3*/, double *Nx /*2x3*/);
+void orc_unit_s2_Mx(const double *vec /*3*/, const double *delta /*2*/, double *Mx /*3x2*/);
+
 /* Unit entry points (one restated reference function each) for the cross-oracle and Eigen-pinning tests:
  * esti_plane<float> common_lib.h:448-493 ; StatesGroup += / - common_lib.h:343-365 ; Exp / Log so3_math.h:54-81. */
 int orc_unit_esti_plane(const float *near /*5x3*/, float threshold, float *pabcd /*4*/);

@@ -245,6 +245,11 @@ void orc_state23_boxminus(const orc_state23 *x, const orc_state23 *o, double *dx
     s2_boxminus(x->grav, o->grav, dx + 21);
 }
 
+/* unit entry points (one restated toolkit function each; used by oracle/ref_eigen's text unit of the updater and by tests) */
+void orc_unit_A_matrix(const double *v /*3*/, double *res /*3x3*/) { A_matrix(v, res); }
+void orc_unit_s2_Nx_yy(const double *vec /*3*/, double *Nx /*2x3*/) { s2_Nx_yy(vec, Nx); }
+void orc_unit_s2_Mx(const double *vec /*3*/, const double *delta /*2*/, double *Mx /*3x2*/) { s2_Mx(vec, delta, Mx); }
+
 /* world point at state s: laserMapping.cpp:980-984 */
 static void world_point23(const orc_state23 *s, const float *pb, float *pw)
 {
@@ -406,12 +411,22 @@ int orc_ikfom_update_dyn_share(orc_state23 *x_, double *P_, double R, int maximu
                         for (int k = 0; k < 12; k++) s += P_[r * N23 + k] * h_x[c * 12 + k];
                         PHt[r * m + c] = s;
                     }
+                /* `h_x_cur * P_ * h_x_cur.transpose() / R` groups as ((H P) H^T) / R (until round 4 this computed H (P H^T): the same to
+                 * rounding, found by running the updater's own text, oracle/ref_eigen ikf).  Columns 12..22 of h_x_cur are zero. */
+                double *HP = (double *)malloc(sizeof(double) * m * N23);    /* m x 23 */
+                for (int r = 0; r < m; r++)
+                    for (int c = 0; c < N23; c++) {
+                        double s = 0.0;
+                        for (int k = 0; k < 12; k++) s += h_x[r * 12 + k] * P_[k * N23 + c];
+                        HP[r * N23 + c] = s;
+                    }
                 for (int r = 0; r < m; r++)
                     for (int c = 0; c < m; c++) {
                         double s = 0.0;
-                        for (int k = 0; k < 12; k++) s += h_x[r * 12 + k] * PHt[k * m + c];
+                        for (int k = 0; k < 12; k++) s += HP[r * N23 + k] * h_x[c * 12 + k];
                         S[r * m + c] = s / R + ((r == c) ? 1.0 : 0.0);
                     }
+                free(HP);
                 status |= orc_inverse(m, S, Si);
                 for (int r = 0; r < N23; r++)
                     for (int c = 0; c < m; c++) {

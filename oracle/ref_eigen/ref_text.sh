@@ -6,9 +6,14 @@
 # needs OpenCV, PCL, vikit and Sophus; taking the text is the only way to get THOSE LINES through a compiler here.
 #   ref_text.sh lio   -> pointBodyToWorld (laserMapping.cpp:272-286), `rematch_num` / `nearest_search_en` (:1472-1473),
 #                        the Mode-18 loop (:1506-1732)
-#   ref_text.sh vio   -> LidarSelector::set_extrinsic (lidar_selection.cpp:35-39), the Jacobian part of init (:41-52, :58-59),
-#                        dpi (:92-103), UpdateState (:743-902), updateFrameState (:904-911), ComputeJ (:967-983)
+#   ref_text.sh vio   -> everything of LidarSelector that is pinned, one unit: set_extrinsic (lidar_selection.cpp:35-39), the Jacobian part of
+#                        init (:41-52, :58-59), dpi (:92-103), getpatch (:119-140), getWarpMatrixAffine (:232-256), warpAffine (:258-296),
+#                        NCC (:298-315), getBestSearchLevel (:317-331), the loop of addFromSparseMap over the grid winners (:476-582),
+#                        UpdateState (:743-902), updateFrameState (:904-911), ComputeJ (:967-983); Frame::w2c / w2f / pos
+#                        (frame.h:89,98,107), Feature::pos (feature.h:58)
 #   ref_text.sh imu   -> ImuProcess::UndistortPcl (IMU_Processing.cpp:611-809)
+#   ref_text.sh ikf   -> dyn_share_datastruct (esekfom.hpp:79-89), esekf::update_iterated_dyn_share_modified (:1619-1928); the state
+#                        type and the manifold operations are stand-ins that forward to oracle/orc_ikfom.c (text/ikf_1.inc)
 # Every range is anchored: the first and the last line must look as they did in the snapshot the line numbers were taken from
 # (reference of 2024-11-08), otherwise the script fails and nothing is built.
 set -e
@@ -17,6 +22,9 @@ HERE=$(cd "$(dirname "$0")" && pwd)
 LM=$REF/src/laserMapping.cpp
 LS=$REF/src/lidar_selection.cpp
 IP=$REF/src/IMU_Processing.cpp
+EK=$REF/include/IKFoM_toolkit/esekfom/esekfom.hpp
+FH=$REF/include/frame.h
+FE=$REF/include/feature.h
 
 anchor() {   # file line regex
     sed -n "$2p" "$1" | grep -Eq "$3" || { echo "ref_text.sh: $1:$2 does not match /$3/ -- the reference differs from the snapshot" >&2; exit 1; }
@@ -60,12 +68,44 @@ vio)
     anchor "$LS" 911 '^\}'
     anchor "$LS" 967 '^void LidarSelector::ComputeJ\('
     anchor "$LS" 983 '^\}'
+    anchor "$FH" 89 'inline Vector2d w2c\(const Vector3d& xyz_w\) const'
+    anchor "$FH" 98 'inline Vector3d w2f\(const Vector3d& xyz_w\) const'
+    anchor "$FH" 107 'inline Vector3d pos\(\) const'
+    anchor "$FE" 58 'inline Vector3d pos\(\) const'
+    anchor "$LS" 119 '^void LidarSelector::getpatch\(cv::Mat img, V2D pc, float\* patch_tmp, int level\)'
+    anchor "$LS" 140 '^\}'
+    anchor "$LS" 232 '^void LidarSelector::getWarpMatrixAffine\('
+    anchor "$LS" 256 '^\}'
+    anchor "$LS" 258 '^void LidarSelector::warpAffine\('
+    anchor "$LS" 296 '^\}'
+    anchor "$LS" 298 '^double LidarSelector::NCC\('
+    anchor "$LS" 315 '^\}'
+    anchor "$LS" 317 '^int LidarSelector::getBestSearchLevel\('
+    anchor "$LS" 331 '^\}'
+    anchor "$LS" 476 '^    for \(int i=0; i<length; i\+\+\)'
+    anchor "$LS" 478 'if \(grid_num\[i\]==TYPE_MAP\)'
+    anchor "$LS" 582 '^    \}'
+    anchor "$LS" 586 'choose %d points from sub_sparse_map'
     cat "$HERE/text/vio_1.inc"
+    range "$FH" 89 89
+    range "$FH" 98 98
+    range "$FH" 107 107
+    cat "$HERE/text/vio_1b.inc"
+    range "$FE" 58 58
+    cat "$HERE/text/vio_1c.inc"
     range "$LS" 35 39
     range "$LS" 41 52
     range "$LS" 58 59
     cat "$HERE/text/vio_2.inc"
     range "$LS" 92 103
+    range "$LS" 119 140
+    range "$LS" 232 256
+    range "$LS" 258 296
+    range "$LS" 298 315
+    range "$LS" 317 331
+    cat "$HERE/text/vio_2b.inc"
+    range "$LS" 476 582
+    cat "$HERE/text/vio_2c.inc"
     range "$LS" 743 902
     range "$LS" 904 911
     range "$LS" 967 983
@@ -79,6 +119,20 @@ imu)
     range "$IP" 611 809
     cat "$HERE/text/imu_2.inc"
     ;;
+ikf)
+    anchor "$EK" 79 '^template<typename T>'
+    anchor "$EK" 80 '^struct dyn_share_datastruct'
+    anchor "$EK" 89 '^\};'
+    anchor "$EK" 1619 'void update_iterated_dyn_share_modified\(double R, double &solve_time\) \{'
+    anchor "$EK" 1926 'solve_time \+= omp_get_wtime\(\) - solve_start;'
+    anchor "$EK" 1928 '^[[:space:]]\}'
+    anchor "$EK" 1930 'void change_x\(state &input_state\)'
+    cat "$HERE/text/ikf_1.inc"
+    range "$EK" 79 89
+    cat "$HERE/text/ikf_2.inc"
+    range "$EK" 1619 1928
+    cat "$HERE/text/ikf_3.inc"
+    ;;
 *)
-    echo "usage: ref_text.sh lio|vio|imu" >&2; exit 2;;
+    echo "usage: ref_text.sh lio|vio|imu|ikf" >&2; exit 2;;
 esac

@@ -19,8 +19,14 @@ written next to it:
     the Mode-18 loop (a whole frame)        laserMapping.cpp:1506-1732  selection, plane rows, pass / search counts identical;
                                                                       state <= 1e-11, covariance <= 1e-12 relative
     UpdateState / ComputeJ                  lidar_selection.cpp       per-patch errors (float), level errors, state, G, cov likewise
+    addFromSparseMap, pixel-level part      lidar_selection.cpp:476-582 over getpatch / getWarpMatrixAffine / warpAffine / NCC /
+                                            getBestSearchLevel: accepted set, search levels identical; patches, errors (float) bit for
+                                            bit against the shim, <= 1e-4 grey levels against a real Eigen (2x2 inverse, float warp)
     ImuProcess::UndistortPcl                IMU_Processing.cpp:611-809  compensated points (float) and kept count identical; poses,
                                                                       state <= 1e-12, covariance <= 1e-12 relative
+    update_iterated_dyn_share_modified      esekfom.hpp:1619-1928     the updater's TEXT over the oracle's manifold operations (the
+                                                                      Boost-generated state type stood in for, text/ikf_1.inc):
+                                                                      callback count identical, state <= 1e-12, covariance <= 1e-12
     state_ikfom boxplus / boxminus          use-ikfom.hpp, MTK        <= 1e-15 / 1e-13                    (needs Boost + Eigen)
     update_iterated_dyn_share_modified      esekfom.hpp:1619-1928     state <= 1e-12, covariance <= 1e-12  (needs Boost + Eigen)
 Round 4: running this file against the shim found that the oracle's Exp multiplied (1 - cos) into K*K instead of into the left K as the
@@ -180,6 +186,33 @@ def test_vio_text_equals_the_oracle(oracle_lib, scene, m, seed, distortion):
     assert np.abs(rr["Tcw"][:9].reshape(3, 3) - Rcw).max() <= 1e-14 and np.abs(rr["Tcw"][9:] - Pcw).max() <= 1e-13
 
 
+@pytest.mark.parametrize("kw,opt", [(dict(m=60, seed=41), {}),
+                                    (dict(m=200, seed=13, n_keyframes=1, discont_frac=0.0), {}),
+                                    (dict(m=300, seed=5, n_keyframes=4), dict(ncc_en=True, ncc_thre=0.5)),
+                                    (dict(m=300, seed=6, distortion=True), {}),
+                                    (dict(m=150, seed=7), dict(outlier_threshold=30.0))])
+def test_patch_selection_text_equals_the_oracle(oracle_lib, kw, opt):
+    """The loop of addFromSparseMap over the grid winners (depth-continuity test, Warp_map reuse, affine warp of the reference patch on
+    three pyramid levels, current patch, NCC gate, outlier gate), the reference's text, against orc_vio_select."""
+    from fast_livo_amd import synth
+    orc = oracle_lib
+    sf = synth.make_select_frame(**kw)
+    cfg = orc.vio_config(sf.vio)
+    depth = orc.vio_depth_image(cfg, sf.Rcw, sf.Pcw, sf.scan_world)
+    a = orc.vio_select(cfg, sf.Rcw, sf.Pcw, sf.vio.img, sf.keyframes, depth, orc.patch_candidates(sf), **opt)
+    b = eigenref.vio_select(cfg, sf.Rcw, sf.Pcw, sf.vio.img, sf.keyframes, depth, orc.patch_candidates(sf), **opt)
+    assert 0 < len(a["idx"]) < kw["m"]
+    assert np.array_equal(a["idx"], b["idx"]) and np.array_equal(a["levels"], b["levels"])
+    if _exact():
+        assert np.array_equal(a["patches"], b["patches"]) and np.array_equal(a["errors"], b["errors"])
+    else:
+        assert np.abs(a["patches"] - b["patches"]).max() <= 1e-4 and np.abs(a["errors"] - b["errors"]).max() <= 1e-3 * a["errors"].max()
+    rs = np.bincount(a["reason"], minlength=5)
+    assert rs[1] > 0 or kw.get("discont_frac") == 0.0            # the depth-discontinuity exit was taken
+    if opt.get("ncc_en"):
+        assert rs[3] > 0                                         # and the NCC gate
+
+
 def test_vio_text_without_patches(oracle_lib, scene):
     """total_points == 0: UpdateState returns 0 and ComputeJ leaves the state alone (:745-746, :969-970)."""
     from fast_livo_amd import synth
@@ -221,6 +254,56 @@ def test_undistort_text_equals_the_oracle(oracle_lib, kw):
     for fld in ("acc_s_last", "angvel_last"):
         assert _close(np.array(getattr(po, fld)), np.array(getattr(pr, fld)), 1e-12)
     assert po.last_lidar_end_time == pr.last_lidar_end_time and po.last_imu.t == pr.last_imu.t
+
+
+def _few(cb):
+    def w(xs, valid, converge):
+        v, hx, hv = cb(xs, valid, converge)
+        return v, hx[:15].copy(), hv[:15].copy()
+    return w
+
+
+def _flaky(cb):
+    k = dict(i=0)
+
+    def w(xs, valid, converge):
+        k["i"] += 1
+        v, hx, hv = cb(xs, valid, converge)
+        return (k["i"] != 2), hx, hv
+    return w
+
+
+@pytest.mark.parametrize("n,max_iter,pseed,wrap,limit", [
+    (3000, 4, None, None, None),            # avia.yaml: rows >= 23 branch (:1779-1806)
+    (3000, 10, 1, None, None),              # NTU_VIRAL.yaml max_iteration, a dense prior covariance
+    (400, 3, 2, None, None),
+    (3000, 4, 3, _few, None),               # fewer rows than states: K = P H^T (H P H^T / R + I)^-1 / R (:1712-1741)
+    (2000, 5, 4, _flaky, 1e-30),            # an invalid pass (:1651-1654) + limits nothing meets: forced rematch (:1826-1829), exit at the last pass
+])
+def test_mode23_updater_text_equals_the_oracle(oracle_lib, scene, n, max_iter, pseed, wrap, limit):
+    """esekf::update_iterated_dyn_share_modified, the reference's text compiled as it stands (over the oracle's manifold operations),
+    against orc_ikfom_update_dyn_share -- both around the C oracle's h_share_model and an exact brute-force k-NN."""
+    import test_cross_oracle_cpu as xo
+    from fast_livo_amd import synth
+    orc = oracle_lib
+    fr = synth.make_lio_frame(n, scene=scene)
+    P0 = fr.cov23.copy() if pseed is None else xo._spd23(pseed, 1e-3)
+    lim = np.full(23, 0.001 if limit is None else limit)
+    wrap = wrap or (lambda cb: cb)
+    x_c = orc.state23_from_frame(fr, synth.quat_from_R)
+    P_c = P0.copy()
+    cb_c, _ = xo._c_rows_callback(orc, fr, scene.map_xyz)
+    cnt_c = dict(calls=0, searches=0)
+    r_c = orc.ikfom_update_dyn_share(x_c, P_c, 0.001, max_iter, xo._counting(wrap(cb_c), cnt_c), limit=lim)
+    cb_r, _ = xo._c_rows_callback(orc, fr, scene.map_xyz)
+    cnt_r = dict(calls=0, searches=0)
+    s_r, P_r, calls = eigenref.ikfom_update_text(orc.state23_from_frame(fr, synth.quat_from_R).vec(), P0, 0.001, max_iter,
+                                                 xo._counting(wrap(cb_r), cnt_r), limit=lim)
+    assert calls == cnt_r["calls"] == cnt_c["calls"] == r_c["out"].iterations
+    assert cnt_r["searches"] == cnt_c["searches"] >= 2
+    assert _close(x_c.vec(), s_r, 1e-12)
+    assert _close(P_c, P_r, 1e-12)
+    assert not np.array_equal(P_r, P0)
 
 
 def test_mode23_against_the_reference_toolkit(oracle_lib, scene):
