@@ -73,6 +73,15 @@ def lib():
         L.ref_vio_compute_j.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]
         L.ref_imu_undistort.argtypes = [vp, vp, vp, C.c_int, C.c_double, vp, C.c_int, vp, vp, vp, vp]
         L.ref_vio_select.argtypes = [vp, dp, dp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, vp, vp, vp, vp, vp]
+        L.ref_vmap_create.restype = C.c_void_p
+        L.ref_vmap_create.argtypes = [vp, C.c_int]
+        L.ref_vmap_destroy.argtypes = [vp]
+        L.ref_vmap_size.argtypes = [vp]
+        L.ref_vmap_get_point.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+        L.ref_vmap_get_grid.argtypes = [vp, vp, vp]
+        L.ref_vmap_add_sparse.argtypes = [vp, dp, dp, vp, vp, C.c_int, C.c_int]
+        L.ref_vmap_select.argtypes = [vp, dp, dp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, vp, vp, vp, vp, vp]
+        L.ref_vmap_add_observation.argtypes = [vp, dp, dp, vp, C.c_int]
         L.ref_ikfom_update_text.argtypes = [dp, dp, C.c_double, C.c_int, dp, H_FN, C.c_void_p]
         if L.ref_have_mtk():
             L.ref_state23_boxplus.argtypes = [dp, dp]
@@ -214,6 +223,68 @@ def vio_select(cfg, Rcw, Pcw, cur_img, keyframes, depth, cand, ncc_en=False, ncc
         raise RuntimeError("ref_vio_select failed: %d" % rc)
     k = na.value
     return dict(idx=idx[:k].copy(), errors=err[:k].copy(), levels=lvl[:k].copy(), patches=patches[:k].copy())
+
+
+class VMap:
+    """The visual map of LidarSelector, the reference's text (addSparseMap / AddPoint / addFromSparseMap / addObservation over the
+    reference's Feature and Point), driven as detect() drives it.  Same methods as oracle.VMap; images handed in must stay alive
+    as long as the map (the reference's Features keep a header over their frame's pixels)."""
+
+    def __init__(self, cfg, grid_size):
+        self.L, self.cfg = lib(), cfg
+        self.cells = (cfg.width // grid_size) * (cfg.height // grid_size)
+        self.m = self.L.ref_vmap_create(C.addressof(cfg), grid_size)
+        self._keep = []
+
+    def close(self):
+        if self.m:
+            self.L.ref_vmap_destroy(self.m)
+            self.m = None
+
+    def size(self):
+        return self.L.ref_vmap_size(self.m)
+
+    def get_point(self, i):
+        from . import oracle as orc
+        pos = np.zeros(3, np.float64); val = C.c_float(0); nobs = C.c_int32(0)
+        obs = (orc.VmapObs * 20)()
+        assert self.L.ref_vmap_get_point(self.m, i, pos.ctypes.data, C.addressof(val), C.addressof(nobs), C.addressof(obs)) == 0
+        return pos, val.value, [obs[k] for k in range(nobs.value)]
+
+    def get_grid(self):
+        mv = np.zeros(self.cells, np.float32); gn = np.zeros(self.cells, np.int32)
+        self.L.ref_vmap_get_grid(self.m, mv.ctypes.data, gn.ctypes.data)
+        return mv, gn
+
+    def _pose(self, Rcw, Pcw, img):
+        Rcw = np.ascontiguousarray(Rcw, np.float64).reshape(9); Pcw = np.ascontiguousarray(Pcw, np.float64)
+        img = np.ascontiguousarray(img, np.uint8)
+        self._keep.append(img)
+        return Rcw, Pcw, img
+
+    def add_sparse(self, Rcw, Pcw, img, scan_world, kf_id, frame_id):
+        Rcw, Pcw, img = self._pose(Rcw, Pcw, img)
+        scan = np.ascontiguousarray(scan_world, np.float32).reshape(-1, 3)
+        return self.L.ref_vmap_add_sparse(self.m, _d(Rcw), _d(Pcw), img.ctypes.data, scan.ctypes.data, len(scan), frame_id)
+
+    def select(self, Rcw, Pcw, cur_img, keyframes, scan_down_world, ncc_en=False, ncc_thre=0.0, outlier_threshold=300.0, frame_id=-1):
+        Rcw, Pcw, cur = self._pose(Rcw, Pcw, cur_img)
+        scan = np.ascontiguousarray(scan_down_world, np.float32).reshape(-1, 3)
+        m = self.cells
+        sel = np.zeros(m, np.int32); err = np.zeros(m, np.float32); lvl = np.zeros(m, np.int32); patches = np.zeros((m, 192), np.float32)
+        ns = C.c_int32(0)
+        rc = self.L.ref_vmap_select(self.m, _d(Rcw), _d(Pcw), cur.ctypes.data, scan.ctypes.data, len(scan), 1 if ncc_en else 0, ncc_thre,
+                                    outlier_threshold, frame_id, sel.ctypes.data, err.ctypes.data, lvl.ctypes.data, patches.ctypes.data,
+                                    C.addressof(ns))
+        if rc != 0:
+            raise RuntimeError("ref_vmap_select failed: %d" % rc)
+        k = ns.value
+        return dict(points=sel[:k].copy(), errors=err[:k].copy(), levels=lvl[:k].copy(), patches=patches[:k].copy())
+
+    def add_observation(self, Rcw, Pcw, img, sel_points, levels, kf_id, frame_id):
+        """sel_points / levels are what the last select() left in the reference's sub_sparse_map (arguments kept for oracle.VMap's shape)."""
+        Rcw, Pcw, img = self._pose(Rcw, Pcw, img)
+        return self.L.ref_vmap_add_observation(self.m, _d(Rcw), _d(Pcw), img.ctypes.data, frame_id)
 
 
 def have_mtk():

@@ -6,11 +6,12 @@
 # needs OpenCV, PCL, vikit and Sophus; taking the text is the only way to get THOSE LINES through a compiler here.
 #   ref_text.sh lio   -> pointBodyToWorld (laserMapping.cpp:272-286), `rematch_num` / `nearest_search_en` (:1472-1473),
 #                        the Mode-18 loop (:1506-1732)
-#   ref_text.sh vio   -> everything of LidarSelector that is pinned, one unit: set_extrinsic (lidar_selection.cpp:35-39), the Jacobian part of
-#                        init (:41-52, :58-59), dpi (:92-103), getpatch (:119-140), getWarpMatrixAffine (:232-256), warpAffine (:258-296),
-#                        NCC (:298-315), getBestSearchLevel (:317-331), the loop of addFromSparseMap over the grid winners (:476-582),
-#                        UpdateState (:743-902), updateFrameState (:904-911), ComputeJ (:967-983); Frame::w2c / w2f / pos
-#                        (frame.h:89,98,107), Feature::pos (feature.h:58)
+#   ref_text.sh vio   -> everything of LidarSelector / Feature / Point that is pinned, one unit: struct Feature (feature.h:27-63), class Point
+#                        (point.h:27-107) with its member functions (point.cpp:23-98, 110-247), Frame::w2c / w2f / pos (frame.h:89,98,107);
+#                        lidar_selection.cpp: set_extrinsic :35-39, init :41-71 + :73, reset_grid :81-90, dpi :92-103, getpatch :119-140,
+#                        addSparseMap :142-202, AddPoint :204-230, getWarpMatrixAffine :232-256, warpAffine :258-296, NCC :298-315,
+#                        getBestSearchLevel :317-331, addFromSparseMap :346-587 (and its loop :476-582 once more on its own),
+#                        UpdateState :743-902, updateFrameState :904-911, addObservation :913-965, ComputeJ :967-983
 #   ref_text.sh imu   -> ImuProcess::UndistortPcl (IMU_Processing.cpp:611-809)
 #   ref_text.sh ikf   -> dyn_share_datastruct (esekfom.hpp:79-89), esekf::update_iterated_dyn_share_modified (:1619-1928); the state
 #                        type and the manifold operations are stand-ins that forward to oracle/orc_ikfom.c (text/ikf_1.inc)
@@ -25,6 +26,8 @@ IP=$REF/src/IMU_Processing.cpp
 EK=$REF/include/IKFoM_toolkit/esekfom/esekfom.hpp
 FH=$REF/include/frame.h
 FE=$REF/include/feature.h
+PH=$REF/include/point.h
+PC=$REF/src/point.cpp
 
 anchor() {   # file line regex
     sed -n "$2p" "$1" | grep -Eq "$3" || { echo "ref_text.sh: $1:$2 does not match /$3/ -- the reference differs from the snapshot" >&2; exit 1; }
@@ -34,6 +37,7 @@ range() {    # file first last
     echo "#line $2 \"$1\""
     sed -n "$2,$3p" "$1"
     echo "// ---- end of reference text"
+    echo "#line 1 \"hand-written piece after $(basename "$1"):$3\""
 }
 
 case "$1" in
@@ -71,9 +75,28 @@ vio)
     anchor "$FH" 89 'inline Vector2d w2c\(const Vector3d& xyz_w\) const'
     anchor "$FH" 98 'inline Vector3d w2f\(const Vector3d& xyz_w\) const'
     anchor "$FH" 107 'inline Vector3d pos\(\) const'
-    anchor "$FE" 58 'inline Vector3d pos\(\) const'
+    anchor "$FE" 27 '^struct Feature'
+    anchor "$FE" 63 '^\};'
+    anchor "$PH" 27 '^typedef Matrix<double, 2, 3> Matrix23d;'
+    anchor "$PH" 30 '^class Point : boost::noncopyable'
+    anchor "$PH" 107 '^\};'
+    anchor "$PC" 23 '^int Point::point_counter_ = 0;'
+    anchor "$PC" 88 '^void Point::deleteFeatureRef\(FeaturePtr ftr\)'
+    anchor "$PC" 98 '^\}'
+    anchor "$PC" 110 '^bool Point::getClosePose\('
+    anchor "$PC" 141 '^bool Point::getCloseViewObs\('
+    anchor "$PC" 219 '^void Point::getFurthestViewObs\('
+    anchor "$PC" 247 '^\}'
+    anchor "$LS" 71 'patch_cache.resize\(patch_size_total\);'
+    anchor "$LS" 73 'pg_down.reset\(new PointCloudXYZI\(\)\);'
+    anchor "$LS" 81 '^void LidarSelector::reset_grid\(\)'
+    anchor "$LS" 90 '^\}'
     anchor "$LS" 119 '^void LidarSelector::getpatch\(cv::Mat img, V2D pc, float\* patch_tmp, int level\)'
     anchor "$LS" 140 '^\}'
+    anchor "$LS" 142 '^void LidarSelector::addSparseMap\('
+    anchor "$LS" 202 '^\}'
+    anchor "$LS" 204 '^void LidarSelector::AddPoint\(PointPtr pt_new\)'
+    anchor "$LS" 230 '^\}'
     anchor "$LS" 232 '^void LidarSelector::getWarpMatrixAffine\('
     anchor "$LS" 256 '^\}'
     anchor "$LS" 258 '^void LidarSelector::warpAffine\('
@@ -82,23 +105,32 @@ vio)
     anchor "$LS" 315 '^\}'
     anchor "$LS" 317 '^int LidarSelector::getBestSearchLevel\('
     anchor "$LS" 331 '^\}'
+    anchor "$LS" 346 '^void LidarSelector::addFromSparseMap\(cv::Mat img, PointCloudXYZI::Ptr pg\)'
     anchor "$LS" 476 '^    for \(int i=0; i<length; i\+\+\)'
     anchor "$LS" 478 'if \(grid_num\[i\]==TYPE_MAP\)'
     anchor "$LS" 582 '^    \}'
-    anchor "$LS" 586 'choose %d points from sub_sparse_map'
+    anchor "$LS" 587 '^\}'
+    anchor "$LS" 913 '^void LidarSelector::addObservation\(cv::Mat img\)'
+    anchor "$LS" 965 '^\}'
     cat "$HERE/text/vio_1.inc"
     range "$FH" 89 89
     range "$FH" 98 98
     range "$FH" 107 107
     cat "$HERE/text/vio_1b.inc"
-    range "$FE" 58 58
+    range "$FE" 27 63
+    range "$PH" 27 107
+    range "$PC" 23 98
+    range "$PC" 110 247
     cat "$HERE/text/vio_1c.inc"
     range "$LS" 35 39
-    range "$LS" 41 52
-    range "$LS" 58 59
+    range "$LS" 41 71
+    range "$LS" 73 73
     cat "$HERE/text/vio_2.inc"
+    range "$LS" 81 90
     range "$LS" 92 103
     range "$LS" 119 140
+    range "$LS" 142 202
+    range "$LS" 204 230
     range "$LS" 232 256
     range "$LS" 258 296
     range "$LS" 298 315
@@ -106,8 +138,10 @@ vio)
     cat "$HERE/text/vio_2b.inc"
     range "$LS" 476 582
     cat "$HERE/text/vio_2c.inc"
+    range "$LS" 346 587
     range "$LS" 743 902
     range "$LS" 904 911
+    range "$LS" 913 965
     range "$LS" 967 983
     cat "$HERE/text/vio_3.inc"
     ;;

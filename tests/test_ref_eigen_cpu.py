@@ -22,6 +22,9 @@ written next to it:
     addFromSparseMap, pixel-level part      lidar_selection.cpp:476-582 over getpatch / getWarpMatrixAffine / warpAffine / NCC /
                                             getBestSearchLevel: accepted set, search levels identical; patches, errors (float) bit for
                                             bit against the shim, <= 1e-4 grey levels against a real Eigen (2x2 inverse, float warp)
+    the visual map over several frames      addFromSparseMap :346-587 (whole), addSparseMap :142-202, AddPoint :204-230, addObservation
+                                            :913-965 over the reference's own Feature / Point (feature.h, point.h, point.cpp): selected
+                                            points, levels, founded points, observation lists identical frame by frame
     ImuProcess::UndistortPcl                IMU_Processing.cpp:611-809  compensated points (float) and kept count identical; poses,
                                                                       state <= 1e-12, covariance <= 1e-12 relative
     update_iterated_dyn_share_modified      esekfom.hpp:1619-1928     the updater's TEXT over the oracle's manifold operations (the
@@ -211,6 +214,54 @@ def test_patch_selection_text_equals_the_oracle(oracle_lib, kw, opt):
     assert rs[1] > 0 or kw.get("discont_frac") == 0.0            # the depth-discontinuity exit was taken
     if opt.get("ncc_en"):
         assert rs[3] > 0                                         # and the NCC gate
+
+
+@pytest.mark.parametrize("frames,step,rot", [(4, (0.2, 0.1, 0.0), (0.0, 0.0, 0.005)),          # the sequence of tests/golden/vmap_sequence.json
+                                             (36, (0.09, 0.04, 0.0), (0.0, 0.0005, 0.004))])    # long enough for points to reach 20 observations
+def test_visual_map_text_equals_the_oracle(oracle_lib, scene, frames, step, rot, capfd):
+    """detect()'s per-frame sequence -- addFromSparseMap, addSparseMap, addObservation -- on a persistent LidarSelector, the reference's
+    text over its own Feature and Point classes (getCloseViewObs, getFurthestViewObs, deleteFeatureRef, addFrameRef ...), against
+    oracle/orc_vmap.c: which map points are selected, their patches, which scan points found new map points, which observations are
+    added and which are dropped at the cap of 20."""
+    import make_golden_lib as mg
+    from fast_livo_amd import synth
+    orc = oracle_lib
+    lio, vf, scan, _, _ = mg.vmap_case(scene)
+    R_wi, p_wi = lio.R_true.copy(), lio.p_true.copy()
+    poses, imgs = [], []
+    for k in range(frames):
+        R_wi = R_wi @ synth.exp_so3(np.array(rot))
+        p_wi = p_wi + np.array(step)
+        poses.append(synth.cam_pose(vf.Rcl, vf.Pcl, lio.R_LI, lio.t_LI, R_wi, p_wi))
+        imgs.append(np.ascontiguousarray(np.roll(vf.img, (k, -2 * k), axis=(0, 1))))
+    cfg = orc.vio_config(vf)
+    a, b = orc.VMap(cfg, 40), eigenref.VMap(cfg, 40)
+    try:
+        for k, ((Rcw, Pcw), img) in enumerate(zip(poses, imgs)):
+            sa = a.select(Rcw, Pcw, img, imgs[:k + 1], scan, outlier_threshold=1e12)
+            sb = b.select(Rcw, Pcw, img, imgs[:k + 1], scan, outlier_threshold=1e12, frame_id=k)
+            assert np.array_equal(sa["points"], sb["points"]) and np.array_equal(sa["levels"], sb["levels"]), k
+            if _exact():
+                assert np.array_equal(sa["errors"], sb["errors"]) and np.array_equal(sa["patches"], sb["patches"]), k
+            else:
+                assert np.abs(sa["patches"] - sb["patches"]).max() <= 1e-4, k
+            assert a.add_sparse(Rcw, Pcw, img, scan, k, k) == b.add_sparse(Rcw, Pcw, img, scan, k, k) > 0
+            assert a.add_observation(Rcw, Pcw, img, sa["points"], sa["levels"], k, k) == b.add_observation(Rcw, Pcw, img, sb["points"], sb["levels"], k, k)
+            assert a.size() == b.size()
+        most = 0
+        for i in range(a.size()):
+            (pa, va, oa), (pb, vb, ob) = a.get_point(i), b.get_point(i)
+            assert np.array_equal(pa, pb) and va == vb and len(oa) == len(ob), i
+            most = max(most, len(oa))
+            for x, y in zip(oa, ob):
+                assert x.frame_id == y.frame_id and x.level == y.level and x.score == y.score
+                assert np.array_equal(np.array(x.px), np.array(y.px)) and np.array_equal(np.array(x.R), np.array(y.R))
+                assert np.array_equal(np.array(x.t), np.array(y.t))
+                assert _close(np.array(x.f), np.array(y.f), 1e-15)
+        assert most == (20 if frames > 30 else 2)           # 36 frames: the cap (getFurthestViewObs + deleteFeatureRef) was reached
+    finally:
+        a.close(); b.close()
+        capfd.readouterr()          # the reference's own printf lines ("[ VIO ]: Add %d 3D points." ...)
 
 
 def test_vio_text_without_patches(oracle_lib, scene):

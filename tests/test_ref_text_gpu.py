@@ -123,3 +123,16 @@ def test_mode23_update_equals_the_reference_updater_text(gpu_lib, oracle_lib, sc
     assert np.abs(xg.vec() - s_r).max() <= 1e-9
     assert np.abs(Pg - P_r).max() <= 1e-10 * max(1.0, np.abs(P_r).max())
     h.close()
+
+
+def test_visual_map_sequence_equals_the_reference_text(gpu_lib, oracle_lib, scene, capfd):
+    """The device's visual map (api_vmap.inc) over 8 frames against the reference's addFromSparseMap / addSparseMap / addObservation
+    text on a persistent LidarSelector: same harness as tests/test_vmap_gpu.py with the reference in the oracle's place."""
+    import types
+
+    import test_vmap_gpu as tv
+    from fast_livo_amd import synth
+    ref = types.SimpleNamespace(vio_config=oracle_lib.vio_config, voxel_grid=oracle_lib.voxel_grid, VMap=eigenref.VMap)
+    st = tv._run(gpu_lib, ref, synth, scene, frames=8, step=np.array([0.04, 0.02, 0.0]), thr=300.0)
+    capfd.readouterr()
+    assert st["added"] > 100 and st["selected"] > 0
