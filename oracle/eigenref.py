@@ -73,6 +73,10 @@ def lib():
         L.ref_vio_compute_j.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]
         L.ref_imu_undistort.argtypes = [vp, vp, vp, C.c_int, C.c_double, vp, C.c_int, vp, vp, vp, vp]
         L.ref_vio_select.argtypes = [vp, dp, dp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, vp, vp, vp, vp, vp]
+        L.ref_localmap_create.argtypes = [vp, C.c_int, C.c_float, C.c_double, C.c_float]
+        L.ref_localmap_fov_segment.argtypes = [dp, vp, vp, vp]
+        L.ref_localmap_incremental.argtypes = [vp, dp, dp, vp, C.c_int, vp]
+        L.ref_localmap_flatten.argtypes = [vp, C.c_int]
         L.ref_vmap_create.restype = C.c_void_p
         L.ref_vmap_create.argtypes = [vp, C.c_int]
         L.ref_vmap_destroy.argtypes = [vp]
@@ -223,6 +227,44 @@ def vio_select(cfg, Rcw, Pcw, cur_img, keyframes, depth, cand, ncc_en=False, ncc
         raise RuntimeError("ref_vio_select failed: %d" % rc)
     k = na.value
     return dict(idx=idx[:k].copy(), errors=err[:k].copy(), levels=lvl[:k].copy(), patches=patches[:k].copy())
+
+
+class LocalMap:
+    """lasermap_fov_segment + map_incremental, the reference's text (laserMapping.cpp:361-421, 692-706) over a persistent ikd-Tree of the
+    reference.  The window is a file-scope variable of the reference: ONE LocalMap per process at a time."""
+
+    def __init__(self, map_xyz, downsample, cube_len, det_range):
+        self.L = lib()
+        m = np.ascontiguousarray(map_xyz, np.float32).reshape(-1, 3)
+        if self.L.ref_localmap_create(m.ctypes.data, len(m), downsample, cube_len, det_range) != 0:
+            raise RuntimeError("another LocalMap is alive in this process")
+        self.open = True
+
+    def close(self):
+        if self.open:
+            self.L.ref_localmap_destroy()
+            self.open = False
+
+    def fov_segment(self, pos):
+        """Returns (window float32[6], boxes (nb, 6), points deleted)."""
+        pos = np.ascontiguousarray(pos, np.float64)
+        win = np.zeros(6, np.float32); boxes = np.zeros((3, 6), np.float32); deleted = C.c_int32(0)
+        nb = self.L.ref_localmap_fov_segment(_d(pos), win.ctypes.data, boxes.ctypes.data, C.addressof(deleted))
+        return win, boxes[:nb].copy(), deleted.value
+
+    def incremental(self, x, R_LI, t_LI, body):
+        """Returns (points the tree grew by, feats_down_world (n, 3))."""
+        R_LI = np.ascontiguousarray(R_LI, np.float64); t_LI = np.ascontiguousarray(t_LI, np.float64)
+        body = np.ascontiguousarray(body, np.float32).reshape(-1, 3)
+        world = np.zeros_like(body)
+        grew = self.L.ref_localmap_incremental(C.addressof(x), _d(R_LI), _d(t_LI), body.ctypes.data, len(body), world.ctypes.data)
+        return grew, world
+
+    def flatten(self):
+        cap = 1 << 20
+        out = np.zeros((cap, 3), np.float32)
+        n = self.L.ref_localmap_flatten(out.ctypes.data, cap)
+        return out[:n].copy()
 
 
 class VMap:

@@ -4,8 +4,9 @@
 # read from $REF at build time and piped straight into the compiler by the Makefile (no reference text is stored in this repository
 # or in oracle/_ref).  The ranges are functions / statements the reference only has inside main() or inside a class whose header
 # needs OpenCV, PCL, vikit and Sophus; taking the text is the only way to get THOSE LINES through a compiler here.
-#   ref_text.sh lio   -> pointBodyToWorld (laserMapping.cpp:272-286), `rematch_num` / `nearest_search_en` (:1472-1473),
-#                        the Mode-18 loop (:1506-1732)
+#   ref_text.sh lio   -> both pointBodyToWorld (laserMapping.cpp:272-301), `rematch_num` / `nearest_search_en` (:1472-1473), the Mode-18
+#                        loop (:1506-1732); DET_RANGE / MOV_THRESHOLD (:83, :90), points_cache_collect (:324-330), lasermap_fov_segment
+#                        (:361-421), map_incremental (:692-706)
 #   ref_text.sh vio   -> everything of LidarSelector / Feature / Point that is pinned, one unit: struct Feature (feature.h:27-63), class Point
 #                        (point.h:27-107) with its member functions (point.cpp:23-98, 110-247), Frame::w2c / w2f / pos (frame.h:89,98,107);
 #                        lidar_selection.cpp: set_extrinsic :35-39, init :41-71 + :73, reset_grid :81-90, dpi :92-103, getpatch :119-140,
@@ -49,8 +50,24 @@ lio)
     anchor "$LM" 1506 'for \(iterCount = -1; iterCount < NUM_MAX_ITERATIONS && flg_EKF_inited; iterCount\+\+\)'
     anchor "$LM" 1731 'if \(EKF_stop_flg\) +break;'
     anchor "$LM" 1732 '^ {12}\}'
+    anchor "$LM" 83 '^float DET_RANGE = 300.0f;'
+    anchor "$LM" 90 'const float MOV_THRESHOLD = 1.5f;'
+    anchor "$LM" 288 '^template<typename T>'
+    anchor "$LM" 301 '^\}'
+    anchor "$LM" 324 '^int points_cache_size = 0;'
+    anchor "$LM" 330 '^\}'
+    anchor "$LM" 361 '^BoxPointType LocalMap_Points;'
+    anchor "$LM" 363 '^void lasermap_fov_segment\(\)'
+    anchor "$LM" 421 '^\}'
+    anchor "$LM" 692 '^void map_incremental\(\)'
+    anchor "$LM" 706 '^\}'
     cat "$HERE/text/lio_1.inc"
-    range "$LM" 272 286
+    range "$LM" 83 83
+    range "$LM" 90 90
+    range "$LM" 272 301
+    range "$LM" 324 330
+    range "$LM" 361 421
+    range "$LM" 692 706
     cat "$HERE/text/lio_2.inc"
     range "$LM" 1472 1473
     cat "$HERE/text/lio_3.inc"

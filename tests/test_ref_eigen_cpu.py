@@ -25,6 +25,8 @@ written next to it:
     the visual map over several frames      addFromSparseMap :346-587 (whole), addSparseMap :142-202, AddPoint :204-230, addObservation
                                             :913-965 over the reference's own Feature / Point (feature.h, point.h, point.cpp): selected
                                             points, levels, founded points, observation lists identical frame by frame
+    lasermap_fov_segment, map_incremental   laserMapping.cpp:361-421, 692-706 over a persistent tree: window, slabs, deleted counts, world
+                                            points (float) bit for bit; the tree's content as a set
     ImuProcess::UndistortPcl                IMU_Processing.cpp:611-809  compensated points (float) and kept count identical; poses,
                                                                       state <= 1e-12, covariance <= 1e-12 relative
     update_iterated_dyn_share_modified      esekfom.hpp:1619-1928     the updater's TEXT over the oracle's manifold operations (the
@@ -305,6 +307,44 @@ def test_undistort_text_equals_the_oracle(oracle_lib, kw):
     for fld in ("acc_s_last", "angvel_last"):
         assert _close(np.array(getattr(po, fld)), np.array(getattr(pr, fld)), 1e-12)
     assert po.last_lidar_end_time == pr.last_lidar_end_time and po.last_imu.t == pr.last_imu.t
+
+
+def test_local_map_text_equals_the_oracle(oracle_lib, scene):
+    """The sensor walks until the window has moved three times: lasermap_fov_segment's window and slabs against orc_fov_segment, the
+    tree behind it against orc_map_delete_boxes / orc_map_add_points on a flat array, map_incremental's world points against
+    fr.world_at rounded as the reference stores them."""
+    from test_ref_ikdtree_cpu import sorted_rows
+    from fast_livo_amd import synth
+    orc = oracle_lib
+    cube, det, ds = 24.0, 4.0, 0.5
+    lm = eigenref.LocalMap(scene.map_xyz, ds, cube, det)
+    try:
+        flat = scene.map_xyz.copy()
+        win = np.zeros(6, np.float32)
+        init = False
+        pos = np.array([0.5, -0.3, 1.0])
+        moves = 0
+        for k in range(40):
+            w_r, boxes_r, deleted = lm.fov_segment(pos)
+            boxes_o, init = orc.fov_segment(win, init, pos, cube, det, 1.5)
+            assert np.array_equal(w_r, win), k
+            assert np.array_equal(boxes_r, boxes_o), k
+            if len(boxes_o):
+                moves += 1
+                flat, info = orc.map_delete_boxes(flat, boxes_o)
+                assert info.n_removed == deleted
+            if k % 4 == 3:                                     # every fourth frame a registered scan goes in
+                fr = synth.make_lio_frame(1500, seed=100 + k, scene=scene)
+                x = orc.state18_from_frame(fr, R=fr.R_true, p=pos)
+                grew, world = lm.incremental(x, fr.R_LI, fr.t_LI, fr.body_xyz)
+                assert np.array_equal(world, fr.world_at(fr.R_true, pos))
+                flat, info = orc.map_add_points(flat, world, ds)
+                assert info.n_after - info.n_before == grew
+            assert np.array_equal(sorted_rows(lm.flatten()), sorted_rows(flat)), k
+            pos = pos + np.array([0.9, 0.35, 0.0])
+        assert moves >= 3
+    finally:
+        lm.close()
 
 
 def _few(cb):
