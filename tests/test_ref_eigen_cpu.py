@@ -266,6 +266,32 @@ def test_visual_map_text_equals_the_oracle(oracle_lib, scene, frames, step, rot,
         capfd.readouterr()          # the reference's own printf lines ("[ VIO ]: Add %d 3D points." ...)
 
 
+def test_ntu_viral_configuration_text_equals_the_oracle(oracle_lib, scene):
+    """BASELINE config 5 at a CPU-sized scan: NTU_VIRAL extrinsics (zero LiDAR offset), max_iteration 10, the 752x480 radtan camera with
+    img_point_cov 1000 -- the LIO frame, then ComputeJ from its posterior."""
+    from fast_livo_amd import synth
+    orc = oracle_lib
+    fr = synth.make_lio_frame(30000, scene=scene, t_LI=synth.NTU_T_LI)
+    vf = synth.make_vio_frame(2000, fr, cam=synth.NTU_CAM, Rcl=synth.NTU_RCL, Pcl=synth.NTU_PCL, distortion=True, img_point_cov=1000.0,
+                              max_iterations=10)
+    tree, knn = _tree_knn(scene.map_xyz)
+    try:
+        xo, xr = orc.state18_from_frame(fr), orc.state18_from_frame(fr)
+        ro = orc.lio18_frame(xo, fr.body_xyz, fr.R_LI, fr.t_LI, fr.laser_point_cov, 10, knn, nthreads=1)
+        rr = eigenref.lio18_frame(xr, fr.body_xyz, scene.map_xyz, fr.R_LI, fr.t_LI, fr.laser_point_cov, 10)
+    finally:
+        tree.close()
+    assert ro["out"].iterations == rr["out"].iterations and ro["out"].effct_feat_num == rr["out"].effct_feat_num
+    assert np.array_equal(ro["sel"], rr["sel"])
+    assert _close(xo.vec(), xr.vec(), 1e-11) and _close(xo.cov_np(), xr.cov_np(), 1e-12)
+    po, pr = xo.copy(), xr.copy()
+    vo = orc.vio_compute_j(vf, xo, po)
+    vr = eigenref.vio_compute_j(vf, xr, pr)
+    assert np.array_equal(vo["errors"], vr["errors"])
+    assert _close(xo.vec(), xr.vec(), 1e-11) and _close(xo.cov_np(), xr.cov_np(), 1e-12)
+    assert sum(vo["outs"][lv].iterations for lv in (2, 1, 0)) >= 6
+
+
 def test_vio_text_without_patches(oracle_lib, scene):
     """total_points == 0: UpdateState returns 0 and ComputeJ leaves the state alone (:745-746, :969-970)."""
     from fast_livo_amd import synth

@@ -61,6 +61,36 @@ def test_compute_j_equals_the_reference_text(gpu_lib, oracle_lib, scene, m, dist
     h.close()
 
 
+def test_config5_full_frame_equals_the_reference_text(gpu_lib, oracle_lib, scene):
+    """BASELINE config 5 (NTU_VIRAL: 200 000 points, max_iteration 10, 752x480 radtan camera, img_point_cov 1000, 2 000 patches): the
+    all-device LIO frame and ComputeJ against the reference's loop over its own tree and its ComputeJ."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    from helpers import copy_state
+    fr = synth.make_lio_frame(200000, scene=scene, t_LI=synth.NTU_T_LI)
+    vf = synth.make_vio_frame(2000, fr, cam=synth.NTU_CAM, Rcl=synth.NTU_RCL, Pcl=synth.NTU_PCL, distortion=True, img_point_cov=1000.0,
+                              max_iterations=10)
+    xr = orc.state18_from_frame(fr)
+    rr = eigenref.lio18_frame(xr, fr.body_xyz, scene.map_xyz, fr.R_LI, fr.t_LI, fr.laser_point_cov, 10)
+    h = capi.Handle(capi.config_from_frames(fr, vf, max_iterations=10))
+    h.map_set_points(scene.map_xyz, 0.5)
+    xg = capi.state18_from_frame(fr)
+    info = h.lio_frame18_dev(xg, fr.body_xyz)
+    assert info.status == 0 and info.iterations == rr["out"].iterations and info.effct_feat_num == rr["out"].effct_feat_num
+    assert np.abs(xg.vec() - xr.vec()).max() <= 1e-9
+    assert np.abs(xg.cov_np() - xr.cov_np()).max() <= 1e-11
+    # ComputeJ from the reference's LIO posterior on both sides: per-patch errors bit for bit
+    xvg, prop = copy_state(capi.State18, xr), copy_state(capi.State18, xr)
+    vr = eigenref.vio_compute_j(vf, xr, xr.copy())
+    h.vio_set_frame(vf.img)
+    h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+    h.vio_compute_j(xvg, prop)
+    assert np.abs(xvg.vec() - xr.vec()).max() <= 1e-9
+    assert np.abs(xvg.cov_np() - xr.cov_np()).max() <= 1e-11
+    assert np.array_equal(h.vio_get_errors(vf.m), vr["errors"])
+    h.close()
+
+
 @pytest.mark.parametrize("m,opt", [(600, {}), (600, dict(ncc_en=True, ncc_thre=0.5))])
 def test_patch_selection_equals_the_reference_text(gpu_lib, oracle_lib, m, opt):
     capi, orc = gpu_lib, oracle_lib
