@@ -73,6 +73,8 @@ def lib():
         L.ref_vio_compute_j.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]
         L.ref_imu_undistort.argtypes = [vp, vp, vp, C.c_int, C.c_double, vp, C.c_int, vp, vp, vp, vp]
         L.ref_vio_select.argtypes = [vp, dp, dp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, vp, vp, vp, vp, vp]
+        L.ref_hsm_begin.argtypes = [vp, C.c_int, vp, C.c_int]
+        L.ref_hsm_get.argtypes = [vp, vp, vp, vp]
         L.ref_localmap_create.argtypes = [vp, C.c_int, C.c_float, C.c_double, C.c_float]
         L.ref_localmap_fov_segment.argtypes = [dp, vp, vp, vp]
         L.ref_localmap_incremental.argtypes = [vp, dp, dp, vp, C.c_int, vp]
@@ -227,6 +229,52 @@ def vio_select(cfg, Rcw, Pcw, cur_img, keyframes, depth, cand, ncc_en=False, ncc
         raise RuntimeError("ref_vio_select failed: %d" % rc)
     k = na.value
     return dict(idx=idx[:k].copy(), errors=err[:k].copy(), levels=lvl[:k].copy(), patches=patches[:k].copy())
+
+
+class HShareModel:
+    """h_share_model, the reference's text (laserMapping.cpp:961-1093) over the reference's own ikd-Tree, for one scan and one map: ONE per
+    process at a time.  `callback` is a C function pointer of the updaters' callback shape -- hand it to `ikfom_update_text_c` (the
+    reference's updater text) or call it through `rows()`."""
+
+    def __init__(self, body_xyz, map_xyz):
+        self.L = lib()
+        self.body = np.ascontiguousarray(body_xyz, np.float32).reshape(-1, 3)
+        m = np.ascontiguousarray(map_xyz, np.float32).reshape(-1, 3)
+        if self.L.ref_hsm_begin(self.body.ctypes.data, len(self.body), m.ctypes.data, len(m)) != 0:
+            raise RuntimeError("another HShareModel is alive in this process")
+        self.open = True
+        self.callback = C.cast(self.L.ref_hsm_callback, H_FN)
+
+    def close(self):
+        if self.open:
+            self.L.ref_hsm_end()
+            self.open = False
+
+    def rows(self, s26, converge):
+        """One call.  Returns (valid, h_x (rows, 12), h (rows,))."""
+        st = np.array(s26, dtype=np.float64).copy()
+        valid, conv, rows = C.c_int(1), C.c_int(1 if converge else 0), C.c_int(0)
+        hx, h = C.POINTER(C.c_double)(), C.POINTER(C.c_double)()
+        self.callback(None, _d(st), C.byref(valid), C.byref(conv), C.byref(rows), C.byref(hx), C.byref(h))
+        r = rows.value
+        return bool(valid.value), np.ctypeslib.as_array(hx, shape=(r, 12)).copy() if r else np.zeros((0, 12)), \
+            np.ctypeslib.as_array(h, shape=(r,)).copy() if r else np.zeros(0)
+
+    def last(self):
+        n = len(self.body)
+        sel = np.zeros(n, np.uint8); nv = np.zeros((n, 4), np.float32); world = np.zeros((n, 3), np.float32); tr = C.c_double(0)
+        eff = self.L.ref_hsm_get(sel.ctypes.data, nv.ctypes.data, world.ctypes.data, C.addressof(tr))
+        return dict(sel=sel, normvec=nv, world=world, effct_feat_num=eff, total_residual=tr.value)
+
+
+def ikfom_update_text_c(s26, P, R, max_iter, c_callback, limit=None):
+    """The reference's updater text around a C callback (e.g. HShareModel.callback: then BOTH halves of the Mode-23 update are the
+    reference's text).  Returns (state26, P, calls)."""
+    limit = np.full(23, 0.001) if limit is None else np.ascontiguousarray(limit, dtype=np.float64)
+    s = np.array(s26, dtype=np.float64).copy()
+    P = np.array(P, dtype=np.float64).copy()
+    calls = lib().ref_ikfom_update_text(_d(s), _d(P), R, max_iter, _d(limit), c_callback, None)
+    return s, P, calls
 
 
 class LocalMap:

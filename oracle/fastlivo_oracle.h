@@ -9,7 +9,8 @@
  * Eigen / PCL / ROS / OpenCV / vikit / Sophus / Boost, none of which exist in this environment.  What the
  * oracle is held to instead:
  *   - its k-NN and map rows: the reference's own ikd-Tree compiled unmodified (oracle/ref_ikdtree) -- PINNED;
- *   - the Mode-18 loop, the VIO update, the patch selection, the IMU undistortion, the IKFoM updater: the reference's own
+ *   - the Mode-18 loop, the VIO update, the patch selection and the visual map, the local map, the IMU undistortion, h_share_model
+ *     and the IKFoM updater: the reference's own
  *     TEXT, read from /root/reference at build time, compiled and run over a stand-in for Eigen's API (oracle/ref_eigen,
  *     tests/test_ref_eigen_cpu.py: bit for bit) -- the reference's logic is pinned, Eigen's own arithmetic is not;
  *   - third-party arithmetic (Eigen's summation orders, vikit, Sophus, PCL, OpenCV, the MTK manifold operations):
@@ -254,6 +255,9 @@ int orc_ikfom_update_dyn_share(orc_state23 *x, double *P, double R, int maximum_
 void orc_state23_boxplus(orc_state23 *x, const double *dx /*23*/);
 void orc_state23_boxminus(const orc_state23 *x, const orc_state23 *other, double *dx /*23*/);
 
+/* Eigen::Quaternion applied to a vector (QuaternionBase::_transformVector) and as a rotation matrix (toRotationMatrix), as orc_ikfom.c restates them */
+void orc_unit_q_rot(const double *q /*x,y,z,w*/, const double *v /*3*/, double *o /*3*/);
+void orc_unit_q_to_R(const double *q /*x,y,z,w*/, double *R /*3x3*/);
 /* MTK::A_matrix (mtkmath.hpp:236-247), S2::S2_Nx_yy / S2_Mx (S2.hpp:259-280); matrices row-major. */
 void orc_unit_A_matrix(const double *v /*3*/, double *res /*3x3*/);
 void orc_unit_s2_Nx_yy(const double *vec /*3*/, double *Nx /*2x3*/);

@@ -246,6 +246,8 @@ void orc_state23_boxminus(const orc_state23 *x, const orc_state23 *o, double *dx
 }
 
 /* unit entry points (one restated toolkit function each; used by oracle/ref_eigen's text unit of the updater and by tests) */
+void orc_unit_q_rot(const double *q /*x,y,z,w*/, const double *v /*3*/, double *o /*3*/) { q_rot(q, v, o); }
+void orc_unit_q_to_R(const double *q /*x,y,z,w*/, double *R /*3x3*/) { q_to_R(q, R); }
 void orc_unit_A_matrix(const double *v /*3*/, double *res /*3x3*/) { A_matrix(v, res); }
 void orc_unit_s2_Nx_yy(const double *vec /*3*/, double *Nx /*2x3*/) { s2_Nx_yy(vec, Nx); }
 void orc_unit_s2_Mx(const double *vec /*3*/, const double *delta /*2*/, double *Mx /*3x2*/) { s2_Mx(vec, delta, Mx); }

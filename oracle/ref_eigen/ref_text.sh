@@ -6,7 +6,8 @@
 # needs OpenCV, PCL, vikit and Sophus; taking the text is the only way to get THOSE LINES through a compiler here.
 #   ref_text.sh lio   -> both pointBodyToWorld (laserMapping.cpp:272-301), `rematch_num` / `nearest_search_en` (:1472-1473), the Mode-18
 #                        loop (:1506-1732); DET_RANGE / MOV_THRESHOLD (:83, :90), points_cache_collect (:324-330), lasermap_fov_segment
-#                        (:361-421), map_incremental (:692-706)
+#                        (:361-421), map_incremental (:692-706); h_share_model (:961-1093, the Mode-23 measurement model; its state type and the
+#                        quaternion arithmetic are stand-ins that forward to oracle/orc_ikfom.c, text/lio_1b.inc)
 #   ref_text.sh vio   -> everything of LidarSelector / Feature / Point that is pinned, one unit: struct Feature (feature.h:27-63), class Point
 #                        (point.h:27-107) with its member functions (point.cpp:23-98, 110-247), Frame::w2c / w2f / pos (frame.h:89,98,107);
 #                        lidar_selection.cpp: set_extrinsic :35-39, init :41-71 + :73, reset_grid :81-90, dpi :92-103, getpatch :119-140,
@@ -68,6 +69,17 @@ lio)
     range "$LM" 324 330
     range "$LM" 361 421
     range "$LM" 692 706
+    anchor "$EK" 79 '^template<typename T>'
+    anchor "$EK" 80 '^struct dyn_share_datastruct'
+    anchor "$EK" 89 '^\};'
+    anchor "$LM" 960 '^#ifdef USE_IKFOM'
+    anchor "$LM" 961 '^void h_share_model\(state_ikfom &s, esekfom::dyn_share_datastruct<double> &ekfom_data\)'
+    anchor "$LM" 1093 '^\}'
+    anchor "$LM" 1094 '^#endif'
+    cat "$HERE/text/lio_1b.inc"
+    range "$EK" 79 89
+    cat "$HERE/text/lio_1c.inc"
+    range "$LM" 961 1093
     cat "$HERE/text/lio_2.inc"
     range "$LM" 1472 1473
     cat "$HERE/text/lio_3.inc"

@@ -29,6 +29,10 @@ written next to it:
                                             points (float) bit for bit; the tree's content as a set
     ImuProcess::UndistortPcl                IMU_Processing.cpp:611-809  compensated points (float) and kept count identical; poses,
                                                                       state <= 1e-12, covariance <= 1e-12 relative
+    h_share_model                           laserMapping.cpp:961-1093  the Mode-23 measurement model's TEXT over the reference's ikd-Tree (the
+                                                                      IKFoM state type stood in for, quaternion arithmetic from the oracle,
+                                                                      text/lio_1b.inc): rows h_x, h, selection bit for bit; and the WHOLE
+                                                                      update with both halves from the reference's text
     update_iterated_dyn_share_modified      esekfom.hpp:1619-1928     the updater's TEXT over the oracle's manifold operations (the
                                                                       Boost-generated state type stood in for, text/ikf_1.inc):
                                                                       callback count identical, state <= 1e-12, covariance <= 1e-12
@@ -421,6 +425,44 @@ def test_mode23_updater_text_equals_the_oracle(oracle_lib, scene, n, max_iter, p
     assert _close(x_c.vec(), s_r, 1e-12)
     assert _close(P_c, P_r, 1e-12)
     assert not np.array_equal(P_r, P0)
+
+
+@pytest.mark.parametrize("n,max_iter", [(3000, 4), (20000, 4), (5000, 10)])
+def test_mode23_measurement_model_and_whole_update_from_the_reference_text(oracle_lib, scene, n, max_iter):
+    """h_share_model's text against orc_h_share_model (a call that searches, a call that does not, at a moved state), then the whole
+    Mode-23 update with the reference's updater text calling the reference's h_share_model text -- against orc_ikfom_update_iterated
+    over an exact brute-force k-NN."""
+    import test_cross_oracle_cpu as xo
+    from fast_livo_amd import synth
+    orc = oracle_lib
+    fr = synth.make_lio_frame(n, scene=scene)
+    x0 = orc.state23_from_frame(fr, synth.quat_from_R)
+    hm = eigenref.HShareModel(fr.body_xyz, scene.map_xyz)
+    try:
+        cb_c, st = xo._c_rows_callback(orc, fr, scene.map_xyz)
+        d = np.zeros(23)
+        d[:6] = [0.01, -0.02, 0.005, 1e-3, -2e-3, 5e-4]
+        x1 = x0.copy()
+        orc.lib().orc_state23_boxplus(C.byref(x1), d.ctypes.data_as(C.POINTER(C.c_double)))
+        for x, search in ((x0, True), (x1, False)):
+            _, hx_o, h_o = cb_c(x.copy(), True, search)
+            valid, hx_r, h_r = hm.rows(x.vec(), search)
+            assert valid and len(h_r) == len(h_o) > 0.9 * n
+            assert _close(hx_o, hx_r, 1e-13) and _close(h_o, h_r, 1e-13)
+            last = hm.last()
+            assert last["effct_feat_num"] == len(h_r)
+            assert np.array_equal(last["sel"] != 0, st["sel"] != 0)
+        s_r, P_r, calls = eigenref.ikfom_update_text_c(x0.vec(), fr.cov23.copy(), 0.001, max_iter, hm.callback)
+    finally:
+        hm.close()
+
+    def knn(w):
+        nb, _, va, _ = orc.knn5_bruteforce(scene.map_xyz, w)
+        return nb, va
+    x_o, P_o = orc.state23_from_frame(fr, synth.quat_from_R), fr.cov23.copy()
+    ro = orc.ikfom_update(x_o, P_o, fr.body_xyz, 0.001, max_iter, knn, nthreads=1)
+    assert calls == ro["out"].iterations
+    assert _close(x_o.vec(), s_r, 1e-12) and _close(P_o, P_r, 1e-12)
 
 
 def test_mode23_against_the_reference_toolkit(oracle_lib, scene):

@@ -166,3 +166,28 @@ def test_visual_map_sequence_equals_the_reference_text(gpu_lib, oracle_lib, scen
     st = tv._run(gpu_lib, ref, synth, scene, frames=8, step=np.array([0.04, 0.02, 0.0]), thr=300.0)
     capfd.readouterr()
     assert st["added"] > 100 and st["selected"] > 0
+
+
+@pytest.mark.parametrize("n,max_iter", [(50000, 4), (5000, 10)])
+def test_mode23_update_equals_the_reference_text_in_both_halves(gpu_lib, oracle_lib, scene, n, max_iter):
+    """fl_ikfom_update_iterated_dev (BASELINE config 2 at n = 50 000) vs the reference's updater text calling the reference's
+    h_share_model text over the reference's ikd-Tree."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    fr = synth.make_lio_frame(n, scene=scene)
+    hm = eigenref.HShareModel(fr.body_xyz, scene.map_xyz)
+    try:
+        s_r, P_r, calls = eigenref.ikfom_update_text_c(orc.state23_from_frame(fr, synth.quat_from_R).vec(), fr.cov23.copy(), 0.001, max_iter,
+                                                       hm.callback)
+        eff = hm.last()["effct_feat_num"]
+    finally:
+        hm.close()
+    h = capi.Handle(capi.config_from_frames(fr, max_iterations=max_iter))
+    h.map_set_points(scene.map_xyz, 0.5)
+    xg = capi.state23_from_frame(fr)
+    Pg = fr.cov23.copy()
+    info = h.ikfom_update_iterated_dev(xg, Pg, fr.body_xyz, 0.001)
+    assert info.iterations == calls and info.effct_feat_num == eff
+    assert np.abs(xg.vec() - s_r).max() <= 1e-9
+    assert np.abs(Pg - P_r).max() <= 1e-10 * max(1.0, np.abs(P_r).max())
+    h.close()
