@@ -88,6 +88,12 @@ def lib():
         L.ref_vmap_add_sparse.argtypes = [vp, dp, dp, vp, vp, C.c_int, C.c_int]
         L.ref_vmap_select.argtypes = [vp, dp, dp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, vp, vp, vp, vp, vp]
         L.ref_vmap_add_observation.argtypes = [vp, dp, dp, vp, C.c_int]
+        L.ref_mtk_state_boxplus.argtypes = [dp, dp]
+        L.ref_mtk_state_boxminus.argtypes = [dp, dp, dp]
+        L.ref_mtk_A_matrix.argtypes = [dp, dp]
+        L.ref_mtk_S2_Bx.argtypes = [dp, dp]
+        L.ref_mtk_S2_Nx_yy.argtypes = [dp, dp]
+        L.ref_mtk_S2_Mx.argtypes = [dp, dp, dp]
         L.ref_ikfom_update_text.argtypes = [dp, dp, C.c_double, C.c_int, dp, H_FN, C.c_void_p]
         if L.ref_have_mtk():
             L.ref_state23_boxplus.argtypes = [dp, dp]
@@ -396,10 +402,43 @@ def state23_boxminus(s26, o26):
     return out
 
 
+def mtk_boxplus(s26, d23):
+    """state_ikfom::boxplus through the toolkit's own text (vect / SO3 / S2 boxplus, MTK::exp, cos_sinc_sqrt)."""
+    s = np.array(s26, dtype=np.float64).copy()
+    d = np.ascontiguousarray(d23, dtype=np.float64)
+    lib().ref_mtk_state_boxplus(_d(s), _d(d))
+    return s
+
+
+def mtk_boxminus(s26, o26):
+    s = np.ascontiguousarray(s26, dtype=np.float64); o = np.ascontiguousarray(o26, dtype=np.float64)
+    out = np.zeros(23)
+    lib().ref_mtk_state_boxminus(_d(s), _d(o), _d(out))
+    return out
+
+
+def mtk_A_matrix(v):
+    v = np.ascontiguousarray(v, dtype=np.float64); out = np.zeros(9)
+    lib().ref_mtk_A_matrix(_d(v), _d(out))
+    return out.reshape(3, 3)
+
+
+def mtk_S2(vec, delta=None):
+    """(Bx 3x2, Nx_yy 2x3, Mx 3x2 or None) of an S2 element with the given vector (not renormalised)."""
+    vec = np.ascontiguousarray(vec, dtype=np.float64)
+    bx, nx, mx = np.zeros(6), np.zeros(6), np.zeros(6)
+    lib().ref_mtk_S2_Bx(_d(vec), _d(bx))
+    lib().ref_mtk_S2_Nx_yy(_d(vec), _d(nx))
+    if delta is not None:
+        delta = np.ascontiguousarray(delta, dtype=np.float64)
+        lib().ref_mtk_S2_Mx(_d(vec), _d(delta), _d(mx))
+    return bx.reshape(3, 2), nx.reshape(2, 3), (mx.reshape(3, 2) if delta is not None else None)
+
+
 def ikfom_update_text(s26, P, R, max_iter, h_dyn_share, limit=None):
-    """The TEXT of esekf::update_iterated_dyn_share_modified (esekfom.hpp:1619-1928) around a Python callback, with the oracle's manifold
-    operations as the stand-in for the Boost-generated state type (oracle/ref_eigen/text/ikf_1.inc).  Same contract as
-    ikfom_update_dyn_share below; needs neither Boost nor a real Eigen."""
+    """The TEXT of esekf::update_iterated_dyn_share_modified (esekfom.hpp:1619-1928) around a Python callback, over the toolkit's own
+    SO3 / S2 / vect / mtkmath text; only the Boost-generated compound state and vectview are stand-ins (oracle/ref_eigen/text/ikf_1.inc,
+    ikf_1c.inc).  Same contract as ikfom_update_dyn_share below; needs neither Boost nor a real Eigen."""
     return _ikfom_update(lib().ref_ikfom_update_text, s26, P, R, max_iter, h_dyn_share, limit)
 
 

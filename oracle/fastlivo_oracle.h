@@ -9,11 +9,11 @@
  * Eigen / PCL / ROS / OpenCV / vikit / Sophus / Boost, none of which exist in this environment.  What the
  * oracle is held to instead:
  *   - its k-NN and map rows: the reference's own ikd-Tree compiled unmodified (oracle/ref_ikdtree) -- PINNED;
- *   - the Mode-18 loop, the VIO update, the patch selection and the visual map, the local map, the IMU undistortion, h_share_model
- *     and the IKFoM updater: the reference's own
+ *   - the Mode-18 loop, the VIO update, the patch selection and the visual map, the local map, the IMU undistortion, h_share_model,
+ *     the IKFoM updater and the toolkit's manifold types (vect / SO3 / S2 / mtkmath): the reference's own
  *     TEXT, read from /root/reference at build time, compiled and run over a stand-in for Eigen's API (oracle/ref_eigen,
  *     tests/test_ref_eigen_cpu.py: bit for bit) -- the reference's logic is pinned, Eigen's own arithmetic is not;
- *   - third-party arithmetic (Eigen's summation orders, vikit, Sophus, PCL, OpenCV, the MTK manifold operations):
+ *   - third-party arithmetic (Eigen's summation orders and its Quaternion, vikit, Sophus, PCL, OpenCV):
  *     PARITY UNPINNED -- restated from the published sources, cross-checked by independent numpy restatements
  *     (oracle/np_oracle.py, oracle/np_ikfom.py), sensitivity studies and analytic properties (tests/).
  */

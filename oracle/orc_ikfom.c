@@ -110,11 +110,15 @@ static void A_matrix(const double *v, double *res)
     double norm = sqrt(squaredNorm);
     for (int i = 0; i < 9; i++) res[i] = (i % 4 == 0) ? 1.0 : 0.0;
     if (!(norm < MTK_TOL)) {
-        double K[9], KK[9];
+        /* `Identity() + a * hat(v) + b * hat(v) * hat(v)` groups as (I + a K) + ((b K) K): the scalar goes into the LEFT factor (until round 4
+         * this computed b (K K): one unit in the last place in a quarter of random vectors, found by running the toolkit's own text,
+         * oracle/ref_eigen ikf) */
+        double K[9], bK[9], bKK[9];
         skew3(v, K);
-        m3_mul(K, K, KK);
         double a = (1 - cos(norm)) / squaredNorm, b = (1 - sin(norm) / norm) / squaredNorm;
-        for (int i = 0; i < 9; i++) res[i] = res[i] + a * K[i] + b * KK[i];
+        for (int i = 0; i < 9; i++) bK[i] = b * K[i];
+        m3_mul(bK, K, bKK);
+        for (int i = 0; i < 9; i++) res[i] = (res[i] + a * K[i]) + bKK[i];
     }
 }
 /* SO3::boxplus, SOn.hpp:233-236 */

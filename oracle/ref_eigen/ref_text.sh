@@ -6,8 +6,8 @@
 # needs OpenCV, PCL, vikit and Sophus; taking the text is the only way to get THOSE LINES through a compiler here.
 #   ref_text.sh lio   -> both pointBodyToWorld (laserMapping.cpp:272-301), `rematch_num` / `nearest_search_en` (:1472-1473), the Mode-18
 #                        loop (:1506-1732); DET_RANGE / MOV_THRESHOLD (:83, :90), points_cache_collect (:324-330), lasermap_fov_segment
-#                        (:361-421), map_incremental (:692-706); h_share_model (:961-1093, the Mode-23 measurement model; its state type and the
-#                        quaternion arithmetic are stand-ins that forward to oracle/orc_ikfom.c, text/lio_1b.inc)
+#                        (:361-421), map_incremental (:692-706); h_share_model (:961-1093, the Mode-23 measurement model; its state type is a stand-in with
+#                        Eigen::Quaternion members, text/lio_1b.inc)
 #   ref_text.sh vio   -> everything of LidarSelector / Feature / Point that is pinned, one unit: struct Feature (feature.h:27-63), class Point
 #                        (point.h:27-107) with its member functions (point.cpp:23-98, 110-247), Frame::w2c / w2f / pos (frame.h:89,98,107);
 #                        lidar_selection.cpp: set_extrinsic :35-39, init :41-71 + :73, reset_grid :81-90, dpi :92-103, getpatch :119-140,
@@ -15,8 +15,11 @@
 #                        getBestSearchLevel :317-331, addFromSparseMap :346-587 (and its loop :476-582 once more on its own),
 #                        UpdateState :743-902, updateFrameState :904-911, addObservation :913-965, ComputeJ :967-983
 #   ref_text.sh imu   -> ImuProcess::UndistortPcl (IMU_Processing.cpp:611-809)
-#   ref_text.sh ikf   -> dyn_share_datastruct (esekfom.hpp:79-89), esekf::update_iterated_dyn_share_modified (:1619-1928); the state
-#                        type and the manifold operations are stand-ins that forward to oracle/orc_ikfom.c (text/ikf_1.inc)
+#   ref_text.sh ikf   -> the IKFoM toolkit as far as the Mode-23 update uses it: vect::boxplus / boxminus (mtk/types/vect.hpp:117-122), pi /
+#                        tolerance / cos_sinc_sqrt / hat / A_matrix / exp / log (mtk/src/mtkmath.hpp:117-122, 142-183, 235-256, 268-288), struct SO3
+#                        (mtk/types/SOn.hpp:177-298), struct S2 (mtk/types/S2.hpp:97-310), dyn_share_datastruct (esekfom.hpp:79-89),
+#                        esekf::update_iterated_dyn_share_modified (:1619-1928); stood in for: vectview, the Matrix base of vect, the
+#                        Boost-generated compound state (text/ikf_1.inc, ikf_1c.inc)
 # Every range is anchored: the first and the last line must look as they did in the snapshot the line numbers were taken from
 # (reference of 2024-11-08), otherwise the script fails and nothing is built.
 set -e
@@ -26,6 +29,10 @@ LM=$REF/src/laserMapping.cpp
 LS=$REF/src/lidar_selection.cpp
 IP=$REF/src/IMU_Processing.cpp
 EK=$REF/include/IKFoM_toolkit/esekfom/esekfom.hpp
+MV=$REF/include/IKFoM_toolkit/mtk/types/vect.hpp
+MM=$REF/include/IKFoM_toolkit/mtk/src/mtkmath.hpp
+MS=$REF/include/IKFoM_toolkit/mtk/types/SOn.hpp
+M2=$REF/include/IKFoM_toolkit/mtk/types/S2.hpp
 FH=$REF/include/frame.h
 FE=$REF/include/feature.h
 PH=$REF/include/point.h
@@ -190,7 +197,31 @@ ikf)
     anchor "$EK" 1926 'solve_time \+= omp_get_wtime\(\) - solve_start;'
     anchor "$EK" 1928 '^[[:space:]]\}'
     anchor "$EK" 1930 'void change_x\(state &input_state\)'
+    anchor "$MV" 117 'void boxplus\(MTK::vectview<const scalar, D> vec, scalar scale=1\) \{'
+    anchor "$MV" 122 '^\t\}|^[[:space:]]\}'
+    anchor "$MM" 117 '^const double pi = M_PI;'
+    anchor "$MM" 122 'tolerance<double>\(\) \{ return 1e-11; \}'
+    anchor "$MM" 143 '^std::pair<scalar, scalar> cos_sinc_sqrt\(const scalar &x2\)\{'
+    anchor "$MM" 183 '^\}'
+    anchor "$MM" 236 'A_matrix\(const Base & v\)\{'
+    anchor "$MM" 250 '^scalar exp\(vectview<scalar, n> result, vectview<const scalar, n> vec, const scalar& scale = 1\) \{'
+    anchor "$MM" 256 '^\}'
+    anchor "$MM" 269 '^void log\(vectview<scalar, n> result,'
+    anchor "$MM" 288 '^\}'
+    anchor "$MS" 178 '^struct SO3 : public Eigen::Quaternion<_scalar, Options> \{'
+    anchor "$MS" 298 '^\};'
+    anchor "$M2" 98 '^struct S2 \{'
+    anchor "$M2" 310 '^\};'
     cat "$HERE/text/ikf_1.inc"
+    range "$MV" 117 122
+    cat "$HERE/text/ikf_1b.inc"
+    range "$MM" 117 122
+    range "$MM" 142 183
+    range "$MM" 235 256
+    range "$MM" 268 288
+    range "$MS" 177 298
+    range "$M2" 97 310
+    cat "$HERE/text/ikf_1c.inc"
     range "$EK" 79 89
     cat "$HERE/text/ikf_2.inc"
     range "$EK" 1619 1928

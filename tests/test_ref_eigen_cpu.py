@@ -30,16 +30,19 @@ written next to it:
     ImuProcess::UndistortPcl                IMU_Processing.cpp:611-809  compensated points (float) and kept count identical; poses,
                                                                       state <= 1e-12, covariance <= 1e-12 relative
     h_share_model                           laserMapping.cpp:961-1093  the Mode-23 measurement model's TEXT over the reference's ikd-Tree (the
-                                                                      IKFoM state type stood in for, quaternion arithmetic from the oracle,
-                                                                      text/lio_1b.inc): rows h_x, h, selection bit for bit; and the WHOLE
-                                                                      update with both halves from the reference's text
-    update_iterated_dyn_share_modified      esekfom.hpp:1619-1928     the updater's TEXT over the oracle's manifold operations (the
-                                                                      Boost-generated state type stood in for, text/ikf_1.inc):
-                                                                      callback count identical, state <= 1e-12, covariance <= 1e-12
+                                                                      IKFoM state type stood in for by a struct with Eigen::Quaternion
+                                                                      members, text/lio_1b.inc): rows h_x, h, selection bit for bit; and
+                                                                      the WHOLE update with both halves from the reference's text
+    update_iterated_dyn_share_modified      esekfom.hpp:1619-1928     the updater's TEXT over the toolkit's own SO3 / S2 / vect / mtkmath
+    vect / SO3 / S2 boxplus, boxminus,      mtk/types/*.hpp,          TEXT (only vectview and the Boost-generated compound state are
+    MTK::exp / log / A_matrix, S2_Bx /      mtk/src/mtkmath.hpp       stand-ins, text/ikf_1.inc): callback count identical, state and
+    S2_Nx_yy / S2_Mx                                                  covariance <= 1e-12; the single functions bit for bit on 3 000
+                                                                      random + edge inputs each
     state_ikfom boxplus / boxminus          use-ikfom.hpp, MTK        <= 1e-15 / 1e-13                    (needs Boost + Eigen)
     update_iterated_dyn_share_modified      esekfom.hpp:1619-1928     state <= 1e-12, covariance <= 1e-12  (needs Boost + Eigen)
 Round 4: running this file against the shim found that the oracle's Exp multiplied (1 - cos) into K*K instead of into the left K as the
-reference's expression does (one unit in the last place in 14 % of random rotations; oracle/orc_math.h fixed).
+reference's expression does (one unit in the last place in 14 % of random rotations; oracle/orc_math.h fixed); likewise the few-rows
+gain of the updater ((H P) H^T) and MTK::A_matrix ((b K) K) in oracle/orc_ikfom.c.
 """
 import ctypes as C
 
@@ -375,6 +378,64 @@ def test_local_map_text_equals_the_oracle(oracle_lib, scene):
         assert moves >= 3
     finally:
         lm.close()
+
+
+def test_mtk_manifold_text_equals_the_oracle(oracle_lib):
+    """The toolkit's own text -- vect / SO3 / S2 boxplus and boxminus over MTK::exp / log / cos_sinc_sqrt, A_matrix, S2_Bx / S2_Nx_yy /
+    S2_Mx (with the `scalar(1/2) == 0` quirk of S2.hpp:277) -- against orc_state23_boxplus / boxminus and the oracle's unit functions:
+    random states and steps from |d| = 3 down to 0 (the Taylor range of cos_sinc_sqrt, the log's tolerance clamp), S2's fallback chart
+    (vec[2] + length <= tolerance) and its opposed-vector branch."""
+    orc = oracle_lib
+    L = orc.lib()
+    rng = np.random.default_rng(7)
+    dp = C.POINTER(C.c_double)
+
+    def rand_state():
+        s = orc.State23()
+        for f, _ in s._fields_:
+            a = getattr(s, f)
+            a[:] = rng.standard_normal(len(a))
+        for f in ("rot", "offset_R_L_I"):
+            q = np.array(getattr(s, f))
+            getattr(s, f)[:] = q / np.linalg.norm(q)
+        g = np.array(s.grav)
+        s.grav[:] = g / np.linalg.norm(g) * 9.809
+        return s
+    tol_p, tol_m = 1e-15 * 10, 1e-13
+    for k in range(1500):
+        a = rand_state()
+        if k % 50 == 0:
+            a.grav[:] = [0, 0, -9.809]
+        if k % 50 == 1:
+            a.grav[:] = [1e-13, 0, -9.809]
+        d = rng.standard_normal(23) * [1.0, 1e-2, 1e-3, 1e-6, 1e-13, 0.0, 3.0][k % 7]
+        b = a.copy()
+        L.orc_state23_boxplus(C.byref(b), d.ctypes.data_as(dp))
+        assert _close(b.vec(), eigenref.mtk_boxplus(a.vec(), d), tol_p), k
+        out = np.zeros(23)
+        L.orc_state23_boxminus(C.byref(b), C.byref(a), out.ctypes.data_as(dp))
+        assert _close(out, eigenref.mtk_boxminus(b.vec(), a.vec()), tol_m), k
+        if k % 300 == 0:                                       # opposed gravity vectors: `res[0] = 3.1415926` (S2.hpp:155)
+            c = a.copy()
+            c.grav[:] = [-x for x in a.grav]
+            L.orc_state23_boxminus(C.byref(c), C.byref(a), out.ctypes.data_as(dp))
+            r = eigenref.mtk_boxminus(c.vec(), a.vec())
+            assert _close(out, r, tol_m) and r[21] == 3.1415926
+    for k in range(1500):
+        v = rng.standard_normal(3) * [1.0, 1e-2, 1e-6, 1e-11, 1e-12, 0.0, 3.0][k % 7]
+        o = np.zeros(9)
+        L.orc_unit_A_matrix(v.ctypes.data_as(dp), o.ctypes.data_as(dp))
+        assert _close(o.reshape(3, 3), eigenref.mtk_A_matrix(v), 1e-15), k
+        g = rng.standard_normal(3)
+        g = g / np.linalg.norm(g) * 9.809
+        if k % 40 == 0:
+            g = np.array([0, 0, -9.809])
+        dl = rng.standard_normal(2) * [1.0, 1e-3, 1e-12, 0.0][k % 4]
+        N, M = np.zeros(6), np.zeros(6)
+        L.orc_unit_s2_Nx_yy(g.ctypes.data_as(dp), N.ctypes.data_as(dp))
+        L.orc_unit_s2_Mx(g.ctypes.data_as(dp), dl.ctypes.data_as(dp), M.ctypes.data_as(dp))
+        _, nx, mx = eigenref.mtk_S2(g, dl)
+        assert _close(N.reshape(2, 3), nx, 1e-15) and _close(M.reshape(3, 2), mx, 1e-14), k
 
 
 def _few(cb):
