@@ -2,8 +2,10 @@
 """Generates tests/golden/*.json from the CPU oracle on small seeded cases and cross-checks the
 LIO / VIO cases against the independent numpy restatement (oracle/np_oracle.py) before writing.
 
-The reference itself cannot be run (no Eigen/PCL/ROS here; IKFoM build is bit-rotted -- SURVEY.md
-section 8c), so these are regression fixtures of the oracle, not reference outputs: PARITY UNPINNED.
+Generated from the oracle.  Since round 4 the reference's own text runs (oracle/ref_eigen, over a stand-in for Eigen's API), and
+tests/test_ref_eigen_cpu.py::test_committed_fixtures_are_outputs_of_the_reference_text re-derives the committed numbers of the VIO
+level, the Mode-23 update, the undistortion, the patch selection and the visual-map sequence from it; the k-NN / map fixtures belong to
+the ikd-Tree (pinned by oracle/ref_ikdtree), the VoxelGrid fixture to PCL (absent: unpinned).
 Run from the repo root:  python tests/golden/make_golden.py
 """
 import json

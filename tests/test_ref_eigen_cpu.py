@@ -438,6 +438,70 @@ def test_mtk_manifold_text_equals_the_oracle(oracle_lib):
         assert _close(N.reshape(2, 3), nx, 1e-15) and _close(M.reshape(3, 2), mx, 1e-14), k
 
 
+def _fixture(name):
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".json")))
+
+
+def _same(got, want, keys):
+    for k in keys:
+        a, b = np.asarray(got[k], dtype=np.float64), np.asarray(want[k], dtype=np.float64)
+        assert a.shape == b.shape, k
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max()), k
+
+
+def test_committed_fixtures_are_outputs_of_the_reference_text(oracle_lib, scene, capfd):
+    """tests/golden/*.json were generated from the CPU oracle (tests/golden/make_golden.py).  Here the same cases are run through the
+    reference's own text and compared with the COMMITTED numbers, at the tolerance tests/test_oracle_cpu.py holds the oracle to them:
+    the fixtures for the VIO level, the Mode-23 update, the undistortion, the patch selection and the visual-map sequence are outputs
+    of the reference's text (the k-NN, map and VoxelGrid fixtures belong to the ikd-Tree / PCL and are pinned or unpinned elsewhere)."""
+    import make_golden_lib as mg
+    from fast_livo_amd import synth
+    orc = oracle_lib
+    # vio_level (make_golden_lib.run_vio_level)
+    fr = synth.make_lio_frame(256, scene=scene)
+    vf = synth.make_vio_frame(40, fr)
+    x = orc.state18_from_frame(fr)
+    r = eigenref.vio_update_state(vf, x, x.copy(), 1e10, 1)
+    _same({"error": [r["error"]], "errors_head": r["errors"][:8].tolist(), "state_after": x.vec().tolist(), "HTH": r["HTH"].reshape(-1).tolist()},
+          _fixture("vio_level"), ("error", "errors_head", "state_after", "HTH"))
+    # ikfom_update: the updater's text calling h_share_model's text over the reference's tree
+    fr = synth.make_lio_frame(1200, scene=scene)
+    hm = eigenref.HShareModel(fr.body_xyz, scene.map_xyz)
+    try:
+        s_r, P_r, calls = eigenref.ikfom_update_text_c(orc.state23_from_frame(fr, synth.quat_from_R).vec(), fr.cov23.copy(), 0.001, 4, hm.callback)
+        neff = hm.last()["effct_feat_num"]
+    finally:
+        hm.close()
+    _same({"iterations": [calls], "neff": [neff], "state_after": s_r.tolist(), "P_diag": np.diag(P_r).tolist(), "P_row0": P_r[0].tolist()},
+          _fixture("ikfom_update"), ("iterations", "neff", "state_after", "P_diag", "P_row0"))
+    # imu_undistort
+    f = synth.make_imu_frame(500, n_imu=12, seed=31)
+    x, pr = orc.state18_from_frame(f.lio), orc.imu_proc_from_frame(f)
+    pts, poses, t_end = eigenref.imu_undistort(pr, x, f.imu, f.pcl_beg_time, f.pts_xyzt)
+    assert len(pts) >= 499 and t_end == f.pcl_end_time       # (this scan's last point is one the reference's own selection drops, see
+    #                                                           test_undistort_text_equals_the_oracle: `pts_mean` of the fixture counts it)
+    _same({"n_poses": [len(poses)], "pose_last_pos": list(poses[-1].pos), "pose_last_rot": list(poses[-1].rot), "state_after": x.vec().tolist(),
+           "cov_diag": np.diag(np.array(x.cov).reshape(18, 18)).tolist(), "pts_head": pts[:4].reshape(-1).tolist(),
+           "acc_s_last": list(pr.acc_s_last)},
+          _fixture("imu_undistort"), ("n_poses", "pose_last_pos", "pose_last_rot", "state_after", "cov_diag", "pts_head", "acc_s_last"))
+    # vio_select (the depth image is the oracle's: the reference builds it inside addFromSparseMap, covered by the visual-map sequence)
+    sf = synth.make_select_frame(60, seed=41)
+    cfg = orc.vio_config(sf.vio)
+    depth = orc.vio_depth_image(cfg, sf.Rcw, sf.Pcw, sf.scan_world)
+    r = eigenref.vio_select(cfg, sf.Rcw, sf.Pcw, sf.vio.img, sf.keyframes, depth, orc.patch_candidates(sf), outlier_threshold=300.0)
+    _same({"idx": r["idx"].tolist(), "levels": r["levels"].tolist(), "errors": r["errors"].tolist(), "patch0": r["patches"][0].tolist(),
+           "patches_checksum": mg._ck(r["patches"])}, _fixture("vio_select"), ("idx", "levels", "errors", "patch0") + (("patches_checksum",) if _exact() else ()))
+    # vmap_sequence: the whole summary (bitwise checksums over positions, values, observation lists)
+    import types
+    ref = types.SimpleNamespace(VMap=eigenref.VMap, vio_config=orc.vio_config)
+    got = mg.run_vmap_sequence(ref, scene)
+    capfd.readouterr()
+    want = _fixture("vmap_sequence")
+    _same(got, want, ("selected", "added", "obs_added", "n_points") + (("pos_checksum", "value_checksum", "n_obs_checksum", "px_checksum", "frame_checksum") if _exact() else ()))
+
+
 def _few(cb):
     def w(xs, valid, converge):
         v, hx, hv = cb(xs, valid, converge)
