@@ -1,7 +1,7 @@
 """ctypes binding of the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
-PARITY UNPINNED: see oracle/fastlivo_oracle.h.
+Parity status (what is pinned to the reference's ikd-Tree, what to the reference's own text, what stays unpinned): oracle/fastlivo_oracle.h.
 """
 from __future__ import annotations
 

@@ -16,7 +16,8 @@
  *   Eigen quaternion product / rotate / toRotationMatrix (third party, unpinned >=3.3.4)
  * Quirk kept on purpose: S2_Mx builds exp_delta with scalar(1/2) == 0 (integer division,
  * S2.hpp:277) so exp_delta is the identity.
- * PARITY UNPINNED -- see fastlivo_oracle.h. (This configuration does not even compile in the
+ * Held to the reference's own text since round 4 (h_share_model, the updater, the toolkit's vect / SO3 / S2 / mtkmath: oracle/ref_eigen,
+ * tests/test_ref_eigen_cpu.py -- bit for bit); Eigen's own arithmetic stays unpinned -- see fastlivo_oracle.h. (This configuration does not even compile in the
  * reference: SURVEY.md fact 1.)
  */
 #include "fastlivo_oracle.h"

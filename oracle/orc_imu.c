@@ -10,7 +10,8 @@
  *   - backward propagation (undistortion) of every point                 :778-809, loops restated literally,
  *     including what they do when the first point is reached before the first IMU interval (it is compensated
  *     again by every earlier interval, :803) and when a point is not later than IMUpose[0] (the loop ends).
- * Exp() is include/so3_math.h:31-52; set_pose6d include/common_lib.h:396-412. PARITY UNPINNED (no reference tests).
+ * Exp() is include/so3_math.h:31-52; set_pose6d include/common_lib.h:396-412. Held to the text of
+ * ImuProcess::UndistortPcl since round 4 (oracle/ref_eigen, tests/test_ref_eigen_cpu.py: bit for bit); no reference tests exist.
  */
 #include "fastlivo_oracle.h"
 

@@ -7,7 +7,7 @@
  *   validity           /root/reference/src/laserMapping.cpp:1549,1567           (5 found && sqdist[4] <= 5)
  * The tree's traversal order decides which of several EXACTLY equidistant points survives; that
  * order is not reproducible without the tree, so ties are broken here by the lower map index
- * (the device search uses the same rule). PARITY UNPINNED -- see fastlivo_oracle.h.
+ * (the device search uses the same rule). PINNED to the reference's own ikd-Tree (oracle/ref_ikdtree, tests/test_ref_ikdtree_cpu.py).
  */
 #include "fastlivo_oracle.h"
 

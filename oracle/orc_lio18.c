@@ -12,7 +12,8 @@
  *   gain solve [D]                     src/laserMapping.cpp:1664-1695
  *   rematch / stop / covariance [E]    src/laserMapping.cpp:1700-1731
  *   StatesGroup += / -                 include/common_lib.h:343-365
- * PARITY UNPINNED (no reference tests; reference not buildable here) -- see fastlivo_oracle.h.
+ * No reference tests exist.  Held to the reference's own text of that loop since round 4 (oracle/ref_eigen, tests/test_ref_eigen_cpu.py:
+ * bit for bit over a stand-in for Eigen); Eigen's own arithmetic stays unpinned -- see fastlivo_oracle.h.
  * OpenMP is used exactly where the reference uses it: over points in [A] only.
  */
 #include "fastlivo_oracle.h"

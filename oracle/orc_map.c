@@ -14,7 +14,8 @@
  * The tree's internals (balancing, lazy deletion, the rebuild thread) do not change WHICH points the map holds, only the order
  * Search_by_range reports them in; that order decides between old points of one box that are exactly equally far from its
  * centre. Not reproducible without the tree: the array order is used (lower index first), as in orc_knn.c. A point that wins
- * its box again keeps its place in the array; added points are appended. PARITY UNPINNED -- see fastlivo_oracle.h.
+ * its box again keeps its place in the array; added points are appended. PINNED to the reference's own ikd-Tree (oracle/ref_ikdtree);
+ * orc_fov_segment also to lasermap_fov_segment's text (oracle/ref_eigen, tests/test_ref_eigen_cpu.py).
  */
 #include "fastlivo_oracle.h"
 

@@ -4,7 +4,8 @@
  * Small fixed-size linear algebra used by the CPU restatement of FAST-LIVO's ESKF hot path.
  * The reference uses Eigen for all of this; Eigen is not available in this container, so the
  * operations it performs are restated here in plain C with a fixed, documented evaluation
- * order (left-to-right dot products, unblocked partial-pivot LU). PARITY UNPINNED: the
+ * order (left-to-right dot products, unblocked partial-pivot LU). The reference's own lines (Exp, Log) are held to their text
+ * since round 4 (oracle/ref_eigen); Eigen's own arithmetic is unpinned: the
  * reference has no tests/golden vectors and cannot be built here.
  *
  * Reference lines restated:

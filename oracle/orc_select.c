@@ -16,7 +16,8 @@
  * What stays with the caller (pointer-chasing over the visual map, out of scope): the voxel lookups and the grid
  * competition (:412-466) and Point::getCloseViewObs (src/point.cpp:141-178), which pick, per grid cell, the map point
  * and the reference observation handed in here as a candidate.
- * Third-party arithmetic not under /root/reference, restated from the published sources (unpinned; PARITY UNPINNED):
+ * Third-party arithmetic not under /root/reference, restated from the published sources (unpinned; the reference's own
+ * lines of this file are held to their text since round 4, oracle/ref_eigen, tests/test_ref_eigen_cpu.py):
  *   vk::interpolateMat_8u (rpg_vikit vision.h): w00=(1-sx)(1-sy), w01=(1-sx)sy, w10=sx(1-sy), w11=1-w00-w01-w10, floats;
  *   vk::PinholeCamera::cam2world: ((u-cx)/fx, (v-cy)/fy, 1).normalized(); with distortion vikit calls cv::undistortPoints,
  *   restated as its five fixed-point sweeps (orc_cam2world in orc_vio.c); world2cam as in orc_vio.c;

@@ -15,7 +15,8 @@
  *                                              memory of vikit_common/src/pinhole_camera.cpp:
  *                                              project2d then radial-tangential distortion
  *                                              when |d0| > 1e-7. d = 0 is the primary parity config.
- * PARITY UNPINNED -- see fastlivo_oracle.h.
+ * The reference's own lines are held to their text since round 4 (oracle/ref_eigen, tests/test_ref_eigen_cpu.py: bit for bit over a stand-in
+ * for Eigen); vikit's camera and Eigen's arithmetic stay unpinned -- see fastlivo_oracle.h.
  */
 #include "fastlivo_oracle.h"
 #include "orc_math.h"

@@ -16,7 +16,8 @@
  * front); `obs_.back()` of :929 is therefore the OLDEST observation.
  * Not reproducible: the iteration order of the two unordered_maps (:412, feat_map buckets) -- it only decides between map
  * points at exactly the same float distance from the camera in one grid cell; here points are visited in the order they
- * entered the map. Third-party arithmetic restated from the published sources (unpinned; PARITY UNPINNED):
+ * entered the map. The reference's own lines are held to their text since round 4 (oracle/ref_eigen,
+ * tests/test_ref_eigen_cpu.py: a 36-frame walk, bit for bit).  Third-party arithmetic restated from the published sources (unpinned):
  *   vk::shiTomasiScore (rpg_vikit vision.cpp): 8x8 box of central differences, (dXX, dYY, dXY) / (2 * 64), smaller eigenvalue;
  *   Sophus::SE3 products / inverse stated with rotation matrices.
  */
