@@ -4,6 +4,8 @@
 // Input: little-endian binary written by tests/test_host_mirror_gpu.py; output: the updated StatesGroup as text.
 #include "fastlivo_shim.hpp"
 
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -50,6 +52,8 @@ int main(int argc, char **argv)
     VoxelGridDev vg; vg.handle = h; vg.setLeafSize(leaf, leaf, leaf);
     LioMode18Dev lio; lio.handle = h;
     if (lio.set_map(map.data(), k_map, cell)) { fprintf(stderr, "set_map: %s\n", fl_last_error_string(h)); return 1; }
+    const StatesGroup state0 = state;                  // (for the timed repetitions at the end)
+    const fl_imu_proc proc0 = imu.proc;
     imu.UndistortPcl(samples, beg, end, state, pts, /*keep_on_device=*/true);
     vg.setInputCloudOnDevice(n);
     const int feats_down_size = vg.filter_to_scan();
@@ -93,6 +97,31 @@ int main(int argc, char **argv)
         for (int i = 0; i < 9; i++) printf("%.17g ", state.rot_end.m[i]);
         for (int i = 0; i < 3; i++) printf("%.17g ", state.pos_end.v[i]);
         printf("\n");
+    }
+    // FL_DEMO_TIME_REPS=N: the LiDAR front (undistortion -> voxel filter -> Mode-18 update, everything between them on the device) repeated
+    // N times from the same inputs, host wall time per frame from plain C++ -- what tools/pipeline_bench.py measures through python.
+    // Printed on stderr (tests parse stdout).
+    if (const char *reps_s = getenv("FL_DEMO_TIME_REPS")) {
+        const int reps = atoi(reps_s);
+        std::vector<double> ms;
+        for (int r = 0; r < reps + 3; r++) {
+            StatesGroup x = state0;
+            imu.proc = proc0;
+            std::vector<float> p = pts;
+            const auto t0 = std::chrono::steady_clock::now();
+            imu.UndistortPcl(samples, beg, end, x, p, /*keep_on_device=*/true);
+            vg.setInputCloudOnDevice(n);
+            vg.filter_to_scan();
+            lio.update(x, nullptr, 0);
+            const auto t1 = std::chrono::steady_clock::now();
+            if (imu.last_status < 0 || vg.last_status < 0 || lio.last_status < 0) { fprintf(stderr, "error: %s\n", fl_last_error_string(h)); return 1; }
+            if (r >= 3) ms.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+        }
+        if (!ms.empty()) {
+            std::sort(ms.begin(), ms.end());
+            fprintf(stderr, "lidar_front_ms median %.4f min %.4f p90 %.4f (%d raw points, %zu frames, C++ over the C ABI)\n", ms[ms.size() / 2], ms[0],
+                    ms[(ms.size() * 9) / 10], n, ms.size());
+        }
     }
     fl_destroy(h);
     return 0;
