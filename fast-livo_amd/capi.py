@@ -187,6 +187,7 @@ SYMBOLS = {
     "fl_get_last_kernel_ms": (C.c_int32, [_H, _fp]),
     "fl_get_frame_timing": (C.c_int32, [_H, C.POINTER(FrameTiming)]),
     "fl_set_option": (C.c_int32, [_H, C.c_int32, C.c_int32]),
+    "fl_abi_revision": (C.c_int32, []),
     "fl_get_diagnostics": (C.c_int32, [_H, C.POINTER(Diagnostics)]),
     "fl_lio_set_points": (C.c_int32, [_H, _fp, C.c_int32]),
     "fl_lio_set_neighbours": (C.c_int32, [_H, _fp, _u8p, C.c_int32]),

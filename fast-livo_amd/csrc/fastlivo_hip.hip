@@ -519,6 +519,8 @@ int32_t fl_set_option(fl_handle h, int32_t option, int32_t value)
     return FL_OK;
 }
 
+int32_t fl_abi_revision(void) { return FL_ABI_REVISION; }
+
 int32_t fl_get_diagnostics(fl_handle h, fl_diagnostics *out)
 {
     if (!h || !out) return fail_arg(h, "fl_get_diagnostics: null argument");
@@ -827,8 +829,10 @@ int32_t fl_lio_begin18(fl_handle h, const fl_state18 *state, const fl_state18 *p
     if (!h || !state || !prop) return fail_arg(h, "fl_lio_begin18: null argument");
     int32_t st = begin18_common(h, state, prop, h->cfg.laser_point_cov);
     if (st) return st;
-    if (h->have_nbr)  // neighbours staged before begin (benchmark order): the search pass is done
+    if (h->have_nbr) {  // neighbours staged before begin (benchmark order): the search pass is done
         HIPCHK(h, hipMemsetAsync((char *)h->d_dev + offsetof(FlDev18, need_search), 0, sizeof(int32_t), h->stream));
+        h->search_certain = false;     // ... and the device will skip the next conditional search (launch_search)
+    }
     return FL_OK;
 }
 
@@ -948,6 +952,7 @@ static int32_t resume_after_timeout(fl_handle h, fl_iter_info *li, F enqueue)
 
 int32_t fl_lio_iterate18(fl_handle h, int32_t count, int32_t flags, fl_iter_info *info)
 {
+    flags &= FL_PUBLIC_ITER_FLAGS;          // internal launch bits (FL_IK_PUBLISH, FL_VIO_DO_COV) are not the caller's to set
     if (!h || count < 0) return fail_arg(h, "fl_lio_iterate18: bad argument");
     if (h->n <= 0 || !h->have_nbr) return fail_arg(h, "fl_lio_iterate18: points/neighbours not staged");
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1016,6 +1021,7 @@ int32_t fl_lio_frame18(fl_handle h, fl_state18 *state_io, const float *body_xyz,
 
 int32_t fl_lio_accumulate18(fl_handle h, double *d_sums, int32_t flags)
 {
+    flags &= FL_PUBLIC_ITER_FLAGS;          // internal launch bits (FL_IK_PUBLISH, FL_VIO_DO_COV) are not the caller's to set
     if (h && (flags & FL_ITER_KEEP_NORMVEC)) h->normvec_valid = true;
     if (!h || !d_sums) return fail_arg(h, "fl_lio_accumulate18: null argument");
     if (h->n <= 0 || !h->have_nbr) return fail_arg(h, "fl_lio_accumulate18: points/neighbours not staged");
@@ -1031,6 +1037,7 @@ int32_t fl_lio_accumulate18(fl_handle h, double *d_sums, int32_t flags)
 
 int32_t fl_lio_solve18(fl_handle h, const double *d_sums, int32_t flags, fl_iter_info *info)
 {
+    flags &= FL_PUBLIC_ITER_FLAGS;          // internal launch bits (FL_IK_PUBLISH, FL_VIO_DO_COV) are not the caller's to set
     if (!h || !d_sums) return fail_arg(h, "fl_lio_solve18: null argument");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipLaunchKernelGGL(eskf18_solve_kernel, dim3(1), dim3(FL_BLOCK), 0, h->stream, h->d_dev, d_sums, 0, (int)flags, (const FlVioConst *)h->d_vc);

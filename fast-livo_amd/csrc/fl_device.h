@@ -137,12 +137,15 @@ __device__ __forceinline__ void so3_Exp(double v1, double v2, double v3, double 
     for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
     if (nrm > 0.00001) {
         double r[3] = {v1 / nrm, v2 / nrm, v3 / nrm};
-        double K[9], KK[9];
+        double K[9], cK[9], cKK[9];
         skew3(r, K);
-        m3_mul(K, K, KK);
         double s = sin(nrm), c = 1.0 - cos(nrm);
+        // `(1.0 - cos) * K * K` groups as ((1 - cos) K) K (so3_math.h:66)
 #pragma unroll
-        for (int i = 0; i < 9; i++) R[i] = R[i] + s * K[i] + c * KK[i];
+        for (int i = 0; i < 9; i++) cK[i] = c * K[i];
+        m3_mul(cK, K, cKK);
+#pragma unroll
+        for (int i = 0; i < 9; i++) R[i] = R[i] + s * K[i] + cKK[i];
     }
 }
 // Log(R), so3_math.h:75-81
@@ -185,6 +188,13 @@ __device__ __forceinline__ void fl_sin_omc(double x, double *s, double *omc)
     }
 }
 
+// s_waitcnt vmcnt(0): this wavefront's outstanding vector-memory operations (loads AND stores on gfx9) have been acknowledged. The
+// explicit wait in front of a barrier behind which ANOTHER wavefront raises a flag for stores of this one (the result mailboxes).
+__device__ __forceinline__ void fl_wait_own_stores()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 #define FL_DEV18_TAIL 512                  /* bytes behind FlDev18 in its device and pinned-host allocations (fastlivo_hip.hip) */
 
 // The result mailbox (FlDev18::pub_flag): called by ALL threads of ONE workgroup as the last action of a frame's last kernel. The
@@ -202,10 +212,11 @@ __device__ __forceinline__ void fl_publish_state(FlDev18 *__restrict__ D)
     const unsigned long long seq = D->pub_seq;
     constexpr int WORDS = (int)((sizeof(FlDev18) + FL_DEV18_TAIL) / 8);
     for (int i = threadIdx.x; i < WORDS; i += blockDim.x) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // Every wavefront waits for its own stores (workgroup-scope release: the counters only), then ONE wavefront pays the system-scope
+    // Every wavefront waits for ITS OWN mirror stores to be acknowledged (s_waitcnt vmcnt(0): on gfx9 the counter covers stores; a
+    // workgroup-scope release fence compiles to lgkmcnt(0) only, which is not that wait), then ONE wavefront pays the system-scope
     // release -- an L2 write-back of a few microseconds whoever issues it: with every wavefront of the workgroup issuing its own the
     // publishing kernel ran 2.5-4.5 us longer (round 4, rocprofv3 time line of the Mode-23 update).
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    fl_wait_own_stores();
     __syncthreads();
     if (threadIdx.x >= 64) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -397,6 +408,7 @@ typedef unsigned int fl_u4_dw __attribute__((ext_vector_type(4), aligned(4)));
 // Phase timestamps for tools/kstamps.py (FL_INSTRUMENT build only): slot i of workgroup 0 and of the last workgroup, under the
 // FL_ITER_STAMP flag. The release build ignores the flag.
 #define FL_ITER_STAMP 4
+#define FL_PUBLIC_ITER_FLAGS 7           /* FL_ITER_FORCE | FL_ITER_KEEP_NORMVEC | FL_ITER_STAMP: what a caller may pass */
 #ifdef FL_INSTRUMENT
 __device__ __forceinline__ void fl_stamp(int flags, int slot)
 {

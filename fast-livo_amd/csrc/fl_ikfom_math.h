@@ -204,21 +204,23 @@ FL_HD void fl_A_matrix(const double *v, double *res)
     for (int i = 0; i < 9; i++) res[i] = (i % 4 == 0) ? 1.0 : 0.0;
 #if FL_IK_SERIES
     if (sq >= FL_MTK_TOL * FL_MTK_TOL && sq <= 0.25) {
-        double K[9], KK[9], a, b;
+        double K[9], bK[9], bKK[9], a, b;
         fl_skew(v, K);
-        fl_m3mul(K, K, KK);
         fl_series_A_coeffs(sq, &a, &b);
-        for (int i = 0; i < 9; i++) res[i] = res[i] + a * K[i] + b * KK[i];
+        for (int i = 0; i < 9; i++) bK[i] = b * K[i];      // `b * hat(v) * hat(v)` groups as (b K) K (mtkmath.hpp:244)
+        fl_m3mul(bK, K, bKK);
+        for (int i = 0; i < 9; i++) res[i] = res[i] + a * K[i] + bKK[i];
         return;
     }
 #endif
     const double norm = sqrt(sq);
     if (!(norm < FL_MTK_TOL)) {
-        double K[9], KK[9];
+        double K[9], bK[9], bKK[9];
         fl_skew(v, K);
-        fl_m3mul(K, K, KK);
         const double a = (1 - cos(norm)) / sq, b = (1 - sin(norm) / norm) / sq;
-        for (int i = 0; i < 9; i++) res[i] = res[i] + a * K[i] + b * KK[i];
+        for (int i = 0; i < 9; i++) bK[i] = b * K[i];
+        fl_m3mul(bK, K, bKK);
+        for (int i = 0; i < 9; i++) res[i] = res[i] + a * K[i] + bKK[i];
     }
 }
 // S2_Bx, S2_typ == 1 (S2.hpp:215-231), 3x2 row-major

@@ -401,14 +401,17 @@ FL_HD void fl_state18_plus(double *x, const double *d /*18*/)
     if (nrm > 0.00001) {
         const double r0 = d[0] / nrm, r1 = d[1] / nrm, r2 = d[2] / nrm;
         const double K[9] = {0.0, -r2, r1, r2, 0.0, -r0, -r1, r0, 0.0};
-        double KK[9], E[9], Rn[9];
+        double cK[9], cKK[9], E[9], Rn[9];
+        const double s = sin(nrm), c = 1.0 - cos(nrm);
+        // the reference's `(1.0 - cos) * K * K` groups as ((1 - cos) K) K (so3_math.h:66)
+#pragma unroll
+        for (int i = 0; i < 9; i++) cK[i] = c * K[i];
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
-            for (int j = 0; j < 3; j++) KK[i * 3 + j] = K[i * 3 + 0] * K[0 * 3 + j] + K[i * 3 + 1] * K[1 * 3 + j] + K[i * 3 + 2] * K[2 * 3 + j];
-        const double s = sin(nrm), c = 1.0 - cos(nrm);
+            for (int j = 0; j < 3; j++) cKK[i * 3 + j] = cK[i * 3 + 0] * K[0 * 3 + j] + cK[i * 3 + 1] * K[1 * 3 + j] + cK[i * 3 + 2] * K[2 * 3 + j];
 #pragma unroll
-        for (int i = 0; i < 9; i++) E[i] = ((i % 4 == 0) ? 1.0 : 0.0) + s * K[i] + c * KK[i];
+        for (int i = 0; i < 9; i++) E[i] = ((i % 4 == 0) ? 1.0 : 0.0) + s * K[i] + cKK[i];
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll

@@ -76,8 +76,12 @@ __device__ __forceinline__ void publish_record(double mine, unsigned epoch, void
         // The tag takes the low 6 bits of the mantissa: the partial travels with 46 of its 52 bits. Rounded to nearest (+ half of the
         // dropped field, carries run into the exponent like any rounding), not truncated -- truncation biased every partial toward
         // zero by up to 2^-46 and the bias of ~1000 like-signed partials (the diagonal of H^T H at millions of points) adds up
-        // instead of averaging out. (inf becomes NaN, NaN stays NaN: both still fail the finiteness check of the solve.)
-        unsigned long long bits = (unsigned long long)__double_as_longlong(mine) + (unsigned long long)((FL_TAG_MASK + 1u) >> 1);
+        // instead of averaging out. inf and NaN (exponent all ones) are NOT rounded: the carry of an all-ones NaN mantissa would run
+        // through the exponent into the sign and come out finite; untouched they still fail the finiteness check of the solve (a NaN
+        // whose only mantissa bits sit in the dropped field becomes inf -- still not finite).
+        unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
+        const bool nonfinite = (bits & 0x7FF0000000000000ull) == 0x7FF0000000000000ull;
+        bits += nonfinite ? 0ull : (unsigned long long)((FL_TAG_MASK + 1u) >> 1);
         bits = (bits & ~(unsigned long long)FL_TAG_MASK) | fl_epoch_tag(epoch);
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(records) + (size_t)blockIdx.x * NV + tid, bits, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);   // sc1 write-through

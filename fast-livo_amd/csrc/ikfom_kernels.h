@@ -66,9 +66,9 @@ __device__ __forceinline__ void fl_publish_state23(FlDev23 *__restrict__ D)
     constexpr int WORDS = (int)(sizeof(FlDev23) / 8);
 #endif
     for (int i = threadIdx.x; i < WORDS; i += blockDim.x) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // every wavefront waits for its own stores (workgroup-scope release: counters only), then ONE wavefront pays the system-scope
-    // release (an L2 write-back, ~3 us whoever issues it: with all four wavefronts issuing their own the publication took 12.8 us)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // every wavefront waits for its own mirror stores (explicit s_waitcnt vmcnt(0), see fl_publish_state), then ONE wavefront pays the
+    // system-scope release (an L2 write-back, ~3 us whoever issues it: with all four wavefronts issuing their own it took 12.8 us)
+    fl_wait_own_stores();
     __syncthreads();
     if (threadIdx.x < 64) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");

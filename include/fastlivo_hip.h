@@ -178,7 +178,12 @@ int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out);
 #define FL_OPT_DEMOTE_AFTER 9
 #define FL_OPT_DEMOTE_CALLS 10
 int32_t fl_set_option(fl_handle h, int32_t option, int32_t value);
-/* Counters of the resident-grid machinery of the multi-pass kernels. */
+/* Counters of the resident-grid machinery of the multi-pass kernels.
+ * ABI note: the struct carries no size member; it is 24 bytes since ABI revision 4 (16 before: the two demotion fields were appended)
+ * and fl_get_diagnostics writes all of it. A caller built against an older header must be rebuilt -- fl_abi_revision() (below) is
+ * the run-time check: it changes whenever a struct of this header grows or a signature changes. */
+#define FL_ABI_REVISION 5
+int32_t fl_abi_revision(void);
 typedef struct fl_diagnostics {
     int32_t multipass_fallbacks;   /* multi-pass launches the admission check sent down the one-launch-per-pass path */
     int32_t frames_resumed;        /* frames / iterate calls resumed per pass after an ABANDONED pass (FL_NUM_TIMEOUT) */
