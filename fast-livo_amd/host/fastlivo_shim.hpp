@@ -122,11 +122,14 @@ inline void h_share_model(state_ikfom &s, esekfom::dyn_share_datastruct<double> 
     int32_t neff = 0;
     ctx.last_status |= fl_h_share_model_sums(ctx.handle, &st, HTH, HTh, &neff, &ctx.total_residual);
     ctx.effct_feat_num = neff;
-    if (neff < 1) { ekfom_data.valid = false; return; }
-    double w[12], V[144];
-    jacobi_eig12(HTH, w, V);
+    // FAST-LIVO's h_share_model has NO early-out for effct_feat_num < 1 (FAST-LIO's sets valid = false there; laserMapping.cpp:1040-1060
+    // resizes h_x to 0 x 12 and returns with valid untouched): the updater then runs its N x N branch over empty matrices, K_h = 0,
+    // K_x = 0, dx = -dx_new. The all-zero surrogate drives the rows >= 23 branch to exactly that (H^T H = 0, H^T z = 0).
     ekfom_data.h_x.resize(23, 12);
     ekfom_data.h.resize(23);
+    if (neff < 1) return;
+    double w[12], V[144];
+    jacobi_eig12(HTH, w, V);
     for (int k = 0; k < 12; k++) {
         const double lam = w[k] > 0 ? w[k] : 0.0, sq = std::sqrt(lam);
         double proj = 0.0;                       // (V^T HTz)_k
