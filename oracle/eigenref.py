@@ -174,6 +174,45 @@ def lio18_frame(x, body, map_xyz, R_LI, t_LI, cov, max_iter):
     return dict(status=st, out=out, sel=sel, normvec=normvec, world=world)
 
 
+MP4_LIB_PATH = os.path.join(_DIR, "_ref", "libeigen_ref_mp4.so")
+_lib_mp4 = None
+
+
+def lib_mp4():
+    """The Mode-18 loop text compiled as CMakeLists.txt:19-37 compiles it on a host with more than 5 cores (-DMP_EN -DMP_PROC_NUM=4): a
+    library of its own (oracle/ref_eigen/Makefile step 4), or None."""
+    global _lib_mp4
+    if _lib_mp4 is None and build() is not None and os.path.exists(MP4_LIB_PATH):
+        L = C.CDLL(MP4_LIB_PATH)
+        vp, dp = C.c_void_p, C.POINTER(C.c_double)
+        L.ref_lio18_frame.argtypes = [vp, vp, C.c_int, vp, C.c_int, dp, dp, C.c_double, C.c_int, vp, vp, vp, vp]
+        L.ref_lio18_timers.argtypes = [dp]
+        _lib_mp4 = L
+    return _lib_mp4
+
+
+def lio18_frame_timed(x, body, map_xyz, R_LI, t_LI, cov, max_iter, mp4=False):
+    """lio18_frame + the reference's OWN timers of that frame (laserMapping.cpp:1508,1535-1554,1604-1605,1729): returns
+    dict(iterations, searches, match_s, solve_s, kdtree_search_s (summed over the loop's threads), threads)."""
+    from . import oracle as orc
+    L = lib_mp4() if mp4 else lib()
+    if L is None:
+        return None
+    if not mp4:
+        L.ref_lio18_timers.argtypes = [C.POINTER(C.c_double)]
+    body = np.ascontiguousarray(body, dtype=np.float32)
+    map_xyz = np.ascontiguousarray(map_xyz, dtype=np.float32)
+    out = orc.LioFrameOut()
+    R_LI = np.ascontiguousarray(R_LI, dtype=np.float64)
+    t_LI = np.ascontiguousarray(t_LI, dtype=np.float64)
+    L.ref_lio18_frame(C.addressof(x), body.ctypes.data, body.shape[0], map_xyz.ctypes.data, len(map_xyz), _d(R_LI), _d(t_LI), cov, max_iter,
+                      None, None, None, C.addressof(out))
+    t = np.zeros(4)
+    L.ref_lio18_timers(_d(t))
+    return dict(iterations=int(out.iterations), searches=int(out.searches), match_s=t[0], solve_s=t[1], kdtree_search_s=t[2], threads=int(t[3]),
+                effct_feat_num=int(out.effct_feat_num))
+
+
 def vio_update_state(vf, x, x_prop, total_residual, level, G=None):
     """LidarSelector::UpdateState, the reference's text (lidar_selection.cpp:743-902).  Mutates x and G."""
     from . import oracle as orc
