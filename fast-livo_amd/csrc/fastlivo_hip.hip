@@ -158,6 +158,12 @@ struct fl_context {
     size_t vox_tmp_bytes = 0;
     int vox_cap = 0;
     int vox_resident = 0;          // points left in d_vox_in by fl_imu_undistort
+    // the sort-free path (voxel_kernels.h, round 5): occupancy bitmap over the grid's cells + counters; zeroed at allocation, left clean by every run
+    unsigned *d_vx_bits = nullptr, *d_vx_l1 = nullptr, *d_vx_l1pre = nullptr, *d_vx_l2flag = nullptr, *d_vx_l2tot = nullptr, *d_vx_cnt = nullptr, *d_vx_ordered = nullptr;
+    FlVxCtl *d_vx_ctl = nullptr;   // two blocks: a run uses [vx_parity] and leaves [1 - vx_parity] zeroed for the next one
+    int vx_parity = 0;
+    long long vx_cells_cap = 0;
+    int opt_voxel_sort = 0;        // FL_OPT_VOXEL_SORT
     // IMU propagation / undistortion (imu_kernels.h)
     FlImuDev *d_imu = nullptr, *h_imu = nullptr;
     FlImuSample *d_imu_samples = nullptr;
@@ -389,6 +395,7 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
 }
 
 static void vox_free(fl_handle h);
+static void vx_free_cells(fl_handle h);
 static int32_t map_free(fl_handle h);
 static void mapupd_free(fl_handle h);
 static void imu_free(fl_handle h);
@@ -409,6 +416,7 @@ int32_t fl_destroy(fl_handle h)
     map_free(h);
     mapupd_free(h);
     vox_free(h);
+    vx_free_cells(h);
     imu_free(h);
     select_free(h);
     vmap_free(h);
@@ -506,6 +514,7 @@ int32_t fl_set_option(fl_handle h, int32_t option, int32_t value)
     case FL_OPT_MAILBOX: h->opt_mailbox = value & 3; break;
     case FL_OPT_SCAN_PULL: h->opt_scan_pull = value != 0; break;
     case FL_OPT_INCR_SEARCH: h->opt_incr_search = value != 0; break;
+    case FL_OPT_VOXEL_SORT: h->opt_voxel_sort = value != 0; break;
     case FL_OPT_DEMOTE_AFTER:
         if (value < 0) return fail_arg(h, "fl_set_option: FL_OPT_DEMOTE_AFTER out of range");
         h->opt_demote_after = value; h->mp_consec_timeouts = 0;

@@ -155,3 +155,290 @@ __global__ __launch_bounds__(FL_BLOCK) void vox_centroid_kernel(const float4 *__
     out[o] = c;
     if (body) { body[3 * o] = c.x; body[3 * o + 1] = c.y; body[3 * o + 2] = c.z; }
 }
+
+
+// ================================================================================================================================
+// Round 5: the same filter WITHOUT a sort (the hipCUB radix sort + scan above were 10 of the 13 launches and 48 of the 69 us of a
+// 24 k-point scan; they stay as the path for very large clouds and as the A/B reference, fl_set_option(FL_OPT_VOXEL_SORT, 1)).
+//
+// PCL's output order is ascending voxel index; the index space of a grid is bounded (dx*dy*dz <= INT32_MAX or PCL does not filter
+// at all), so the ORDER comes from an occupancy bitmap over the cells instead of a sort:
+//     rank(cell) = number of occupied cells with a smaller index
+//                = l2pre[cell >> 18] + l1pre[cell >> 8] + popcount(bits of the cell's 256-cell group below it)
+// and the summation order inside a voxel (ascending cloud index -- PCL leaves it to std::sort, the oracle and the old path fix it
+// so) from counting, per point, the members of its voxel with a smaller index. Eight small launches, plain loads and stores between
+// them, integer atomics only where their order cannot matter (bit claims, counters):
+//   vx_minmax      bounding box of the finite points                          (zero-initialised encodings: no init launch)
+//   vx_claim       voxel index per point; atomicOr claims the cell's bit; the claimer counts its 256-cell group (l1) and marks its
+//                  2^18-cell block (l2flag)
+//   vx_scan_l2     one workgroup per TOUCHED 2^18-cell block: exclusive prefix over its 1024 group counts, block total
+//   vx_rank        per point: rank of its voxel = output slot o; arrival position pos = atomicAdd(cnt[o])
+//   vx_segments    per voxel: a segment of cnt[o] entries (workgroup-aggregated bump allocation)
+//   vx_scatter     per point: member list, arrival order
+//   vx_order       per point: its place among its voxel's members by ascending cloud index
+//   vx_centroid    per voxel: float sums in that order, / count -- and the clean-up: every word this frame set in the bitmap, the
+//                  group counts, the block flags and the voxel counters is zeroed again (touched words only; nothing is memset)
+// Everything the sequence sets it clears, so the (large) bitmap is zeroed once, at allocation. Cells beyond the bitmap's capacity:
+// cells_short is raised, nothing is filtered, the host grows the bitmap and runs the frame again (first frames of a run only).
+// Bit-identical to the sorted path and to oracle/orc_voxel.c: same keys, same output order, same summation order.
+#define FL_VX_NT 256
+#define FL_VX_L1_SHIFT 8            /* 256 cells (8 bitmap words = one 32-byte line) per group */
+#define FL_VX_L2_SHIFT 18           /* 1024 groups per block */
+#define FL_VX_L2_MAX 8192           /* 2^31 cells */
+
+struct FlVxCtl {
+    unsigned mn_enc[3], mx_enc[3];  // atomicMax of ~u / u, u = the ordered image of the float with the sign bit flipped; 0 = no point yet
+    int nfinite;
+    int count;                      // voxels = output points
+    int leaf_too_small;
+    int cells_short;
+    unsigned cursor;                // segment allocator
+    unsigned pad;
+    long long cells;
+};
+
+__device__ __forceinline__ unsigned fl_vx_enc(float f) { return (unsigned)fl_ordered_int(f) ^ 0x80000000u; }
+__device__ __forceinline__ float fl_vx_dec(unsigned u) { return fl_ordered_float((int)(u ^ 0x80000000u)); }
+
+struct FlVxGrid {
+    float inv[3];
+    int min_b[3];
+    int mul[3];
+    int too_small;
+    long long cells;
+};
+__device__ __forceinline__ FlVxGrid fl_vx_grid(const FlVxCtl *C, float ilx, float ily, float ilz, int n)
+{
+    FlVxGrid g;
+    g.inv[0] = ilx; g.inv[1] = ily; g.inv[2] = ilz;
+    int div_b[3];
+    long long d[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float mn = fl_vx_dec(~C->mn_enc[k]), mx = fl_vx_dec(C->mx_enc[k]);
+        d[k] = (long long)((mx - mn) * g.inv[k]) + 1;                 // voxel_grid.hpp: dx, dy, dz
+        g.min_b[k] = (int)floorf(mn * g.inv[k]);
+        div_b[k] = (int)floorf(mx * g.inv[k]) - g.min_b[k] + 1;
+    }
+    g.too_small = (d[0] * d[1] * d[2]) > 2147483647ll;
+    g.mul[0] = 1; g.mul[1] = div_b[0]; g.mul[2] = div_b[0] * div_b[1];
+    // "Leaf size is too small": output = input -- every point its own cell, in cloud order
+    g.cells = g.too_small ? (long long)n : (long long)div_b[0] * (long long)div_b[1] * (long long)div_b[2];
+    return g;
+}
+
+// exclusive prefix over the workgroup (FL_VX_NT threads); total = the sum over all of them
+__device__ __forceinline__ unsigned fl_vx_block_scan(unsigned v, unsigned *lds /* FL_VX_NT / 64 + 1 */, unsigned *total)
+{
+    const int lane = (int)(threadIdx.x & 63u), w = (int)(threadIdx.x >> 6);
+    unsigned inc = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const unsigned o = __shfl_up(inc, s);
+        if (lane >= s) inc += o;
+    }
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    unsigned base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < FL_VX_NT / 64; k++) { const unsigned t = lds[k]; if (k < w) base += t; tot += t; }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(FL_VX_NT) void vx_minmax_kernel(const float4 *__restrict__ in, int n, FlVxCtl *__restrict__ C)
+{
+    unsigned mn[3] = {0u, 0u, 0u}, mx[3] = {0u, 0u, 0u};
+    int cnt = 0;
+    for (int i = blockIdx.x * FL_VX_NT + threadIdx.x; i < n; i += gridDim.x * FL_VX_NT) {
+        const float4 p = in[i];
+        if (!isfinite(p.x) || !isfinite(p.y) || !isfinite(p.z)) continue;
+        const unsigned u[3] = {fl_vx_enc(p.x), fl_vx_enc(p.y), fl_vx_enc(p.z)};
+#pragma unroll
+        for (int k = 0; k < 3; k++) { mn[k] = max(mn[k], ~u[k]); mx[k] = max(mx[k], u[k]); }
+        cnt++;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { mn[k] = max(mn[k], (unsigned)__shfl_xor((int)mn[k], s)); mx[k] = max(mx[k], (unsigned)__shfl_xor((int)mx[k], s)); }
+        cnt += __shfl_xor(cnt, s);
+    }
+    __shared__ unsigned s_red[FL_VX_NT / 64][7];
+    const int w = (int)(threadIdx.x >> 6);
+    if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { s_red[w][k] = mn[k]; s_red[w][3 + k] = mx[k]; }
+        s_red[w][6] = (unsigned)cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {       // one set of atomics per workgroup (same seven words for everybody: ~12 ns each, serialised)
+        for (int v = 1; v < FL_VX_NT / 64; v++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { mn[k] = max(mn[k], s_red[v][k]); mx[k] = max(mx[k], s_red[v][3 + k]); }
+            cnt += (int)s_red[v][6];
+        }
+        if (cnt > 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { atomicMax(&C->mn_enc[k], mn[k]); atomicMax(&C->mx_enc[k], mx[k]); }
+            atomicAdd(&C->nfinite, cnt);
+        }
+    }
+}
+
+__global__ __launch_bounds__(FL_VX_NT) void vx_claim_kernel(const float4 *__restrict__ in, int n, FlVxCtl *__restrict__ C, float ilx, float ily,
+                                                           float ilz, long long cells_cap, unsigned *__restrict__ keys,
+                                                           unsigned *__restrict__ bits, unsigned *__restrict__ l1, unsigned *__restrict__ l2flag)
+{
+    const int i = blockIdx.x * FL_VX_NT + threadIdx.x;
+    if (C->nfinite <= 0) { if (i < n) keys[i] = 0xFFFFFFFFu; return; }
+    const FlVxGrid g = fl_vx_grid(C, ilx, ily, ilz, n);
+    const bool is_short = g.cells > cells_cap;
+    if (i == 0) { C->leaf_too_small = g.too_small; C->cells = g.cells; C->cells_short = is_short ? 1 : 0; }
+    if (i >= n) return;
+    unsigned key = 0xFFFFFFFFu;
+    const float4 p = in[i];
+    if (!is_short && isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+        if (g.too_small) {
+            key = (unsigned)i;
+        } else {
+            const int i0 = (int)(floorf(p.x * g.inv[0]) - (float)g.min_b[0]);
+            const int i1 = (int)(floorf(p.y * g.inv[1]) - (float)g.min_b[1]);
+            const int i2 = (int)(floorf(p.z * g.inv[2]) - (float)g.min_b[2]);
+            key = (unsigned)(i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2]);
+        }
+        const unsigned bit = 1u << (key & 31u);
+        const unsigned old = atomicOr(&bits[key >> 5], bit);
+        if (!(old & bit)) {                                  // this point claimed the voxel
+            atomicAdd(&l1[key >> FL_VX_L1_SHIFT], 1u);
+            l2flag[key >> FL_VX_L2_SHIFT] = 1u;              // (same value from every claimer)
+        }
+    }
+    keys[i] = key;
+}
+
+// grid = blocks the bitmap can hold; block b serves cells [b << 18, (b + 1) << 18)
+// (the prefixes go into an array of their own: written for all 1024 groups of a touched block, read only for groups that hold points of
+// this frame -- nothing of it needs clearing, while the counts in l1 are cleared by exactly the points that raised them)
+__global__ __launch_bounds__(FL_VX_NT) void vx_scan_l2_kernel(const FlVxCtl *__restrict__ C, const unsigned *__restrict__ l1, unsigned *__restrict__ l1pre,
+                                                             const unsigned *__restrict__ l2flag, unsigned *__restrict__ l2tot)
+{
+    __shared__ unsigned s_w[FL_VX_NT / 64 + 1];
+    const int b = (int)blockIdx.x;
+    if (C->nfinite <= 0 || C->cells_short || ((long long)b << FL_VX_L2_SHIFT) >= C->cells) return;
+    if (!l2flag[b]) { if (threadIdx.x == 0) l2tot[b] = 0u; return; }       // (uniform)
+    const size_t g0 = (size_t)b << (FL_VX_L2_SHIFT - FL_VX_L1_SHIFT);       // 1024 group counts: four per thread, consecutive
+    const uint4 v = reinterpret_cast<const uint4 *>(l1 + g0)[threadIdx.x];
+    const unsigned mine = v.x + v.y + v.z + v.w;
+    unsigned total;
+    const unsigned base = fl_vx_block_scan(mine, s_w, &total);
+    reinterpret_cast<uint4 *>(l1pre + g0)[threadIdx.x] = make_uint4(base, base + v.x, base + v.x + v.y, base + v.x + v.y + v.z);
+    if (threadIdx.x == 0) l2tot[b] = total;
+}
+
+__global__ __launch_bounds__(FL_VX_NT) void vx_rank_kernel(int n, FlVxCtl *__restrict__ C, const unsigned *__restrict__ keys, const unsigned *__restrict__ bits,
+                                                          const unsigned *__restrict__ l1pre, const unsigned *__restrict__ l2tot,
+                                                          unsigned *__restrict__ ovox, unsigned *__restrict__ pos, unsigned *__restrict__ cnt)
+{
+    __shared__ unsigned s_l2pre[FL_VX_L2_MAX];
+    __shared__ unsigned s_w[FL_VX_NT / 64 + 1];
+    if (C->nfinite <= 0 || C->cells_short) { if (blockIdx.x == 0 && threadIdx.x == 0) C->count = 0; return; }
+    const int nl2 = (int)((C->cells + (1ll << FL_VX_L2_SHIFT) - 1) >> FL_VX_L2_SHIFT);
+    unsigned run = 0;
+    for (int b0 = 0; b0 < nl2; b0 += FL_VX_NT) {               // exclusive prefix over the block totals (nl2 <= 8192; a handful for a scan)
+        const int b = b0 + (int)threadIdx.x;
+        const unsigned v = b < nl2 ? l2tot[b] : 0u;
+        unsigned total;
+        const unsigned ex = fl_vx_block_scan(v, s_w, &total);
+        if (b < nl2) s_l2pre[b] = run + ex;
+        run += total;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) C->count = (int)run;
+    const int i = blockIdx.x * FL_VX_NT + threadIdx.x;
+    if (i >= n) return;
+    const unsigned key = keys[i];
+    if (key == 0xFFFFFFFFu) return;
+    const unsigned grp = key >> FL_VX_L1_SHIFT;
+    const uint4 *w4 = reinterpret_cast<const uint4 *>(bits + ((size_t)grp << 3));
+    const uint4 a = w4[0], b = w4[1];
+    const unsigned wv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const unsigned wi = (key >> 5) & 7u;
+    unsigned below = 0;
+#pragma unroll
+    for (unsigned k = 0; k < 8; k++) {
+        const unsigned m = (k < wi) ? 0xFFFFFFFFu : ((k == wi) ? ((1u << (key & 31u)) - 1u) : 0u);
+        below += (unsigned)__popc(wv[k] & m);
+    }
+    const unsigned o = s_l2pre[key >> FL_VX_L2_SHIFT] + l1pre[grp] + below;
+    ovox[i] = o;
+    pos[i] = atomicAdd(&cnt[o], 1u);
+}
+
+__global__ __launch_bounds__(FL_VX_NT) void vx_segments_kernel(FlVxCtl *__restrict__ C, const unsigned *__restrict__ cnt, unsigned *__restrict__ seg)
+{
+    __shared__ unsigned s_w[FL_VX_NT / 64 + 1];
+    __shared__ unsigned s_base;
+    const int U = C->count;
+    const int o0 = blockIdx.x * FL_VX_NT;
+    if (o0 >= U) return;                                        // (uniform)
+    const int o = o0 + (int)threadIdx.x;
+    const unsigned c = o < U ? cnt[o] : 0u;
+    unsigned total;
+    const unsigned ex = fl_vx_block_scan(c, s_w, &total);
+    if (threadIdx.x == 0) s_base = atomicAdd(&C->cursor, total);
+    __syncthreads();
+    if (o < U) seg[o] = s_base + ex;
+}
+
+__global__ __launch_bounds__(FL_VX_NT) void vx_scatter_kernel(int n, const unsigned *__restrict__ keys, const unsigned *__restrict__ ovox,
+                                                             const unsigned *__restrict__ pos, const unsigned *__restrict__ seg,
+                                                             unsigned *__restrict__ members)
+{
+    const int i = blockIdx.x * FL_VX_NT + threadIdx.x;
+    if (i >= n || keys[i] == 0xFFFFFFFFu) return;
+    members[seg[ovox[i]] + pos[i]] = (unsigned)i;
+}
+
+__global__ __launch_bounds__(FL_VX_NT) void vx_order_kernel(int n, const unsigned *__restrict__ keys, const unsigned *__restrict__ ovox,
+                                                           const unsigned *__restrict__ cnt, const unsigned *__restrict__ seg,
+                                                           const unsigned *__restrict__ members, unsigned *__restrict__ ordered)
+{
+    const int i = blockIdx.x * FL_VX_NT + threadIdx.x;
+    if (i >= n || keys[i] == 0xFFFFFFFFu) return;
+    const unsigned o = ovox[i], s = seg[o], c = cnt[o];
+    unsigned r = 0;
+    for (unsigned k = 0; k < c; k++) r += (members[s + k] < (unsigned)i) ? 1u : 0u;
+    ordered[s + r] = (unsigned)i;
+}
+
+// out: centroids (x, y, z, intensity); body (nullable): xyz only, the staged-scan layout. The launch covers max(points, voxels)
+// threads: thread t serves voxel t and cleans up behind point t. `next`: the control block of the NEXT frame, zeroed here.
+__global__ __launch_bounds__(FL_VX_NT) void vx_centroid_kernel(const float4 *__restrict__ in, int n, const FlVxCtl *__restrict__ C,
+                                                              const unsigned *__restrict__ keys, unsigned *__restrict__ cnt,
+                                                              const unsigned *__restrict__ seg, const unsigned *__restrict__ ordered,
+                                                              float4 *__restrict__ out, float *__restrict__ body, unsigned *__restrict__ bits,
+                                                              unsigned *__restrict__ l1, unsigned *__restrict__ l2flag, FlVxCtl *__restrict__ next)
+{
+    const int t = blockIdx.x * FL_VX_NT + threadIdx.x;
+    if (t == 0) { FlVxCtl z; memset(&z, 0, sizeof z); *next = z; }
+    if (C->nfinite <= 0 || C->cells_short) return;
+    if (t < C->count) {
+        const unsigned s = seg[t], c = cnt[t];
+        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+        for (unsigned k = 0; k < c; k++) {
+            const float4 p = in[ordered[s + k]];
+            sx = sx + p.x; sy = sy + p.y; sz = sz + p.z; si = si + p.w;
+        }
+        const float fc = (float)c;
+        const float4 ce = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+        out[t] = ce;
+        if (body) { body[3 * t] = ce.x; body[3 * t + 1] = ce.y; body[3 * t + 2] = ce.z; }
+        cnt[t] = 0u;
+    }
+    if (t < n) {
+        const unsigned key = keys[t];
+        if (key != 0xFFFFFFFFu) { bits[key >> 5] = 0u; l1[key >> FL_VX_L1_SHIFT] = 0u; l2flag[key >> FL_VX_L2_SHIFT] = 0u; }
+    }
+}

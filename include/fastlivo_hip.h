@@ -177,6 +177,9 @@ int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out);
 #define FL_OPT_INCR_SEARCH 8
 #define FL_OPT_DEMOTE_AFTER 9
 #define FL_OPT_DEMOTE_CALLS 10
+#define FL_OPT_VOXEL_SORT 11    /* 0 (default): fl_scan_voxel_filter orders the voxels through an occupancy bitmap over the grid's cells (8 small
+                                 * launches, no sort); 1: the round-1 form (hipCUB radix sort of (voxel index, point) + scan, 13 launches), which clouds
+                                 * above FL_VX_SORT_ABOVE points always take. Results are bit-identical either way. */
 int32_t fl_set_option(fl_handle h, int32_t option, int32_t value);
 /* Counters of the resident-grid machinery of the multi-pass kernels.
  * ABI note: the struct carries no size member; it is 24 bytes since ABI revision 4 (16 before: the two demotion fields were appended)

@@ -99,3 +99,33 @@ def test_stage_as_scan_feeds_the_lio_frame(gpu_lib):
     ib = h.lio_frame18_dev(xb, np.ascontiguousarray(ref[:, :3]))
     assert ia.iterations == ib.iterations and ia.effct_feat_num == ib.effct_feat_num
     assert bytes(xa) == bytes(xb)
+
+
+def test_sort_free_path_equals_the_sorted_path(gpu_lib):
+    """fl_set_option(FL_OPT_VOXEL_SORT): the round-1 form (radix sort of (voxel index, point)) and the occupancy-bitmap form give the same
+    bits; dense voxels (hundreds of members each: the per-point ordering), the same handle run after run (the bitmap is left clean)."""
+    from fast_livo_amd import capi, synth
+    h = capi.Handle(capi.config_from_frames(synth.make_lio_frame(1000)))
+    clouds = [(_cloud(30000, 21), 0.15), (_cloud(30000, 22, span=3.0), 0.5), (_cloud(5000, 23, span=1.0), 0.8), (_cloud(70000, 24), 0.3),
+              (_cloud(30000, 21), 0.15)]
+    for p, leaf in clouds:
+        h.set_option(capi.FL_OPT_VOXEL_SORT, 1)
+        a, ma, _ = h.scan_voxel_filter(p, leaf)
+        h.set_option(capi.FL_OPT_VOXEL_SORT, 0)
+        b, mb, _ = h.scan_voxel_filter(p, leaf)
+        assert ma == mb and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        _check(h, p, leaf)
+
+
+def test_grid_larger_than_the_first_bitmap(gpu_lib):
+    """a 150 m x 150 m x 60 m cloud at leaf 0.1: 1500 x 1500 x 600 = 1.35e9 cells > the 2^27 the bitmap starts with -- the run reports it, the
+    bitmap grows, the filter runs again; smaller grids afterwards reuse the larger bitmap"""
+    from fast_livo_amd import capi, synth
+    h = capi.Handle(capi.config_from_frames(synth.make_lio_frame(1000)))
+    rng = np.random.default_rng(31)
+    p = np.empty((40000, 4), np.float32)
+    p[:, 0] = rng.uniform(-75, 75, 40000); p[:, 1] = rng.uniform(-75, 75, 40000); p[:, 2] = rng.uniform(-30, 30, 40000)
+    p[:, 3] = rng.uniform(0, 255, 40000)
+    _check(h, p, 0.1)
+    _check(h, _cloud(24000, 32), 0.15)
+    _check(h, p, 0.1)
