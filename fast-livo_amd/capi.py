@@ -170,6 +170,8 @@ SYMBOLS = {
                                          C.POINTER(C.c_int32)]),
     "fl_imu_undistort": (C.c_int32, [_H, C.POINTER(ImuProc), C.POINTER(State18), C.POINTER(ImuSample), C.c_int32, C.c_double, C.c_double,
                                      _fp, C.c_int32, _fp, C.POINTER(Pose6d), C.POINTER(C.c_int32)]),
+    "fl_lidar_front": (C.c_int32, [_H, C.POINTER(ImuProc), C.POINTER(State18), C.POINTER(ImuSample), C.c_int32, C.c_double, C.c_double, _fp, C.c_int32,
+                                   C.c_float, C.c_int32, C.POINTER(IterInfo), C.POINTER(C.c_int32)]),
     "fl_vio_grid_select": (C.c_int32, [_H, _dp, _dp, _dp, _fp, C.c_int32, C.c_int32, _i32p, _fp, _fp, _i32p, _i32p]),
     "fl_vio_add_keyframe": (C.c_int32, [_H, _u8p, C.c_int32, C.c_int32, C.c_int32, _i32p]),
     "fl_vio_drop_keyframe": (C.c_int32, [_H, C.c_int32]),
@@ -455,6 +457,16 @@ class Handle:
                                           pts.ctypes.data_as(_fp) if n else None, n, out.ctypes.data_as(_fp) if (want and n) else None,
                                           poses, C.byref(npz)), "fl_imu_undistort")
         return out, [poses[i] for i in range(npz.value)]
+
+    def lidar_front(self, proc, state, imu, pcl_beg_time, pcl_end_time, pts_xyzt, leaf, staged=False):
+        """fl_lidar_front: undistortion -> voxel filter -> Mode-18 update in one enqueue. Mutates proc and state; returns (info, scan points)."""
+        samples = imu if not isinstance(imu, np.ndarray) else imu_samples(imu)
+        pts = pts_xyzt if (isinstance(pts_xyzt, np.ndarray) and pts_xyzt.dtype == np.float32 and pts_xyzt.flags["C_CONTIGUOUS"]) \
+            else np.ascontiguousarray(pts_xyzt, np.float32)
+        info = IterInfo(); m = C.c_int32(0)
+        self._chk(self.L.fl_lidar_front(self.h, C.byref(proc), C.byref(state), samples, len(samples), pcl_beg_time, pcl_end_time,
+                                        pts.ctypes.data_as(_fp), pts.shape[0], leaf, 1 if staged else 0, C.byref(info), C.byref(m)), "fl_lidar_front")
+        return info, m.value
 
     def scan_voxel_filter_resident(self, n, leaf, stage_as_scan=True):
         """VoxelGrid of the n-point cloud fl_imu_undistort left on the device; result staged as the scan."""

@@ -159,13 +159,21 @@ struct fl_context {
     int vox_cap = 0;
     int vox_resident = 0;          // points left in d_vox_in by fl_imu_undistort
     // the sort-free path (voxel_kernels.h, round 5): occupancy bitmap over the grid's cells + counters; zeroed at allocation, left clean by every run
-    unsigned *d_vx_bits = nullptr, *d_vx_l1 = nullptr, *d_vx_l1pre = nullptr, *d_vx_l2flag = nullptr, *d_vx_l2tot = nullptr, *d_vx_cnt = nullptr, *d_vx_ordered = nullptr;
+    unsigned *d_vx_bits = nullptr, *d_vx_l1pre = nullptr, *d_vx_l2flag = nullptr, *d_vx_l2tot = nullptr, *d_vx_cnt = nullptr, *d_vx_ordered = nullptr;
+    FlVxPartial *d_vx_partial = nullptr;       // workgroup bounding boxes (vx_minmax_kernel / undistort_apply_kernel)
     FlVxCtl *d_vx_ctl = nullptr;   // two blocks: a run uses [vx_parity] and leaves [1 - vx_parity] zeroed for the next one
     int vx_parity = 0;
     long long vx_cells_cap = 0;
     int opt_voxel_sort = 0;        // FL_OPT_VOXEL_SORT
+    // fl_lidar_front: while its launches are enqueued the scan's size lives on the device only (the voxel filter's count); h->n is then
+    // the CAPACITY the grids are sized for and the kernels read the size through this pointer (nullptr everywhere else)
+    const int *n_dev = nullptr;
+    bool front_refused = false;    // a pass launch of fl_lidar_front lost its multi-pass admission (launch_lio_passes)
+    bool imu_busy = false;         // h_imu (page-locked) may still be read by a copy command of the last fl_lidar_front
     // IMU propagation / undistortion (imu_kernels.h)
     FlImuDev *d_imu = nullptr, *h_imu = nullptr;
+    FlImuDev *d_himu = nullptr;                // h_imu (page-locked) as the device addresses it (fl_lidar_front: the kernel fetches it)
+    FlImuSample *h_imu_samples = nullptr, *d_himu_samples = nullptr;    // page-locked staging of v_imu for the same purpose
     FlImuSample *d_imu_samples = nullptr;
     FlPose6 *d_imu_poses = nullptr;
     int *d_imu_head = nullptr, *d_imu_blockmin = nullptr;
@@ -612,8 +620,6 @@ static int32_t ensure_points(fl_handle h, int n)
 // producers + 1 solver workgroup (handoff.h). fl_set_option(FL_OPT_MAX_PRODUCERS) caps the producers.
 static inline int lio_grid(fl_handle h, int n)
 {
-    int b = (n + FL_LIO_NT - 1) / FL_LIO_NT;
-    if (b < 1) b = 1;
     // One gather sweep covers 256 records (handoff.h): keep small/medium scans to a single sweep and
     // let each lane take several points; spread over more workgroups only when the point loop
     // dominates (measured crossover, bench.py --sweep: 200k pts 9.8 us @255 vs 14.4 us @1023;
@@ -621,10 +627,7 @@ static inline int lio_grid(fl_handle h, int n)
     // Round 2, multi-pass kernel: a wavefront of the gather pays ~0.1 us per 16-byte load instruction (one per 16 records) while a
     // producer lane's second point costs about as much -- 50 k pts: 7.05 us @196 (one point per lane), 6.72 @160; 65 k: 7.56 @254,
     // 6.8 @96..160; 100 k: 7.64 @255, 7.25..7.32 @128..160; 200 k: 8.05 @255, 8.27 @160.
-    int cap = (n <= 130000) ? 160 : ((n <= 300000) ? 255 : ((n <= 2000000) ? 511 : (FL_MAX_BLOCKS - 1)));
-    if (h->opt_max_producers > 0 && cap > h->opt_max_producers) cap = h->opt_max_producers;
-    if (b > cap) b = cap;
-    return b + 1;
+    return fl_lio_producers(n, h->opt_max_producers) + 1;     // (lio_kernels.h: the device derives the same number from the scan's size, fl_lidar_front)
 }
 
 // The records of a pass (handoff.h) validate themselves with a 6-bit tag of the launch epoch, so a record that the PREVIOUS launch
@@ -930,9 +933,13 @@ static bool launch_lio_passes(fl_handle h, int grid, int count, int flags, bool 
     ensure_gates(h);
     if (const unsigned seq = (allow_multi && count > 1) ? multipass_reserve(h, grid) : 0u) {
         hipLaunchKernelGGL(lio18_multipass_kernel, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_gate, h->d_plane, h->d_sel, h->d_normvec,
-                           h->n, h->d_dev, records_lio(h), h->d_epoch, h->d_bcast, (int)count, (int)flags, h->d_mp_done, seq, (int)extra);
+                           h->n, h->d_dev, records_lio(h), h->d_epoch, h->d_bcast, (int)count, (int)flags, h->d_mp_done, seq, (int)extra, h->n_dev,
+                           (int)h->opt_max_producers);
         return extra != 0;
     }
+    // (fl_lidar_front: the per-pass kernels take the scan's size from the host, which does not have it yet -- nothing is launched, the
+    // driver reads the size back and finishes the frame with launches that know it)
+    if (h->n_dev) { h->front_refused = true; return false; }
     for (int i = 0; i < count; i++)
         hipLaunchKernelGGL(lio18_pass_kernel<0>, dim3(grid), dim3(FL_LIO_NT), 0, h->stream, h->d_gate, h->d_plane, h->d_sel,
                            h->d_normvec, h->n, h->d_dev, records_lio(h), h->d_epoch, (double *)nullptr, (int)flags);
@@ -1134,6 +1141,7 @@ int32_t fl_debug_drop_record(fl_handle h, int32_t passes_ahead)
 #include "api_map.inc"
 #include "api_voxel.inc"
 #include "api_imu.inc"
+#include "api_front.inc"
 #include "api_select.inc"
 #include "api_vmap.inc"
 #include "api_comm.inc"

@@ -77,6 +77,17 @@ struct FlDev18 {
     unsigned long long *pub_flag;
     void *pub_dst;
     unsigned long long pub_seq;
+    // fl_lidar_front (round 5): the scan's size is decided on the device (the voxel filter's count); the first search of the frame
+    // leaves it here for the host (0: the host knew it)
+    int32_t n_scan, n_scan_pad;
+};
+
+// What fl_lidar_front's kernels leave for the host in the tail behind FlDev18 (FL_DEV18_TAIL bytes, travels with the result mailbox)
+struct FlFrontTail {
+    double acc_s_last[3], angvel_last[3];      // ImuProcess members the next frame starts from (IMU_Processing.cpp:731-732)
+    int32_t n_poses;
+    int32_t vox_count, vox_leaf_too_small, vox_cells_short, vox_nfinite, pad;
+    long long vox_cells;
 };
 
 // VIO constants (lidar_selection.cpp:35-59 + camera), computed on the host once per handle.
@@ -195,6 +206,7 @@ __device__ __forceinline__ void fl_wait_own_stores()
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#define FL_MAX_BLOCKS 1024                 /* largest pass grid (records buffer; fastlivo_hip.hip repeats the definition) */
 #define FL_DEV18_TAIL 512                  /* bytes behind FlDev18 in its device and pinned-host allocations (fastlivo_hip.hip) */
 
 // The result mailbox (FlDev18::pub_flag): called by ALL threads of ONE workgroup as the last action of a frame's last kernel. The

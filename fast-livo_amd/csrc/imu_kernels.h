@@ -76,33 +76,50 @@ __device__ __forceinline__ void fl_so3_exp_dt(const double *w, double dt, double
 }
 
 #define FL_IMU_NT 384
-// element (i, j) of F_x (:700-709) and cov_w (:701, :711-714) from the step's 3x3 pieces
+// the 3x3 pieces of F_x (:700-709) and cov_w (:701, :711-714) of one interval
 struct FlImuStep {
     double Exp_m[9], RAdt[9], Rdt[9], Cacc[9];   // Exp(w,-dt), R*[a]x*dt, R*dt, R diag(cov_acc) R^T dt^2
     double dt, dt2;
 };
-__device__ __forceinline__ void fl_imu_FC(const FlImuStep &S, const double *cg, const double *cbg, const double *cba, int i, int j, double &F,
-                                          double &C)
+// sum over k of F_x(a, k) * v[k * stride], the terms of row a that are not structurally zero, in ascending k, starting from 0.0: the
+// value (and the bits) of the dense 18-term loop, whose other terms are exact zeros
+__device__ __forceinline__ double fl_imu_row_dot(const FlImuStep &S, int a, const double *v, int stride)
+{
+    const int ba = a / 3, r = a % 3;
+    double q = 0.0;
+    if (ba == 0) {                      // rot:  Exp(w, -dt) | -dt I at bias_g
+        q = q + S.Exp_m[r * 3 + 0] * v[0 * stride];
+        q = q + S.Exp_m[r * 3 + 1] * v[1 * stride];
+        q = q + S.Exp_m[r * 3 + 2] * v[2 * stride];
+        q = q + (-S.dt) * v[(9 + r) * stride];
+    } else if (ba == 1) {               // pos:  I | dt I at vel
+        q = q + 1.0 * v[a * stride];
+        q = q + S.dt * v[(6 + r) * stride];
+    } else if (ba == 2) {               // vel:  -R [a]x dt at rot | I | -R dt at bias_a | dt I at gravity
+        q = q + (-S.RAdt[r * 3 + 0]) * v[0 * stride];
+        q = q + (-S.RAdt[r * 3 + 1]) * v[1 * stride];
+        q = q + (-S.RAdt[r * 3 + 2]) * v[2 * stride];
+        q = q + 1.0 * v[a * stride];
+        q = q + (-S.Rdt[r * 3 + 0]) * v[12 * stride];
+        q = q + (-S.Rdt[r * 3 + 1]) * v[13 * stride];
+        q = q + (-S.Rdt[r * 3 + 2]) * v[14 * stride];
+        q = q + S.dt * v[(15 + r) * stride];
+    } else {                            // bias_g, bias_a, gravity: I
+        q = q + 1.0 * v[a * stride];
+    }
+    return q;
+}
+// cov_w(i, j) (:701, :711-714)
+__device__ __forceinline__ double fl_imu_cov_w(const FlImuStep &S, const double *cg, const double *cbg, const double *cba, int i, int j)
 {
     const int bi = i / 3, bj = j / 3, r = i % 3, c = j % 3;
-    const double eye = (r == c) ? 1.0 : 0.0;
-    F = (i == j) ? 1.0 : 0.0;
-    C = 0.0;
-    if (bi == 0) {
-        if (bj == 0) { F = S.Exp_m[r * 3 + c]; C = (r == c) ? cg[r] * S.dt * S.dt : 0.0; }
-        else if (bj == 3) F = (r == c) ? -S.dt : 0.0;
-    } else if (bi == 1) {
-        if (bj == 2) F = eye * S.dt;
-    } else if (bi == 2) {
-        if (bj == 0) F = -S.RAdt[r * 3 + c];
-        else if (bj == 4) F = -S.Rdt[r * 3 + c];
-        else if (bj == 5) F = eye * S.dt;
-        else if (bj == 2) C = S.Cacc[r * 3 + c];
-    } else if (bi == 3) {
-        if (bj == 3) C = (r == c) ? cbg[r] * S.dt * S.dt : 0.0;
-    } else if (bi == 4) {
-        if (bj == 4) C = (r == c) ? cba[r] * S.dt * S.dt : 0.0;
-    }
+    if (bi != bj) return 0.0;
+    if (bi == 2) return S.Cacc[r * 3 + c];
+    if (r != c) return 0.0;
+    if (bi == 0) return cg[r] * S.dt * S.dt;
+    if (bi == 3) return cbg[r] * S.dt * S.dt;
+    if (bi == 4) return cba[r] * S.dt * S.dt;
+    return 0.0;
 }
 
 // The loop over the IMU intervals (:658-741) carries three chains of different weight: the per-interval quantities that depend
@@ -114,10 +131,45 @@ __device__ __forceinline__ void fl_imu_FC(const FlImuStep &S, const double *cg, 
 // covariance chain, one element per lane. Every quantity is computed by the same expression as before, so the results are
 // bit-identical; only the schedule changed.
 #define FL_IMU_CH 64
+// out18 / tail (fl_lidar_front, nullable): the propagated state goes straight into the LIO state block on the device -- state,
+// state_propagat (:1292 of laserMapping.cpp: state_propagat = state) and cov -- and the members the next frame starts from into the
+// tail behind it; nothing of it visits the host between the propagation and the update.
+// pull (fl_lidar_front with everything in page-locked host memory, nullable): the launch then needs no copy command in front of it --
+//   in_host     the FlImuDev block as the host filled it (its device address): workgroup 0 copies it into D first
+//   x18_host    the update's state block in the handle's mirror: workgroup 0 copies it into out18 (then overwrites state and cov)
+//   v           may itself point into page-locked host memory (each sample is read once)
+//   scan_host   the raw scan: workgroups 1 .. gridDim.x - 1 copy it into scan_dev BESIDE the propagation (the upload used to go through a
+//               second stream and two events; ~33 us for 100 k points either way, now inside this launch)
+struct FlImuPull {
+    const FlImuDev *in_host;
+    const FlDev18 *x18_host;
+    const float4 *scan_host;
+    float4 *scan_dev;
+    int n_scan;
+};
 __global__ __launch_bounds__(FL_IMU_NT) void imu_forward_kernel(FlImuDev *__restrict__ D, const FlImuSample *__restrict__ v, int nv,
-                                                               FlPose6 *__restrict__ poses)
+                                                               FlPose6 *__restrict__ poses, FlDev18 *__restrict__ out18 = nullptr,
+                                                               FlFrontTail *__restrict__ tail = nullptr, FlImuPull pull = FlImuPull{})
 {
-    __shared__ double sF[324], sP[324], sT[324], sC[324];
+    if (blockIdx.x > 0) {                       // scan fetch: 16 bytes per lane and load, every byte once
+        const int stride = ((int)gridDim.x - 1) * FL_IMU_NT;
+        const fl_u4 *src = reinterpret_cast<const fl_u4 *>(pull.scan_host);
+        fl_u4 *dst = reinterpret_cast<fl_u4 *>(pull.scan_dev);
+        for (int i = ((int)blockIdx.x - 1) * FL_IMU_NT + (int)threadIdx.x; i < pull.n_scan; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+        return;
+    }
+    if (pull.in_host) {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(pull.in_host);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(D);
+        for (int w = (int)threadIdx.x; w < (int)(sizeof(FlImuDev) / 8); w += FL_IMU_NT) dst[w] = __builtin_nontemporal_load(src + w);
+    }
+    if (pull.x18_host && out18) {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(pull.x18_host);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(out18);
+        for (int w = (int)threadIdx.x; w < (int)(sizeof(FlDev18) / 8); w += FL_IMU_NT) dst[w] = __builtin_nontemporal_load(src + w);
+    }
+    if (pull.in_host || pull.x18_host) { __threadfence_block(); __syncthreads(); }
+    __shared__ double sP[324], sT[324];        // the covariance; (F cov)^T of the interval in flight
     __shared__ FlImuStep sS[FL_IMU_CH];
     __shared__ double sExpF[FL_IMU_CH][9], sW[FL_IMU_CH][3], sA[FL_IMU_CH][3], sRb[FL_IMU_CH][9];
     __shared__ int sGo[FL_IMU_CH];
@@ -221,32 +273,25 @@ __global__ __launch_bounds__(FL_IMU_NT) void imu_forward_kernel(FlImuDev *__rest
                 }
         }
         __syncthreads();
-        // (D) the covariance chain: cov = F cov F^T + cov_w (:716)
+        // (D) the covariance chain: cov = F cov F^T + cov_w (:716). F_x is the identity plus five 3x3 blocks (:700-709): every row has
+        // 1, 2, 4 or 8 entries that are not structurally zero, and the dense 18-term dot products of the reference add an exact 0 * x for
+        // all the others -- skipping those terms (same order for the rest, same start from 0.0) gives the same bits with less than half
+        // the dependent additions, no F / cov_w matrices in LDS and two barriers per interval instead of three (round 5; the dense form
+        // was 1.6 us per interval, 32 of the kernel's 43 us). Phase 1: T = F P, thread (i, j) = row i of F against column j of P, T kept
+        // TRANSPOSED; phase 2: thread (j, i) -- consecutive lanes share row j of F, i.e. the branch -- T^T's column against that row, + cov_w.
         for (int st = 0; st < ns; st++) {
             if (!sGo[st]) continue;                                                // uniform over the workgroup
-            if (t < 324) {
-                double f, c;
-                fl_imu_FC(sS[st], cg, cbg, cba, ti, tj, f, c);
-                sF[t] = f; sC[t] = c;
-            }
+            if (t < 324) sT[tj * 18 + ti] = fl_imu_row_dot(sS[st], ti, sP + tj, 18);      // T(i, j) = sum_k F(i, k) P(k, j)
             __syncthreads();
             if (t < 324) {
-                double q = 0.0;
-#pragma unroll
-                for (int k = 0; k < 18; k++) q += sF[ti * 18 + k] * sP[k * 18 + tj];
-                sT[t] = q;
-            }
-            __syncthreads();
-            if (t < 324) {
-                double q = 0.0;
-#pragma unroll
-                for (int k = 0; k < 18; k++) q += sT[ti * 18 + k] * sF[tj * 18 + k];
-                sP[t] = q + sC[t];
+                const int i2 = tj, j2 = ti;                                        // this thread's element of the new covariance: (i2, j2)
+                const double q = fl_imu_row_dot(sS[st], j2, sT + i2, 18);          // sum_k T(i2, k) F(j2, k), T(i2, k) at sT[k * 18 + i2]
+                sP[i2 * 18 + j2] = q + fl_imu_cov_w(sS[st], cg, cbg, cba, i2, j2);
             }
             __syncthreads();
         }
     }
-    if (t < 324) D->P[t] = sP[t];
+    if (t < 324) { D->P[t] = sP[t]; if (out18) out18->P[t] = sP[t]; }
     if (t == 0) {
         const double imu_end_time = v[nv - 1].t, end = D->pcl_end_time;
         double note, dt;                                                           // :743-759
@@ -269,6 +314,16 @@ __global__ __launch_bounds__(FL_IMU_NT) void imu_forward_kernel(FlImuDev *__rest
         for (int k = 0; k < 3; k++) D->exrR_extT[k] = o[k];
         D->n_poses = s_K;
         D->term = -1;
+        if (out18) {
+            double x[24];
+            for (int k = 0; k < 9; k++) x[k] = Rend[k];
+            for (int k = 0; k < 3; k++) { x[9 + k] = D->pos[k]; x[12 + k] = D->vel[k]; x[15 + k] = bg[k]; x[18 + k] = ba[k]; x[21 + k] = grav[k]; }
+            for (int k = 0; k < 24; k++) { out18->x[k] = x[k]; out18->xprop[k] = x[k]; out18->xold[k] = x[k]; }
+        }
+        if (tail) {
+            for (int k = 0; k < 3; k++) { tail->acc_s_last[k] = s_acc[k]; tail->angvel_last[k] = s_w[k]; }
+            tail->n_poses = s_K;
+        }
     }
 }
 
@@ -356,20 +411,39 @@ __device__ __forceinline__ void fl_undistort_point(const FlImuDev *D, const FlPo
     x = (float)(c[0] - D->exrR_extT[0]); y = (float)(c[1] - D->exrR_extT[1]); z = (float)(c[2] - D->exrR_extT[2]);
 }
 
+// box (fl_lidar_front, nullable): the workgroup's bounding box of the FINAL points for the voxel filter that follows (voxel_kernels.h
+// FlVxPartial; what vx_minmax_kernel would compute in a launch of its own)
 __global__ __launch_bounds__(FL_BLOCK) void undistort_apply_kernel(float4 *__restrict__ pts, int n, const FlImuDev *__restrict__ D,
-                                                                  const FlPose6 *__restrict__ poses, const int *__restrict__ head)
+                                                                  const FlPose6 *__restrict__ poses, const int *__restrict__ head,
+                                                                  FlVxPartial *__restrict__ box = nullptr)
 {
     const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
-    if (i >= n) return;
     const int K = D->n_poses;
-    if (K < 2 || i <= D->term) return;
-    float4 p = pts[i];
-    const double t = (double)p.w / 1000.0;
-    const int hd = head[i];
-    fl_undistort_point(D, poses[hd], t, p.x, p.y, p.z);
-    if (i == 0) {
-        for (int k = hd - 1; k >= 0; k--)                                          // :803: no step back after the first point
-            if (t > poses[k].offset_time) fl_undistort_point(D, poses[k], t, p.x, p.y, p.z);
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+        const bool moves = !(K < 2 || i <= D->term);
+        if (moves || box) p = pts[i];
+        if (moves) {
+            const double t = (double)p.w / 1000.0;
+            const int hd = head[i];
+            fl_undistort_point(D, poses[hd], t, p.x, p.y, p.z);
+            if (i == 0) {
+                for (int k = hd - 1; k >= 0; k--)                                  // :803: no step back after the first point
+                    if (t > poses[k].offset_time) fl_undistort_point(D, poses[k], t, p.x, p.y, p.z);
+            }
+            pts[i] = p;
+        }
     }
-    pts[i] = p;
+    if (!box) return;
+    static_assert(FL_BLOCK == 256, "fl_vx_block_box");
+    __shared__ unsigned s_red[4][7];
+    unsigned mn[3] = {0u, 0u, 0u}, mx[3] = {0u, 0u, 0u};
+    int cnt = 0;
+    if (i < n && isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+        mn[0] = ~fl_vx_enc(p.x); mn[1] = ~fl_vx_enc(p.y); mn[2] = ~fl_vx_enc(p.z);
+        mx[0] = fl_vx_enc(p.x); mx[1] = fl_vx_enc(p.y); mx[2] = fl_vx_enc(p.z);
+        cnt = 1;
+    }
+    const FlVxPartial r = fl_vx_block_box(mn, mx, cnt, s_red);
+    if (threadIdx.x == 0) box[blockIdx.x] = r;
 }

@@ -273,8 +273,11 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
                                                                   float *__restrict__ body_keep /* nullable */,
                                                                   const DEV *__restrict__ host_state /* nullable */,
                                                                   float4 *ids /* nullable n x 5: the 5 winners of every query (position, map index), kept between searches */,
-                                                                  int incremental)
+                                                                  int incremental, const int *__restrict__ n_dev = nullptr)
 {
+    // n_dev != nullptr (fl_lidar_front): the scan was produced by the voxel filter earlier in the stream and only the device knows its
+    // size -- `n` is the capacity the grid was sized for, the workgroups beyond the real scan leave at once.
+    if (n_dev) n = *n_dev;
     // ids / incremental (the SECOND search of a frame, and every later one over the same scan and map): the winners of the search
     // before (kept with their positions, so the bound needs no second trip through the map) are 5 distinct map points, so the largest of their distances to the query's NEW world point bounds the new 5th-best
     // distance from above (B2) whatever the pose did in between. Only cells whose box lies within sqrt(B2) of the query can hold a
@@ -307,9 +310,11 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
             __threadfence();
             __syncthreads();
         }
+        if constexpr (MODE == 18) { if (n_dev && threadIdx.x == 0) D->n_scan = n; }      // (behind the copy of the block: the mirror does not know it)
         fl_search_prepare<DEV>(D);
         return;
     }
+    if ((int)blockIdx.x * FL_KNN_QPB >= n) return;         // capacity-sized grid (n_dev), or an empty scan
     // (the first search of a frame always runs: begin raises need_search; with host_state the block is not on the device yet)
     if (!host_state && (cond & 1) && (!D->need_search || D->stop || (D->status & 8 /* FL_NUM_TIMEOUT: abandoned chain */))) return;
     const bool stamp = (cond & 2) && threadIdx.x == 0 && blockIdx.x < 512;

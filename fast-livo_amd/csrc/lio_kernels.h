@@ -236,6 +236,16 @@ __global__ __launch_bounds__(FL_LIO_NT, FL_LIO_PASS_WAVES) void lio18_pass_kerne
 }
 
 #define FL_LIO_DO_COV 1
+// producers of a scan of n points: lio_grid() of fastlivo_hip.hip minus the solver (host and device share this one definition)
+__host__ __device__ __forceinline__ int fl_lio_producers(int n, int max_prod)
+{
+    int b = (n + FL_LIO_NT - 1) / FL_LIO_NT;
+    if (b < 1) b = 1;
+    int cap = (n <= 130000) ? 160 : ((n <= 300000) ? 255 : ((n <= 2000000) ? 511 : (FL_MAX_BLOCKS - 1)));
+    if (max_prod > 0 && cap > max_prod) cap = max_prod;
+    if (b > cap) b = cap;
+    return b;
+}
 __device__ __attribute__((noinline)) void eskf18_cov_outofline(FlDev18 *D);      // (out of line: its LDS and registers stay out of the pass loop)
 // -------------------------------------------------------------------------------------------- K1m
 // Up to `count` passes in ONE launch (the LIO block of a frame between two searches): the kernel boundary (~1.5 us), the
@@ -251,22 +261,38 @@ __global__ __launch_bounds__(FL_LIO_NT, 2) void lio18_multipass_kernel(const flo
                                                                    FlDev18 *__restrict__ D, void *__restrict__ records,
                                                                    unsigned *__restrict__ epoch_ptr, unsigned long long *__restrict__ bcast,
                                                                    int count, int flags, unsigned *__restrict__ done_word, unsigned done_seq,
-                                                                   int extra)
+                                                                   int extra, const int *__restrict__ n_dev = nullptr, int max_prod = 0)
 {
     // extra & FL_LIO_DO_COV (the LAST pass launch of fl_lio_frame18_dev): the solver workgroup ends with the covariance update
     // P <- (I - G) P of eskf18_cov_update_kernel -- also when the launch has no pass left to run (the filter stopped in the first
     // segment), not when the chain was abandoned (the host resumes and enqueues the kernel).
     constexpr int NT = FL_LIO_NT;
-    const int nprod = gridDim.x - 1;
+    const int solver_block = gridDim.x - 1;
+    int nprod = solver_block;
+    // n_dev (fl_lidar_front): the scan's size is known to the device only; the grid was sized for the raw scan. The producers that
+    // lio_grid() would give a scan of the real size take the points (same partition, same record order: same bits as the staged
+    // calls); the workgroups beyond them mark their record slot "never written" (tag 0 -- a later, larger launch must not meet an old
+    // tag there, see records_for) and leave.
+    if (n_dev) {
+        n = *n_dev;
+        const int want = fl_lio_producers(n, max_prod);
+        if ((int)blockIdx.x < solver_block && (int)blockIdx.x >= want) {
+            if (threadIdx.x < FL_SUMS18)
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(records) + (size_t)blockIdx.x * FL_SUMS18 + threadIdx.x, 0ull, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        nprod = min(nprod, want);
+    }
     const bool force = (flags & FL_ITER_FORCE) != 0;
-    if (fl_pass_skipped(D, flags, count, blockIdx.x == nprod && threadIdx.x == 0)) {
-        if ((extra & FL_LIO_DO_COV) && blockIdx.x == nprod) eskf18_cov_outofline(D);
-        fl_mp_done(done_word, done_seq, blockIdx.x == nprod);
+    if (fl_pass_skipped(D, flags, count, (int)blockIdx.x == solver_block && threadIdx.x == 0)) {
+        if ((extra & FL_LIO_DO_COV) && (int)blockIdx.x == solver_block) eskf18_cov_outofline(D);
+        fl_mp_done(done_word, done_seq, (int)blockIdx.x == solver_block);
         return;
     }
     const unsigned epoch0 = *epoch_ptr;
 
-    if (blockIdx.x == nprod) {
+    if ((int)blockIdx.x == solver_block) {
         // ------------------------------------------------------------------ solver workgroup
         __shared__ double s_fin[2 * NT];
         __shared__ double s_sums[FL_SUMS18];

@@ -167,17 +167,18 @@ __global__ __launch_bounds__(FL_BLOCK) void vox_centroid_kernel(const float4 *__
 //                = l2pre[cell >> 18] + l1pre[cell >> 8] + popcount(bits of the cell's 256-cell group below it)
 // and the summation order inside a voxel (ascending cloud index -- PCL leaves it to std::sort, the oracle and the old path fix it
 // so) from counting, per point, the members of its voxel with a smaller index. Eight small launches, plain loads and stores between
-// them, integer atomics only where their order cannot matter (bit claims, counters):
-//   vx_minmax      bounding box of the finite points                          (zero-initialised encodings: no init launch)
-//   vx_claim       voxel index per point; atomicOr claims the cell's bit; the claimer counts its 256-cell group (l1) and marks its
-//                  2^18-cell block (l2flag)
-//   vx_scan_l2     one workgroup per TOUCHED 2^18-cell block: exclusive prefix over its 1024 group counts, block total
+// them, integer atomics only where their order cannot matter (bit claims, member counters):
+//   vx_minmax      bounding box of the finite points, one record per workgroup (fl_lidar_front: written by the undistortion's last kernel
+//                  instead -- seven launches); vx_claim folds the records
+//   vx_claim       voxel index per point; a fire-and-forget atomicOr raises the cell's bit; the point marks its 2^18-cell block (l2flag)
+//   vx_scan_l2     one workgroup per TOUCHED 2^18-cell block: group counts (popcounts of the bitmap), exclusive prefix over its 1024
+//                  groups, block total
 //   vx_rank        per point: rank of its voxel = output slot o; arrival position pos = atomicAdd(cnt[o])
 //   vx_segments    per voxel: a segment of cnt[o] entries (workgroup-aggregated bump allocation)
 //   vx_scatter     per point: member list, arrival order
 //   vx_order       per point: its place among its voxel's members by ascending cloud index
 //   vx_centroid    per voxel: float sums in that order, / count -- and the clean-up: every word this frame set in the bitmap, the
-//                  group counts, the block flags and the voxel counters is zeroed again (touched words only; nothing is memset)
+//                  block flags and the voxel counters is zeroed again (touched words only; nothing is memset)
 // Everything the sequence sets it clears, so the (large) bitmap is zeroed once, at allocation. Cells beyond the bitmap's capacity:
 // cells_short is raised, nothing is filtered, the host grows the bitmap and runs the frame again (first frames of a run only).
 // Bit-identical to the sorted path and to oracle/orc_voxel.c: same keys, same output order, same summation order.
@@ -197,6 +198,10 @@ struct FlVxCtl {
     long long cells;
 };
 
+// bounding box of one workgroup's finite points, in the encodings of FlVxCtl (0 = no point). vx_minmax_kernel writes one per workgroup;
+// in fl_lidar_front the undistortion's last kernel does (it holds every final point in a register anyway: one launch less);
+// vx_claim_kernel folds them -- every workgroup for itself, a few KB from L2.
+struct FlVxPartial { unsigned mn[3], mx[3]; int cnt, pad; };
 __device__ __forceinline__ unsigned fl_vx_enc(float f) { return (unsigned)fl_ordered_int(f) ^ 0x80000000u; }
 __device__ __forceinline__ float fl_vx_dec(unsigned u) { return fl_ordered_float((int)(u ^ 0x80000000u)); }
 
@@ -207,7 +212,7 @@ struct FlVxGrid {
     int too_small;
     long long cells;
 };
-__device__ __forceinline__ FlVxGrid fl_vx_grid(const FlVxCtl *C, float ilx, float ily, float ilz, int n)
+__device__ __forceinline__ FlVxGrid fl_vx_grid(const unsigned *mn_enc, const unsigned *mx_enc, float ilx, float ily, float ilz, int n)
 {
     FlVxGrid g;
     g.inv[0] = ilx; g.inv[1] = ily; g.inv[2] = ilz;
@@ -215,7 +220,7 @@ __device__ __forceinline__ FlVxGrid fl_vx_grid(const FlVxCtl *C, float ilx, floa
     long long d[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const float mn = fl_vx_dec(~C->mn_enc[k]), mx = fl_vx_dec(C->mx_enc[k]);
+        const float mn = fl_vx_dec(~mn_enc[k]), mx = fl_vx_dec(mx_enc[k]);
         d[k] = (long long)((mx - mn) * g.inv[k]) + 1;                 // voxel_grid.hpp: dx, dy, dz
         g.min_b[k] = (int)floorf(mn * g.inv[k]);
         div_b[k] = (int)floorf(mx * g.inv[k]) - g.min_b[k] + 1;
@@ -247,7 +252,38 @@ __device__ __forceinline__ unsigned fl_vx_block_scan(unsigned v, unsigned *lds /
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(FL_VX_NT) void vx_minmax_kernel(const float4 *__restrict__ in, int n, FlVxCtl *__restrict__ C)
+// the calling workgroup's (256 threads) bounding box: every thread brings the encodings of its own point(s) (0 = none) and its count;
+// thread 0 returns the workgroup's record
+__device__ __forceinline__ FlVxPartial fl_vx_block_box(unsigned (&mn)[3], unsigned (&mx)[3], int cnt, unsigned (*s_red)[7] /* [4][7] LDS */)
+{
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { mn[k] = max(mn[k], (unsigned)__shfl_xor((int)mn[k], s)); mx[k] = max(mx[k], (unsigned)__shfl_xor((int)mx[k], s)); }
+        cnt += __shfl_xor(cnt, s);
+    }
+    const int w = (int)(threadIdx.x >> 6);
+    if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { s_red[w][k] = mn[k]; s_red[w][3 + k] = mx[k]; }
+        s_red[w][6] = (unsigned)cnt;
+    }
+    __syncthreads();
+    FlVxPartial r;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { r.mn[k] = 0u; r.mx[k] = 0u; }
+    r.cnt = 0; r.pad = 0;
+    if (threadIdx.x == 0) {
+        for (int v = 0; v < 4; v++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { r.mn[k] = max(r.mn[k], s_red[v][k]); r.mx[k] = max(r.mx[k], s_red[v][3 + k]); }
+            r.cnt += (int)s_red[v][6];
+        }
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(FL_VX_NT) void vx_minmax_kernel(const float4 *__restrict__ in, int n, FlVxPartial *__restrict__ partial)
 {
     unsigned mn[3] = {0u, 0u, 0u}, mx[3] = {0u, 0u, 0u};
     int cnt = 0;
@@ -259,41 +295,46 @@ __global__ __launch_bounds__(FL_VX_NT) void vx_minmax_kernel(const float4 *__res
         for (int k = 0; k < 3; k++) { mn[k] = max(mn[k], ~u[k]); mx[k] = max(mx[k], u[k]); }
         cnt++;
     }
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) { mn[k] = max(mn[k], (unsigned)__shfl_xor((int)mn[k], s)); mx[k] = max(mx[k], (unsigned)__shfl_xor((int)mx[k], s)); }
-        cnt += __shfl_xor(cnt, s);
-    }
     __shared__ unsigned s_red[FL_VX_NT / 64][7];
-    const int w = (int)(threadIdx.x >> 6);
-    if ((threadIdx.x & 63u) == 0) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) { s_red[w][k] = mn[k]; s_red[w][3 + k] = mx[k]; }
-        s_red[w][6] = (unsigned)cnt;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {       // one set of atomics per workgroup (same seven words for everybody: ~12 ns each, serialised)
-        for (int v = 1; v < FL_VX_NT / 64; v++) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) { mn[k] = max(mn[k], s_red[v][k]); mx[k] = max(mx[k], s_red[v][3 + k]); }
-            cnt += (int)s_red[v][6];
-        }
-        if (cnt > 0) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) { atomicMax(&C->mn_enc[k], mn[k]); atomicMax(&C->mx_enc[k], mx[k]); }
-            atomicAdd(&C->nfinite, cnt);
-        }
-    }
+    const FlVxPartial r = fl_vx_block_box(mn, mx, cnt, s_red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
 __global__ __launch_bounds__(FL_VX_NT) void vx_claim_kernel(const float4 *__restrict__ in, int n, FlVxCtl *__restrict__ C, float ilx, float ily,
                                                            float ilz, long long cells_cap, unsigned *__restrict__ keys,
-                                                           unsigned *__restrict__ bits, unsigned *__restrict__ l1, unsigned *__restrict__ l2flag)
+                                                           unsigned *__restrict__ bits, unsigned *__restrict__ l2flag,
+                                                           const FlVxPartial *__restrict__ partial, int npartial)
 {
     const int i = blockIdx.x * FL_VX_NT + threadIdx.x;
-    if (C->nfinite <= 0) { if (i < n) keys[i] = 0xFFFFFFFFu; return; }
-    const FlVxGrid g = fl_vx_grid(C, ilx, ily, ilz, n);
+    // the cloud's bounding box from the workgroup records (every workgroup folds them itself: npartial x 32 bytes)
+    __shared__ unsigned s_red[FL_VX_NT / 64][7];
+    __shared__ unsigned s_box[7];
+    {
+        unsigned mn[3] = {0u, 0u, 0u}, mx[3] = {0u, 0u, 0u};
+        int cnt = 0;
+        for (int b = (int)threadIdx.x; b < npartial; b += FL_VX_NT) {
+            const FlVxPartial q = partial[b];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { mn[k] = max(mn[k], q.mn[k]); mx[k] = max(mx[k], q.mx[k]); }
+            cnt += q.cnt;
+        }
+        const FlVxPartial r = fl_vx_block_box(mn, mx, cnt, s_red);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { s_box[k] = r.mn[k]; s_box[3 + k] = r.mx[k]; }
+            s_box[6] = (unsigned)r.cnt;
+        }
+        __syncthreads();
+    }
+    const unsigned mn_enc[3] = {s_box[0], s_box[1], s_box[2]}, mx_enc[3] = {s_box[3], s_box[4], s_box[5]};
+    const int nfinite = (int)s_box[6];
+    if (i == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { C->mn_enc[k] = mn_enc[k]; C->mx_enc[k] = mx_enc[k]; }
+        C->nfinite = nfinite;
+    }
+    if (nfinite <= 0) { if (i < n) keys[i] = 0xFFFFFFFFu; return; }
+    const FlVxGrid g = fl_vx_grid(mn_enc, mx_enc, ilx, ily, ilz, n);
     const bool is_short = g.cells > cells_cap;
     if (i == 0) { C->leaf_too_small = g.too_small; C->cells = g.cells; C->cells_short = is_short ? 1 : 0; }
     if (i >= n) return;
@@ -308,32 +349,33 @@ __global__ __launch_bounds__(FL_VX_NT) void vx_claim_kernel(const float4 *__rest
             const int i2 = (int)(floorf(p.z * g.inv[2]) - (float)g.min_b[2]);
             key = (unsigned)(i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2]);
         }
-        const unsigned bit = 1u << (key & 31u);
-        const unsigned old = atomicOr(&bits[key >> 5], bit);
-        if (!(old & bit)) {                                  // this point claimed the voxel
-            atomicAdd(&l1[key >> FL_VX_L1_SHIFT], 1u);
-            l2flag[key >> FL_VX_L2_SHIFT] = 1u;              // (same value from every claimer)
-        }
+        atomicOr(&bits[key >> 5], 1u << (key & 31u));        // (result unused: a fire-and-forget atomic -- the counts come from popcounts, vx_scan_l2)
+        l2flag[key >> FL_VX_L2_SHIFT] = 1u;                  // (same value from everybody)
     }
     keys[i] = key;
 }
 
 // grid = blocks the bitmap can hold; block b serves cells [b << 18, (b + 1) << 18)
-// (the prefixes go into an array of their own: written for all 1024 groups of a touched block, read only for groups that hold points of
-// this frame -- nothing of it needs clearing, while the counts in l1 are cleared by exactly the points that raised them)
-__global__ __launch_bounds__(FL_VX_NT) void vx_scan_l2_kernel(const FlVxCtl *__restrict__ C, const unsigned *__restrict__ l1, unsigned *__restrict__ l1pre,
+// (group counts = popcounts of the group's eight bitmap words: no counter to raise while claiming, none to clear afterwards. The prefixes
+// are written for all 1024 groups of a touched block and read only for groups that hold points of this frame: nothing of them needs clearing.)
+__global__ __launch_bounds__(FL_VX_NT) void vx_scan_l2_kernel(const FlVxCtl *__restrict__ C, const unsigned *__restrict__ bits, unsigned *__restrict__ l1pre,
                                                              const unsigned *__restrict__ l2flag, unsigned *__restrict__ l2tot)
 {
     __shared__ unsigned s_w[FL_VX_NT / 64 + 1];
     const int b = (int)blockIdx.x;
     if (C->nfinite <= 0 || C->cells_short || ((long long)b << FL_VX_L2_SHIFT) >= C->cells) return;
     if (!l2flag[b]) { if (threadIdx.x == 0) l2tot[b] = 0u; return; }       // (uniform)
-    const size_t g0 = (size_t)b << (FL_VX_L2_SHIFT - FL_VX_L1_SHIFT);       // 1024 group counts: four per thread, consecutive
-    const uint4 v = reinterpret_cast<const uint4 *>(l1 + g0)[threadIdx.x];
-    const unsigned mine = v.x + v.y + v.z + v.w;
+    const size_t g0 = ((size_t)b << (FL_VX_L2_SHIFT - FL_VX_L1_SHIFT)) + 4u * threadIdx.x;   // four consecutive groups per thread: 32 words
+    const uint4 *w4 = reinterpret_cast<const uint4 *>(bits + (g0 << 3));
+    unsigned c[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint4 a = w4[2 * k], d = w4[2 * k + 1];
+        c[k] = (unsigned)(__popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(d.x) + __popc(d.y) + __popc(d.z) + __popc(d.w));
+    }
     unsigned total;
-    const unsigned base = fl_vx_block_scan(mine, s_w, &total);
-    reinterpret_cast<uint4 *>(l1pre + g0)[threadIdx.x] = make_uint4(base, base + v.x, base + v.x + v.y, base + v.x + v.y + v.z);
+    const unsigned base = fl_vx_block_scan(c[0] + c[1] + c[2] + c[3], s_w, &total);
+    reinterpret_cast<uint4 *>(l1pre + g0)[0] = make_uint4(base, base + c[0], base + c[0] + c[1], base + c[0] + c[1] + c[2]);
     if (threadIdx.x == 0) l2tot[b] = total;
 }
 
@@ -419,10 +461,17 @@ __global__ __launch_bounds__(FL_VX_NT) void vx_centroid_kernel(const float4 *__r
                                                               const unsigned *__restrict__ keys, unsigned *__restrict__ cnt,
                                                               const unsigned *__restrict__ seg, const unsigned *__restrict__ ordered,
                                                               float4 *__restrict__ out, float *__restrict__ body, unsigned *__restrict__ bits,
-                                                              unsigned *__restrict__ l1, unsigned *__restrict__ l2flag, FlVxCtl *__restrict__ next)
+                                                              unsigned *__restrict__ l2flag, FlVxCtl *__restrict__ next,
+                                                              FlFrontTail *__restrict__ tail = nullptr)
 {
     const int t = blockIdx.x * FL_VX_NT + threadIdx.x;
-    if (t == 0) { FlVxCtl z; memset(&z, 0, sizeof z); *next = z; }
+    if (t == 0) {
+        FlVxCtl z; memset(&z, 0, sizeof z); *next = z;
+        if (tail) {      // fl_lidar_front: what the host wants to know of the filter rides back behind the state block
+            tail->vox_count = C->count; tail->vox_leaf_too_small = C->leaf_too_small; tail->vox_cells_short = C->cells_short;
+            tail->vox_nfinite = C->nfinite; tail->vox_cells = C->cells;
+        }
+    }
     if (C->nfinite <= 0 || C->cells_short) return;
     if (t < C->count) {
         const unsigned s = seg[t], c = cnt[t];
@@ -439,6 +488,6 @@ __global__ __launch_bounds__(FL_VX_NT) void vx_centroid_kernel(const float4 *__r
     }
     if (t < n) {
         const unsigned key = keys[t];
-        if (key != 0xFFFFFFFFu) { bits[key >> 5] = 0u; l1[key >> FL_VX_L1_SHIFT] = 0u; l2flag[key >> FL_VX_L2_SHIFT] = 0u; }
+        if (key != 0xFFFFFFFFu) { bits[key >> 5] = 0u; l2flag[key >> FL_VX_L2_SHIFT] = 0u; }
     }
 }

@@ -122,6 +122,59 @@ int main(int argc, char **argv)
             fprintf(stderr, "lidar_front_ms median %.4f min %.4f p90 %.4f (%d raw points, %zu frames, C++ over the C ABI)\n", ms[ms.size() / 2], ms[0],
                     ms[(ms.size() * 9) / 10], n, ms.size());
         }
+        // the same frames through fl_lidar_front (LidarFrontDev): one enqueue, one wait -- and the state must come out bit for bit the same
+        LidarFrontDev front; front.handle = h; front.imu = &imu; front.filter_size_surf = leaf;
+        // the raw scan in page-locked memory of the library (fl_host_alloc): the frame's first launch fetches it itself, no copy command
+        float *pinned = nullptr;
+        if (fl_host_alloc(h, sizeof(float) * pts.size(), (void **)&pinned) || !pinned) { fprintf(stderr, "fl_host_alloc: %s\n", fl_last_error_string(h)); return 1; }
+        memcpy(pinned, pts.data(), sizeof(float) * pts.size());
+        std::vector<double> mf, mp;
+        StatesGroup x_staged = state0, x_fused = state0;
+        {
+            imu.proc = proc0;
+            std::vector<float> p = pts;
+            imu.UndistortPcl(samples, beg, end, x_staged, p, true);
+            vg.setInputCloudOnDevice(n); vg.filter_to_scan(); lio.update(x_staged, nullptr, 0);
+        }
+        for (int r = 0; r < reps + 3; r++) {
+            StatesGroup x = state0;
+            imu.proc = proc0;
+            const auto t0 = std::chrono::steady_clock::now();
+            front.update(samples, beg, end, x, pts);
+            const auto t1 = std::chrono::steady_clock::now();
+            if (front.last_status < 0) { fprintf(stderr, "fl_lidar_front: %s\n", fl_last_error_string(h)); return 1; }
+            if (r >= 3) mf.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+            x_fused = x;
+        }
+        if (!mf.empty()) {
+            std::sort(mf.begin(), mf.end());
+            const bool same = memcmp(&x_staged, &x_fused, sizeof(StatesGroup)) == 0;
+            fprintf(stderr, "lidar_front_fused_ms median %.4f min %.4f p90 %.4f (fl_lidar_front, scan %d, state %s the staged calls')\n", mf[mf.size() / 2],
+                    mf[0], mf[(mf.size() * 9) / 10], front.feats_down_size, same ? "bit-identical to" : "DIFFERS from");
+        }
+        StatesGroup x_pinned = state0;
+        for (int r = 0; r < reps + 3; r++) {
+            StatesGroup x = state0;
+            imu.proc = proc0;
+            fl_state18 st18;
+            to_abi(x, st18);
+            fl_iter_info info;
+            int32_t m = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            const int32_t rc = fl_lidar_front(h, &imu.proc, &st18, samples.data(), (int)samples.size(), beg, end, pinned, n, leaf, 0, &info, &m);
+            const auto t1 = std::chrono::steady_clock::now();
+            if (rc < 0) { fprintf(stderr, "fl_lidar_front (pinned): %s\n", fl_last_error_string(h)); return 1; }
+            from_abi(st18, x);
+            if (r >= 3) mp.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+            x_pinned = x;
+        }
+        if (!mp.empty()) {
+            std::sort(mp.begin(), mp.end());
+            const bool same = memcmp(&x_staged, &x_pinned, sizeof(StatesGroup)) == 0;
+            fprintf(stderr, "lidar_front_fused_pinned_ms median %.4f min %.4f p90 %.4f (fl_lidar_front, raw scan in fl_host_alloc memory, state %s the staged calls')\n",
+                    mp[mp.size() / 2], mp[0], mp[(mp.size() * 9) / 10], same ? "bit-identical to" : "DIFFERS from");
+        }
+        fl_host_free(h, pinned);
     }
     fl_destroy(h);
     return 0;

@@ -340,6 +340,39 @@ struct ImuProcessDev {
 };
 
 // ------------------------------------------------------------------------------------------------
+// The LiDAR half of the frame loop in one call (round 5): `p_imu->Process2(LidarMeasures, state, feats_undistort)` (laserMapping.cpp:1359) ->
+// `downSizeFilterSurf.setInputCloud(feats_undistort); downSizeFilterSurf.filter(*feats_down_body)` (:1398-1399) -> the Mode-18 block
+// `if(lidar_en){ for(iterCount = -1; ...) }` (:1504-1733) with the map search on the device. One enqueue, one wait (fl_lidar_front);
+// `imu` holds the ImuProcess members exactly as ImuProcessDev does, feats_down_size comes back with the state.
+// ------------------------------------------------------------------------------------------------
+struct LidarFrontDev {
+    fl_handle handle = nullptr;
+    ImuProcessDev *imu = nullptr;
+    float filter_size_surf = 0.5f;
+    int32_t last_status = 0;
+    int feats_down_size = 0, effct_feat_num = 0, iterCount = 0;
+    double total_residual = 0.0;
+
+    void update(const std::vector<fl_imu_sample> &samples, double pcl_beg_time, double pcl_end_time, StatesGroup &state,
+                const std::vector<float> &pcl_xyzt, bool staged = false)
+    {
+        fl_state18 st;
+        to_abi(state, st);
+        fl_iter_info info;
+        int32_t m = 0;
+        last_status = fl_lidar_front(handle, &imu->proc, &st, samples.data(), (int)samples.size(), pcl_beg_time, pcl_end_time, pcl_xyzt.data(),
+                                     (int)(pcl_xyzt.size() / 4), filter_size_surf, staged ? FL_FRONT_STAGED : 0, &info, &m);
+        if (last_status < 0) return;
+        from_abi(st, state);
+        feats_down_size = m;
+        effct_feat_num = info.effct_feat_num;
+        total_residual = info.total_residual;
+        iterCount = info.iterations - 1;
+        last_status = info.status;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
 // LidarSelector::ComputeJ(cv::Mat img) -> UpdateState(img, err, level) x 3, lidar_selection.cpp:967-983
 // ------------------------------------------------------------------------------------------------
 struct VioUpdater {

@@ -414,6 +414,24 @@ int32_t fl_imu_undistort(fl_handle h, fl_imu_proc *proc_io, fl_state18 *state_io
                          fl_pose6d *poses_out, int32_t *n_poses_out);
 
 /* ------------------------------------------------------------------------------------------------
+ * The LiDAR half of a frame in ONE enqueue (round 5): what laserMapping.cpp does between the sync of a measurement group and the
+ * map update -- p_imu->Process2 / UndistortPcl (src/IMU_Processing.cpp:611-809), downSizeFilterSurf (src/laserMapping.cpp:1398-1399,
+ * leaf = filter_size_surf), the Mode-18 iterated update over the device map (:1504-1733) -- i.e. the three calls
+ *     fl_imu_undistort(h, proc, state, imu, n_imu, beg, end, pts, n, NULL, NULL, &k);
+ *     fl_scan_voxel_filter(h, NULL, n, leaf, leaf, leaf, 1, NULL, &m, &small);
+ *     fl_lio_frame18_dev(h, state, NULL, 0, info);
+ * with identical results (every bit of the state, the covariance and the selection), but nothing returns to the host in between:
+ * the propagated state goes into the update's state block on the device, the filtered scan's size stays on the device, the result
+ * comes back through the mailbox of the frame's last kernel (csrc/api_front.inc). scan_points_out (nullable): feats_down_size.
+ * Needs a map (fl_map_set_points / fl_map_add_points). flags: FL_FRONT_STAGED runs the three calls above instead (A/B, tests); the
+ * library also falls back to them by itself when the frame cannot be fused (no multi-pass admission, FL_OPT_VOXEL_SORT, a sharded handle).
+ * ---------------------------------------------------------------------------------------------- */
+#define FL_FRONT_STAGED 1
+int32_t fl_lidar_front(fl_handle h, fl_imu_proc *proc_io, fl_state18 *state_io, const fl_imu_sample *imu, int32_t n_imu,
+                       double pcl_beg_time, double pcl_end_time, const float *pts_xyzt, int32_t n, float leaf_size, int32_t flags,
+                       fl_iter_info *info, int32_t *scan_points_out);
+
+/* ------------------------------------------------------------------------------------------------
  * VIO patch selection + affine warp on the device (pixel-level part of
  * LidarSelector::addFromSparseMap, src/lidar_selection.cpp:346-587): depth image of the scan (:376-410) and, per
  * candidate, depth-continuity test (:484-506), getWarpMatrixAffine (:232-256), getBestSearchLevel (:315-329),

@@ -1,10 +1,14 @@
 #!/bin/bash
 # Kernel time line (rocprofv3 --kernel-trace) of a python tool, last N dispatches printed.  usage: tools/ktrace.sh N tools/x.py [args]
-N=$1; shift
+N=$1; shift   # FL_KT_CMD=1: the rest is a command line, not a python tool
 R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/kt_tmp
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/kt_tmp -- python $R/"$@" > $OUT/kt_tmp.out 2> $OUT/kt_tmp.err
+if [ -n "$FL_KT_CMD" ]; then
+    (cd $R && rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/kt_tmp -- "$@" > $OUT/kt_tmp.out 2> $OUT/kt_tmp.err)
+else
+    rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/kt_tmp -- python $R/"$@" > $OUT/kt_tmp.out 2> $OUT/kt_tmp.err
+fi
 tail -n 3 $OUT/kt_tmp.out
 python - "$OUT/kt_tmp" "$N" <<'PY'
 import csv, glob, sys

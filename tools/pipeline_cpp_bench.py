@@ -44,5 +44,7 @@ with tempfile.TemporaryDirectory() as d:
         fh.write(f.pts_xyzt.astype("<f4").tobytes()); fh.write(lio.scene.map_xyz.astype("<f4").tobytes())
     out = subprocess.run([demo, fn], capture_output=True, text=True, timeout=600, env=dict(os.environ, FL_DEMO_TIME_REPS=str(a.reps)))
 print(out.stdout.strip().splitlines()[0])
-print(out.stderr.strip().splitlines()[-1] if out.stderr.strip() else "(no timing line)")
+for line in out.stderr.strip().splitlines():
+    if line.startswith("lidar_front"):
+        print(line)
 sys.exit(out.returncode)
