@@ -54,7 +54,7 @@ VIO_LEVEL = 0
 LIO_BYTES_PER_POINT = 12 + 16 + 1      # body xyz + cached plane (n,d) + selection flag (the kernel itself reads 16 + 16: DESIGN.md 4.2)
 VIO_BYTES_PER_PATCH = 405 + 4          # 256 ref + 121 image footprint + 24 pos + 4 level, + 4 written
 HBM_PEAK_GBS = 8000.0                  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-SECTIONS = ("at_scale", "vio_sweep", "mode23", "frame", "restage", "config4", "config5", "cpu_frame")
+SECTIONS = ("at_scale", "vio_sweep", "mode23", "frame", "restage", "config4", "config5", "cpu_frame", "pipeline")
 
 
 def parse():
@@ -664,6 +664,124 @@ def section_cpu_frame(synth, scene, fr, vf, budget_s):
                     "the figure beside `frame` (same inputs, same pass counts)"}
 
 
+def section_pipeline(capi, synth, scene, budget_s, with_cpu=True):
+    """The two halves of a FRAME around the ESKF passes, driver-visible (round 5; SURVEY 8f N1-N4 + the path itself):
+      lidar_front   raw scan + IMU samples -> UndistortPcl -> voxel filter -> Mode-18 update over the device map, as ONE enqueue
+                    (fl_lidar_front) and as the three staged calls it replaces (bit-identical results, tests/test_front_gpu.py);
+      camera_half   LidarSelector::detect (addFromSparseMap -> addSparseMap -> ComputeJ -> addObservation) through the host mirror;
+    through python + ctypes here, and from plain C++ (fast-livo_amd/host/demo_pipeline, built by __graft_entry__.build()) where that
+    binary is present; the CPU oracle's pipeline (4-thread k-d tree for the LiDAR half) beside them."""
+    import struct
+    import subprocess
+    import tempfile
+    raw, leaf, cell, n_imu = 100000, 0.15, 0.5, 20
+    lio = synth.make_lio_frame(raw, scene=scene)
+    f = synth.make_imu_frame(raw, n_imu=n_imu, lio=lio, quiet=True)
+    f.pts_xyzt[:, :3] = lio.body_xyz                   # the raw scan = every synthetic return, in time order
+    h = capi.Handle(capi.config_from_frames(lio, max_iterations=10))
+    h.map_set_points(scene.map_xyz, cell)
+    pts = h.host_alloc((raw, 4), np.float32)
+    pts[:] = f.pts_xyzt
+
+    def run(staged):
+        x = capi.state18_from_frame(lio); pr = capi.imu_proc_from_frame(f)
+        t0 = time.perf_counter()
+        info, m = h.lidar_front(pr, x, f.imu, f.pcl_beg_time, f.pcl_end_time, pts, leaf, staged=staged)
+        return time.perf_counter() - t0, x, m, info
+    out = {"raw_points": raw, "imu_samples": n_imu, "leaf": leaf, "map_points": int(len(scene.map_xyz))}
+    states = {}
+    for name, staged in (("fused", False), ("staged", True)):
+        ts = []
+        for r in range(33):
+            t, x, m, info = run(staged)
+            if r >= 3:
+                ts.append(t)
+        states[name] = bytes(x)
+        out["lidar_front_%s_ms" % name] = float(np.median(ts)) * 1e3
+        out["scan_points"], out["lio_passes"], out["effective_points"] = m, int(info.iterations), int(info.effct_feat_num)
+    out["fused_equals_staged_bit_for_bit"] = states["fused"] == states["staged"]
+    out["what"] = ("lidar_front_*: host wall time of one call through python + ctypes (raw scan in page-locked memory: the fused form fetches it "
+                   "with its first launch; staged = fl_imu_undistort + fl_scan_voxel_filter + fl_lio_frame18_dev)")
+    h.host_free(pts)
+    h.close()
+    # ---- the same from plain C++ (host mirror demo), camera half included
+    demo = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fast-livo_amd", "host", "demo_pipeline")
+    if os.path.exists(demo):
+        try:
+            with tempfile.TemporaryDirectory() as d:
+                fn = os.path.join(d, "pipe.bin")
+                x0 = capi.state18_from_frame(lio)
+                with open(fn, "wb") as fh:
+                    fh.write(struct.pack("<iiiiffdd", raw, f.imu.shape[0], scene.map_xyz.shape[0], 10, leaf, cell, f.pcl_beg_time, f.pcl_end_time))
+                    fh.write(np.asarray(lio.R_LI, dtype="<f8").tobytes()); fh.write(np.asarray(lio.t_LI, dtype="<f8").tobytes())
+                    fh.write(x0.vec().astype("<f8").tobytes()); fh.write(np.asarray(x0.cov_np(), dtype="<f8").tobytes())
+                    fh.write(bytes(capi.imu_proc_from_frame(f)))
+                    fh.write(np.ascontiguousarray(f.imu, dtype="<f8").tobytes())
+                    fh.write(f.pts_xyzt.astype("<f4").tobytes()); fh.write(scene.map_xyz.astype("<f4").tobytes())
+                    Rci = np.eye(3) @ lio.R_LI.T
+                    fh.write(np.asarray(Rci, dtype="<f8").tobytes()); fh.write(np.asarray(-lio.R_LI.T @ lio.t_LI, dtype="<f8").tobytes())
+                    fh.write(synth.make_image(640, 512, seed=3).tobytes())
+                r = subprocess.run([demo, fn], capture_output=True, text=True, timeout=300, env=dict(os.environ, FL_DEMO_TIME_REPS="30"))
+            cpp = {}
+            for line in r.stderr.splitlines():
+                w = line.split()
+                if len(w) > 2 and w[1] == "median" and w[0].endswith("_ms"):
+                    cpp[w[0]] = float(w[2])
+                    if w[0] == "camera_half_ms":
+                        cpp["camera_half_note"] = line[line.index("("):]
+                if "DIFFERS" in line:
+                    cpp["mismatch"] = line
+            out["cpp"] = cpp if r.returncode == 0 else {"failed": (r.stderr or r.stdout)[-300:]}
+        except Exception as e:                                  # the section must not take the bench line down
+            out["cpp"] = {"failed": repr(e)[:300]}
+    else:
+        out["cpp"] = {"skipped": "fast-livo_amd/host/demo_pipeline not built"}
+    # ---- CPU counterpart (bounded: a few frames)
+    if with_cpu:
+        from oracle import oracle as orc
+
+        def cpu_front():
+            x = orc.state18_from_frame(lio); pr = orc.imu_proc_from_frame(f)
+            t0 = time.perf_counter()
+            p2, _ = orc.imu_undistort(pr, x, f.imu, f.pcl_beg_time, f.pcl_end_time, f.pts_xyzt); t1 = time.perf_counter()
+            vox, _ = orc.voxel_grid(p2, leaf); t2 = time.perf_counter()
+            orc.lio18_frame(x, np.ascontiguousarray(vox[:, :3]), lio.R_LI, lio.t_LI, lio.laser_point_cov, 10, lambda w: synth.knn5(scene, w), nthreads=4)
+            return t1 - t0, t2 - t1, time.perf_counter() - t2
+        parts = [cpu_front() for _ in range(2)]
+        und, vox_t, lio_t = (float(np.median([p_[i] for p_ in parts])) * 1e3 for i in range(3))
+        out["cpu_lidar_front_ms"] = und + vox_t + lio_t
+        out["cpu_lidar_front_parts_ms"] = {"undistort": und, "voxel_filter": vox_t, "lio_frame_4_threads": lio_t}
+        # camera half on the CPU: the oracle's visual map driven as detect() drives it, on the demo's inputs (one image, two frames; the second tracks)
+        try:
+            vf = synth.make_vio_frame(8, lio)
+            img = synth.make_image(640, 512, seed=3)
+            vm = orc.VMap(orc.vio_config(vf), 40)
+            x = orc.state18_from_frame(lio)
+            Rci = np.eye(3) @ lio.R_LI.T; Pci = -lio.R_LI.T @ lio.t_LI
+            world = lio.world_at(np.array(x.rot).reshape(3, 3), np.array(x.pos[:])).astype(np.float32)[:20000]
+            down, _ = orc.voxel_grid(np.concatenate([world, np.zeros((len(world), 1), np.float32)], axis=1), 0.2)
+            down = np.ascontiguousarray(down[:, :3])
+            tc = []
+            for k in range(3):
+                R = np.array(x.rot).reshape(3, 3); Rcw = Rci @ R.T; Pcw = -(Rcw @ np.array(x.pos[:])) + Pci
+                t0 = time.perf_counter()
+                o = vm.select(Rcw, Pcw, img, [img] * (k + 1), down, outlier_threshold=1e12)
+                vm.add_sparse(Rcw, Pcw, img, world, k, k)
+                vm.add_observation(Rcw, Pcw, img, o["points"], o["levels"], k, k)
+                tc.append((time.perf_counter() - t0, len(o["points"])))
+            vm.close()
+            out["cpu_camera_half_ms_without_ComputeJ"] = tc[-1][0] * 1e3
+            out["cpu_camera_half_patches"] = tc[-1][1]
+            out["cpu_camera_half_note"] = ("oracle visual map (select + addSparseMap + addObservation) on the demo's inputs; ComputeJ on the CPU is "
+                                           "`cpu_frame.*.vio_computej_ms` (2 000 patches) -- ~0.4 ms per 100 tracked patches")
+        except Exception as e:
+            out["cpu_camera_half_ms_without_ComputeJ"] = None
+            out["cpu_camera_half_note"] = "failed: " + repr(e)[:200]
+        if "lidar_front_fused_ms" in out:
+            out["lidar_front_speedup_vs_cpu"] = out["cpu_lidar_front_ms"] / out["lidar_front_fused_ms"]
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     global AT_SCALE_POINTS, VIO_SWEEP
@@ -743,7 +861,8 @@ def main():
                "restage": lambda: section_restage(capi, synth, fr, cfg, x0, nbr, valid),
                "config4": lambda: section_config4(capi, synth, scene),
                "config5": lambda: section_config5(capi, synth, scene),
-               "cpu_frame": lambda: section_cpu_frame(synth, scene, fr, vf, args.cpu_seconds)}[args.only]()
+               "cpu_frame": lambda: section_cpu_frame(synth, scene, fr, vf, args.cpu_seconds),
+               "pipeline": lambda: section_pipeline(capi, synth, scene, args.cpu_seconds)}[args.only]()
         print(json.dumps({"section": args.only, "result": sec}), flush=True)
         return
 
@@ -995,6 +1114,7 @@ def main():
         extras["restage"] = section_restage(capi, synth, fr, cfg, x0, nbr, valid)
         extras["config4"] = section_config4(capi, synth, scene)
         extras["config5"] = section_config5(capi, synth, scene)
+        extras["pipeline"] = section_pipeline(capi, synth, scene, args.cpu_seconds, with_cpu=not args.no_cpu_baseline)
         if args.sweep:
             sweep(capi, synth, scene, cfg, x0, sys.stderr)
 

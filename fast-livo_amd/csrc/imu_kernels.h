@@ -168,6 +168,9 @@ __global__ __launch_bounds__(FL_IMU_NT) void imu_forward_kernel(FlImuDev *__rest
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(out18);
         for (int w = (int)threadIdx.x; w < (int)(sizeof(FlDev18) / 8); w += FL_IMU_NT) dst[w] = __builtin_nontemporal_load(src + w);
     }
+    // the first chunk's samples travel with the blocks above (one trip over the host link for all of them when v is host memory too)
+    FlImuSample pre_head = {}, pre_tail = {};
+    if ((int)threadIdx.x < min(FL_IMU_CH, nv - 1)) { pre_head = v[threadIdx.x]; pre_tail = v[threadIdx.x + 1]; }
     if (pull.in_host || pull.x18_host) { __threadfence_block(); __syncthreads(); }
     __shared__ double sP[324], sT[324];        // the covariance; (F cov)^T of the interval in flight
     __shared__ FlImuStep sS[FL_IMU_CH];
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(FL_IMU_NT) void imu_forward_kernel(FlImuDev *__rest
         const int ns = min(FL_IMU_CH, nv - 1 - c0);
         // (A) sample-only part of interval c0 + t
         if (t < ns) {
-            const FlImuSample head = v[c0 + t], tail = v[c0 + t + 1];
+            const FlImuSample head = c0 == 0 ? pre_head : v[c0 + t], tail = c0 == 0 ? pre_tail : v[c0 + t + 1];
             const int go = !(tail.t < last_end);                                   // :666
             sGo[t] = go;
             sTail[t] = tail.t;

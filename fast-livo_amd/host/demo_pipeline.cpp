@@ -66,38 +66,7 @@ int main(int argc, char **argv)
     printf("\n");
     for (int i = 0; i < 18; i++) printf("%.17g ", state.cov[i * 18 + i]);
     printf("\n%.17g %.17g\n", imu.proc.last_lidar_end_time, imu.proc.acc_s_last[2]);
-    // the frame's tail: window check at the new position, then the scan goes into the map (laserMapping.cpp:1395,1758)
-    LocalMapDev lm; lm.handle = h; lm.cube_len = 24.0; lm.DET_RANGE = 4.0f; lm.downsample_size = leaf;
-    V3D pos_lid = state.pos_end;
-    lm.lasermap_fov_segment(pos_lid);                 // first call: centres the window
-    pos_lid.v[0] += 8.0;                               // pretend the sensor moved: the window follows, one slab is cut off
-    const int cut = lm.lasermap_fov_segment(pos_lid);
-    const int removed = lm.kdtree_delete_counter;
-    lm.map_incremental();
-    if (lm.last_status < 0) { fprintf(stderr, "map: %s\n", fl_last_error_string(h)); return 1; }
-    printf("map %d boxes %d removed %d before %d after %d added %d\n", lm.last_status, cut, removed, lm.last.n_before, lm.last.n_after,
-           lm.last.n_added);
-    // optional camera half (LidarSelectorDev::detect), two frames on the same image: the first founds map points, the second tracks them
-    if (have_cam) {
-        std::vector<float> pg((size_t)feats_down_size * 3), pg_down((size_t)feats_down_size * 4);
-        if (fl_lio_get_world_points(h, pg.data())) { fprintf(stderr, "world points: %s\n", fl_last_error_string(h)); return 1; }
-        std::vector<float> pg4((size_t)feats_down_size * 4, 0.0f);
-        for (int i = 0; i < feats_down_size; i++) for (int k = 0; k < 3; k++) pg4[(size_t)i * 4 + k] = pg[(size_t)i * 3 + k];
-        int32_t n_down = 0, small = 0;
-        if (fl_scan_voxel_filter(h, pg4.data(), feats_down_size, 0.2f, 0.2f, 0.2f, 0, pg_down.data(), &n_down, &small) < 0) return 1;   // downSizeFilter (:352-353)
-        std::vector<float> down3((size_t)n_down * 3);
-        for (int i = 0; i < n_down; i++) for (int k = 0; k < 3; k++) down3[(size_t)i * 3 + k] = pg_down[(size_t)i * 4 + k];
-        LidarSelectorDev sel; sel.handle = h; sel.grid_size = 40; sel.outlier_threshold = 1e12;
-        if (sel.init() < 0) { fprintf(stderr, "vmap: %s\n", fl_last_error_string(h)); return 1; }
-        for (int f2 = 0; f2 < 2; f2++) {
-            sel.detect(image.data(), cfg.img_width, cfg.img_height, cfg.img_width, pg.data(), feats_down_size, down3.data(), n_down, Rci, Pci, state);
-            if (sel.last_status < 0) { fprintf(stderr, "detect: %s\n", fl_last_error_string(h)); return 1; }
-            printf("cam %d selected %d founded %d observed %d\n", f2, sel.n_selected, sel.n_founded, sel.n_observed);
-        }
-        for (int i = 0; i < 9; i++) printf("%.17g ", state.rot_end.m[i]);
-        for (int i = 0; i < 3; i++) printf("%.17g ", state.pos_end.v[i]);
-        printf("\n");
-    }
+    // (timed HERE, before the map changes below: the figures are for the map the frame was registered against)
     // FL_DEMO_TIME_REPS=N: the LiDAR front (undistortion -> voxel filter -> Mode-18 update, everything between them on the device) repeated
     // N times from the same inputs, host wall time per frame from plain C++ -- what tools/pipeline_bench.py measures through python.
     // Printed on stderr (tests parse stdout).
@@ -175,6 +144,58 @@ int main(int argc, char **argv)
                     mp[mp.size() / 2], mp[0], mp[(mp.size() * 9) / 10], same ? "bit-identical to" : "DIFFERS from");
         }
         fl_host_free(h, pinned);
+    }
+    // the frame's tail: window check at the new position, then the scan goes into the map (laserMapping.cpp:1395,1758)
+    LocalMapDev lm; lm.handle = h; lm.cube_len = 24.0; lm.DET_RANGE = 4.0f; lm.downsample_size = leaf;
+    V3D pos_lid = state.pos_end;
+    lm.lasermap_fov_segment(pos_lid);                 // first call: centres the window
+    pos_lid.v[0] += 8.0;                               // pretend the sensor moved: the window follows, one slab is cut off
+    const int cut = lm.lasermap_fov_segment(pos_lid);
+    const int removed = lm.kdtree_delete_counter;
+    lm.map_incremental();
+    if (lm.last_status < 0) { fprintf(stderr, "map: %s\n", fl_last_error_string(h)); return 1; }
+    printf("map %d boxes %d removed %d before %d after %d added %d\n", lm.last_status, cut, removed, lm.last.n_before, lm.last.n_after,
+           lm.last.n_added);
+    // optional camera half (LidarSelectorDev::detect), two frames on the same image: the first founds map points, the second tracks them
+    if (have_cam) {
+        std::vector<float> pg((size_t)feats_down_size * 3), pg_down((size_t)feats_down_size * 4);
+        if (fl_lio_get_world_points(h, pg.data())) { fprintf(stderr, "world points: %s\n", fl_last_error_string(h)); return 1; }
+        std::vector<float> pg4((size_t)feats_down_size * 4, 0.0f);
+        for (int i = 0; i < feats_down_size; i++) for (int k = 0; k < 3; k++) pg4[(size_t)i * 4 + k] = pg[(size_t)i * 3 + k];
+        int32_t n_down = 0, small = 0;
+        if (fl_scan_voxel_filter(h, pg4.data(), feats_down_size, 0.2f, 0.2f, 0.2f, 0, pg_down.data(), &n_down, &small) < 0) return 1;   // downSizeFilter (:352-353)
+        std::vector<float> down3((size_t)n_down * 3);
+        for (int i = 0; i < n_down; i++) for (int k = 0; k < 3; k++) down3[(size_t)i * 3 + k] = pg_down[(size_t)i * 4 + k];
+        LidarSelectorDev sel; sel.handle = h; sel.grid_size = 40; sel.outlier_threshold = 1e12;
+        if (sel.init() < 0) { fprintf(stderr, "vmap: %s\n", fl_last_error_string(h)); return 1; }
+        for (int f2 = 0; f2 < 2; f2++) {
+            sel.detect(image.data(), cfg.img_width, cfg.img_height, cfg.img_width, pg.data(), feats_down_size, down3.data(), n_down, Rci, Pci, state);
+            if (sel.last_status < 0) { fprintf(stderr, "detect: %s\n", fl_last_error_string(h)); return 1; }
+            printf("cam %d selected %d founded %d observed %d\n", f2, sel.n_selected, sel.n_founded, sel.n_observed);
+        }
+        for (int i = 0; i < 9; i++) printf("%.17g ", state.rot_end.m[i]);
+        for (int i = 0; i < 3; i++) printf("%.17g ", state.pos_end.v[i]);
+        printf("\n");
+        // FL_DEMO_TIME_REPS: the camera half (LidarSelectorDev::detect = the body of LidarSelector::detect, lidar_selection.cpp:1027-1076) again and
+        // again on the same image from the same state, host wall time per frame from plain C++ (stderr)
+        if (const char *reps_s = getenv("FL_DEMO_TIME_REPS")) {
+            const int reps = atoi(reps_s);
+            std::vector<double> ms;
+            const StatesGroup xc0 = state;
+            for (int r = 0; r < reps + 3; r++) {
+                StatesGroup xc = xc0;
+                const auto t0 = std::chrono::steady_clock::now();
+                sel.detect(image.data(), cfg.img_width, cfg.img_height, cfg.img_width, pg.data(), feats_down_size, down3.data(), n_down, Rci, Pci, xc);
+                const auto t1 = std::chrono::steady_clock::now();
+                if (sel.last_status < 0) { fprintf(stderr, "detect: %s\n", fl_last_error_string(h)); return 1; }
+                if (r >= 3) ms.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+            }
+            if (!ms.empty()) {
+                std::sort(ms.begin(), ms.end());
+                fprintf(stderr, "camera_half_ms median %.4f min %.4f p90 %.4f (detect: %d patches tracked, %d scan points, %d down-sampled; C++ over the C ABI)\n",
+                        ms[ms.size() / 2], ms[0], ms[(ms.size() * 9) / 10], sel.n_selected, feats_down_size, n_down);
+            }
+        }
     }
     fl_destroy(h);
     return 0;

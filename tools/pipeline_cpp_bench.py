@@ -24,6 +24,7 @@ ap.add_argument("--raw", type=int, default=100000)
 ap.add_argument("--leaf", type=float, default=0.15)
 ap.add_argument("--cell", type=float, default=0.5)
 ap.add_argument("--reps", type=int, default=30)
+ap.add_argument("--camera", action="store_true", help="also time the camera half (LidarSelectorDev::detect)")
 a = ap.parse_args()
 hostdir = os.path.join(ROOT, "fast-livo_amd", "host")
 demo = os.path.join(hostdir, "demo_pipeline")
@@ -42,9 +43,14 @@ with tempfile.TemporaryDirectory() as d:
         fh.write(bytes(pr0))
         fh.write(np.ascontiguousarray(f.imu, dtype="<f8").tobytes())
         fh.write(f.pts_xyzt.astype("<f4").tobytes()); fh.write(lio.scene.map_xyz.astype("<f4").tobytes())
+        if a.camera:      # the camera half: extrinsics of the state frame + a 640 x 512 grey image (tests/test_host_mirror_gpu.py)
+            Rci = np.eye(3) @ lio.R_LI.T
+            Pci = np.eye(3) @ (-lio.R_LI.T @ lio.t_LI)
+            fh.write(np.asarray(Rci, dtype="<f8").tobytes()); fh.write(np.asarray(Pci, dtype="<f8").tobytes())
+            fh.write(synth.make_image(640, 512, seed=3).tobytes())
     out = subprocess.run([demo, fn], capture_output=True, text=True, timeout=600, env=dict(os.environ, FL_DEMO_TIME_REPS=str(a.reps)))
 print(out.stdout.strip().splitlines()[0])
 for line in out.stderr.strip().splitlines():
-    if line.startswith("lidar_front"):
+    if line.startswith("lidar_front") or line.startswith("camera_half"):
         print(line)
 sys.exit(out.returncode)
