@@ -256,7 +256,7 @@ DEBUG_SYMBOLS = {
     "fl_debug_drop_record": (C.c_int32, [_H, C.c_int32]),
 }
 FL_OPT_MULTIPASS, FL_OPT_MAX_PRODUCERS, FL_OPT_IK_PRODUCERS, FL_OPT_MP_CAPACITY, FL_OPT_VIO_WHOLE_CU, FL_OPT_MAILBOX, FL_OPT_SCAN_PULL, FL_OPT_INCR_SEARCH = 1, 2, 3, 4, 5, 6, 7, 8
-FL_OPT_DEMOTE_AFTER, FL_OPT_DEMOTE_CALLS, FL_OPT_VOXEL_SORT = 9, 10, 11
+FL_OPT_DEMOTE_AFTER, FL_OPT_DEMOTE_CALLS, FL_OPT_VOXEL_SORT, FL_OPT_MAP_INCREMENTAL = 9, 10, 11, 12
 DEBUG_LIB_PATH = os.path.join(PKG_DIR, "libfastlivo_hip_debug.so")
 
 _lib = None
@@ -909,21 +909,23 @@ def _knn_methods():
     def map_clear(self, cell_size=0.5):
         self._chk(self.L.fl_map_clear(self.h, cell_size), "fl_map_clear")
 
-    def map_add_points(self, world_xyz, downsample_size):
-        """map_incremental on the device map; world_xyz None = the staged scan under the device's 18-state. Returns MapInfo."""
+    def map_add_points(self, world_xyz, downsample_size, want_info=True):
+        """map_incremental on the device map; world_xyz None = the staged scan under the device's 18-state. Returns MapInfo
+        (want_info=False: no counters asked for -- the in-place form then returns without waiting for the device)."""
         info = MapInfo()
+        ip = C.addressof(info) if want_info else None
         if world_xyz is None:
-            self._chk(self.L.fl_map_add_points(self.h, None, 0, downsample_size, C.addressof(info)), "fl_map_add_points")
+            self._chk(self.L.fl_map_add_points(self.h, None, 0, downsample_size, ip), "fl_map_add_points")
         else:
             w = np.ascontiguousarray(world_xyz, dtype=np.float32).reshape(-1, 3)
-            self._chk(self.L.fl_map_add_points(self.h, _p(w, C.c_float), w.shape[0], downsample_size, C.addressof(info)), "fl_map_add_points")
-        return info
+            self._chk(self.L.fl_map_add_points(self.h, _p(w, C.c_float), w.shape[0], downsample_size, ip), "fl_map_add_points")
+        return info if want_info else None
 
-    def map_delete_boxes(self, boxes):
+    def map_delete_boxes(self, boxes, want_info=True):
         b = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
         info = MapInfo()
-        self._chk(self.L.fl_map_delete_boxes(self.h, _p(b, C.c_float), b.shape[0], C.addressof(info)), "fl_map_delete_boxes")
-        return info
+        self._chk(self.L.fl_map_delete_boxes(self.h, _p(b, C.c_float), b.shape[0], C.addressof(info) if want_info else None), "fl_map_delete_boxes")
+        return info if want_info else None
 
     def map_get_points(self):
         n = C.c_int32(0)

@@ -14,6 +14,7 @@
 #include "knn_kernels.h"
 #include "voxel_kernels.h"
 #include "mapupd_kernels.h"
+#include "mapinc_kernels.h"
 #include "vmap_kernels.h"
 #include "imu_kernels.h"
 #include "select_kernels.h"
@@ -145,6 +146,18 @@ struct fl_context {
     int map_cap = 0, map_n = 0, map_max_ring = 0;
     unsigned map_hcap = 0, map_hslots = 0;   // allocated / used slots of the cell table (power of two >= 2 x points)
     float map_cell = 0.f;
+    // the map updated in place (mapinc_kernels.h, round 5): per-slot capacity / dirty flag / queue head, per-new-point queue link, per-index
+    // dead flag, device control block + its page-locked status copy (read lazily: before the NEXT use of the map)
+    unsigned *d_mi_cellcap = nullptr, *d_mi_dirty = nullptr, *d_mi_pend_head = nullptr, *d_mi_pend_next = nullptr;
+    unsigned char *d_mi_dead = nullptr;
+    FlMapIncCtl *d_mi_ctl = nullptr, *h_mi_status = nullptr, *d_mi_status = nullptr;
+    unsigned long long mi_seq = 0, mi_seen = 0;      // status blocks requested / read
+    int mi_pend_cap = 0;
+    int mi_live = 0;                       // live points as of the last status read (map_n is the RAW length: live + dead)
+    bool map_has_dead = false;             // the raw array holds dead entries (compacted by the next full rebuild)
+    bool map_index_stale = false;          // the last status said needs_rebuild
+    int opt_map_incr = 1;                  // FL_OPT_MAP_INCREMENTAL
+    size_t map_pool_cap = 0;               // float4 entries of d_map_pts
     bool map_cell_auto = false;            // cell size follows the map's density (cell_size <= 0 at fl_map_set_points / fl_map_clear)
     unsigned *d_map_occ = nullptr, *h_map_occ = nullptr;    // occupied slots among the sampled ones (device counter, pinned copy)
     unsigned map_occ_sample = 0, map_occ_slots = 0;          // of the build the pinned copy belongs to
@@ -523,6 +536,7 @@ int32_t fl_set_option(fl_handle h, int32_t option, int32_t value)
     case FL_OPT_SCAN_PULL: h->opt_scan_pull = value != 0; break;
     case FL_OPT_INCR_SEARCH: h->opt_incr_search = value != 0; break;
     case FL_OPT_VOXEL_SORT: h->opt_voxel_sort = value != 0; break;
+    case FL_OPT_MAP_INCREMENTAL: h->opt_map_incr = value != 0; break;
     case FL_OPT_DEMOTE_AFTER:
         if (value < 0) return fail_arg(h, "fl_set_option: FL_OPT_DEMOTE_AFTER out of range");
         h->opt_demote_after = value; h->mp_consec_timeouts = 0;

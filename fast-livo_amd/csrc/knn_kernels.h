@@ -144,16 +144,23 @@ __global__ __launch_bounds__(FL_BLOCK) void knn_occupancy_kernel(const FlCellEnt
 struct FlCellCount {
     __host__ __device__ __forceinline__ unsigned operator()(const FlCellEntry &e) const { return e.count; }
 };
+// capacity of a cell's region in the point pool for c points (round 5, mapinc_kernels.h: the map is updated in place, so every cell gets
+// room behind its points): half as many again, at least 4, a multiple of 4
+__host__ __device__ __forceinline__ unsigned fl_mi_cap(unsigned c) { const unsigned w = c + (c >> 1) + 3u; return w < 4u ? 4u : (w & ~3u); }
+struct FlCellCap {
+    __host__ __device__ __forceinline__ unsigned operator()(const FlCellEntry &e) const { return e.count ? fl_mi_cap(e.count) : 0u; }
+};
 
 __global__ __launch_bounds__(FL_BLOCK) void knn_place_kernel(const float *__restrict__ map_xyz, int k, const unsigned *__restrict__ slot_of,
                                                             const unsigned *__restrict__ rank_of, const unsigned *__restrict__ first,
-                                                            float4 *__restrict__ pts, FlCellEntry *__restrict__ htab)
+                                                            float4 *__restrict__ pts, FlCellEntry *__restrict__ htab,
+                                                            unsigned *__restrict__ cellcap)
 {
     const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
     if (i >= k) return;
-    const unsigned s = slot_of[i], r = rank_of[i], f = first[s];
+    const unsigned s = slot_of[i], r = rank_of[i], f = first[s];      // first[]: prefix over the cells' CAPACITIES (FlCellCap)
     pts[f + r] = make_float4(map_xyz[i * 3], map_xyz[i * 3 + 1], map_xyz[i * 3 + 2], __int_as_float(i));
-    if (r == 0u) htab[s].start = f;
+    if (r == 0u) { htab[s].start = f; cellcap[s] = fl_mi_cap(htab[s].count); }
 }
 
 // Sorted best-5 list of keys. key bits = (float bits of the squared distance + 0x00100000) << 32 | original map

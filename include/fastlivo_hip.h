@@ -180,6 +180,11 @@ int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out);
 #define FL_OPT_VOXEL_SORT 11    /* 0 (default): fl_scan_voxel_filter orders the voxels through an occupancy bitmap over the grid's cells (8 small
                                  * launches, no sort); 1: the round-1 form (hipCUB radix sort of (voxel index, point) + scan, 13 launches), which clouds
                                  * above FL_VX_SORT_ABOVE points always take. Results are bit-identical either way. */
+#define FL_OPT_MAP_INCREMENTAL 12  /* 1 (default): fl_map_add_points / fl_map_delete_boxes update the device map IN PLACE -- only the cells of the new
+                                    * and of the deleted points are touched, nothing waits for the host (csrc/mapinc_kernels.h); the whole map is
+                                    * compacted and re-indexed only when its arrays fill up or its cell size goes out of tune. 0: every update
+                                    * compacts the map array and rebuilds the index (rounds 1-4). The map's content (fl_map_get_points) and every
+                                    * search result are identical either way. */
 int32_t fl_set_option(fl_handle h, int32_t option, int32_t value);
 /* Counters of the resident-grid machinery of the multi-pass kernels.
  * ABI note: the struct carries no size member; it is 24 bytes since ABI revision 4 (16 before: the two demotion fields were appended)

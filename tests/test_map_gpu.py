@@ -228,3 +228,99 @@ def test_resident_scan_under_the_ikfom_state(gpu_lib, oracle_lib, scene):
     if oi.n_ambiguous == 0:
         assert np.array_equal(h.map_get_points(), want)
     h.close()
+
+
+def _search(h, capi, fr):
+    x = capi.state18_from_frame(fr)
+    h.lio_set_points(fr.body_xyz); h.lio_begin18(x, x)
+    nbr, valid = h.lio_search18(fr.n)
+    return nbr, valid, h.lio_get_world_points(fr.n)
+
+
+def test_in_place_updates_keep_the_index_exact_between_read_backs(gpu_lib, oracle_lib, scene):
+    """FL_OPT_MAP_INCREMENTAL (default): 12 updates in a row -- map_incremental with and without down-sampling, slab deletions, scans that
+    open new cells far from the map, cells that outgrow their slack -- with NO read-back of the map in between (fl_map_get_points would
+    compact and re-index). After every update the device search over the in-place index must equal brute force over the oracle's map,
+    neighbour for neighbour; at the end the compacted array equals the oracle's, order included."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    rng = np.random.default_rng(41)
+    fr = synth.make_lio_frame(3000, scene=scene)
+    h = _handle(capi, synth, fr)
+    cur = scene.map_xyz[rng.choice(len(scene.map_xyz), 15000, replace=False)].copy()
+    h.map_set_points(cur, 0.5)
+    lo, hi = cur.min(0), cur.max(0)
+    for k in range(12):
+        if k % 4 == 3:                                               # lasermap_fov_segment: a slab leaves
+            a = lo[0] + rng.uniform(0, 10)
+            boxes = np.array([[a, lo[1] - 1, lo[2] - 1, a + 1.5, hi[1] + 1, hi[2] + 1]], dtype=np.float32)
+            h.map_delete_boxes(boxes, want_info=False)
+            cur, _ = orc.map_delete_boxes(cur, boxes)
+        else:
+            new = _scan_world(scene, rng, 4000, 0.05)
+            if k == 5:
+                new = np.concatenate([new, (rng.uniform(40, 44, (500, 3))).astype(np.float32)])      # cells the table has never seen
+            if k == 6:
+                new = np.concatenate([new, (np.float32([1.0, 1.0, 0.0]) + rng.normal(0, 0.1, (3000, 3))).astype(np.float32)])   # one spot, many points: cells move
+            ds = (0.3, 0.2, 0.0)[k % 3]
+            h.map_add_points(new, ds, want_info=False)
+            cur, oi = orc.map_add_points(cur, new, ds)
+            assert oi.n_ambiguous == 0
+        nbr_g, valid_g, world = _search(h, capi, fr)
+        nbr_o, _, valid_o, _ = orc.knn5_bruteforce(cur, world)
+        assert np.array_equal(valid_g, valid_o), f"update {k}"
+        ok = valid_o != 0
+        assert np.array_equal(nbr_g[ok], nbr_o[ok]), f"update {k}"
+    assert np.array_equal(h.map_get_points(), cur)
+    h.close()
+
+
+def test_in_place_and_rebuilding_forms_agree(gpu_lib, scene):
+    """fl_set_option(FL_OPT_MAP_INCREMENTAL, 0 / 1): same counters, same map, same neighbours over a short sequence"""
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    fr = synth.make_lio_frame(2000, scene=scene)
+    outs = []
+    for incr in (0, 1):
+        rng = np.random.default_rng(5)
+        h = _handle(capi, synth, fr)
+        h.set_option(capi.FL_OPT_MAP_INCREMENTAL, incr)
+        h.map_set_points(scene.map_xyz[::3], 0.0)                   # automatic cell size
+        rec = []
+        for k in range(6):
+            new = _scan_world(scene, rng, 5000, 0.04)
+            i = h.map_add_points(new, 0.25)
+            rec.append((i.n_before, i.n_after, i.n_added, i.n_removed, i.n_ambiguous))
+            if k == 3:
+                lo = scene.map_xyz.min(0)
+                i = h.map_delete_boxes(np.array([[lo[0], lo[1], lo[2], lo[0] + 4, lo[1] + 30, lo[2] + 10]], dtype=np.float32))
+                rec.append((i.n_before, i.n_after, i.n_removed))
+        nbr, valid, _ = _search(h, capi, fr)
+        outs.append((rec, h.map_get_points(), nbr, valid))
+        h.close()
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][3], outs[1][3]) and np.array_equal(outs[0][2][outs[0][3] != 0], outs[1][2][outs[1][3] != 0])
+
+
+def test_many_in_place_updates_run_into_the_full_rebuild(gpu_lib, oracle_lib, scene):
+    """60 updates of 6 000 points on a 10 k-point map: the raw array (appended to by every update) and the pool fill up and the lazy
+    status check compacts / re-indexes in between -- nothing of that may show in the map or in the search"""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    rng = np.random.default_rng(77)
+    fr = synth.make_lio_frame(2000, scene=scene)
+    h = _handle(capi, synth, fr)
+    cur = scene.map_xyz[rng.choice(len(scene.map_xyz), 10000, replace=False)].copy()
+    h.map_set_points(cur, 0.5)
+    for k in range(60):
+        new = _scan_world(scene, rng, 6000, 0.05)
+        h.map_add_points(new, 0.3, want_info=False)
+        cur, _ = orc.map_add_points(cur, new, 0.3)
+        if k % 20 == 19:
+            nbr_g, valid_g, world = _search(h, capi, fr)
+            nbr_o, _, valid_o, _ = orc.knn5_bruteforce(cur, world)
+            ok = valid_o != 0
+            assert np.array_equal(valid_g, valid_o) and np.array_equal(nbr_g[ok], nbr_o[ok]), f"update {k}"
+    assert np.array_equal(h.map_get_points(), cur)
+    h.close()
