@@ -54,7 +54,7 @@ VIO_LEVEL = 0
 LIO_BYTES_PER_POINT = 12 + 16 + 1      # body xyz + cached plane (n,d) + selection flag (the kernel itself reads 16 + 16: DESIGN.md 4.2)
 VIO_BYTES_PER_PATCH = 405 + 4          # 256 ref + 121 image footprint + 24 pos + 4 level, + 4 written
 HBM_PEAK_GBS = 8000.0                  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-SECTIONS = ("at_scale", "vio_sweep", "mode23", "frame", "restage", "config4", "config5", "cpu_frame", "pipeline")
+SECTIONS = ("at_scale", "vio_sweep", "mode23", "frame", "restage", "config4", "config5", "cpu_frame", "pipeline", "map_scale")
 
 
 def parse():
@@ -595,8 +595,36 @@ def section_config5(capi, synth, scene):
         if rep >= 5:
             tlu.append(time.perf_counter() - t0)
     h.host_free(scan); h.close()
+    # the same frame against a map at the SCAN'S density (round-4 review: a 200 k-point scan against the 55 k-point room map is not a
+    # dense-map workload): the room sampled at 5 cm spacing = filter_size_surf 0.05 of the config's name, ~0.5 M points, cell size automatic
+    dense = None
+    try:
+        dscene = synth.make_scene(map_spacing=0.05)
+        hd = capi.Handle(cfg)
+        hd.map_set_points(dscene.map_xyz, 0.0)
+        scan_d = hd.host_alloc(fr.body_xyz.shape, np.float32)
+        scan_d[...] = synth.in_voxel_order(fr, 0.5).body_xyz
+        td, itd, effd = [], 0, 0
+        for rep in range(20):
+            x = capi.state18_from_frame(fr)
+            t0 = time.perf_counter()
+            info = hd.lio_frame18_dev(x, scan_d)
+            if rep >= 5:
+                td.append(time.perf_counter() - t0)
+            itd, effd = int(info.iterations), int(info.effct_feat_num)
+        hd.set_timing(True)
+        hd.lio_set_points(scan_d); hd.lio_begin18(x0, x0)
+        ks = []
+        for _ in range(5):
+            hd.lio_search18(fr.n, want=False); ks.append(hd.last_kernel_ms() * 1e3)
+        dense = {"map_points": int(len(dscene.map_xyz)), "map_spacing_m": 0.05, "cell_size_chosen_m": float(hd.map_cell_size()) if hasattr(hd, "map_cell_size") else None,
+                 "lio_frame_ms": float(np.median(td)) * 1e3, "lio_passes": itd, "effective_points": effd, "first_search_us": float(np.median(ks))}
+        hd.host_free(scan_d); hd.close()
+    except Exception as e:                                   # must not take the section down
+        dense = {"failed": repr(e)[:300]}
     lio_ms, vio_ms = float(np.median(tl)) * 1e3, float(np.median(tv)) * 1e3
     return {"workload": f"BASELINE config 5 at N = 1: NTU_VIRAL camera and extrinsics, {fr.n} points + {vf.m} patches, max_iteration 10, full LIVO frame on ONE GPU",
+            "dense_map": dense,
             "lio_pass_us": lio_us, "vio_pass_us": vio_us, "iterations_per_s": 1e6 / (lio_us + vio_us),
             "lio_frame_ms": lio_ms, "vio_computej_ms": vio_ms, "frame_ms": lio_ms + vio_ms, "lio_passes": its, "vio_passes_3_levels": acc,
             "frame_iterations_per_s": (its + acc) / ((lio_ms + vio_ms) * 1e-3),
@@ -662,6 +690,20 @@ def section_cpu_frame(synth, scene, fr, vf, budget_s):
             "reference_threading": ref, "best_over_thread_counts": best,
             "what": f"one whole frame on the host: LIO ({fr.n} pts: searches by the reference's ikd-Tree + plane fits + passes + covariance) + ComputeJ ({vf.m} patches, 3 levels); "
                     "the figure beside `frame` (same inputs, same pass counts)"}
+
+
+def section_map_scale(capi, synth, scene, sizes=(55000, 500000, 2000000, 5000000)):
+    """The per-frame map update (fl_map_add_points = map_incremental, laserMapping.cpp:692-706 / :1758: 20 k registered points, down-sampling
+    0.3 m) and the Mode-18 frame (50 k points, device k-NN) against local maps of 55 k ... 5 M points at constant density (the room tiled over a
+    growing area): in place (FL_OPT_MAP_INCREMENTAL 1, round 5: only the cells of the new points are touched, no host synchronisation) and
+    with the compact-and-rebuild form of rounds 1-4. The reference's KD_TREE::Add_Points is O(new x log map); the rebuild form was O(map)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import map_scale_bench
+    rows = map_scale_bench.run(list(sizes), reps=10)
+    a, b = rows[0]["in_place"]["map_add_wall_ms"], rows[-1]["in_place"]["map_add_wall_ms"]
+    return {"rows": rows, "in_place_update_cost_ratio_largest_over_smallest_map": b / a,
+            "what": "map_add_*: 20 k new points incl. their upload and a stream synchronisation behind the call (the in-place form itself returns without one); "
+                    "lio_frame_ms: fl_lio_frame18_dev of a 50 k-point scan, host wall time"}
 
 
 def section_pipeline(capi, synth, scene, budget_s, with_cpu=True):
@@ -862,7 +904,8 @@ def main():
                "config4": lambda: section_config4(capi, synth, scene),
                "config5": lambda: section_config5(capi, synth, scene),
                "cpu_frame": lambda: section_cpu_frame(synth, scene, fr, vf, args.cpu_seconds),
-               "pipeline": lambda: section_pipeline(capi, synth, scene, args.cpu_seconds)}[args.only]()
+               "pipeline": lambda: section_pipeline(capi, synth, scene, args.cpu_seconds),
+               "map_scale": lambda: section_map_scale(capi, synth, scene)}[args.only]()
         print(json.dumps({"section": args.only, "result": sec}), flush=True)
         return
 
@@ -1115,6 +1158,7 @@ def main():
         extras["config4"] = section_config4(capi, synth, scene)
         extras["config5"] = section_config5(capi, synth, scene)
         extras["pipeline"] = section_pipeline(capi, synth, scene, args.cpu_seconds, with_cpu=not args.no_cpu_baseline)
+        extras["map_scale"] = section_map_scale(capi, synth, scene)
         if args.sweep:
             sweep(capi, synth, scene, cfg, x0, sys.stderr)
 

@@ -20,9 +20,9 @@ def tiled_map(scene, k, rng):
     return np.ascontiguousarray(np.concatenate(parts)[:k], dtype=np.float32)
 
 
-def run(sizes, n_new=20000, ds=0.3, reps=12):
+def run(sizes, n_new=20000, ds=0.3, reps=12, scene=None):
     rng = np.random.default_rng(0)
-    scene = synth.make_scene()
+    scene = scene or synth.make_scene()
     fr = synth.make_lio_frame(50000, scene=scene)
     out = []
     for K in sizes:
