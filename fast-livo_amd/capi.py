@@ -172,6 +172,8 @@ SYMBOLS = {
                                      _fp, C.c_int32, _fp, C.POINTER(Pose6d), C.POINTER(C.c_int32)]),
     "fl_lidar_front": (C.c_int32, [_H, C.POINTER(ImuProc), C.POINTER(State18), C.POINTER(ImuSample), C.c_int32, C.c_double, C.c_double, _fp, C.c_int32,
                                    C.c_float, C.c_int32, C.POINTER(IterInfo), C.POINTER(C.c_int32)]),
+    "fl_vio_detect": (C.c_int32, [_H, _u8p, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int32, _fp, C.c_int32, _dp, _dp, C.POINTER(State18), C.c_int32,
+                                  C.c_int32, C.c_double, C.c_double, _i32p, _i32p, _i32p]),
     "fl_vio_grid_select": (C.c_int32, [_H, _dp, _dp, _dp, _fp, C.c_int32, C.c_int32, _i32p, _fp, _fp, _i32p, _i32p]),
     "fl_vio_add_keyframe": (C.c_int32, [_H, _u8p, C.c_int32, C.c_int32, C.c_int32, _i32p]),
     "fl_vio_drop_keyframe": (C.c_int32, [_H, C.c_int32]),
@@ -467,6 +469,17 @@ class Handle:
         self._chk(self.L.fl_lidar_front(self.h, C.byref(proc), C.byref(state), samples, len(samples), pcl_beg_time, pcl_end_time,
                                         pts.ctypes.data_as(_fp), pts.shape[0], leaf, 1 if staged else 0, C.byref(info), C.byref(m)), "fl_lidar_front")
         return info, m.value
+
+    def vio_detect(self, img, pg, pg_down, Rci, Pci, state, frame_id, ncc_en=False, ncc_thre=0.0, outlier_threshold=300.0):
+        """fl_vio_detect: LidarSelector::detect in one call. Mutates state; returns (selected, founded, observed)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        pg = np.ascontiguousarray(pg, np.float32).reshape(-1, 3); pd = np.ascontiguousarray(pg_down, np.float32).reshape(-1, 3)
+        Rci = np.ascontiguousarray(Rci, np.float64).reshape(9); Pci = np.ascontiguousarray(Pci, np.float64)
+        a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._chk(self.L.fl_vio_detect(self.h, img.ctypes.data_as(_u8p), img.shape[1], img.shape[0], img.shape[1], pg.ctypes.data_as(_fp), len(pg),
+                                       pd.ctypes.data_as(_fp), len(pd), Rci.ctypes.data_as(_dp), Pci.ctypes.data_as(_dp), C.byref(state), frame_id,
+                                       1 if ncc_en else 0, ncc_thre, outlier_threshold, C.byref(a), C.byref(b), C.byref(c)), "fl_vio_detect")
+        return a.value, b.value, c.value
 
     def scan_voxel_filter_resident(self, n, leaf, stage_as_scan=True):
         """VoxelGrid of the n-point cloud fl_imu_undistort left on the device; result staged as the scan."""

@@ -434,28 +434,14 @@ struct LidarSelectorDev {
     void detect(const uint8_t *img, int width, int height, int stride, const float *pg, int n_pg, const float *pg_down, int n_down,
                 const double *Rci, const double *Pci, StatesGroup &state)
     {
-        int32_t kf = -1;
-        last_status = fl_vio_set_frame(handle, img, width, height, stride);
-        if (last_status >= 0) last_status = fl_vio_add_keyframe(handle, nullptr, width, height, width, &kf);   // the staged image
-        if (last_status < 0) return;
-        double Rcw[9], Pcw[3];
-        frame_pose(Rci, Pci, state, Rcw, Pcw);
+        fl_state18 st;
+        to_abi(state, st);
         int32_t ns = 0, na = 0, no = 0;
-        last_status = fl_vmap_select(handle, Rcw, Pcw, pg_down, n_down, ncc_en ? 1 : 0, ncc_thre, outlier_threshold, &ns, nullptr, nullptr,
-                                     nullptr, nullptr);                                             // addFromSparseMap (:1050)
+        // the whole body of LidarSelector::detect (:1027-1076) in one ABI call
+        last_status = fl_vio_detect(handle, img, width, height, stride, pg, n_pg, pg_down, n_down, Rci, Pci, &st, frame_id, ncc_en ? 1 : 0, ncc_thre,
+                                    outlier_threshold, &ns, &na, &no);
         if (last_status < 0) return;
-        last_status = fl_vmap_add_sparse(handle, Rcw, Pcw, pg, n_pg, kf, frame_id, &na);           // addSparseMap (:1054)
-        if (last_status < 0) return;
-        if (ns > 0) {                                                                               // ComputeJ (:1060)
-            fl_state18 st, sp;
-            to_abi(state, st);
-            sp = st;
-            last_status = fl_vio_compute_j(handle, &st, &sp, nullptr);
-            if (last_status < 0) return;
-            from_abi(st, state);
-            frame_pose(Rci, Pci, state, Rcw, Pcw);
-        }
-        last_status = fl_vmap_add_observation(handle, Rcw, Pcw, kf, frame_id, &no);                 // addObservation (:1064)
+        from_abi(st, state);
         n_selected = ns; n_founded = na; n_observed = no;
         frame_id++;
     }

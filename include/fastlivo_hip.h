@@ -507,6 +507,16 @@ int32_t fl_vmap_select(fl_handle h, const double *Rcw, const double *Pcw, const 
 int32_t fl_vmap_add_sparse(fl_handle h, const double *Rcw, const double *Pcw, const float *scan_world_xyz, int32_t n, int32_t keyframe_id,
                            int32_t frame_id, int32_t *n_added);
 int32_t fl_vmap_add_observation(fl_handle h, const double *Rcw, const double *Pcw, int32_t keyframe_id, int32_t frame_id, int32_t *n_added);
+
+/* LidarSelector::detect in one call (src/lidar_selection.cpp:1027-1076): addFromSparseMap -> addSparseMap -> ComputeJ -> addObservation
+ * on the device's visual map, i.e. fl_vio_set_frame + fl_vio_add_keyframe (the staged image) + fl_vmap_select + fl_vmap_add_sparse +
+ * fl_vio_compute_j + fl_vmap_add_observation, the frame pose taken from state_io before and after ComputeJ as updateFrameState does
+ * (:904-911; Rci, Pci: camera extrinsics of the state frame, lidar_selection.cpp:35-52). pg_world_xyz: the registered scan (n_pg x 3),
+ * pg_down_world_xyz: its 0.2 m down-sampled form (:352-353). state_io: in = state_propagat = the LIO result, out = after ComputeJ. */
+int32_t fl_vio_detect(fl_handle h, const uint8_t *gray, int32_t width, int32_t height, int32_t stride, const float *pg_world_xyz, int32_t n_pg,
+                      const float *pg_down_world_xyz, int32_t n_down, const double *Rci, const double *Pci, fl_state18 *state_io,
+                      int32_t frame_id, int32_t ncc_en, double ncc_thre, double outlier_threshold, int32_t *n_selected, int32_t *n_founded,
+                      int32_t *n_observed);
 /* Frees the keyframe images (fl_vio_add_keyframe) that no observation of the map refers to any more -- what the reference's
  * reference counting of Feature::img does; call now and then on long runs (one image per frame is 0.3 MB). */
 int32_t fl_vmap_release_keyframes(fl_handle h, int32_t *n_released);
