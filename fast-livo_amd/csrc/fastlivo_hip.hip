@@ -157,6 +157,7 @@ struct fl_context {
     bool map_has_dead = false;             // the raw array holds dead entries (compacted by the next full rebuild)
     bool map_index_stale = false;          // the last status said needs_rebuild
     int opt_map_incr = 1;                  // FL_OPT_MAP_INCREMENTAL
+    int opt_vio_spec = 1;                  // FL_OPT_VIO_SPECULATE
     size_t map_pool_cap = 0;               // float4 entries of d_map_pts
     bool map_cell_auto = false;            // cell size follows the map's density (cell_size <= 0 at fl_map_set_points / fl_map_clear)
     unsigned *d_map_occ = nullptr, *h_map_occ = nullptr;    // occupied slots among the sampled ones (device counter, pinned copy)
@@ -537,6 +538,7 @@ int32_t fl_set_option(fl_handle h, int32_t option, int32_t value)
     case FL_OPT_INCR_SEARCH: h->opt_incr_search = value != 0; break;
     case FL_OPT_VOXEL_SORT: h->opt_voxel_sort = value != 0; break;
     case FL_OPT_MAP_INCREMENTAL: h->opt_map_incr = value != 0; break;
+    case FL_OPT_VIO_SPECULATE: h->opt_vio_spec = value != 0; break;
     case FL_OPT_DEMOTE_AFTER:
         if (value < 0) return fail_arg(h, "fl_set_option: FL_OPT_DEMOTE_AFTER out of range");
         h->opt_demote_after = value; h->mp_consec_timeouts = 0;

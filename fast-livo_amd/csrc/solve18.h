@@ -51,6 +51,12 @@ struct FlSolveLds {
     int audited;
     // hand-off of the judgement to wavefront 1 (eskf18_solve_block): passes judged so far / the flag wavefront 0 raises when delta is in LDS
     int jpass, jflag;
+    // VIO, round 5 -- a FRAGILE ACCEPT that went ahead on the fp64 decision (vio_spec_confirm below): the pass whose float-chain
+    // verdict is still out, what a rejection of it leaves, and what its acceptance still has to write
+    int spec_pending, spec_buf, spec_accepted, spec_iters, spec_acc_buf;
+    unsigned spec_epoch, spec_acc_epoch;
+    float spec_nall, spec_last_error, spec_last_exact;
+    double def_xold[24], def_sums[FL_SUMS18], def_sol[18];      // old_state / sums_acc / solution of that pass, written to the device block once it is confirmed
 };
 
 enum { FL_EPI_LIO = 0, FL_EPI_VIO = 1 };
@@ -290,7 +296,7 @@ __device__ __forceinline__ void eskf18_prefetch_commit(double v, FlSolveLds &L)
     else if (tid == 200) L.acc_epoch = (unsigned)v;
     else if (tid == 201) L.last_exact_valid = (int)v;
     else if (tid == 202) L.last_exact = (float)v;
-    else if (tid == 203) { L.jpass = 0; L.jflag = 0; }
+    else if (tid == 203) { L.jpass = 0; L.jflag = 0; L.spec_pending = 0; }
     __syncthreads();
     eskf18_form_vec(L);
     __syncthreads();
@@ -501,7 +507,10 @@ __device__ __forceinline__ void eskf18_judge(FlDev18 *__restrict__ D, const doub
     }
 }
 
-template <int KIND>
+// SPEC (VIO, vio_multipass_kernel<1, 1> only): a fragile ACCEPT may go ahead on the fp64 decision (see `spec` below). A template
+// parameter, not a run-time flag: the forced passes of the headline and every other caller keep the code they had (a handful of extra
+// uniform values in this function cost the VIO multi-pass kernel 0.9 us per pass -- it lives at its SGPR limit).
+template <int KIND, int SPEC = 0>
 __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, const double *s_sums, FlSolveLds &L, const FlSolveRegs &G_in,
                                                    int gather_status, unsigned long long *bcast = nullptr, unsigned bepoch = 0u,
                                                    const FlVioExact ex = FlVioExact{}, const FlVioConst *__restrict__ VC = nullptr, int dbg = 0)
@@ -531,7 +540,7 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
 
     if (wave == 3 && lane < FL_SUMS18) D->sums[lane] = s_sums[lane];
 
-    bool slow = false, need_exact = false;
+    bool slow = false, need_exact = false, spec = false;
     if (KIND == FL_EPI_VIO) {
         // error = sum(res^2) / n_meas ; accept iff error <= last_error (lidar_selection.cpp:857-861).
         // The reference forms `error` as a FLOAT running sum: per patch `patch_error += res*res` over its 64 pixels, then
@@ -560,6 +569,31 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
         const float thr = (n_meas * (1.0f / 64.0f) + 8.0f) * 5.9604645e-8f;
         need_exact = (last < 1e9f && fabsf(error - last) <= thr * fabsf(error));
         slow = need_exact && can_replay;
+        // Round 5: a fragile pass the fp64 test ACCEPTS does not wait for the float chain (the auditor's total arrives ~6 us after the
+        // records): it solves and publishes the pose at once, the producers start the next pass, and the chain's verdict is taken when
+        // it is there -- after the NEXT gather, or at the end of the launch (vio_spec_confirm). Until then the pass's writes that a
+        // rejection would have to undo (old_state, sums_acc, solution, the error bookkeeping) stay in LDS. Needs the exact value of the
+        // last accepted error (it always is there: every confirmed pass leaves it). A fragile REJECT still waits -- it ends the level.
+        if constexpr (SPEC != 0) {
+            const bool cand = slow && error <= last;
+            if (cand && !L.last_exact_valid) {      // (uniform) the exact value of the last accepted error: out of the auditor's ring, as vio_exact_decide takes it
+                if (tid == 0) {
+                    float fl = 0.f;
+                    if (vio_audit_read(ex.words + 2 * (size_t)ex.cap, L.acc_epoch, 64, &fl)) { L.last_exact = fl / n_meas; L.last_exact_valid = 1; }
+                }
+                __syncthreads();
+            }
+            spec = cand && L.last_exact_valid;
+        }
+        if (spec) {
+            slow = false;
+            FL_INSTR(if (tid == 0) g_fl_wall[2040]++;)        // (debug build: speculated / confirmed / rolled back, tools/fuzz_vio_spec.py)
+            if (tid == 0) {
+                L.spec_pending = 1; L.spec_epoch = ex.epoch; L.spec_buf = L.iters_run & 1; L.spec_nall = n_meas;
+                L.spec_last_error = L.last_error; L.spec_last_exact = L.last_exact; L.spec_accepted = L.accepted; L.spec_iters = L.iters_run;
+                L.spec_acc_buf = L.acc_buf; L.spec_acc_epoch = L.acc_epoch;
+            }
+        }
         if (slow && tid == 0) L.exact_timeout = 0;
         if (slow) {      // uniform over the workgroup
             vio_exact_decide(ex, &L, (float)s_sums[FL_S_NEFF]);
@@ -798,6 +832,12 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
     }
     FL_INSTR(fl_stamp(dbg, 36);)
     // ---- off the hand-off's critical path: what the host, the next pass's solver and the finish kernels read
+    if (KIND == FL_EPI_VIO && SPEC != 0 && spec) {      // (uniform) an unconfirmed accept: these wait in LDS for the chain's verdict (vio_spec_confirm)
+        if (lane < 18) L.def_sol[lane] = dl;
+        if (lane < FL_SUMS18) L.def_sums[lane] = s_sums[lane];
+        if (lane < 24) L.def_xold[lane] = G.xl;
+        return;
+    }
     if (lane < 18) D->solution[lane] = dl;
     if (lane < FL_SUMS18) D->sums_acc[lane] = s_sums[lane];   // LIO: last executed pass ; VIO: last accepted pass
     if (KIND == FL_EPI_VIO && lane < 24) D->xold[lane] = G.xl;   // old_state = *state (:863)
@@ -805,6 +845,109 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
         D->error = vio_error; D->last_error = vio_error;
         D->err_acc_buf = L.acc_buf; D->err_acc_epoch = ex.epoch; D->last_exact_valid = vio_exact; D->last_exact = vio_error;
     }
+}
+
+// The float chain's verdict on a fragile accept that went ahead (eskf18_solve_block, `spec`). Whole workgroup, barriers inside; called
+// by vio_multipass_kernel's solver after the NEXT pass's gather (bcast != nullptr: the producers of that pass wait for a control word)
+// or when the launch ends right behind the speculative pass (bcast == nullptr). Confirmed (the usual case): the deferred writes
+// land, with the chain's value as last_error, exactly what the waiting form leaves. Rejected: the state goes back to old_state and the
+// level ends as lidar_selection.cpp:888-892 ends it -- the iteration count, the error, the per-patch errors (restored from the pass's own
+// half of the word buffer when a later pass has overwritten the array) are those of the rejecting pass. Returns 1 if it rolled back.
+// the two rare branches of vio_spec_confirm, out of line and with scalar arguments only (a by-value FlVioExact went to scratch at the
+// call site and cost the kernel its second wavefront per SIMD; everything inlined cost every pass 1.8 us of register shuffling)
+__device__ __attribute__((noinline)) void vio_spec_replay(FlSolveLds *Lp, const unsigned long long *words, int cap, int m, float *scratch)
+{
+    FlSolveLds &L = *Lp;
+    FlVioExact ex{};
+    ex.words = words; ex.m = m; ex.cap = cap; ex.epoch = L.spec_epoch; ex.scratch = scratch; ex.enabled = 1; ex.own = nullptr; ex.peer = nullptr;
+    ex.rank = 0; ex.world = 1; ex.xe = 0u;
+    const float fc = vio_exact_chain(ex, words + (size_t)L.spec_buf * cap, L.spec_epoch, 0, &L.exact_cur, &L.exact_timeout);
+    __syncthreads();
+    if (threadIdx.x == 0) L.exact_cur = fc;
+    __syncthreads();
+}
+__device__ __attribute__((noinline)) void vio_spec_rollback(FlDev18 *D, FlSolveLds *Lp, const unsigned long long *words, int cap, int m, float *errors,
+                                                           const FlVioConst *VC, unsigned long long *bcast, unsigned bepoch)
+{
+    FlSolveLds &L = *Lp;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const float exact = L.exact_cur;
+    FlSolveRegs G;
+    eskf18_load_regs(L, G, VC);
+    if (tid < 24) {
+        const double xo = D->xold[tid];              // old_state of the rejected pass: its deferred write never happened
+        D->x[tid] = xo;
+        if (tid < 12) L.xn[tid] = xo;
+        if (tid >= 9) L.xadd[tid - 9] = xo;
+    }
+    __syncthreads();
+    if (VC && tid < 12) {
+        const double ce = vio_cam_element(lane, L.xn, G.rci, G.pci);
+        if (tid < 9) D->Rcw[tid] = ce; else D->Pcw[tid - 9] = ce;
+        L.cam[tid] = ce;
+        if (bcast) fl_bcast_store(bcast, tid, ce, bepoch);
+    }
+    if (bcast) {                                     // a later pass has run: the per-patch errors are the rejecting pass's again
+        const unsigned long long *w = words + (size_t)L.spec_buf * cap;
+        for (int i = tid; i < m; i += blockDim.x) errors[i] = __uint_as_float((unsigned)(w[i] >> 32));
+    }
+    if (tid == 0) {
+        const int it = L.spec_iters + 1;
+        D->error = exact;
+        D->iters_run = it; L.iters_run = it;
+        D->accepted = L.spec_accepted; L.accepted = L.spec_accepted;
+        D->stop = 1; D->converged = 1;
+        D->total_residual = (double)L.spec_last_error;
+        L.last_error = L.spec_last_error; L.last_exact = L.spec_last_exact; L.last_exact_valid = 1;
+        L.acc_buf = L.spec_acc_buf; L.acc_epoch = L.spec_acc_epoch;
+        L.sticky |= L.fragile;
+        D->status = L.sticky;
+        L.ctrl = 1;
+        L.spec_pending = 0;
+        if (bcast) fl_bcast_ctrl(bcast, 1, bepoch);
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ int vio_spec_confirm(FlDev18 *D, FlSolveLds *Lp, const unsigned long long *words, int cap, int m, float *scratch, float *errors,
+                                                const FlVioConst *VC, unsigned long long *bcast, unsigned bepoch)
+{
+    FlSolveLds &L = *Lp;
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long *audit = words + 2 * (size_t)cap;
+        const unsigned sepoch = L.spec_epoch;
+        float fc = 0.f;
+        const unsigned at = (unsigned)__hip_atomic_load(audit + FL_AUDIT_RING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ok = (int)(at + 1u - sepoch) >= 0 && vio_audit_read(audit, sepoch, 1 << 12, &fc);
+        L.exact_cur = fc;
+        L.audited = ok ? 1 : 0;
+        L.exact_timeout = 0;
+    }
+    __syncthreads();
+    if (!L.audited) vio_spec_replay(Lp, words, cap, m, scratch);      // the auditor is not there (or gave up on that pass): the workgroup adds the chain up itself
+    const float exact = L.exact_cur / L.spec_nall;
+    const bool accept = L.exact_timeout ? true : (exact <= L.spec_last_exact);      // (a chain that timed out: the fp64 decision stands, as in the waiting form)
+    FL_INSTR(if (tid == 0) g_fl_wall[accept ? 2041 : 2042]++;)
+    if (!accept) {       // the chain says the error went UP: revert (lidar_selection.cpp:888-892), the level ends at that pass --
+        if (tid == 0) L.exact_cur = exact;      // the caller leaves its pass loop and calls vio_spec_rollback BEHIND it (a call site inside the loop costs every pass)
+        __syncthreads();
+        return 1;
+    }
+    if (tid < 24) D->xold[tid] = L.def_xold[tid];
+    else if (tid >= 64 && tid < 64 + FL_SUMS18) D->sums_acc[tid - 64] = L.def_sums[tid - 64];
+    else if (tid >= 128 && tid < 146) D->solution[tid - 128] = L.def_sol[tid - 128];
+    if (tid == 0) {
+        const bool have = !L.exact_timeout;
+        const float e = have ? exact : L.last_error;
+        // (only if no later pass has been accepted since: there is none -- the verdict is taken before the next decision)
+        D->error = e; D->last_error = e; D->err_acc_buf = L.acc_buf; D->err_acc_epoch = L.spec_epoch;
+        D->last_exact_valid = have ? 1 : 0; D->last_exact = e; D->total_residual = (double)e;
+        L.last_error = e; L.last_exact = e; L.last_exact_valid = have ? 1 : 0;
+        L.spec_pending = 0;
+    }
+    __syncthreads();
+    return 0;
 }
 
 // Multi-pass kernels: after eskf18_solve_block (and a __syncthreads) make the new state the solve input of the next

@@ -870,7 +870,9 @@ __device__ __attribute__((noinline)) void vio_cov_outofline(FlDev18 *D) { vio_co
 // WAVES = the register budget (launch bound): 2 = two workgroups per CU (256 VGPRs), the form every concurrent or sharded use needs;
 // 1 = a CU's registers to one workgroup (256 VGPRs + AGPRs, no scratch): 8.5 instead of 9.2 us per pass, taken when the launch has the
 // device to itself (api_vio.inc vio_mp_variant). Same code, same arithmetic, same bits.
-template <int WAVES>
+// SPEC = 1 (fl_vio_compute_j / fl_vio_update_state launches that have the device to themselves; never forced passes): fragile accepts go
+// ahead on the fp64 decision and are confirmed a pass later (solve18.h vio_spec_confirm).
+template <int WAVES, int SPEC = 0>
 __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const uint8_t *__restrict__ img, const float *__restrict__ ref,
                                                                  const double *__restrict__ pos, const int32_t *__restrict__ slevel,
                                                                  float *__restrict__ errors, int m, int level,
@@ -946,6 +948,7 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
         const FlPeerView PV = fl_peer_view_lds(D, s_peers);
         const unsigned xe0 = PV.world > 1 ? *D->xchg_epoch : 0u;
         int done = 0;
+        int rollback = 0;          // SPEC: 1 = a verdict taken at the top of pass `done - 1` rejected the pass before it, 2 = taken behind the launch's last pass
         for (int p = 0; p < count; p++) {
             const unsigned epoch = epoch0 + (unsigned)p;
             FlSolveRegs G;
@@ -958,10 +961,20 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
             FlVioExact ex;
             ex.words = err_base; ex.m = m; ex.cap = err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !force;
             ex.own = PV.own; ex.peer = PV.peer; ex.rank = PV.rank; ex.world = PV.world; ex.xe = xe0 + (unsigned)p;
+            // the float chain's verdict on the PREVIOUS pass, if that one went ahead without it: it is there by now (the auditor needs
+            // ~6 us from the records, a pass takes 7); a rejection ends the level here, this pass's records are dropped
+            if constexpr (SPEC != 0) if (s_solve.spec_pending) {      // (uniform: LDS, written before the barriers of the last pass)
+                if (!gst && vio_spec_confirm(D, &s_solve, err_base, err_cap, m, s_ex, errors, VC, bcast, epoch + 1u)) { done = p + 1; rollback = 1; break; }
+                eskf18_load_regs(s_solve, G, VC);              // last_error is the chain's value now
+            }
             // wave 0 solves, derives the camera pose of the new state and publishes it (+ the control word) for the producers
-            eskf18_solve_block<FL_EPI_VIO>(D, s_sums, s_solve, G, gst, bcast, epoch + 1u, ex, VC, (p == 5) ? (flags & FL_ITER_STAMP) : 0);
+            eskf18_solve_block<FL_EPI_VIO, SPEC>(D, s_sums, s_solve, G, gst, bcast, epoch + 1u, ex, VC, (p == 5) ? (flags & FL_ITER_STAMP) : 0);
             FL_INSTR(if (p == 5) fl_stamp(flags, 35);)
             __syncthreads();
+            // ... and on THIS pass if the launch ends behind it (stop raised, or the last pass asked for): the wait of the old form, but
+            // the solve has been done in the meantime
+            if constexpr (SPEC != 0) if (s_solve.spec_pending && !(s_solve.ctrl & 4) && ((!force && (s_solve.ctrl & 3)) || p + 1 == count))
+                if (vio_spec_confirm(D, &s_solve, err_base, err_cap, m, s_ex, errors, VC, nullptr, 0u)) rollback = 2;
             FL_AUDIT_STAMP(16 * (epoch & 15) + 9, wall_clock64());
             FL_AUDIT_STAMP(16 * (epoch & 15) + 10, s_solve.fragile + 2 * s_solve.audited + 4 * s_solve.exact_timeout + 8 * s_solve.accept);
             FL_INSTR(if (p == 5) fl_stamp(flags, 18);)
@@ -973,6 +986,11 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
             }
             if (!force && (ctrl & 3)) break;
             if (p + 1 < count) eskf18_restage(s_solve);
+        }
+        if constexpr (SPEC != 0) {
+            // the revert of a fragile accept the float chain did not confirm (rare; out of the loop and out of line). rollback == 1: the
+            // producers of pass done - 1 wait for a control word -- they get "stop"; their records are dropped
+            if (rollback) vio_spec_rollback(D, &s_solve, err_base, err_cap, m, errors, VC, rollback == 1 ? bcast : (unsigned long long *)nullptr, epoch0 + (unsigned)done);
         }
         if (threadIdx.x == 0) {
             *epoch_ptr = epoch0 + (unsigned)done;

@@ -185,6 +185,10 @@ int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out);
                                     * compacted and re-indexed only when its arrays fill up or its cell size goes out of tune. 0: every update
                                     * compacts the map array and rebuilds the index (rounds 1-4). The map's content (fl_map_get_points) and every
                                     * search result are identical either way. */
+#define FL_OPT_VIO_SPECULATE 13    /* 1 (default): in fl_vio_compute_j / fl_vio_update_state a pass whose accept test is decided inside float rounding
+                                    * noise AND accepted by the fp64 test does not wait for the reference's float running sum (~6 us): it goes ahead
+                                    * and the sum's verdict is applied a pass later, with a roll-back on the (rare) disagreement. 0: every such pass
+                                    * waits (round 2-4). Accept / revert sequences, states and per-patch errors are bit-identical either way. */
 int32_t fl_set_option(fl_handle h, int32_t option, int32_t value);
 /* Counters of the resident-grid machinery of the multi-pass kernels.
  * ABI note: the struct carries no size member; it is 24 bytes since ABI revision 4 (16 before: the two demotion fields were appended)
