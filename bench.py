@@ -825,9 +825,20 @@ def section_pipeline(capi, synth, scene, budget_s, with_cpu=True):
 
 
 # ------------------------------------------------------------------------------------------------ main
+def _json_only_stdout():
+    """The contract is ONE JSON line on stdout.  The reference's ikd-Tree text (compiled under oracle/_ref for the CPU baselines) printf()s from
+    its constructor, so file descriptor 1 is pointed at stderr for the whole run and the JSON lines go out through a duplicate of the
+    original descriptor."""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(keep, "w")
+
+
 def main():
     global AT_SCALE_POINTS, VIO_SWEEP
     args = parse()
+    json_out = _json_only_stdout()
     if args.at_scale_points:
         AT_SCALE_POINTS = tuple(args.at_scale_points)
     if args.vio_sweep_patches:
@@ -906,7 +917,7 @@ def main():
                "cpu_frame": lambda: section_cpu_frame(synth, scene, fr, vf, args.cpu_seconds),
                "pipeline": lambda: section_pipeline(capi, synth, scene, args.cpu_seconds),
                "map_scale": lambda: section_map_scale(capi, synth, scene)}[args.only]()
-        print(json.dumps({"section": args.only, "result": sec}), flush=True)
+        print(json.dumps({"section": args.only, "result": sec}), file=json_out, flush=True)
         return
 
     hl = capi.Handle(cfg)   # LIO filter
@@ -1237,7 +1248,7 @@ def main():
         import ctypes
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
 
 
 def sweep(capi, synth, scene, cfg, x0, fh):

@@ -150,7 +150,7 @@ int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out);
  *   FL_OPT_VIO_WHOLE_CU   1 (default): a VIO multi-pass launch that has the device to itself uses the one-workgroup-per-CU register
  *                         budget; 0: always the co-resident form. Results are bit-identical either way.
  *   FL_OPT_MAILBOX        bit 0 (1): fl_vio_compute_j, bit 1 (2): fl_lio_frame18_dev get their results through a word the frame's last
- *                         kernel writes into page-locked host memory, polled by the calling thread, instead
+ *                         kernel writes into page-locked host memory, polled by the calling thread (profiles/HISTORY.md section 4.1.1), instead
  *                         of a device-to-host copy and a stream synchronisation (-4 .. -5 us per call). Default 3. (A large copy
  *                         command enqueued right behind a call that ended this way starts ~6 us later than behind a synchronised
  *                         stream: callers that upload scans with copy commands may prefer 2.) Results are bit-identical either way.

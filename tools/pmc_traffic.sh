@@ -6,7 +6,7 @@ OUT=${1:-gpurun_out/pmc_hbm_traffic.json}
 R=$PWD; cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$C
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$C -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extras > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$C -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extras > /dev/null 2>&1
 done
 cd $R
 python - "$OUT" <<'PY'
