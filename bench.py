@@ -261,16 +261,20 @@ def section_vio_sweep(capi, synth, fr, vf, cfg, x0, distinct_cap=None):
     out = []
     for m in VIO_SWEEP:
         row = {"kernel": "vio_pass_kernel", "patches": m, "algorithmic_bytes": VIO_BYTES_PER_PATCH * m}
-        for kind in ("tiled", "distinct"):
+        wide = m >= 65536                    # FL_OPT_VIO_WIDE (default 1): one patch per lane from 65 536 patches on (vio_produce_wide)
+        row["producers"] = "one patch per lane (vio_pass_kernel<0, 1>)" if wide else "16 lanes per patch (vio_pass_kernel<0, 0>)"
+        for kind in ("tiled", "distinct") + (("tiled_16lane",) if wide else ()):
             if kind == "distinct" and m <= vf.m:
                 continue                     # (the 2 k set IS distinct)
-            base = vf if kind == "tiled" else synth.make_vio_frame(min(m, distinct_cap), fr, patch_seed=synth.SEED + 977)
+            base = vf if kind != "distinct" else synth.make_vio_frame(min(m, distinct_cap), fr, patch_seed=synth.SEED + 977)
             reps = (m + base.m - 1) // base.m
             ref = np.tile(base.ref_patch, (reps, 1, 1))[:m]
             pos = np.tile(base.pos, (reps, 1))[:m]
             sl = np.tile(base.search_level, reps)[:m]
             h = capi.Handle(cfg)
             h.set_stream(torch.cuda.current_stream().cuda_stream)
+            if kind == "tiled_16lane":
+                h.set_option(capi.FL_OPT_VIO_WIDE, 0)      # the 16-lanes-per-patch producers at the same size, for comparison
             h.vio_set_frame(vf.img)
             h.vio_set_patches(ref, pos, sl)
             del ref
@@ -294,7 +298,7 @@ def section_vio_sweep(capi, synth, fr, vf, cfg, x0, distinct_cap=None):
             h.close()
             if (check["status"] & ~16) != 0 or not check["state_finite"] or check["n_meas"] != 64 * m:
                 raise SystemExit(f"[bench] VIO pass over {m} patches ({kind}) failed its check: {check}")
-            key = "" if kind == "tiled" else "_distinct"
+            key = "" if kind == "tiled" else "_" + kind.replace("tiled_", "")
             row.update({"pass_us" + key: us, "achieved" + key: gbs, "frac" + key: gbs / HBM_PEAK_GBS, "ns_per_patch" + key: us * 1e3 / m,
                         "check" + key: check})
             if kind == "distinct":

@@ -158,6 +158,7 @@ struct fl_context {
     bool map_index_stale = false;          // the last status said needs_rebuild
     int opt_map_incr = 1;                  // FL_OPT_MAP_INCREMENTAL
     int opt_vio_spec = 1;                  // FL_OPT_VIO_SPECULATE
+    int opt_vio_wide = 1;                  // FL_OPT_VIO_WIDE
     size_t map_pool_cap = 0;               // float4 entries of d_map_pts
     bool map_cell_auto = false;            // cell size follows the map's density (cell_size <= 0 at fl_map_set_points / fl_map_clear)
     unsigned *d_map_occ = nullptr, *h_map_occ = nullptr;    // occupied slots among the sampled ones (device counter, pinned copy)
@@ -539,6 +540,11 @@ int32_t fl_set_option(fl_handle h, int32_t option, int32_t value)
     case FL_OPT_VOXEL_SORT: h->opt_voxel_sort = value != 0; break;
     case FL_OPT_MAP_INCREMENTAL: h->opt_map_incr = value != 0; break;
     case FL_OPT_VIO_SPECULATE: h->opt_vio_spec = value != 0; break;
+    case FL_OPT_VIO_WIDE:
+        if (value < 0 || value > 2) return fail_arg(h, "fl_set_option: FL_OPT_VIO_WIDE out of range");
+        if (value != h->opt_vio_wide)         // another grid for the same patches: stale records must not carry a live tag
+            HIPCHK(h, hipMemsetAsync(h->d_records, 0, (size_t)16 * FL_MAX_BLOCKS * FL_SUMS23, h->stream));
+        h->opt_vio_wide = value; break;
     case FL_OPT_DEMOTE_AFTER:
         if (value < 0) return fail_arg(h, "fl_set_option: FL_OPT_DEMOTE_AFTER out of range");
         h->opt_demote_after = value; h->mp_consec_timeouts = 0;
@@ -650,7 +656,7 @@ static inline int lio_grid(fl_handle h, int n)
 // did not rewrite must not be looked at by the next one: LIO, VIO and Mode-23 passes of one handle share the buffer with different
 // grids and record sizes, and a stale tail could carry a matching tag once the epoch has advanced by a multiple of 63 in between.
 // Whatever lies beyond the bytes the previous launch covered is zeroed (tag 0 = "never written") before a larger launch reads it.
-static inline int vio_grid(int m);
+static inline int vio_grid_h(fl_handle h);
 static inline int ik_grid(fl_handle h, int n);
 static void *records_for(fl_handle h, size_t need_bytes)
 {
@@ -660,7 +666,7 @@ static void *records_for(fl_handle h, size_t need_bytes)
     return h->d_records;
 }
 static inline void *records_lio(fl_handle h) { return records_for(h, (size_t)lio_grid(h, h->n) * FL_SUMS18 * 8); }
-static inline void *records_vio(fl_handle h) { return records_for(h, (size_t)vio_grid(h->m) * FL_SUMS18 * 8); }
+static inline void *records_vio(fl_handle h) { return records_for(h, (size_t)vio_grid_h(h) * FL_SUMS18 * 8); }
 static inline void *records_ik(fl_handle h) { return records_for(h, (size_t)ik_grid(h, h->n) * FL_SUMS23I * 8); }
 
 // everything fl_lio_set_points does except moving the points (and clearing the selection flags, which the search + fit kernel

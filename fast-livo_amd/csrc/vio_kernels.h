@@ -681,6 +681,243 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
     }
 }
 
+// ---- the at-scale producer: ONE PATCH PER LANE (round 5) -----------------------------------------------------------------------
+// vio_produce gives a patch to the 16 lanes of a DPP row, which is what a 2 000-patch pass wants (125 workgroups with something to
+// do, one iteration each: the pass is a chain of hand-offs). A pass over 10^5 .. 10^6 patches is bound by instruction issue instead
+// (tools/vio_pmc.sh: 438 vector instructions per wavefront iteration = 110 per patch, 60 % VALU utilisation at two wavefronts per
+// SIMD), and most of those instructions exist only because a patch is spread over lanes:
+//   * every pixel fetches and converts its own 12 taps and forms its own 5 bilinear values (centre, left, right, up, down): 768 tap
+//     conversions and 320 interpolations per patch, where the patch has 121 taps and 96 distinct bilinear values -- the value right
+//     of pixel (x, y) IS the centre value of pixel (x, y + 1), the same expression over the same operands, hence the same bits;
+//   * the six Gram sums cross the 16 lanes (72 DPP instructions per iteration), the 2x6 matrix M and the 29 outputs go through LDS,
+//     the per-patch float chain runs with a quarter of the lanes.
+// Here a lane walks its own patch: 11 tap rows of 11 bytes (one 16-byte load per row at the finest level), a rolling window of three
+// rows of bilinear values, pixels in the reference's order x * 8 + y -- so the float chain `patch_error += res * res` is simply the
+// lane's own running value --, the Gram sums in the lane's registers, M and the 29 outputs once per patch with all 64 lanes busy
+// (fl_patch_M / fl_patch_accum: the round-1 arithmetic). No cross-lane traffic until the record is reduced at the end of the pass.
+// The reference patches (256 contiguous bytes per patch and level) are fetched by the wavefront together -- 16 loads of 1 KB, four
+// patches each, straight into LDS (global_load_lds_dwordx4: no staging registers) -- and read back by their lanes.
+// Float part: the reference's expressions and operand order (lidar_selection.cpp:826-829,837), no contraction: per-patch errors are
+// bit-identical to vio_produce's and to the oracle's. fp64 sums: other order than vio_produce, compared by tolerance like every sum.
+// One tap row of a patch that is not served by the row loads of the common case (coarser pyramid scale, a patch reaching over the
+// image border, a row stride that is not a multiple of 4): 11 bytes at column c0 + b * scale of image row `row`, packed like the
+// common case's aligned words. The reference reads unchecked; rows and columns are clamped instead of faulting (vio_produce does
+// the same). Out of line: 11 x 11 inlined copies of the clamped address arithmetic cost the common path its registers.
+typedef unsigned int fl_u3 __attribute__((ext_vector_type(3)));
+__device__ __attribute__((noinline)) fl_u3 vio_tap_row_bytes(const uint8_t *__restrict__ img, int W, int Hm1, int Wm1, int row, int c0, int scale)
+{
+    row = row < 0 ? 0 : (row > Hm1 ? Hm1 : row);
+    const uint8_t *q = img + (size_t)row * W;
+    unsigned t[12];
+#pragma unroll
+    for (int b = 0; b < 11; b++) {
+        int cc = c0 + b * scale;
+        cc = cc < 0 ? 0 : (cc > Wm1 ? Wm1 : cc);
+        t[b] = q[cc];
+    }
+    t[11] = 0u;
+    fl_u3 d;
+    d.x = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
+    d.y = t[4] | (t[5] << 8) | (t[6] << 16) | (t[7] << 24);
+    d.z = t[8] | (t[9] << 8) | (t[10] << 16) | (t[11] << 24);
+    return d;
+}
+#define FL_VIO_WIDE_RS 64                    /* floats per patch in the LDS copy of the reference patches */
+#define FL_VIO_WIDE_PPB FL_VIO_NT            /* patches per workgroup and sweep */
+template <int NT>
+__device__ __forceinline__ void vio_produce_wide(const uint8_t *__restrict__ img, const float *__restrict__ ref, const double *__restrict__ pos,
+                                                 const int32_t *__restrict__ slevel, float *__restrict__ errors, int m, int level,
+                                                 const FlVioConst *__restrict__ VC, const FlDev18 *__restrict__ D, int nprod,
+                                                 double *s_red, unsigned epoch, void *__restrict__ records,
+                                                 unsigned long long *__restrict__ err_words /* this pass's half, nullable */,
+                                                 float *s_ref /* LDS: (NT / 64) * 64 * FL_VIO_WIDE_RS */)
+{
+    constexpr int WPB = NT / 64;
+    typedef float fl_f4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *sr = s_ref + wave * (64 * FL_VIO_WIDE_RS);
+    // The pass's fp64 constants (camera pose, intrinsics, the extrinsic Jacobians: 41 doubles) are wave-uniform, but fp64 vector
+    // instructions take them from vector registers: carried through the loop they are 90 registers of every lane (and the scalar file
+    // is full: FlVioConst by value is 82 SGPRs). They wait in LDS instead and are fetched where an iteration needs them -- through an
+    // offset the compiler cannot see through, or it hoists the reads out of the loop again.
+    double *s_const = s_red + WPB * FL_SUMS18;      // [0..8] Rcw [9..11] Pcw [12..15] fx fy cx cy [16..20] d [21..22] fx_abs fy_abs [23..31] Jdphi_dR [32..40] Jdp_dR
+    static_assert(FL_VIO_GPW * WPB * FL_SUMS18 >= WPB * FL_SUMS18 + 41, "the constants fit behind the record sums");
+    {
+        const int t = threadIdx.x;
+        double cv = 0.0;
+        if (t < 9) cv = D->Rcw[t];
+        else if (t < 12) cv = D->Pcw[t - 9];
+        else if (t == 12) cv = VC->fx;
+        else if (t == 13) cv = VC->fy;
+        else if (t == 14) cv = VC->cx;
+        else if (t == 15) cv = VC->cy;
+        else if (t < 21) cv = VC->d[t - 16];
+        else if (t == 21) cv = VC->fx_abs;
+        else if (t == 22) cv = VC->fy_abs;
+        else if (t < 32) cv = VC->Jdphi_dR[t - 23];
+        else if (t < 41) cv = VC->Jdp_dR[t - 32];
+        if (t < 41) s_const[t] = cv;
+    }
+    __syncthreads();
+    const int distort = VC->distort;
+    const int W = VC->stride, Hm1 = VC->height - 1, Wm1 = VC->width - 1;
+    const __amdgpu_buffer_rsrc_t img_rs = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, W * (Hm1 + 1) + 16, 0x00020000);
+    const bool rows_dword_phase = (W & 3) == 0;
+    double acc = 0.0;                              // lane L: this wavefront's total of record value L >> 1
+    const int wave_stride = nprod * WPB * 64;
+    for (int ib0 = (blockIdx.x * WPB + wave) * 64; ib0 < m; ib0 += wave_stride) {
+        const int i = ib0 + lane;
+        const bool active = i < m;
+        const int ii = active ? i : 0;
+        // the 64 reference patches of this sweep straight into LDS, four patches (1 KB) per load instruction j: lane (cc, q) fetches
+        // chunk (cc - j) & 15 (16 bytes) of patch 4 j + q, so that patch p = 4 j + q finds its chunk c at slot ((c + j) & 15, q) of
+        // group j -- the 16-byte reads of 16 consecutive lanes then fall on 16 different bank groups (the destination of an LDS-direct
+        // load is linear in the lane, the permutation has to sit in the source address).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (the lanes have read the previous sweep's patches)
+        // (addresses from a few per-iteration values, not from 16 + 16 loop-invariant registers: `lq` is opaque to the compiler)
+        int lq = lane >> 2;
+        asm volatile("" : "+v"(lq));
+        {
+            const char *rb = reinterpret_cast<const char *>(ref + (size_t)ib0 * 192 + 64 * level);      // (wave-uniform)
+            const int last = m - 1 - ib0;                                                            // last patch of the sweep that exists
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                int pq = 4 * j + (lane & 3);
+                pq = pq < last ? pq : last;
+                const unsigned voff = (unsigned)pq * 768u + (unsigned)((lq - j) & 15) * 16u;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rb + voff),
+                                                 (__attribute__((address_space(3))) void *)(sr + j * 256), 16, 0, 0);
+            }
+        }
+        const int scale = 1 << (level + slevel[ii]);
+        const double ps[3] = {pos[ii * 3 + 0], pos[ii * 3 + 1], pos[ii * 3 + 2]};
+        FlPatchGeom g;
+        {
+            int co = 0;
+            asm volatile("" : "+v"(co));
+            const double *cp = s_const + co;
+            double Rcw[9], Pcw[3];
+#pragma unroll
+            for (int k = 0; k < 9; k++) Rcw[k] = cp[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) Pcw[k] = cp[9 + k];
+            FlVioConst vcl;
+            vcl.fx = cp[12]; vcl.fy = cp[13]; vcl.cx = cp[14]; vcl.cy = cp[15];
+#pragma unroll
+            for (int k = 0; k < 5; k++) vcl.d[k] = cp[16 + k];
+            vcl.fx_abs = cp[21]; vcl.fy_abs = cp[22];
+            vcl.distort = distort;
+            fl_patch_geom(vcl, Rcw, Pcw, ps, scale, g);
+        }
+        const bool inside = (g.v_i - 5 * scale >= 0) && (g.v_i + 5 * scale <= Hm1) && (g.u_i - 5 * scale >= 0) && (g.u_i + 5 * scale <= Wm1);
+        const bool fast = rows_dword_phase && (__ballot(inside && scale == 1) == ~0ull);
+        // tap rows a = 0 .. 10 = image rows v_i + (a - 5) scale, tap columns b = 0 .. 10 = image columns u_i + (b - 5) scale: 11 bytes
+        // per row, as three words
+        fl_u3 d[11];
+        if (fast) {
+            const int off0 = (g.v_i - 5) * W + (g.u_i - 5);            // >= 0: the patch is inside the image
+            const unsigned sh = (unsigned)off0 & 3u;                   // the same for every row: W % 4 == 0
+            const int voff = off0 & ~3;
+#pragma unroll
+            for (int a = 0; a < 11; a++) {
+                const fl_u4 rw = __builtin_bit_cast(fl_u4, __builtin_amdgcn_raw_buffer_load_b128(img_rs, voff, a * W, 0));
+                d[a].x = __builtin_amdgcn_alignbyte(rw.y, rw.x, sh); d[a].y = __builtin_amdgcn_alignbyte(rw.z, rw.y, sh);
+                d[a].z = __builtin_amdgcn_alignbyte(rw.w, rw.z, sh);
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 11; a++) d[a] = vio_tap_row_bytes(img, W, Hm1, Wm1, g.v_i + (a - 5) * scale, g.u_i - 5 * scale, scale);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the reference patches have landed (the tap rows too)
+        const float wtl = g.wtl, wtr = g.wtr, wbl = g.wbl, wbr = g.wbr;
+        const float *srp = sr + lq * 256 + (lane & 3) * 4;
+        float Tp[11], Ia[10], Ib[10], Ic[10];
+        double S[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        float pe = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 11; b++) Tp[b] = 0.f;
+#pragma unroll
+        for (int b = 0; b < 10; b++) { Ia[b] = 0.f; Ib[b] = 0.f; Ic[b] = 0.f; }
+#pragma unroll
+        for (int a = 0; a < 11; a++) {
+            float Tc[11];
+#pragma unroll
+            for (int b = 0; b < 11; b++) {
+                const unsigned dd = (b < 4) ? d[a].x : ((b < 8) ? d[a].y : d[a].z);
+                Tc[b] = (float)((dd >> (8 * (b & 3))) & 0xffu);
+            }
+            if (a >= 1) {
+                // bilinear values of row r = a - 1 (taps of rows r and r + 1); the four corners of the 10 x 10 array are never used
+#pragma unroll
+                for (int b = 0; b < 10; b++) { Ia[b] = Ib[b]; Ib[b] = Ic[b]; }
+#pragma unroll
+                for (int b = 0; b < 10; b++) {
+                    const bool corner = (a == 1 || a == 10) && (b == 0 || b == 9);
+                    Ic[b] = corner ? 0.f : (wtl * Tp[b] + wtr * Tp[b + 1] + wbl * Tc[b] + wbr * Tc[b + 1]);
+                }
+            }
+            if (a >= 3) {
+                // pixel row x = a - 3: centre values Ib (row x + 1), the rows above / below Ia, Ic
+                const int x = a - 3;
+                int lr = lq;
+                asm volatile("" : "+v"(lr));                      // (keeps the reads in their row: hoisted, they are 64 registers)
+                const fl_f4 r0 = *reinterpret_cast<const fl_f4 *>(srp + ((2 * x + lr) & 15) * 16),
+                            r1 = *reinterpret_cast<const fl_f4 *>(srp + ((2 * x + 1 + lr) & 15) * 16);
+                const float rf[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+                for (int y = 0; y < 8; y++) {
+                    const float du = 0.5f * (Ib[y + 2] - Ib[y]);
+                    const float dv = 0.5f * (Ic[y + 1] - Ia[y + 1]);
+                    const float res = Ib[y + 1] - rf[y];
+                    const double dud = (double)du, dvd = (double)dv, rd = (double)res;
+                    S[0] = fma(dud, dud, S[0]); S[1] = fma(dud, dvd, S[1]); S[2] = fma(dvd, dvd, S[2]);
+                    S[3] = fma(dud, rd, S[3]); S[4] = fma(dvd, rd, S[4]); S[5] = fma(rd, rd, S[5]);
+                    pe = (float)fma(rd, rd, (double)pe);           // lidar_selection.cpp:849 (the product of two floats is exact in double)
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 11; b++) Tp[b] = Tc[b];
+            // A row at a time: left alone, the compiler converts all 121 taps and forms all 96 bilinear values up front and sinks the
+            // pixels' sums behind them -- 480 registers. Everything a row hands to the next one passes through this statement.
+            asm volatile("" : "+v"(Tp[0]), "+v"(Tp[1]), "+v"(Tp[2]), "+v"(Tp[3]), "+v"(Tp[4]), "+v"(Tp[5]), "+v"(Tp[6]), "+v"(Tp[7]), "+v"(Tp[8]),
+                              "+v"(Tp[9]), "+v"(Tp[10]), "+v"(Ic[0]), "+v"(Ic[1]), "+v"(Ic[2]), "+v"(Ic[3]), "+v"(Ic[4]), "+v"(Ic[5]), "+v"(Ic[6]),
+                              "+v"(Ic[7]), "+v"(Ic[8]), "+v"(Ic[9]), "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(S[4]), "+v"(S[5]), "+v"(pe));
+        }
+        // the patch's 29 outputs (M^T G M, M^T g, count, sum res^2), summed over the wavefront's 64 patches right away: 32 accumulators
+        // per lane carried through the pixel rows would be 64 registers of the loop's budget
+        double w[FL_SUMS18];
+#pragma unroll
+        for (int k = 0; k < FL_SUMS18; k++) w[k] = 0.0;
+        if (active) {
+            errors[i] = pe;
+            if (err_words)
+                __hip_atomic_store(err_words + i, ((unsigned long long)__float_as_uint(pe) << 32) | (unsigned long long)epoch, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            int co = 0;
+            asm volatile("" : "+v"(co));
+            const double *cp = s_const + co;
+            double Rcw[9], J1[9], J2[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) { Rcw[k] = cp[k]; J1[k] = cp[23 + k]; J2[k] = cp[32 + k]; }
+            double M[2][6];
+            fl_patch_M(g, J1, J2, Rcw, M);
+            fl_patch_accum(w, M, S);
+        }
+        wave_transpose_reduce32(w, lane);
+        acc += w[0];
+    }
+    double *s_fin = s_red;                          // WPB * 32 doubles
+    if ((lane & 1) == 0) s_fin[wave * FL_SUMS18 + (lane >> 1)] = acc;
+    __syncthreads();
+    double mine = 0.0;
+    if (threadIdx.x < FL_SUMS18) {
+        mine = s_fin[threadIdx.x];
+#pragma unroll
+        for (int wv = 1; wv < WPB; wv++) mine += s_fin[wv * FL_SUMS18 + threadIdx.x];
+    }
+    publish_record<FL_SUMS18>(mine, epoch, records);
+}
+
 // The AUDITOR workgroup (block `nprod`): the reference's float running sum `error += patch_error` over the patches in order
 // (lidar_selection.cpp:849-857; solve18.h, eskf18_solve_block) for EVERY pass, computed beside the producers and the solver instead of
 // by the solver when it finds the accept test fragile: the m additions start as soon as the
@@ -689,9 +926,14 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
 // slot = epoch & 15, tagged with the epoch like every hand-off word. The chain itself is exact_chain.h's lane-parallel form (~3 us
 // at 2 k patches): the auditor is done before the solver asks.
 // (not inlined: its registers and its staging stay out of the pass kernels' allocation)
-__device__ __attribute__((noinline)) int vio_audit_pass(unsigned long long *__restrict__ err_base, int err_cap, int buf, int m, unsigned epoch)
+// EXT: the staging buffer is the caller's (s_ext, FL_EXACT_LDS floats) -- the one-patch-per-lane pass kernel lends the auditor workgroup
+// its reference-patch array, which keeps the kernel's LDS under half a CU's
+template <bool EXT = false>
+__device__ __attribute__((noinline)) int vio_audit_pass(unsigned long long *__restrict__ err_base, int err_cap, int buf, int m, unsigned epoch,
+                                                        float *s_ext = nullptr)
 {
-    __shared__ __attribute__((aligned(16))) float s_aud[FL_EXACT_LDS];
+    __shared__ __attribute__((aligned(16))) float s_own[EXT ? 4 : FL_EXACT_LDS];
+    float *s_aud = EXT ? s_ext : s_own;
     __shared__ int s_to;
     if (threadIdx.x == 0) {
         s_to = 0;
@@ -708,8 +950,9 @@ __device__ __attribute__((noinline)) int vio_audit_pass(unsigned long long *__re
     return to;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__restrict__ img, const float *__restrict__ ref,
+// WIDE 1: the producers are vio_produce_wide's (one patch per lane; passes over >= FL_VIO_WIDE_MIN patches, api_vio.inc)
+template <int MODE, int WIDE = 0>
+__global__ __launch_bounds__(FL_VIO_NT, WIDE ? 2 : 1) void vio_pass_kernel(const uint8_t *__restrict__ img, const float *__restrict__ ref,
                                                             const double *__restrict__ pos, const int32_t *__restrict__ slevel,
                                                             float *__restrict__ errors, int m, int level_arg,
                                                             const FlVioConst *__restrict__ VC, FlDev18 *__restrict__ D,
@@ -722,14 +965,16 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
     // producers' arrays -- a workgroup has ONE role --, which keeps two workgroups per CU), 4 in the accumulate-only form (its third
     // workgroup per CU is worth more than the longer batch)
     constexpr int CB = (MODE == 0) ? 8 : FL_VIO_CHAIN_BATCH;
+    constexpr int RES_FLOATS = WIDE ? WPB * 64 * FL_VIO_WIDE_RS : FL_VIO_GPW * WPB * CB * 64;      // (WIDE: the lanes' reference patches)
     __shared__ double s_red[FL_VIO_GPW * WPB * FL_SUMS18];
-    __shared__ __attribute__((aligned(16))) float s_res[FL_VIO_GPW * WPB * CB * 64];
+    __shared__ __attribute__((aligned(16))) float s_res[RES_FLOATS];
     static_assert(sizeof(double) * FL_VIO_GPW * WPB * FL_SUMS18 >= sizeof(double) * 2 * NT, "the solver's gather buffer fits the producers' reduction buffer");
-    static_assert(MODE != 0 || sizeof(float) * FL_VIO_GPW * WPB * CB * 64 >= sizeof(float) * FL_EXACT_LDS, "the solver's replay buffer fits the producers' residual buffer");
+    static_assert(MODE != 0 || sizeof(float) * RES_FLOATS >= sizeof(float) * FL_EXACT_LDS, "the solver's replay buffer fits the producers' residual buffer");
     const int nprod = gridDim.x - 2;              // then the solver and the auditor (FL_VIO_SOLVER_BLOCK / FL_VIO_AUDITOR_BLOCK)
     const int solver_block = FL_VIO_SOLVER_BLOCK(nprod), auditor_block = FL_VIO_AUDITOR_BLOCK(nprod);
     FL_INSTR(if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[blockIdx.x] = (long long)wall_clock64();)
-    const FlVioFirst pf = vio_prefetch_first(ref, pos, slevel, m, level_arg, nprod);
+    FlVioFirst pf;
+    if constexpr (!WIDE) pf = vio_prefetch_first(ref, pos, slevel, m, level_arg, nprod);
     double pf_solver = 0.0;
     if (MODE == 0 && blockIdx.x == solver_block) pf_solver = eskf18_prefetch_issue(D);
     if (D->status & FL_NUM_TIMEOUT) {             // an earlier pass of the chain was abandoned (solve18.h): the host resumes
@@ -743,7 +988,8 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
         // ------------------------------------------------------------------ auditor workgroup (single-rank fused passes only: the
         // sharded form chains the sum through the ranks, solve18.h vio_exact_chain)
         if (MODE != 0 || (flags & FL_ITER_FORCE) || !D->err_words || D->xchg_world > 1) return;
-        vio_audit_pass(D->err_words, D->err_cap, D->iters_run & 1, m, epoch);
+        if constexpr (WIDE) vio_audit_pass<true>(D->err_words, D->err_cap, D->iters_run & 1, m, epoch, s_res);
+        else vio_audit_pass(D->err_words, D->err_cap, D->iters_run & 1, m, epoch);
         return;
     }
     if (blockIdx.x == solver_block) {
@@ -784,18 +1030,23 @@ __global__ __launch_bounds__(FL_VIO_NT) void vio_pass_kernel(const uint8_t *__re
 
     // -------------------------------------------------------------------- producer workgroups
     const int level = (level_arg >= 0) ? level_arg : D->level;
-    // wave-uniform camera pose, derived from the state by the previous pass's solver (vio_derive_pose)
-    const FlVioConst vc = *VC;
-    double Rcw[9], Pcw[3];
+    if constexpr (WIDE) {
+        unsigned long long *ew = D->err_words ? D->err_words + (size_t)(D->iters_run & 1) * D->err_cap : nullptr;
+        vio_produce_wide<NT>(img, ref, pos, slevel, errors, m, level, VC, D, nprod, s_red, epoch, records, ew, s_res);
+    } else {
+        // wave-uniform camera pose, derived from the state by the previous pass's solver (vio_derive_pose)
+        const FlVioConst vc = *VC;
+        double Rcw[9], Pcw[3];
 #pragma unroll
-    for (int i = 0; i < 9; i++) Rcw[i] = D->Rcw[i];
+        for (int i = 0; i < 9; i++) Rcw[i] = D->Rcw[i];
 #pragma unroll
-    for (int i = 0; i < 3; i++) Pcw[i] = D->Pcw[i];
-    __shared__ int s_pidx[FL_VIO_GPW * WPB * CB];
-    unsigned long long *ew = D->err_words ? D->err_words + (size_t)(D->iters_run & 1) * D->err_cap : nullptr;
-    FlVioLaneRole role = fl_vio_lane_role((int)(threadIdx.x & 15), VC);
-    fl_vio_lane_role_pose(role, (int)(threadIdx.x & 15), D->Rcw);
-    vio_produce<CB>(img, ref, pos, slevel, errors, m, level_arg, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags, ew, s_res, s_pidx, role);
+        for (int i = 0; i < 3; i++) Pcw[i] = D->Pcw[i];
+        unsigned long long *ew = D->err_words ? D->err_words + (size_t)(D->iters_run & 1) * D->err_cap : nullptr;
+        __shared__ int s_pidx[FL_VIO_GPW * WPB * CB];
+        FlVioLaneRole role = fl_vio_lane_role((int)(threadIdx.x & 15), VC);
+        fl_vio_lane_role_pose(role, (int)(threadIdx.x & 15), D->Rcw);
+        vio_produce<CB>(img, ref, pos, slevel, errors, m, level_arg, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records, flags, ew, s_res, s_pidx, role);
+    }
     FL_INSTR(if (blockIdx.x == 0) fl_stamp(flags, 2);)
     FL_INSTR(if ((flags & FL_ITER_STAMP) && threadIdx.x == 0 && blockIdx.x < 1024) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();)
 }
