@@ -656,7 +656,7 @@ static inline int lio_grid(fl_handle h, int n)
 // did not rewrite must not be looked at by the next one: LIO, VIO and Mode-23 passes of one handle share the buffer with different
 // grids and record sizes, and a stale tail could carry a matching tag once the epoch has advanced by a multiple of 63 in between.
 // Whatever lies beyond the bytes the previous launch covered is zeroed (tag 0 = "never written") before a larger launch reads it.
-static inline int vio_grid_h(fl_handle h);
+static inline int vio_grid_h(fl_handle h, int level);
 static inline int ik_grid(fl_handle h, int n);
 static void *records_for(fl_handle h, size_t need_bytes)
 {
@@ -666,7 +666,7 @@ static void *records_for(fl_handle h, size_t need_bytes)
     return h->d_records;
 }
 static inline void *records_lio(fl_handle h) { return records_for(h, (size_t)lio_grid(h, h->n) * FL_SUMS18 * 8); }
-static inline void *records_vio(fl_handle h) { return records_for(h, (size_t)vio_grid_h(h) * FL_SUMS18 * 8); }
+static inline void *records_vio(fl_handle h, int level) { return records_for(h, (size_t)vio_grid_h(h, level) * FL_SUMS18 * 8); }
 static inline void *records_ik(fl_handle h) { return records_for(h, (size_t)ik_grid(h, h->n) * FL_SUMS23I * 8); }
 
 // everything fl_lio_set_points does except moving the points (and clearing the selection flags, which the search + fit kernel

@@ -174,3 +174,31 @@ def test_wide_is_automatic_at_scale(gpu_lib, scene):
     assert np.array_equal(out[1][3], out[0][3])
     assert np.abs(out[1][4] - out[0][4]).max() <= 1e-9
     assert abs(out[1][0] - out[0][0]) <= 1e-6 * abs(out[0][0])
+
+
+def test_compute_j_at_scale_mixes_the_forms(gpu_lib, scene):
+    """ComputeJ over 70 000 patches with the default option: levels 2 and 1 run on the 16-lane producers (they have row loads for tap
+    scales 4 and 2), level 0 on the one-patch-per-lane ones -- other grids, the same record buffer. Against the 16-lane form throughout:
+    same pass and accept counts per level, per-patch errors bit for bit, state 1e-9."""
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    fr, vf = _frames(synth, scene, 2000)
+    m = 70000
+    reps = (m + vf.m - 1) // vf.m
+    ref = np.tile(vf.ref_patch, (reps, 1, 1))[:m]
+    pos = np.tile(vf.pos, (reps, 1))[:m]
+    sl = np.tile(vf.search_level, reps)[:m]
+    out = {}
+    for wide in (1, 0):
+        h = capi.Handle(capi.config_from_frames(fr, vf, max_iterations=4))
+        h.set_option(capi.FL_OPT_VIO_WIDE, wide)
+        h.vio_set_frame(vf.img)
+        h.vio_set_patches(ref, pos, sl)
+        xg = capi.state18_from_frame(fr)
+        infos = h.vio_compute_j(xg, xg.copy())
+        out[wide] = ([(infos[lv].iterations, infos[lv].accepted) for lv in (2, 1, 0)], h.vio_get_errors(m), xg.vec().copy(), xg.cov_np().copy())
+        h.close()
+    assert out[1][0] == out[0][0]
+    assert np.array_equal(out[1][1], out[0][1])
+    assert np.abs(out[1][2] - out[0][2]).max() <= 1e-9
+    assert np.abs(out[1][3] - out[0][3]).max() <= 1e-12
