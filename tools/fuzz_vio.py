@@ -1,5 +1,6 @@
 """Randomised cross-check of the VIO side (run on the GPU box): random patch counts / iteration caps, ComputeJ vs the oracle
-(state 1e-9, errors 1e-5 rel), selection vs the oracle (bit-identical)."""
+(state 1e-9, per-patch errors bit for bit), selection vs the oracle (bit-identical). FL_FUZZ_WIDE=2: ComputeJ on the one-patch-per-lane
+producers (FL_OPT_VIO_WIDE)."""
 import os, sys, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,6 +17,8 @@ for trial in range(T):
     lio = synth.make_lio_frame(500, seed=synth.SEED + seed % 7)
     vf = synth.make_vio_frame(m, lio, max_iterations=max_iter, patch_seed=seed)
     h = capi.Handle(capi.config_from_frames(lio, vf, max_iterations=max_iter))
+    if os.environ.get("FL_FUZZ_WIDE"):           # e.g. 2: every pass on the one-patch-per-lane producers (FL_OPT_VIO_WIDE)
+        h.set_option(capi.FL_OPT_VIO_WIDE, int(os.environ["FL_FUZZ_WIDE"]))
     xg = capi.state18_from_frame(lio); xp = capi.state18_from_frame(lio)
     h.vio_set_frame(vf.img); h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
     ig = h.vio_compute_j(xg, xp)
