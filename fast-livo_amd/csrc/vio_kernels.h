@@ -722,6 +722,11 @@ __device__ __attribute__((noinline)) fl_u3 vio_tap_row_bytes(const uint8_t *__re
     d.z = t[8] | (t[9] << 8) | (t[10] << 16) | (t[11] << 24);
     return d;
 }
+#if defined(FL_INSTRUMENT) && defined(FL_WIDE_STAMPS)     /* tools/vio_wide_stamps.py: phases of the sweeps of producer wavefront 0 */
+#define FL_WSTAMP(k, j) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (k) < 250) g_fl_wall[8 * (k) + (j)] = (long long)wall_clock64(); } while (0)
+#else
+#define FL_WSTAMP(k, j) do { } while (0)
+#endif
 #define FL_VIO_WIDE_RS 64                    /* floats per patch in the LDS copy of the reference patches */
 #define FL_VIO_WIDE_PPB FL_VIO_NT            /* patches per workgroup and sweep */
 template <int NT>
@@ -765,10 +770,12 @@ __device__ __forceinline__ void vio_produce_wide(const uint8_t *__restrict__ img
     const bool rows_dword_phase = (W & 3) == 0;
     double acc = 0.0;                              // lane L: this wavefront's total of record value L >> 1
     const int wave_stride = nprod * WPB * 64;
-    for (int ib0 = (blockIdx.x * WPB + wave) * 64; ib0 < m; ib0 += wave_stride) {
+    int sweep = 0;
+    for (int ib0 = (blockIdx.x * WPB + wave) * 64; ib0 < m; ib0 += wave_stride, sweep++) {
         const int i = ib0 + lane;
         const bool active = i < m;
         const int ii = active ? i : 0;
+        FL_WSTAMP(sweep, 0);
         // the 64 reference patches of this sweep straight into LDS, four patches (1 KB) per load instruction j: lane (cc, q) fetches
         // chunk (cc - j) & 15 (16 bytes) of patch 4 j + q, so that patch p = 4 j + q finds its chunk c at slot ((c + j) & 15, q) of
         // group j -- the 16-byte reads of 16 consecutive lanes then fall on 16 different bank groups (the destination of an LDS-direct
@@ -789,6 +796,7 @@ __device__ __forceinline__ void vio_produce_wide(const uint8_t *__restrict__ img
                                                  (__attribute__((address_space(3))) void *)(sr + j * 256), 16, 0, 0);
             }
         }
+        FL_WSTAMP(sweep, 5);
         const int scale = 1 << (level + slevel[ii]);
         const double ps[3] = {pos[ii * 3 + 0], pos[ii * 3 + 1], pos[ii * 3 + 2]};
         FlPatchGeom g;
@@ -813,6 +821,10 @@ __device__ __forceinline__ void vio_produce_wide(const uint8_t *__restrict__ img
         const bool fast = rows_dword_phase && (__ballot(inside && scale == 1) == ~0ull);
         // tap rows a = 0 .. 10 = image rows v_i + (a - 5) scale, tap columns b = 0 .. 10 = image columns u_i + (b - 5) scale: 11 bytes
         // per row, as three words
+#if defined(FL_INSTRUMENT) && defined(FL_WIDE_STAMPS)
+        asm volatile("" :: "v"(g.u_i), "v"(g.v_i));
+#endif
+        FL_WSTAMP(sweep, 6);
         fl_u3 d[11];
         if (fast) {
             const int off0 = (g.v_i - 5) * W + (g.u_i - 5);            // >= 0: the patch is inside the image
@@ -828,7 +840,9 @@ __device__ __forceinline__ void vio_produce_wide(const uint8_t *__restrict__ img
 #pragma unroll
             for (int a = 0; a < 11; a++) d[a] = vio_tap_row_bytes(img, W, Hm1, Wm1, g.v_i + (a - 5) * scale, g.u_i - 5 * scale, scale);
         }
+        FL_WSTAMP(sweep, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the reference patches have landed (the tap rows too)
+        FL_WSTAMP(sweep, 2);
         const float wtl = g.wtl, wtr = g.wtr, wbl = g.wbl, wbr = g.wbr;
         const float *srp = sr + lq * 256 + (lane & 3) * 4;
         float Tp[11], Ia[10], Ib[10], Ic[10];
@@ -883,6 +897,7 @@ __device__ __forceinline__ void vio_produce_wide(const uint8_t *__restrict__ img
                               "+v"(Tp[9]), "+v"(Tp[10]), "+v"(Ic[0]), "+v"(Ic[1]), "+v"(Ic[2]), "+v"(Ic[3]), "+v"(Ic[4]), "+v"(Ic[5]), "+v"(Ic[6]),
                               "+v"(Ic[7]), "+v"(Ic[8]), "+v"(Ic[9]), "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(S[4]), "+v"(S[5]), "+v"(pe));
         }
+        FL_WSTAMP(sweep, 3);
         // the patch's 29 outputs (M^T G M, M^T g, count, sum res^2), summed over the wavefront's 64 patches right away: 32 accumulators
         // per lane carried through the pixel rows would be 64 registers of the loop's budget
         double w[FL_SUMS18];
@@ -905,6 +920,7 @@ __device__ __forceinline__ void vio_produce_wide(const uint8_t *__restrict__ img
         }
         wave_transpose_reduce32(w, lane);
         acc += w[0];
+        FL_WSTAMP(sweep, 4);
     }
     double *s_fin = s_red;                          // WPB * 32 doubles
     if ((lane & 1) == 0) s_fin[wave * FL_SUMS18 + (lane >> 1)] = acc;
@@ -916,6 +932,9 @@ __device__ __forceinline__ void vio_produce_wide(const uint8_t *__restrict__ img
         for (int wv = 1; wv < WPB; wv++) mine += s_fin[wv * FL_SUMS18 + threadIdx.x];
     }
     publish_record<FL_SUMS18>(mine, epoch, records);
+#if defined(FL_INSTRUMENT) && defined(FL_WIDE_STAMPS)
+    if (threadIdx.x == 0 && blockIdx.x < 1000) g_fl_wall[1024 + blockIdx.x] = (long long)wall_clock64();      // every producer's end
+#endif
 }
 
 // The AUDITOR workgroup (block `nprod`): the reference's float running sum `error += patch_error` over the patches in order
@@ -1001,7 +1020,13 @@ __global__ __launch_bounds__(FL_VIO_NT, WIDE ? 2 : 1) void vio_pass_kernel(const
         FlSolveRegs G;
         if (MODE == 0) { eskf18_prefetch_commit(pf_solver, s_solve); eskf18_load_regs(s_solve, G, VC); }
         FL_INSTR(fl_stamp(flags, 9);)
+#if defined(FL_INSTRUMENT) && defined(FL_WIDE_STAMPS)
+        if (WIDE && threadIdx.x == 0) g_fl_wall[2040] = (long long)wall_clock64();
+#endif
         int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
+#if defined(FL_INSTRUMENT) && defined(FL_WIDE_STAMPS)
+        if (WIDE && threadIdx.x == 0) g_fl_wall[2041] = (long long)wall_clock64();
+#endif
         FL_INSTR(fl_stamp(flags, 10);)
         if (threadIdx.x == 0) *epoch_ptr = epoch + 1u;
         const int world = (MODE == 0) ? D->xchg_world : 1;
@@ -1025,6 +1050,9 @@ __global__ __launch_bounds__(FL_VIO_NT, WIDE ? 2 : 1) void vio_pass_kernel(const
             if (threadIdx.x < FL_SUMS18) sums_out[threadIdx.x] = s_sums[threadIdx.x];
         }
         FL_INSTR(fl_stamp(flags, 11);)
+#if defined(FL_INSTRUMENT) && defined(FL_WIDE_STAMPS)
+        if (WIDE && threadIdx.x == 0) g_fl_wall[2042] = (long long)wall_clock64();
+#endif
         return;
     }
 
