@@ -103,6 +103,8 @@ struct fl_context {
     struct FlVmapCount *d_vm_cnt = nullptr;
     float *d_vm_scan = nullptr;
     int vm_n = 0, vm_cap = 0, vm_length = 0, vm_grid = 0, vm_scan_cap = 0, vm_nsel = 0;
+    bool vm_defer_count = false, vm_added_pending = false;   // fl_vio_detect: fl_vmap_add_sparse's count read with the frame's last block
+    int vm_added_last = 0;
     unsigned vm_set_cap = 0;
     // peer exchange of the sharded form (api_p2p.inc)
     unsigned long long *d_xchg = nullptr;    // this rank's exchange buffer (fine-grained), [2][world][64] words
