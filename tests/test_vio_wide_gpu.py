@@ -202,3 +202,25 @@ def test_compute_j_at_scale_mixes_the_forms(gpu_lib, scene):
     assert np.array_equal(out[1][1], out[0][1])
     assert np.abs(out[1][2] - out[0][2]).max() <= 1e-9
     assert np.abs(out[1][3] - out[0][3]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("wide", [2, 0])
+def test_image_width_not_a_multiple_of_four(gpu_lib, oracle_lib, scene, wide):
+    """A 642-pixel-wide image: the device copy's row stride (= the width) is not a multiple of 4, so the byte phase of a patch's tap rows
+    changes from row to row and neither producer form may use its aligned row loads -- both take their byte paths at every level."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    cam = dict(synth.PINHOLE, width=642)
+    fr, vf = _frames(synth, scene, 300, cam=cam)
+    vf.max_iterations = 1
+    for level in (0, 1):
+        xo = orc.state18_from_frame(fr)
+        ro = orc.vio_update_state(vf, xo, xo.copy(), 1e10, level)
+        h = _handle(capi, fr, vf, wide)
+        xg = capi.state18_from_frame(fr)
+        h.vio_begin(xg, xg)
+        err, info = h.vio_update_state(1e10, level)
+        assert np.array_equal(h.vio_get_errors(vf.m), ro["errors"]), level
+        assert_delta_close(np.array(info.solution)[:18], np.array(ro["out"].solution))
+        assert np.abs(h.vio_get_state18().vec() - xo.vec()).max() <= 1e-9
+        h.close()
