@@ -727,6 +727,8 @@ __device__ __attribute__((noinline)) fl_u3 vio_tap_row_bytes(const uint8_t *__re
 #else
 #define FL_WSTAMP(k, j) do { } while (0)
 #endif
+#define FL_VIO_WIDE_PRIO_ROWS 0x5B6           /* tap rows (bit a) on which the second workgroup of a CU runs at priority 1: a % 3 != 0 */
+#define FL_VIO_WIDE_CUS_SHIFT 16             /* launch flags (internal), bits 16..: the device's CU count = the first block that shares a CU */
 #define FL_VIO_WIDE_RS 64                    /* floats per patch in the LDS copy of the reference patches */
 #define FL_VIO_WIDE_PPB FL_VIO_NT            /* patches per workgroup and sweep */
 template <int NT>
@@ -735,7 +737,8 @@ __device__ __forceinline__ void vio_produce_wide(const uint8_t *__restrict__ img
                                                  const FlVioConst *__restrict__ VC, const FlDev18 *__restrict__ D, int nprod,
                                                  double *s_red, unsigned epoch, void *__restrict__ records,
                                                  unsigned long long *__restrict__ err_words /* this pass's half, nullable */,
-                                                 float *s_ref /* LDS: (NT / 64) * 64 * FL_VIO_WIDE_RS */)
+                                                 float *s_ref /* LDS: (NT / 64) * 64 * FL_VIO_WIDE_RS */,
+                                                 int first_younger /* first block that shares its CU with an earlier one; 0: none */)
 {
     constexpr int WPB = NT / 64;
     typedef float fl_f4 __attribute__((ext_vector_type(4)));
@@ -770,6 +773,12 @@ __device__ __forceinline__ void vio_produce_wide(const uint8_t *__restrict__ img
     const bool rows_dword_phase = (W & 3) == 0;
     double acc = 0.0;                              // lane L: this wavefront's total of record value L >> 1
     const int wave_stride = nprod * WPB * 64;
+    // Two producer workgroups share a CU, and a SIMD issues for its OLDER wavefront whenever both are ready: the second workgroup of a CU
+    // (the dispatcher hands out blocks 0 .. CUs-1 first) ran a quarter slower and ended 20 us behind the first one at 1 M patches -- and
+    // the launch lasts as long as its slowest producer (end stamps of all producers: tools/vio_wide_stamps.py). The second workgroup
+    // therefore raises its priority on 7 of the 11 tap rows: the ends' means move from 78 / 99 us to 91 / 86, the last producer from
+    // 107 to 100, the pass from 123-125 to 113-116 us. A scheduling hint only: results do not depend on it.
+    const bool younger = first_younger > 0 && (int)blockIdx.x >= first_younger;
     int sweep = 0;
     for (int ib0 = (blockIdx.x * WPB + wave) * 64; ib0 < m; ib0 += wave_stride, sweep++) {
         const int i = ib0 + lane;
@@ -855,6 +864,7 @@ __device__ __forceinline__ void vio_produce_wide(const uint8_t *__restrict__ img
 #pragma unroll
         for (int a = 0; a < 11; a++) {
             float Tc[11];
+            if (younger) { if ((FL_VIO_WIDE_PRIO_ROWS >> a) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #pragma unroll
             for (int b = 0; b < 11; b++) {
                 const unsigned dd = (b < 4) ? d[a].x : ((b < 8) ? d[a].y : d[a].z);
@@ -1060,7 +1070,8 @@ __global__ __launch_bounds__(FL_VIO_NT, WIDE ? 2 : 1) void vio_pass_kernel(const
     const int level = (level_arg >= 0) ? level_arg : D->level;
     if constexpr (WIDE) {
         unsigned long long *ew = D->err_words ? D->err_words + (size_t)(D->iters_run & 1) * D->err_cap : nullptr;
-        vio_produce_wide<NT>(img, ref, pos, slevel, errors, m, level, VC, D, nprod, s_red, epoch, records, ew, s_res);
+        vio_produce_wide<NT>(img, ref, pos, slevel, errors, m, level, VC, D, nprod, s_red, epoch, records, ew, s_res,
+                             (int)((unsigned)flags >> FL_VIO_WIDE_CUS_SHIFT));
     } else {
         // wave-uniform camera pose, derived from the state by the previous pass's solver (vio_derive_pose)
         const FlVioConst vc = *VC;
