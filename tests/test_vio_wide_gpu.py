@@ -1,13 +1,13 @@
 """GPU parity of the one-patch-per-lane VIO producers (csrc/vio_kernels.h vio_produce_wide, FL_OPT_VIO_WIDE).
 
 The at-scale form of the photometric pass gives every lane a patch of its own (shared taps and bilinear values, no cross-lane
-reductions); passes over >= 65 536 patches take it by themselves, FL_OPT_VIO_WIDE = 2 forces it at any size. The float part follows
+reductions); passes over >= 8 192 patches take it by themselves, FL_OPT_VIO_WIDE = 2 forces it at any size. The float part follows
 the reference's expressions and operand order (lidar_selection.cpp:826-829,837,849), so per-patch errors are compared BIT FOR BIT with
 the CPU oracle and with the 16-lanes-per-patch form; the fp64 sums differ in their order only (state delta 1e-9 like every fp64 sum).
 Covered: every pyramid level (the finest level takes the 16-byte row loads, the coarser ones and patches reaching over the image
 border the out-of-line byte path), ragged sizes (1, 63, 64, 65, 300, 2 000 patches: partial wavefronts, several workgroups), non-zero
 search levels, the distorting camera, a whole ComputeJ with accept / revert, the accumulate-only kernel of the sharded form, and the
-automatic switch at 65 536 patches (against the 16-lane form at the same size: the oracle would take minutes there).
+automatic switch at 8 192 patches (against the 16-lane form at the same size: the oracle would take minutes there).
 """
 import numpy as np
 import pytest
