@@ -827,7 +827,9 @@ __device__ __forceinline__ void vio_produce_wide(const uint8_t *__restrict__ img
             fl_patch_geom(vcl, Rcw, Pcw, ps, scale, g);
         }
         const bool inside = (g.v_i - 5 * scale >= 0) && (g.v_i + 5 * scale <= Hm1) && (g.u_i - 5 * scale >= 0) && (g.u_i + 5 * scale <= Wm1);
-        const bool fast = rows_dword_phase && (__ballot(inside && scale == 1) == ~0ull);
+        // (row loads need the whole wavefront inside the image and at ONE pyramid scale, 1, 2 or 4)
+        const int scale_u = __builtin_amdgcn_readfirstlane(scale);
+        const bool uniform = rows_dword_phase && (__ballot(inside && scale == scale_u) == ~0ull);
         // tap rows a = 0 .. 10 = image rows v_i + (a - 5) scale, tap columns b = 0 .. 10 = image columns u_i + (b - 5) scale: 11 bytes
         // per row, as three words
 #if defined(FL_INSTRUMENT) && defined(FL_WIDE_STAMPS)
@@ -835,7 +837,7 @@ __device__ __forceinline__ void vio_produce_wide(const uint8_t *__restrict__ img
 #endif
         FL_WSTAMP(sweep, 6);
         fl_u3 d[11];
-        if (fast) {
+        if (uniform && scale_u == 1) {
             const int off0 = (g.v_i - 5) * W + (g.u_i - 5);            // >= 0: the patch is inside the image
             const unsigned sh = (unsigned)off0 & 3u;                   // the same for every row: W % 4 == 0
             const int voff = off0 & ~3;
@@ -844,6 +846,55 @@ __device__ __forceinline__ void vio_produce_wide(const uint8_t *__restrict__ img
                 const fl_u4 rw = __builtin_bit_cast(fl_u4, __builtin_amdgcn_raw_buffer_load_b128(img_rs, voff, a * W, 0));
                 d[a].x = __builtin_amdgcn_alignbyte(rw.y, rw.x, sh); d[a].y = __builtin_amdgcn_alignbyte(rw.z, rw.y, sh);
                 d[a].z = __builtin_amdgcn_alignbyte(rw.w, rw.z, sh);
+            }
+        } else if (uniform && scale_u == 2) {
+            // tap scale 2 (level 1 of a ComputeJ): the 11 taps of a row are every other byte of a 21-byte span -- six dwords (16 + 8
+            // bytes), lined up, then the even bytes of each pair of dwords gathered into one (v_perm_b32): the same three words per row
+            const int off0 = (g.v_i - 10) * W + (g.u_i - 10);
+            const unsigned sh = (unsigned)off0 & 3u;
+            const int voff = off0 & ~3;
+#pragma unroll
+            for (int a = 0; a < 11; a++) {
+                const fl_u4 w4 = __builtin_bit_cast(fl_u4, __builtin_amdgcn_raw_buffer_load_b128(img_rs, voff, a * 2 * W, 0));
+                const fl_u2 w2 = __builtin_bit_cast(fl_u2, __builtin_amdgcn_raw_buffer_load_b64(img_rs, voff + 16, a * 2 * W, 0));
+                const unsigned e0 = __builtin_amdgcn_alignbyte(w4.y, w4.x, sh), e1 = __builtin_amdgcn_alignbyte(w4.z, w4.y, sh),
+                               e2 = __builtin_amdgcn_alignbyte(w4.w, w4.z, sh), e3 = __builtin_amdgcn_alignbyte(w2.x, w4.w, sh),
+                               e4 = __builtin_amdgcn_alignbyte(w2.y, w2.x, sh), e5 = __builtin_amdgcn_alignbyte(0u, w2.y, sh);
+                d[a].x = __builtin_amdgcn_perm(e1, e0, 0x06040200u); d[a].y = __builtin_amdgcn_perm(e3, e2, 0x06040200u);
+                d[a].z = __builtin_amdgcn_perm(e5, e4, 0x06040200u);
+            }
+        } else if (uniform && scale_u == 4) {
+            // tap scale 4 (level 2): tap b is byte `sh` of dword b of an 11-dword span (16 + 16 + 12 bytes) -- gathered straight out of the
+            // loaded dwords with per-lane selectors. Two batches of rows (6 + 5): all 121 dwords at once would not fit the registers.
+            const int off0 = (g.v_i - 20) * W + (g.u_i - 20);
+            const unsigned sh = (unsigned)off0 & 3u;
+            const int voff = off0 & ~3;
+            const unsigned sel2 = sh | ((4u + sh) << 8) | 0x0c0c0000u;       // [lo.b(sh), hi.b(sh), 0, 0]
+            const unsigned sel1 = sh | 0x0c0c0c00u;                          // [lo.b(sh), 0, 0, 0]
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                fl_u4 wa[6], wb[6];
+                fl_u3 wc[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    const int a = half * 6 + k;
+                    if (a < 11) {
+                        wa[k] = __builtin_bit_cast(fl_u4, __builtin_amdgcn_raw_buffer_load_b128(img_rs, voff, a * 4 * W, 0));
+                        wb[k] = __builtin_bit_cast(fl_u4, __builtin_amdgcn_raw_buffer_load_b128(img_rs, voff + 16, a * 4 * W, 0));
+                        wc[k] = __builtin_bit_cast(fl_u3, __builtin_amdgcn_raw_buffer_load_b96(img_rs, voff + 32, a * 4 * W, 0));
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    const int a = half * 6 + k;
+                    if (a < 11) {
+                        const unsigned p01 = __builtin_amdgcn_perm(wa[k].y, wa[k].x, sel2), p23 = __builtin_amdgcn_perm(wa[k].w, wa[k].z, sel2),
+                                       p45 = __builtin_amdgcn_perm(wb[k].y, wb[k].x, sel2), p67 = __builtin_amdgcn_perm(wb[k].w, wb[k].z, sel2),
+                                       p89 = __builtin_amdgcn_perm(wc[k].y, wc[k].x, sel2), pA = __builtin_amdgcn_perm(0u, wc[k].z, sel1);
+                        d[a].x = __builtin_amdgcn_perm(p23, p01, 0x05040100u); d[a].y = __builtin_amdgcn_perm(p67, p45, 0x05040100u);
+                        d[a].z = __builtin_amdgcn_perm(pA, p89, 0x0c040100u);
+                    }
+                }
             }
         } else {
 #pragma unroll

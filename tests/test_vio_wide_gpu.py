@@ -4,8 +4,8 @@ The at-scale form of the photometric pass gives every lane a patch of its own (s
 reductions); passes over >= 8 192 patches take it by themselves, FL_OPT_VIO_WIDE = 2 forces it at any size. The float part follows
 the reference's expressions and operand order (lidar_selection.cpp:826-829,837,849), so per-patch errors are compared BIT FOR BIT with
 the CPU oracle and with the 16-lanes-per-patch form; the fp64 sums differ in their order only (state delta 1e-9 like every fp64 sum).
-Covered: every pyramid level (the finest level takes the 16-byte row loads, the coarser ones and patches reaching over the image
-border the out-of-line byte path), ragged sizes (1, 63, 64, 65, 300, 2 000 patches: partial wavefronts, several workgroups), non-zero
+Covered: every pyramid level (tap scales 1, 2 and 4 each have row loads of their own; patches reaching over the image border, mixed
+search levels and an image width that is not a multiple of 4 take the out-of-line byte path), ragged sizes (1, 63, 64, 65, 300, 2 000 patches: partial wavefronts, several workgroups), non-zero
 search levels, the distorting camera, a whole ComputeJ with accept / revert, the accumulate-only kernel of the sharded form, and the
 automatic switch at 8 192 patches (against the 16-lane form at the same size: the oracle would take minutes there).
 """
@@ -176,10 +176,10 @@ def test_wide_is_automatic_at_scale(gpu_lib, scene):
     assert abs(out[1][0] - out[0][0]) <= 1e-6 * abs(out[0][0])
 
 
-def test_compute_j_at_scale_mixes_the_forms(gpu_lib, scene):
-    """ComputeJ over 70 000 patches with the default option: levels 2 and 1 run on the 16-lane producers (they have row loads for tap
-    scales 4 and 2), level 0 on the one-patch-per-lane ones -- other grids, the same record buffer. Against the 16-lane form throughout:
-    same pass and accept counts per level, per-patch errors bit for bit, state 1e-9."""
+def test_compute_j_at_scale_equals_the_16_lane_form(gpu_lib, scene):
+    """ComputeJ over 70 000 patches with the default option: all three levels (tap scales 4, 2, 1: each with its own row loads) run on the
+    one-patch-per-lane producers, one launch per pass. Against the 16-lane form throughout: same pass and accept counts per level,
+    per-patch errors bit for bit, state 1e-9."""
     capi = gpu_lib
     from fast_livo_amd import synth
     fr, vf = _frames(synth, scene, 2000)
