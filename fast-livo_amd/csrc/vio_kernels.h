@@ -683,15 +683,16 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
 
 // ---- the at-scale producer: ONE PATCH PER LANE (round 5) -----------------------------------------------------------------------
 // vio_produce gives a patch to the 16 lanes of a DPP row, which is what a 2 000-patch pass wants (125 workgroups with something to
-// do, one iteration each: the pass is a chain of hand-offs). A pass over 10^5 .. 10^6 patches is bound by instruction issue instead
-// (tools/vio_pmc.sh: 438 vector instructions per wavefront iteration = 110 per patch, 60 % VALU utilisation at two wavefronts per
-// SIMD), and most of those instructions exist only because a patch is spread over lanes:
+// do, one iteration each: the pass is a chain of hand-offs). A pass over 10^4 .. 10^6 patches has no such concern and pays for the
+// spreading (tools/vio_pmc.sh: 438 vector instructions per wavefront iteration = 110 per patch, 60 % VALU utilisation at two wavefronts
+// per SIMD); most of those instructions exist only because a patch is spread over lanes:
 //   * every pixel fetches and converts its own 12 taps and forms its own 5 bilinear values (centre, left, right, up, down): 768 tap
 //     conversions and 320 interpolations per patch, where the patch has 121 taps and 96 distinct bilinear values -- the value right
 //     of pixel (x, y) IS the centre value of pixel (x, y + 1), the same expression over the same operands, hence the same bits;
 //   * the six Gram sums cross the 16 lanes (72 DPP instructions per iteration), the 2x6 matrix M and the 29 outputs go through LDS,
 //     the per-patch float chain runs with a quarter of the lanes.
-// Here a lane walks its own patch: 11 tap rows of 11 bytes (one 16-byte load per row at the finest level), a rolling window of three
+// Here a lane walks its own patch: 11 tap rows of 11 bytes (tap scale 1: one 16-byte load per row; scales 2 and 4: 24 / 44 bytes per row
+// and a v_perm_b32 gather; all three end in the same three packed words per row), a rolling window of three
 // rows of bilinear values, pixels in the reference's order x * 8 + y -- so the float chain `patch_error += res * res` is simply the
 // lane's own running value --, the Gram sums in the lane's registers, M and the 29 outputs once per patch with all 64 lanes busy
 // (fl_patch_M / fl_patch_accum: the round-1 arithmetic). No cross-lane traffic until the record is reduced at the end of the pass.
@@ -699,9 +700,11 @@ __device__ __forceinline__ void vio_produce(const uint8_t *__restrict__ img, con
 // patches each, straight into LDS (global_load_lds_dwordx4: no staging registers) -- and read back by their lanes.
 // Float part: the reference's expressions and operand order (lidar_selection.cpp:826-829,837), no contraction: per-patch errors are
 // bit-identical to vio_produce's and to the oracle's. fp64 sums: other order than vio_produce, compared by tolerance like every sum.
-// One tap row of a patch that is not served by the row loads of the common case (coarser pyramid scale, a patch reaching over the
-// image border, a row stride that is not a multiple of 4): 11 bytes at column c0 + b * scale of image row `row`, packed like the
-// common case's aligned words. The reference reads unchecked; rows and columns are clamped instead of faulting (vio_produce does
+// (40.7 vector instructions per patch; the pass is then bound by its memory requests and by the slower of the two workgroups of a CU:
+// DESIGN.md 4.2.1.)
+// One tap row of a patch that is not served by the row loads (a wavefront whose patches are at different pyramid scales, a patch
+// reaching over the image border, a row stride that is not a multiple of 4): 11 bytes at column c0 + b * scale of image row `row`,
+// packed like the row loads' words. The reference reads unchecked; rows and columns are clamped instead of faulting (vio_produce does
 // the same). Out of line: 11 x 11 inlined copies of the clamped address arithmetic cost the common path its registers.
 typedef unsigned int fl_u3 __attribute__((ext_vector_type(3)));
 __device__ __attribute__((noinline)) fl_u3 vio_tap_row_bytes(const uint8_t *__restrict__ img, int W, int Hm1, int Wm1, int row, int c0, int scale)
