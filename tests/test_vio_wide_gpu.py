@@ -224,3 +224,34 @@ def test_image_width_not_a_multiple_of_four(gpu_lib, oracle_lib, scene, wide):
         assert_delta_close(np.array(info.solution)[:18], np.array(ro["out"].solution))
         assert np.abs(h.vio_get_state18().vec() - xo.vec()).max() <= 1e-9
         h.close()
+
+
+def test_mid_size_update_takes_the_wide_form_per_pass(gpu_lib, scene):
+    """10 000 patches, default option, a real update of several passes (fl_vio_update_state, up to 6): the wide form's grid (42 workgroups)
+    would pass the admission test of a multi-pass launch, but the multi-pass kernels only exist for the 16-lane producers -- the passes
+    must go out one by one on the wide producers (a 16-lane multi-pass kernel on 42 workgroups is correct and several times slower: the
+    last assertion). Against the 16-lane form (627 workgroups: one launch per pass as well): same counts, per-patch errors bit for bit."""
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    fr, vf = _frames(synth, scene, 2000)
+    m = 10000
+    reps = (m + vf.m - 1) // vf.m
+    ref = np.tile(vf.ref_patch, (reps, 1, 1))[:m]
+    pos = np.tile(vf.pos, (reps, 1))[:m]
+    sl = np.tile(vf.search_level, reps)[:m]
+    out = {}
+    for wide in (1, 0):
+        h = capi.Handle(capi.config_from_frames(fr, vf, max_iterations=6))
+        h.set_option(capi.FL_OPT_VIO_WIDE, wide)
+        h.set_timing(True)
+        h.vio_set_frame(vf.img)
+        h.vio_set_patches(ref, pos, sl)
+        xg = capi.state18_from_frame(fr)
+        h.vio_begin(xg, xg)
+        err, info = h.vio_update_state(1e10, 0)
+        out[wide] = (info.iterations, info.accepted, h.vio_get_errors(m), h.vio_get_state18().vec(), h.last_kernel_ms())
+        h.close()
+    assert out[1][0] == out[0][0] and out[1][1] == out[0][1]
+    assert np.array_equal(out[1][2], out[0][2])
+    assert np.abs(out[1][3] - out[0][3]).max() <= 1e-9
+    assert out[1][4] < 1.5 * out[0][4] + 0.05, (out[1][4], out[0][4])       # (a 16-lane multi-pass kernel on 42 workgroups would take several times longer)
