@@ -261,7 +261,7 @@ def section_vio_sweep(capi, synth, fr, vf, cfg, x0, distinct_cap=None):
     out = []
     for m in VIO_SWEEP:
         row = {"kernel": "vio_pass_kernel", "patches": m, "algorithmic_bytes": VIO_BYTES_PER_PATCH * m}
-        wide = m >= 8192                     # FL_OPT_VIO_WIDE (default 1): one patch per lane from 8 192 patches on (vio_produce_wide)
+        wide = m >= 16384                    # FL_OPT_VIO_WIDE (default 1): one patch per lane from 16 384 patches on (vio_produce_wide)
         row["producers"] = "one patch per lane (vio_pass_kernel<0, 1>)" if wide else "16 lanes per patch (vio_pass_kernel<0, 0>)"
         for kind in ("tiled", "distinct") + (("tiled_16lane",) if wide else ()):
             if kind == "distinct" and m <= vf.m:

@@ -189,7 +189,7 @@ int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out);
                                     * noise AND accepted by the fp64 test does not wait for the reference's float running sum (~6 us): it goes ahead
                                     * and the sum's verdict is applied a pass later, with a roll-back on the (rare) disagreement. 0: every such pass
                                     * waits (round 2-4). Accept / revert sequences, states and per-patch errors are bit-identical either way. */
-#define FL_OPT_VIO_WIDE 14         /* 1 (default): VIO passes over >= 8 192 patches (any pyramid level) run with ONE PATCH PER LANE (csrc/vio_kernels.h
+#define FL_OPT_VIO_WIDE 14         /* 1 (default): VIO passes over >= 16 384 patches (any pyramid level) run with ONE PATCH PER LANE (csrc/vio_kernels.h
                                     * vio_produce_wide: shared taps and bilinear values, no cross-lane reductions) instead of a patch per 16 lanes -- at
                                     * these sizes a pass is bound by instruction issue and memory requests, not by hand-offs. 2: every pass does, at
                                     * every level and size, one launch per pass (tests); 0: never. Per-patch errors are bit-identical either way, the

@@ -1,13 +1,13 @@
 """GPU parity of the one-patch-per-lane VIO producers (csrc/vio_kernels.h vio_produce_wide, FL_OPT_VIO_WIDE).
 
 The at-scale form of the photometric pass gives every lane a patch of its own (shared taps and bilinear values, no cross-lane
-reductions); passes over >= 8 192 patches take it by themselves, FL_OPT_VIO_WIDE = 2 forces it at any size. The float part follows
+reductions); passes over >= 16 384 patches take it by themselves, FL_OPT_VIO_WIDE = 2 forces it at any size. The float part follows
 the reference's expressions and operand order (lidar_selection.cpp:826-829,837,849), so per-patch errors are compared BIT FOR BIT with
 the CPU oracle and with the 16-lanes-per-patch form; the fp64 sums differ in their order only (state delta 1e-9 like every fp64 sum).
 Covered: every pyramid level (tap scales 1, 2 and 4 each have row loads of their own; patches reaching over the image border, mixed
 search levels and an image width that is not a multiple of 4 take the out-of-line byte path), ragged sizes (1, 63, 64, 65, 300, 2 000 patches: partial wavefronts, several workgroups), non-zero
 search levels, the distorting camera, a whole ComputeJ with accept / revert, the accumulate-only kernel of the sharded form, and the
-automatic switch at 8 192 patches (against the 16-lane form at the same size: the oracle would take minutes there).
+automatic switch at 16 384 patches (against the 16-lane form at the same size: the oracle would take minutes there).
 """
 import numpy as np
 import pytest
@@ -227,14 +227,14 @@ def test_image_width_not_a_multiple_of_four(gpu_lib, oracle_lib, scene, wide):
 
 
 def test_mid_size_update_takes_the_wide_form_per_pass(gpu_lib, scene):
-    """10 000 patches, default option, a real update of several passes (fl_vio_update_state, up to 6): the wide form's grid (42 workgroups)
+    """20 000 patches, default option, a real update of several passes (fl_vio_update_state, up to 6): the wide form's grid (81 workgroups)
     would pass the admission test of a multi-pass launch, but the multi-pass kernels only exist for the 16-lane producers -- the passes
     must go out one by one on the wide producers (a 16-lane multi-pass kernel on 42 workgroups is correct and several times slower: the
-    last assertion). Against the 16-lane form (627 workgroups: one launch per pass as well): same counts, per-patch errors bit for bit."""
+    last assertion). Against the 16-lane form (1 024 workgroups: one launch per pass as well): same counts, per-patch errors bit for bit."""
     capi = gpu_lib
     from fast_livo_amd import synth
     fr, vf = _frames(synth, scene, 2000)
-    m = 10000
+    m = 20000
     reps = (m + vf.m - 1) // vf.m
     ref = np.tile(vf.ref_patch, (reps, 1, 1))[:m]
     pos = np.tile(vf.pos, (reps, 1))[:m]
@@ -254,4 +254,4 @@ def test_mid_size_update_takes_the_wide_form_per_pass(gpu_lib, scene):
     assert out[1][0] == out[0][0] and out[1][1] == out[0][1]
     assert np.array_equal(out[1][2], out[0][2])
     assert np.abs(out[1][3] - out[0][3]).max() <= 1e-9
-    assert out[1][4] < 1.5 * out[0][4] + 0.05, (out[1][4], out[0][4])       # (a 16-lane multi-pass kernel on 42 workgroups would take several times longer)
+    assert out[1][4] < 1.5 * out[0][4] + 0.05, (out[1][4], out[0][4])       # (a 16-lane multi-pass kernel on 81 workgroups would take several times longer)
