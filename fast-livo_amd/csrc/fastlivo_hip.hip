@@ -1157,6 +1157,17 @@ int32_t fl_debug_drop_record(fl_handle h, int32_t passes_ahead)
     HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(g_fl_fault_epoch), &e, sizeof e));
     return FL_OK;
 }
+int32_t fl_debug_map_pool_limit(fl_handle h, int32_t spare_entries)
+{
+    if (!h || spare_entries < 0 || !h->d_mi_ctl) return fail_arg(h, "fl_debug_map_pool_limit: bad argument / no map index");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    FlMapIncCtl c;
+    HIPCHK(h, hipMemcpy(&c, h->d_mi_ctl, sizeof c, hipMemcpyDeviceToHost));
+    c.pool_cap = c.pool_top + (unsigned)spare_entries;
+    HIPCHK(h, hipMemcpy(h->d_mi_ctl, &c, sizeof c, hipMemcpyHostToDevice));
+    return FL_OK;
+}
 #endif   /* FL_INSTRUMENT */
 
 #include "api_vio.inc"

@@ -34,6 +34,10 @@ int32_t fl_debug_chain(fl_handle h, const float *e, int32_t n, float init, float
 /* Fault injection: producer workgroup 0 of the pass launched `passes_ahead` passes from now (0 = the next one) does not publish its
  * record, so that pass's bounded gather expires and the pass is ABANDONED (FL_NUM_TIMEOUT): exercises the resume paths. */
 int32_t fl_debug_drop_record(fl_handle h, int32_t passes_ahead);
+/* Leaves the in-place map index `spare_entries` pool entries (device-side control block only: the host's pre-check of the next
+ * update keeps seeing the old size), so that update runs out of pool, drops its queued points from the index and raises
+ * needs_rebuild -- the path every search must notice before it reads the index (tests/test_map_gpu.py). */
+int32_t fl_debug_map_pool_limit(fl_handle h, int32_t spare_entries);
 
 #ifdef __cplusplus
 }

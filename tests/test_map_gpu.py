@@ -324,3 +324,29 @@ def test_many_in_place_updates_run_into_the_full_rebuild(gpu_lib, oracle_lib, sc
             assert np.array_equal(valid_g, valid_o) and np.array_equal(nbr_g[ok], nbr_o[ok]), f"update {k}"
     assert np.array_equal(h.map_get_points(), cur)
     h.close()
+
+
+def test_search_after_an_update_that_ran_out_of_pool_sees_every_point(gpu_lib, oracle_lib, scene):
+    """an in-place update that runs out of pool room drops its queued points from the INDEX and raises needs_rebuild; the
+    next search must read that status (map_index_ready) and re-index first. The pool is starved through the debug library's
+    fl_debug_map_pool_limit (device-side only, so the host's pre-check does not see it coming); no fl_map_* call between the update
+    and the search."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    rng = np.random.default_rng(91)
+    fr = synth.make_lio_frame(2000, scene=scene)
+    h = capi.Handle(capi.config_from_frames(fr, max_iterations=10), debug=True)
+    cur = scene.map_xyz[rng.choice(len(scene.map_xyz), 20000, replace=False)].copy()
+    h.map_set_points(cur, 0.5)
+    h.debug_map_pool_limit(16)
+    # dense: many points per touched cell, so cells outgrow their slack and want to move to the (exhausted) pool top
+    world0 = fr.world_at(fr.R_prior, fr.p_prior).astype(np.float32)
+    new = (world0[rng.integers(0, len(world0), 8000)] + rng.normal(0, 0.01, (8000, 3))).astype(np.float32)
+    h.map_add_points(new, 0.0, want_info=False)
+    cur, _ = orc.map_add_points(cur, new, 0.0)
+    nbr_g, valid_g, world = _search(h, capi, fr)
+    nbr_o, _, valid_o, _ = orc.knn5_bruteforce(cur, world)
+    ok = valid_o != 0
+    assert np.array_equal(valid_g, valid_o) and np.array_equal(nbr_g[ok], nbr_o[ok])
+    assert np.array_equal(h.map_get_points(), cur)
+    h.close()

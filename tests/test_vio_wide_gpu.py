@@ -7,8 +7,11 @@ the CPU oracle and with the 16-lanes-per-patch form; the fp64 sums differ in the
 Covered: every pyramid level (tap scales 1, 2 and 4 each have row loads of their own; patches reaching over the image border, mixed
 search levels and an image width that is not a multiple of 4 take the out-of-line byte path), ragged sizes (1, 63, 64, 65, 300, 2 000 patches: partial wavefronts, several workgroups), non-zero
 search levels, the distorting camera, a whole ComputeJ with accept / revert, the accumulate-only kernel of the sharded form, and the
-automatic switch at 16 384 patches (against the 16-lane form at the same size: the oracle would take minutes there).
+automatic switch at 16 384 patches -- against the 16-lane form at the same size AND against the CPU oracle (orc_vio_set_threads: its
+patch loop spread over the host's cores, bit-identical by construction) at 16 384 and 70 000 DISTINCT patches, default option, every
+level, plus a whole ComputeJ with its accept / revert decisions.
 """
+import os
 import numpy as np
 import pytest
 
@@ -255,3 +258,71 @@ def test_mid_size_update_takes_the_wide_form_per_pass(gpu_lib, scene):
     assert np.array_equal(out[1][2], out[0][2])
     assert np.abs(out[1][3] - out[0][3]).max() <= 1e-9
     assert out[1][4] < 1.5 * out[0][4] + 0.05, (out[1][4], out[0][4])       # (a 16-lane multi-pass kernel on 81 workgroups would take several times longer)
+
+
+def _oracle_threads(orc):
+    n = min(os.cpu_count() or 1, 64)
+    orc.lib().orc_vio_set_threads(n)
+    return n
+
+
+@pytest.mark.parametrize("m,level", [(16384, 0), (16384, 1), (16384, 2), (70000, 0), (70000, 1), (70000, 2), (16385, 0), (33000, 2)])
+def test_auto_wide_pass_matches_oracle_at_scale(gpu_lib, oracle_lib, scene, m, level):
+    """the sizes at which the wide producers switch on BY THEMSELVES (FL_OPT_VIO_WIDE left at its default 1: auto-switch
+    at 16 384 patches, >= 2 sweeps per wavefront at 70 000, priority hint live), m DISTINCT patch positions (not the 2 000-set tiled),
+    against the CPU oracle: per-patch errors bit for bit (lidar_selection.cpp:826-829,837,849-861), measurement count, accept decision,
+    state and solution to 1e-9. 16 385 / 33 000: a ragged last wavefront behind full sweeps."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    fr, vf = _frames(synth, scene, m)
+    assert len(np.unique(vf.pos, axis=0)) == m
+    vf.max_iterations = 1
+    _oracle_threads(orc)
+    try:
+        xo = orc.state18_from_frame(fr)
+        ro = orc.vio_update_state(vf, xo, xo.copy(), 1e10, level)
+    finally:
+        orc.lib().orc_vio_set_threads(1)
+    h = capi.Handle(capi.config_from_frames(fr, vf, max_iterations=1))        # (no set_option: the default takes the wide form from 16 384 patches on)
+    h.vio_set_frame(vf.img)
+    h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+    xg = capi.state18_from_frame(fr)
+    h.vio_begin(xg, xg)
+    err, info = h.vio_update_state(1e10, level)
+    assert info.iterations == ro["out"].iterations == 1 and info.accepted == ro["out"].accepted == 1
+    assert info.effct_feat_num == ro["out"].n_meas == 64 * m
+    assert abs(err - ro["error"]) <= 1e-5 * ro["error"]
+    assert np.array_equal(h.vio_get_errors(m), ro["errors"])
+    assert_delta_close(np.array(info.solution)[:18], np.array(ro["out"].solution))
+    assert np.abs(h.vio_get_state18().vec() - xo.vec()).max() <= 1e-9
+    h.close()
+
+
+@pytest.mark.parametrize("m,max_iter", [(16384, 5), (70000, 3)])
+def test_auto_wide_compute_j_matches_oracle_at_scale(gpu_lib, oracle_lib, scene, m, max_iter):
+    """The same sizes through a whole ComputeJ (levels 2, 1, 0; one launch per pass on the wide producers; the reference's float running
+    sum over all patches decides accept / revert, lidar_selection.cpp:849-861,888-892): per-level pass and accept counts equal the
+    oracle's, per-patch errors bit for bit, state 1e-9, covariance 1e-12."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    fr, vf = _frames(synth, scene, m)
+    vf.max_iterations = max_iter
+    _oracle_threads(orc)
+    try:
+        xo = orc.state18_from_frame(fr)
+        ro = orc.vio_compute_j(vf, xo, xo.copy())
+    finally:
+        orc.lib().orc_vio_set_threads(1)
+    h = capi.Handle(capi.config_from_frames(fr, vf, max_iterations=max_iter))
+    h.vio_set_frame(vf.img)
+    h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+    xg = capi.state18_from_frame(fr)
+    infos = h.vio_compute_j(xg, xg.copy())
+    for lv in (2, 1, 0):
+        assert infos[lv].iterations == ro["outs"][lv].iterations, lv
+        assert infos[lv].accepted == ro["outs"][lv].accepted, lv
+        assert abs(infos[lv].total_residual - ro["outs"][lv].error) <= 1e-5 * ro["outs"][lv].error
+    assert np.array_equal(h.vio_get_errors(m), ro["errors"])
+    assert np.abs(xg.vec() - xo.vec()).max() <= 1e-9
+    assert np.abs(xg.cov_np() - xo.cov_np()).max() <= 1e-12
+    h.close()
