@@ -260,6 +260,7 @@ DEBUG_SYMBOLS = {
 }
 FL_OPT_MULTIPASS, FL_OPT_MAX_PRODUCERS, FL_OPT_IK_PRODUCERS, FL_OPT_MP_CAPACITY, FL_OPT_VIO_WHOLE_CU, FL_OPT_MAILBOX, FL_OPT_SCAN_PULL, FL_OPT_INCR_SEARCH = 1, 2, 3, 4, 5, 6, 7, 8
 FL_OPT_DEMOTE_AFTER, FL_OPT_DEMOTE_CALLS, FL_OPT_VOXEL_SORT, FL_OPT_MAP_INCREMENTAL, FL_OPT_VIO_SPECULATE, FL_OPT_VIO_WIDE = 9, 10, 11, 12, 13, 14
+FL_OPT_DETECT_FUSED = 15
 DEBUG_LIB_PATH = os.path.join(PKG_DIR, "libfastlivo_hip_debug.so")
 
 _lib = None

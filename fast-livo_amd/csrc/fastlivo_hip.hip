@@ -161,6 +161,9 @@ struct fl_context {
     int opt_map_incr = 1;                  // FL_OPT_MAP_INCREMENTAL
     int opt_vio_spec = 1;                  // FL_OPT_VIO_SPECULATE
     int opt_vio_wide = 1;                  // FL_OPT_VIO_WIDE
+    int opt_detect_fused = 1;              // FL_OPT_DETECT_FUSED
+    struct FlDetectParams *d_det_prm = nullptr;    // fl_vio_detect, fused form (api_vmap.inc)
+    unsigned *d_det_ticket = nullptr;
     size_t map_pool_cap = 0;               // float4 entries of d_map_pts
     bool map_cell_auto = false;            // cell size follows the map's density (cell_size <= 0 at fl_map_set_points / fl_map_clear)
     unsigned *d_map_occ = nullptr, *h_map_occ = nullptr;    // occupied slots among the sampled ones (device counter, pinned copy)
@@ -542,6 +545,7 @@ int32_t fl_set_option(fl_handle h, int32_t option, int32_t value)
     case FL_OPT_VOXEL_SORT: h->opt_voxel_sort = value != 0; break;
     case FL_OPT_MAP_INCREMENTAL: h->opt_map_incr = value != 0; break;
     case FL_OPT_VIO_SPECULATE: h->opt_vio_spec = value != 0; break;
+    case FL_OPT_DETECT_FUSED: h->opt_detect_fused = value != 0; break;
     case FL_OPT_VIO_WIDE:
         if (value < 0 || value > 2) return fail_arg(h, "fl_set_option: FL_OPT_VIO_WIDE out of range");
         if (value != h->opt_vio_wide)         // another grid for the same patches: stale records must not carry a live tag

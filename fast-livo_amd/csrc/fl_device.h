@@ -79,10 +79,16 @@ struct FlDev18 {
     unsigned long long pub_seq;
     // fl_lidar_front (round 5): the scan's size is decided on the device (the voxel filter's count); the first search of the frame
     // leaves it here for the host (0: the host knew it)
-    int32_t n_scan, n_scan_pad;
+    int32_t n_scan;
+    // fl_vio_detect, fused form (api_vmap.inc): the number of selected patches is decided on the device (the selection's last kernel
+    // writes it here); vio_multipass_kernel launched with FL_VIO_M_DEV sizes its passes from it instead of from its argument
+    int32_t m_dev;
 };
 
 // What fl_lidar_front's kernels leave for the host in the tail behind FlDev18 (FL_DEV18_TAIL bytes, travels with the result mailbox)
+// ... and what fl_vio_detect's fused form leaves there BEHIND the three FlVioLevelInfo of ComputeJ (offset FL_DETECT_TAIL_OFF)
+struct FlDetectTail { int32_t n_cand, n_selected, n_added, n_observed; };
+#define FL_DETECT_TAIL_OFF 512
 struct FlFrontTail {
     double acc_s_last[3], angvel_last[3];      // ImuProcess members the next frame starts from (IMU_Processing.cpp:731-732)
     int32_t n_poses;
@@ -207,7 +213,7 @@ __device__ __forceinline__ void fl_wait_own_stores()
 }
 
 #define FL_MAX_BLOCKS 1024                 /* largest pass grid (records buffer; fastlivo_hip.hip repeats the definition) */
-#define FL_DEV18_TAIL 512                  /* bytes behind FlDev18 in its device and pinned-host allocations (fastlivo_hip.hip) */
+#define FL_DEV18_TAIL 576                  /* bytes behind FlDev18 in its device and pinned-host allocations (fastlivo_hip.hip) */
 
 // The result mailbox (FlDev18::pub_flag): called by ALL threads of ONE workgroup as the last action of a frame's last kernel. The
 // block was last written by this workgroup or by earlier kernels; it travels as 8-byte words over the host link (~7 KB: well under a

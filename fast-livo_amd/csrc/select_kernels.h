@@ -28,11 +28,10 @@ struct FlSelectParams {
     int32_t ncc_en, m;
 };
 
-__global__ __launch_bounds__(FL_BLOCK) void vio_depth_kernel(const float *__restrict__ scan, int n, const FlSelectParams *__restrict__ S,
-                                                            const FlVioConst *__restrict__ VC, unsigned long long *__restrict__ depth64)
+// one scan point of the depth image (:393-409)
+__device__ __forceinline__ void fl_depth_point(const float *__restrict__ scan, int i, const FlSelectParams *__restrict__ S,
+                                               const FlVioConst *__restrict__ VC, unsigned long long *__restrict__ depth64)
 {
-    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
-    if (i >= n) return;
     const double pw[3] = {(double)scan[3 * i], (double)scan[3 * i + 1], (double)scan[3 * i + 2]};
     double pc[3];
     pc[0] = (S->Rcw[0] * pw[0] + S->Rcw[1] * pw[1] + S->Rcw[2] * pw[2]) + S->Pcw[0];
@@ -44,6 +43,13 @@ __global__ __launch_bounds__(FL_BLOCK) void vio_depth_kernel(const float *__rest
     if (!(u >= b && u < W - b && v >= b && v < H - b)) return;
     const unsigned long long key = ((unsigned long long)(unsigned)i << 32) | (unsigned long long)__float_as_uint((float)pc[2]);
     atomicMax(&depth64[(size_t)W * v + u], key);
+}
+__global__ __launch_bounds__(FL_BLOCK) void vio_depth_kernel(const float *__restrict__ scan, int n, const FlSelectParams *__restrict__ S,
+                                                            const FlVioConst *__restrict__ VC, unsigned long long *__restrict__ depth64)
+{
+    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fl_depth_point(scan, i, S, VC, depth64);
 }
 
 // vk::PinholeCamera::cam2world; with distortion = cv::undistortPoints' five fixed-point sweeps on a float pixel (oracle/orc_vio.c)
@@ -273,6 +279,39 @@ __global__ __launch_bounds__(64) void vio_select_scatter_kernel(const FlPatchCan
     if (lane == 3) { d_slevel[s] = slevel[ci]; acc_slevel[s] = slevel[ci]; }
     if (lane == 4) { d_errors[s] = errors[ci]; acc_errors[s] = errors[ci]; }
     if (lane == 5) accepted_idx[s] = ci;
+}
+
+// fl_vio_detect's fused form: vio_select_compact_kernel + vio_select_scatter_kernel (+ vmap_selected_kernel) in one launch sized for an
+// UPPER BOUND of the candidate count (one per grid cell): the count is S->m, written by the kernel that formed the candidates. One
+// wavefront per candidate; its slot = the number of accepted candidates in front of it (a ballot walk over reason[0 .. ci): at most
+// cells / 64 trips), so the patch tensor comes out in ascending candidate order as after the scan (:572-579). The wavefront of the
+// last candidate also leaves the number of accepted patches for the host (count_out) and for ComputeJ's launches (FlDev18::m_dev).
+__global__ __launch_bounds__(64) void vio_select_finish_kernel(const FlPatchCandidate *__restrict__ cand, const FlSelectParams *__restrict__ S,
+                                                              const int32_t *__restrict__ reason, const float *__restrict__ patches,
+                                                              const float *__restrict__ errors, const int32_t *__restrict__ slevel,
+                                                              float *__restrict__ d_ref, double *__restrict__ d_pos, int32_t *__restrict__ d_slevel,
+                                                              float *__restrict__ d_errors, int32_t *__restrict__ accepted_idx,
+                                                              float *__restrict__ acc_errors, int32_t *__restrict__ acc_slevel,
+                                                              int32_t *__restrict__ sel_point, int32_t *__restrict__ count_out, FlDev18 *__restrict__ D)
+{
+    const int ci = blockIdx.x, lane = (int)threadIdx.x;
+    const int m = S->m;
+    if (ci >= m) return;
+    int s = 0;
+    for (int i0 = 0; i0 < ci; i0 += 64) {
+        const int i = i0 + lane;
+        s += (int)__popcll(__ballot(i < ci && reason[i] == 0));
+    }
+    const bool acc = reason[ci] == 0;
+    if (ci == m - 1 && lane == 0) { *count_out = s + (acc ? 1 : 0); D->m_dev = s + (acc ? 1 : 0); }
+    if (!acc) return;
+#pragma unroll
+    for (int k = 0; k < 3; k++) d_ref[(size_t)s * 192 + 64 * k + lane] = patches[(size_t)ci * 192 + 64 * k + lane];
+    if (lane < 3) d_pos[(size_t)s * 3 + lane] = cand[ci].pos[lane];
+    if (lane == 3) { d_slevel[s] = slevel[ci]; acc_slevel[s] = slevel[ci]; }
+    if (lane == 4) { d_errors[s] = errors[ci]; acc_errors[s] = errors[ci]; }
+    if (lane == 5) accepted_idx[s] = ci;
+    if (lane == 6) sel_point[s] = cand[ci].reserved;          // sub_sparse_map->voxel_points as indices into the map (vmap_selected_kernel)
 }
 
 

@@ -1207,6 +1207,10 @@ __device__ __forceinline__ void vio_cov_update_body(FlDev18 *__restrict__ D)
 // (out of line: its registers and LDS addressing stay out of the pass loop's allocation, as eskf18_cov_outofline for the LIO kernel)
 __device__ __attribute__((noinline)) void vio_cov_outofline(FlDev18 *D) { vio_cov_update_body(D); }
 #define FL_VIO_DO_COV 0x200            /* launch flag (internal): the LAST level launch of fl_vio_compute_j ends with the covariance update */
+#define FL_VIO_M_DEV 0x400             /* launch flag (internal, fl_vio_detect's fused form): the patch count is FlDev18::m_dev -- the launch's grid
+                                          is sized for an upper bound, the kernel uses the workgroups api_vio.inc's vio_grid() would have launched
+                                          for the real count (same partition, same record order, same bits), the others leave at once; no
+                                          patches: no passes (ComputeJ returns at once then, lidar_selection.cpp:969) */
 
 // Up to `count` passes of one pyramid level in ONE launch (see lio18_multipass_kernel): the solver broadcasts the derived camera
 // pose (Rcw, Pcw: what the producers consume) and the stop bit; a rejected solve (error went up, lidar_selection.cpp:888-892)
@@ -1231,7 +1235,15 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
     // needs one launch per level instead of three.
     constexpr int NT = FL_VIO_NT;
     constexpr int WPB = NT / 64;
-    const int nprod = gridDim.x - 2;              // then the solver and the auditor (FL_VIO_SOLVER_BLOCK / FL_VIO_AUDITOR_BLOCK)
+    int nprod = gridDim.x - 2;                    // then the solver and the auditor (FL_VIO_SOLVER_BLOCK / FL_VIO_AUDITOR_BLOCK)
+    if (flags & FL_VIO_M_DEV) {                   // (uniform over the grid)
+        m = D->m_dev;
+        int want = (m + FL_VIO_GPW * WPB - 1) / (FL_VIO_GPW * WPB);
+        want = want < 1 ? 1 : want;
+        nprod = want < nprod ? want : nprod;
+        if ((int)blockIdx.x >= nprod + 2) return;
+        if (m <= 0) count = 0;
+    }
     const int solver_block = FL_VIO_SOLVER_BLOCK(nprod), auditor_block = FL_VIO_AUDITOR_BLOCK(nprod);
     const bool force = (flags & FL_ITER_FORCE) != 0;
     const bool begin = begin_residual >= 0.f;

@@ -67,10 +67,9 @@ __device__ __forceinline__ void fl_frame_pos(const double *R, const double *t, d
 }
 
 // ---- fl_vmap_select ----------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(FL_BLOCK) void vmap_subkeys_kernel(const float *__restrict__ scan, int n, unsigned long long *__restrict__ set, unsigned mask)
+// one scan point's voxel key into the set of voxels the scan touches (sub_feat_map, :383-391)
+__device__ __forceinline__ void fl_subkey_point(const float *__restrict__ scan, int i, unsigned long long *__restrict__ set, unsigned mask)
 {
-    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
-    if (i >= n) return;
     const int kx = (int)floor((double)scan[3 * i] / (double)0.5f), ky = (int)floor((double)scan[3 * i + 1] / (double)0.5f),
               kz = (int)floor((double)scan[3 * i + 2] / (double)0.5f);                       // :387-389
     const unsigned long long key = fl_cell_key(kx, ky, kz);
@@ -80,6 +79,12 @@ __global__ __launch_bounds__(FL_BLOCK) void vmap_subkeys_kernel(const float *__r
         if (prev == FL_KNN_EMPTY || prev == key) break;
         h = (h + 1) & mask;
     }
+}
+__global__ __launch_bounds__(FL_BLOCK) void vmap_subkeys_kernel(const float *__restrict__ scan, int n, unsigned long long *__restrict__ set, unsigned mask)
+{
+    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fl_subkey_point(scan, i, set, mask);
 }
 
 __global__ __launch_bounds__(FL_BLOCK) void vmap_project_kernel(const FlVPoint *__restrict__ pts, const FlVmapParams *__restrict__ G,
@@ -141,7 +146,8 @@ __device__ __forceinline__ int fl_close_view_obs(const FlVPoint *P, const double
 #define FL_VMAP_WG 256
 __global__ __launch_bounds__(FL_VMAP_WG) void vmap_candidates_kernel(const FlVPoint *__restrict__ pts, const FlVmapParams *__restrict__ G,
                                                                     const unsigned long long *__restrict__ key, const int32_t *__restrict__ gnum,
-                                                                    FlPatchCandidate *__restrict__ cand, FlVmapCount *__restrict__ cnt)
+                                                                    FlPatchCandidate *__restrict__ cand, FlVmapCount *__restrict__ cnt,
+                                                                    int32_t *__restrict__ sel_m /* nullable; fused detect: FlSelectParams::m */)
 {
     __shared__ int s_scan[FL_VMAP_WG];
     __shared__ int s_base;
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(FL_VMAP_WG) void vmap_candidates_kernel(const FlVPo
         if (t == FL_VMAP_WG - 1) s_base = base + s_scan[t];
         __syncthreads();
     }
-    if (t == 0) cnt->cand = s_base;
+    if (t == 0) { cnt->cand = s_base; if (sel_m) *sel_m = s_base; }
 }
 
 // sub_sparse_map->voxel_points of the accepted candidates, as indices into the map
@@ -275,6 +281,61 @@ __global__ __launch_bounds__(FL_VMAP_WG) void vmap_commit_kernel(const float *__
 }
 
 // ---- fl_vmap_add_observation -------------------------------------------------------------------------------------------------
+// one selected map point of addObservation; pose (Rcw, Pcw, fpos) = the frame's after ComputeJ. Returns 1 if an observation was added.
+__device__ __forceinline__ int fl_addobs_point(FlVPoint *__restrict__ P, const double *__restrict__ Rcw, const double *__restrict__ Pcw,
+                                               const double *__restrict__ fpos, int kf_id, int frame_id, const FlVioConst *__restrict__ VC,
+                                               const uint8_t *__restrict__ img, int level)
+{
+    int added = 0;
+    const double p[3] = {P->pos[0], P->pos[1], P->pos[2]};
+    double pc3[3], pc[2];
+    fl_se3_apply(Rcw, Pcw, p, pc3);
+    fl_world2cam(*VC, pc3, pc);
+    const FlVObs *last = &P->obs[P->n_obs - 1];                     // obs_.back(): the oldest
+    double Rd[9], td[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++)
+            Rd[a * 3 + b] = last->R[a * 3] * Rcw[b * 3] + last->R[a * 3 + 1] * Rcw[b * 3 + 1] + last->R[a * 3 + 2] * Rcw[b * 3 + 2];
+#pragma unroll
+    for (int a = 0; a < 3; a++) td[a] = last->t[a] - (Rd[a * 3] * Pcw[0] + Rd[a * 3 + 1] * Pcw[1] + Rd[a * 3 + 2] * Pcw[2]);
+    const double delta_p = sqrt(td[0] * td[0] + td[1] * td[1] + td[2] * td[2]);
+    const double tr = Rd[0] + Rd[4] + Rd[8];
+    const double delta_theta = (tr > 3.0 - 1e-6) ? 0.0 : acos(0.5 * (tr - 1));
+    bool add_flag = (delta_p > 0.5 || delta_theta > 10);           // :939
+    const double e0 = pc[0] - last->px[0], e1 = pc[1] - last->px[1];
+    if (sqrt(e0 * e0 + e1 * e1) > 40) add_flag = true;              // :942-944
+    int n = P->n_obs;
+    if (n >= 20) {                                                  // getFurthestViewObs + deleteFeatureRef
+        int far = 0;
+        double maxdist = 0.0;
+        for (int k = 0; k < n; k++) {
+            double c[3];
+            fl_frame_pos(P->obs[k].R, P->obs[k].t, c);
+            const double d0 = c[0] - fpos[0], d1 = c[1] - fpos[1], d2 = c[2] - fpos[2];
+            const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+            if (dist > maxdist) { maxdist = dist; far = k; }
+        }
+        for (int k = far; k + 1 < n; k++) P->obs[k] = P->obs[k + 1];
+        n--;
+    }
+    if (add_flag) {
+        const float score = fl_shi_tomasi(img, VC->width, VC->height, (int)pc[0], (int)pc[1]);
+        P->value = score;
+        for (int k = n; k > 0; k--) P->obs[k] = P->obs[k - 1];      // push_front
+        FlVObs *o = &P->obs[0];
+        o->px[0] = pc[0]; o->px[1] = pc[1];
+        fl_cam2world(*VC, pc[0], pc[1], o->f);
+        for (int k = 0; k < 9; k++) o->R[k] = Rcw[k];
+        for (int k = 0; k < 3; k++) o->t[k] = Pcw[k];
+        o->score = score; o->level = level; o->kf_id = kf_id; o->frame_id = frame_id;
+        n++;
+        added = 1;
+    }
+    P->n_obs = n;
+    return added;
+}
 __global__ __launch_bounds__(FL_BLOCK) void vmap_addobs_kernel(FlVPoint *__restrict__ pts, const FlVmapParams *__restrict__ G,
                                                               const FlVioConst *__restrict__ VC, const uint8_t *__restrict__ img,
                                                               const int32_t *__restrict__ sel_point, const int32_t *__restrict__ levels, int n_sel,
@@ -282,58 +343,117 @@ __global__ __launch_bounds__(FL_BLOCK) void vmap_addobs_kernel(FlVPoint *__restr
 {
     const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
     int added = 0;
-    if (i < n_sel) {
-        FlVPoint *P = pts + sel_point[i];
-        const double p[3] = {P->pos[0], P->pos[1], P->pos[2]};
-        double pc3[3], pc[2];
-        fl_se3_apply(G->Rcw, G->Pcw, p, pc3);
-        fl_world2cam(*VC, pc3, pc);
-        const FlVObs *last = &P->obs[P->n_obs - 1];                     // obs_.back(): the oldest
-        double Rd[9], td[3];
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++)
-                Rd[a * 3 + b] = last->R[a * 3] * G->Rcw[b * 3] + last->R[a * 3 + 1] * G->Rcw[b * 3 + 1] + last->R[a * 3 + 2] * G->Rcw[b * 3 + 2];
-#pragma unroll
-        for (int a = 0; a < 3; a++) td[a] = last->t[a] - (Rd[a * 3] * G->Pcw[0] + Rd[a * 3 + 1] * G->Pcw[1] + Rd[a * 3 + 2] * G->Pcw[2]);
-        const double delta_p = sqrt(td[0] * td[0] + td[1] * td[1] + td[2] * td[2]);
-        const double tr = Rd[0] + Rd[4] + Rd[8];
-        const double delta_theta = (tr > 3.0 - 1e-6) ? 0.0 : acos(0.5 * (tr - 1));
-        bool add_flag = (delta_p > 0.5 || delta_theta > 10);           // :939
-        const double e0 = pc[0] - last->px[0], e1 = pc[1] - last->px[1];
-        if (sqrt(e0 * e0 + e1 * e1) > 40) add_flag = true;              // :942-944
-        int n = P->n_obs;
-        if (n >= 20) {                                                  // getFurthestViewObs + deleteFeatureRef
-            int far = 0;
-            double maxdist = 0.0;
-            for (int k = 0; k < n; k++) {
-                double c[3];
-                fl_frame_pos(P->obs[k].R, P->obs[k].t, c);
-                const double d0 = c[0] - G->fpos[0], d1 = c[1] - G->fpos[1], d2 = c[2] - G->fpos[2];
-                const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-                if (dist > maxdist) { maxdist = dist; far = k; }
-            }
-            for (int k = far; k + 1 < n; k++) P->obs[k] = P->obs[k + 1];
-            n--;
-        }
-        if (add_flag) {
-            const float score = fl_shi_tomasi(img, VC->width, VC->height, (int)pc[0], (int)pc[1]);
-            P->value = score;
-            for (int k = n; k > 0; k--) P->obs[k] = P->obs[k - 1];      // push_front
-            FlVObs *o = &P->obs[0];
-            o->px[0] = pc[0]; o->px[1] = pc[1];
-            fl_cam2world(*VC, pc[0], pc[1], o->f);
-            for (int k = 0; k < 9; k++) o->R[k] = G->Rcw[k];
-            for (int k = 0; k < 3; k++) o->t[k] = G->Pcw[k];
-            o->score = score; o->level = levels[i]; o->kf_id = G->kf_id; o->frame_id = G->frame_id;
-            n++;
-            added = 1;
-        }
-        P->n_obs = n;
-    }
+    if (i < n_sel) added = fl_addobs_point(pts + sel_point[i], G->Rcw, G->Pcw, G->fpos, G->kf_id, G->frame_id, VC, img, levels[i]);
     const unsigned long long b = __ballot(added != 0);
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(&cnt->obs_added, (int)__popcll(b));
+}
+
+// ---- fl_vio_detect, fused form (api_vmap.inc): LidarSelector::detect (:1027-1076) as ONE enqueue ---------------------------------
+// Nothing returns to the host between the frame's first copy command and its result mailbox: the candidate count, the number of
+// accepted patches (ComputeJ's size) and the counts of founded / observed points stay on the device; launches that depend on them are
+// sized for their upper bound (one candidate per grid cell) and read the real count from memory.
+struct FlDetectParams {             // one small upload per frame
+    FlVmapParams vm;                // pose at the call: addFromSparseMap + addSparseMap (updateFrameState at :1039)
+    FlSelectParams sel;             // the same pose + the gates; m is written by vmap_candidates_kernel
+    double Rci[9], Pci[3];          // camera <- IMU: the pose after ComputeJ is derived on the device (updateFrameState, :904-911)
+};
+
+// every clear of the frame in one launch (they were 4 fills + vio_grid_init_kernel) + the keyframe copy of the staged image + the keyframe
+// table entry + the record slots of ComputeJ's launches (sized for the upper bound; what a launch does not rewrite must carry no tag)
+__global__ __launch_bounds__(FL_BLOCK) void vmap_frame_init_kernel(unsigned long long *__restrict__ depth64, int n_depth, unsigned long long *__restrict__ set,
+                                                                  int n_set, int *__restrict__ owner, int n_owner, unsigned long long *__restrict__ best,
+                                                                  unsigned long long *__restrict__ key, int *__restrict__ val, int32_t *__restrict__ gnum,
+                                                                  int length, unsigned long long *__restrict__ records, int n_rec_words,
+                                                                  const uint4 *__restrict__ img, uint4 *__restrict__ kf_img, int n_img16,
+                                                                  const uint8_t **__restrict__ kf_table, int kf_id, FlVmapCount *__restrict__ cnt,
+                                                                  int32_t *__restrict__ sel_count, unsigned *__restrict__ ticket)
+{
+    const int t = blockIdx.x * FL_BLOCK + threadIdx.x, nt = gridDim.x * FL_BLOCK;
+    for (int i = t; i < n_depth; i += nt) depth64[i] = 0ull;
+    for (int i = t; i < n_set; i += nt) set[i] = FL_KNN_EMPTY;
+    for (int i = t; i < n_owner; i += nt) owner[i] = 0x7F7F7F7F;                                   // "no owner yet" = a huge index
+    for (int i = t; i < length; i += nt) {
+        best[i] = 0ull;
+        key[i] = ((unsigned long long)__float_as_uint(10000.f) << 32) | 0xFFFFFFFFull;             // reset_grid + map_value = 0 (:355-356)
+        val[i] = 0;
+        gnum[i] = 3;
+    }
+    for (int i = t; i < n_rec_words; i += nt) records[i] = 0ull;
+    for (int i = t; i < n_img16; i += nt) kf_img[i] = img[i];
+    if (t == 0) {
+        kf_table[kf_id] = reinterpret_cast<const uint8_t *>(kf_img);
+        cnt->cand = 0; cnt->added = 0; cnt->obs_added = 0;
+        *sel_count = 0;
+        *ticket = 0u;
+    }
+}
+
+// vio_depth_kernel + vmap_subkeys_kernel: one walk over the down-sampled scan
+__global__ __launch_bounds__(FL_BLOCK) void vmap_scan_kernel(const float *__restrict__ scan, int n, const FlSelectParams *__restrict__ S,
+                                                            const FlVioConst *__restrict__ VC, unsigned long long *__restrict__ depth64,
+                                                            unsigned long long *__restrict__ set, unsigned mask)
+{
+    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fl_depth_point(scan, i, S, VC, depth64);
+    fl_subkey_point(scan, i, set, mask);
+}
+
+// addObservation under the pose of the state ComputeJ left (derived here as the host's vmap_frame_pose derives it: Rcw = Rci R^T,
+// Pcw = -Rcw p + Pci, the same operations in the same order), sized for the upper bound of the selection; the workgroup that finishes
+// last writes the frame's counts behind the state block and serves the result mailbox.
+__global__ __launch_bounds__(FL_BLOCK) void vmap_addobs_dev_kernel(FlVPoint *__restrict__ pts, const FlDetectParams *__restrict__ P,
+                                                                  const FlVioConst *__restrict__ VC, const uint8_t *__restrict__ img,
+                                                                  const int32_t *__restrict__ sel_point, const int32_t *__restrict__ levels,
+                                                                  const int32_t *__restrict__ n_sel_ptr, FlVmapCount *__restrict__ cnt,
+                                                                  FlDev18 *__restrict__ D, unsigned *__restrict__ ticket,
+                                                                  unsigned long long *pub_flag, void *pub_dst, unsigned long long pub_seq)
+{
+    __shared__ double s_pose[15];            // Rcw, Pcw, fpos
+    __shared__ int s_last;
+    const int n_sel = *n_sel_ptr;
+    const bool abandoned = (D->status & FL_NUM_TIMEOUT) != 0;      // ComputeJ did not finish: the host resumes it and adds the observations then
+    if (threadIdx.x == 0) {
+        const double *rot = D->x, *pos = D->x + 9;
+        double Rcw[9], Pcw[3];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double a = 0.0;
+                for (int k = 0; k < 3; k++) a += P->Rci[i * 3 + k] * rot[j * 3 + k];
+                Rcw[i * 3 + j] = a;
+            }
+        for (int i = 0; i < 3; i++) {
+            double a = 0.0;
+            for (int k = 0; k < 3; k++) a += Rcw[i * 3 + k] * pos[k];
+            Pcw[i] = -a + P->Pci[i];
+        }
+        for (int i = 0; i < 9; i++) s_pose[i] = Rcw[i];
+        for (int i = 0; i < 3; i++) s_pose[9 + i] = Pcw[i];
+        for (int i = 0; i < 3; i++) s_pose[12 + i] = -(Rcw[i] * Pcw[0] + Rcw[3 + i] * Pcw[1] + Rcw[6 + i] * Pcw[2]);   // new_frame_->pos()
+    }
+    __syncthreads();
+    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
+    int added = 0;
+    if (i < n_sel && !abandoned)
+        added = fl_addobs_point(pts + sel_point[i], s_pose, s_pose + 9, s_pose + 12, P->vm.kf_id, P->vm.frame_id, VC, img, levels[i]);
+    const unsigned long long b = __ballot(added != 0);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&cnt->obs_added, (int)__popcll(b));
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1u);
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+        FlDetectTail *T = reinterpret_cast<FlDetectTail *>(reinterpret_cast<char *>(D) + sizeof(FlDev18) + FL_DETECT_TAIL_OFF);
+        T->n_cand = __hip_atomic_load(&cnt->cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        T->n_selected = n_sel;
+        T->n_added = __hip_atomic_load(&cnt->added, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        T->n_observed = __hip_atomic_load(&cnt->obs_added, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        D->pub_flag = pub_flag; D->pub_dst = pub_dst; D->pub_seq = pub_seq;
+        *ticket = 0u;
+        __threadfence();
+    }
+    fl_publish_state(D);
 }
 
 // how many observations of the map refer to keyframe `kf` (fl_vio_drop_keyframe refuses while any does: the reference keeps such an

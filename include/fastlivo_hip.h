@@ -194,6 +194,10 @@ int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out);
                                     * these sizes a pass is bound by instruction issue and memory requests, not by hand-offs. 2: every pass does, at
                                     * every level and size, one launch per pass (tests); 0: never. Per-patch errors are bit-identical either way, the
                                     * fp64 sums differ in their order only. */
+#define FL_OPT_DETECT_FUSED 15     /* 1 (default): fl_vio_detect is ONE enqueue -- the candidate / accepted-patch / founded / observed counts stay on the
+                                    * device, launches that depend on them are sized for the number of grid cells, the result comes back through one
+                                    * mailbox (csrc/api_vmap.inc). 0: the six staged calls sequenced inside the library (round 5: three returns to the
+                                    * host). The visual map, the state and every count are bit-identical either way. */
 int32_t fl_set_option(fl_handle h, int32_t option, int32_t value);
 /* Counters of the resident-grid machinery of the multi-pass kernels.
  * ABI note: the struct carries no size member; it is 24 bytes since ABI revision 4 (16 before: the two demotion fields were appended)

@@ -1,0 +1,135 @@
+"""fl_vio_detect as ONE enqueue (round 6, csrc/api_vmap.inc: FL_OPT_DETECT_FUSED) -- LidarSelector::detect (lidar_selection.cpp:1027-1076:
+addFromSparseMap -> addSparseMap -> ComputeJ -> addObservation) with the candidate / accepted-patch / founded / observed counts kept on the
+device, the launches sized for their upper bound (one per grid cell), one result mailbox.
+
+Against (a) the staged form (the six calls sequenced inside the library): counts, state, covariance, per-patch errors and the whole visual
+map BIT FOR BIT over a multi-frame walk -- same partition, same record order, same arithmetic; (b) the CPU oracle driven as detect() drives it
+(oracle/orc_vmap.c + orc_vio.c): the same points tracked / founded / observed every frame, state 1e-9, covariance 1e-11, visual maps equal.
+Frames without a selection (the first one: empty map; one with the camera turned away) take ComputeJ's early return (:969): state untouched."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class _VF:                       # what oracle.vio_compute_j / vio_config read
+    pass
+
+
+def _frame_pose(Rci, Pci, rot9, pos3):
+    """vmap_frame_pose of api_vmap.inc, operation for operation (plain python floats: no fused multiply-add)"""
+    Rcw = np.zeros((3, 3)); Pcw = np.zeros(3)
+    for i in range(3):
+        for j in range(3):
+            a = 0.0
+            for k in range(3):
+                a += float(Rci[i, k]) * float(rot9[j * 3 + k])
+            Rcw[i, j] = a
+    for i in range(3):
+        a = 0.0
+        for k in range(3):
+            a += float(Rcw[i, k]) * float(pos3[k])
+        Pcw[i] = -a + float(Pci[i])
+    return Rcw, Pcw
+
+
+def _walk(capi, orc, synth, scene, frames, n_scan, max_iter, grid, fused, with_oracle, blind_frame=-1, outlier=3000.0):
+    fr0 = synth.make_lio_frame(n_scan, scene=scene)
+    vf0 = synth.make_vio_frame(8, fr0, max_iterations=max_iter)
+    h = capi.Handle(capi.config_from_frames(fr0, vf0, max_iterations=max_iter))
+    h.set_option(capi.FL_OPT_DETECT_FUSED, 1 if fused else 0)
+    h.vmap_clear(grid)
+    Rli = fr0.R_LI.T
+    Rci = vf0.Rcl @ Rli
+    Pci = vf0.Rcl @ (-fr0.R_LI.T @ fr0.t_LI) + vf0.Pcl
+    vm = orc.VMap(orc.vio_config(vf0), grid) if with_oracle else None
+    R_t, p_t = fr0.R_true.copy(), fr0.p_true.copy()
+    xg = capi.State18.make(R_t, p_t, fr0.vel, fr0.bg, fr0.ba, fr0.grav, fr0.cov18)
+    xo = orc.State18.make(R_t, p_t, fr0.vel, fr0.bg, fr0.ba, fr0.grav, fr0.cov18)
+    Q = np.diag([1e-5] * 3 + [1e-4] * 3 + [1e-3] * 3 + [1e-8] * 9)
+    kf_imgs, log = [], []
+    for k in range(frames):
+        R_t = R_t @ synth.exp_so3(np.array([0.0, 0.0, 0.01]))
+        p_t = p_t + np.array([0.05, 0.03, 0.0])
+        body = synth.scan_from_pose(scene, R_t, p_t, n_scan, seed=600 + k)
+        Rc_t, Pc_t = synth.cam_pose(vf0.Rcl, vf0.Pcl, fr0.R_LI, fr0.t_LI, R_t, p_t)
+        img = synth.render_image(scene, vf0.cam, Rc_t, Pc_t, seed=k)
+        # the LIO posterior stands in as "true pose + a small error": the camera half is what is under test
+        dR = synth.exp_so3(np.array([0.002, -0.001, 0.0015])); dp = np.array([0.01, -0.008, 0.005])
+        xg = capi.State18.make(R_t @ dR, p_t + dp, fr0.vel, fr0.bg, fr0.ba, fr0.grav, xg.cov_np() + Q)
+        world = (body.astype(np.float64) @ (R_t @ fr0.R_LI).T + (R_t @ fr0.t_LI + p_t)).astype(np.float32)
+        if k == blind_frame:
+            world = (world + np.float32(500.0)).astype(np.float32)        # a scan nowhere near the map: nothing is selected
+        down, _ = orc.voxel_grid(np.concatenate([world, np.zeros((n_scan, 1), np.float32)], axis=1), 0.2)
+        down = np.ascontiguousarray(down[:, :3])
+        x_in = xg.copy()
+        ns, na, no = h.vio_detect(img, world, down, Rci, Pci, xg, k, outlier_threshold=outlier)
+        rec = dict(counts=(ns, na, no), x=xg.vec().copy(), P=xg.cov_np().copy(), errors=h.vio_get_errors(ns).copy() if ns > 0 else np.zeros(0, np.float32))
+        if ns == 0:
+            assert np.array_equal(xg.vec(), x_in.vec()) and np.array_equal(xg.cov_np(), x_in.cov_np()), f"frame {k}: no selection, state must be untouched"
+        log.append(rec)
+        if not with_oracle:
+            continue
+        xo = orc.State18.make(R_t @ dR, p_t + dp, fr0.vel, fr0.bg, fr0.ba, fr0.grav, xo.cov_np() + Q)
+        kf_imgs.append(img)
+        Rcw, Pcw = _frame_pose(Rci, Pci, xo.rot, xo.pos)
+        o = vm.select(Rcw, Pcw, img, kf_imgs, down, outlier_threshold=outlier)
+        na_o = vm.add_sparse(Rcw, Pcw, img, world, k, k)
+        m = len(o["points"])
+        assert (ns, na) == (m, na_o), f"frame {k}: selected / founded {ns, na} vs oracle {m, na_o}"
+        if m > 0:
+            vf = _VF()
+            for a in ("Rcl", "Pcl", "R_LI", "t_LI", "cam", "img_point_cov", "max_iterations", "patch_size"):
+                setattr(vf, a, getattr(vf0, a))
+            vf.m = m; vf.img = img
+            vf.ref_patch = np.ascontiguousarray(o["patches"].reshape(m, 3, 64))
+            vf.pos = np.ascontiguousarray(np.stack([vm.get_point(int(i))[0] for i in o["points"]]))
+            vf.search_level = np.ascontiguousarray(o["levels"].astype(np.int32))
+            ro = orc.vio_compute_j(vf, xo, xo.copy())
+            assert np.abs(xg.vec() - xo.vec()).max() <= 1e-9, f"frame {k} state"
+            assert np.abs(xg.cov_np() - xo.cov_np()).max() <= 1e-11, f"frame {k} cov"
+            assert np.array_equal(rec["errors"], ro["errors"]), f"frame {k}: per-patch errors"
+        Rc2, Pc2 = _frame_pose(Rci, Pci, xo.rot, xo.pos)
+        no_o = vm.add_observation(Rc2, Pc2, img, o["points"], o["levels"], k, k)
+        assert no == no_o, f"frame {k}: observed {no} vs oracle {no_o}"
+        # the next frame starts from the device's state on both sides (the comparison is per frame, not of accumulated drift)
+        xo = orc.State18.make(np.array(xg.rot).reshape(3, 3), xg.pos[:], xg.vel[:], xg.bg[:], xg.ba[:], xg.grav[:], xg.cov_np())
+    vmap = [h.vmap_get_point(i) for i in range(h.vmap_size())]
+    if with_oracle:
+        assert h.vmap_size() == vm.size()
+        for i in range(vm.size()):
+            pg, vg, obg = vmap[i]
+            po, vo, obo = vm.get_point(i)
+            assert np.array_equal(pg, po) and vg == vo and len(obg) == len(obo), f"visual map point {i}"
+        vm.close()
+    h.close()
+    return log, vmap
+
+
+def _same_obs(a, b):
+    return all(np.array_equal(np.frombuffer(bytes(x), np.uint8), np.frombuffer(bytes(y), np.uint8)) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("n_scan,grid,max_iter", [(3000, 40, 4), (6000, 20, 10)])
+def test_fused_detect_equals_staged_bit_for_bit(gpu_lib, oracle_lib, scene, n_scan, grid, max_iter):
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    logs = {}
+    for fused in (True, False):
+        logs[fused] = _walk(capi, orc, synth, scene, 7, n_scan, max_iter, grid, fused, False, blind_frame=4)
+    (lf, mf), (ls, ms) = logs[True], logs[False]
+    assert sum(r["counts"][0] for r in lf) > 100 and lf[4]["counts"][0] == 0, [r["counts"] for r in lf]
+    for k, (a, b) in enumerate(zip(lf, ls)):
+        assert a["counts"] == b["counts"], f"frame {k}: {a['counts']} vs {b['counts']}"
+        assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["P"], b["P"]), f"frame {k}: state"
+        assert np.array_equal(a["errors"], b["errors"]), f"frame {k}: per-patch errors"
+    assert len(mf) == len(ms)
+    for i, (p, q) in enumerate(zip(mf, ms)):
+        assert np.array_equal(p[0], q[0]) and p[1] == q[1] and len(p[2]) == len(q[2]) and _same_obs(p[2], q[2]), f"visual map point {i}"
+
+
+def test_fused_detect_matches_the_oracle(gpu_lib, oracle_lib, scene):
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    log, _ = _walk(capi, orc, synth, scene, 6, 3000, 4, 40, True, True, blind_frame=3)
+    assert sum(r["counts"][0] for r in log) > 60 and sum(r["counts"][2] for r in log) > 0, [r["counts"] for r in log]
