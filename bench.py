@@ -54,7 +54,7 @@ VIO_LEVEL = 0
 LIO_BYTES_PER_POINT = 12 + 16 + 1      # body xyz + cached plane (n,d) + selection flag (the kernel itself reads 16 + 16: DESIGN.md 4.2)
 VIO_BYTES_PER_PATCH = 405 + 4          # 256 ref + 121 image footprint + 24 pos + 4 level, + 4 written
 HBM_PEAK_GBS = 8000.0                  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-SECTIONS = ("at_scale", "vio_sweep", "mode23", "frame", "restage", "config4", "config5", "cpu_frame", "pipeline", "map_scale")
+SECTIONS = ("at_scale", "vio_sweep", "mode23", "frame", "restage", "config4", "config5", "cpu_frame", "pipeline", "map_scale", "latency_model")
 
 
 def parse():
@@ -237,12 +237,130 @@ def lio_pass_at(capi, synth, scene, cfg, x0, n):
     return us, gbs, check
 
 
+def _interp_fan_in(fan, P, words):
+    """fan-in time (us) for P records of `words` words from the probe's table {"P:words": ns}"""
+    pts = sorted((int(k.split(":")[0]), v) for k, v in fan.items() if int(k.split(":")[1]) == words and v > 0)
+    if not pts:
+        return None
+    for (p0, v0), (p1, v1) in zip(pts, pts[1:]):
+        if p0 <= P <= p1:
+            return (v0 + (v1 - v0) * (P - p0) / max(1, p1 - p0)) * 1e-3
+    return (pts[0][1] if P < pts[0][0] else pts[-1][1]) * 1e-3
+
+
+def section_latency_model(capi, synth, fr, vf, nbr, valid, cfg, x0, lio_us, vio_us, mode23):
+    """The ceiling that applies at the metric's size: a pass of 50 k points / 2 k patches moves 1.45 / 0.82 MB -- 0.2 us at
+    8 TB/s -- and takes 6-7 us because it is TWO cross-workgroup hand-offs and a solve chain on one wavefront, not a stream. Measured IN THIS RUN:
+      * tools/hop_bench.bin --json: one hop (8-byte tagged word, sc1 store -> sc1 load) inside an XCD and across XCDs; the fan-in of P records into
+        one collector workgroup, from its go word to the last record held (= pose broadcast hop + record publication + gather sweep), for the
+        record counts of the three pass kernels;
+      * the instrumented library's phase stamps inside a multi-pass launch (pass 5 of 11): the producers' work between seeing the pose and having
+        issued their record, the solver's work between holding all records and publishing the next pose.
+    handoff_floor_us = fan_in(P): what the chip charges for the structure whatever the arithmetic costs; modelled_pass_us = handoff floor + the
+    producers' and the solver's own phases. frac_of_latency_floor = handoff_floor_us / measured pass."""
+    import subprocess
+    probe = os.path.join(ROOT, "tools", "hop_bench.bin")
+    out = {"what": section_latency_model.__doc__.split("Measured IN THIS RUN")[0].strip().replace("\n    ", " ")}
+    n_lio = min((fr.n + 255) // 256, 160)                       # fl_lio_producers (csrc/lio_kernels.h), 256-thread producers
+    n_vio = (vf.m + 15) // 16                                   # vio_grid (csrc/api_vio.inc): 16 patches per producer workgroup
+    n_ik = min((fr.n + 255) // 256, 128)                        # ik_grid (csrc/api_ikfom.inc), 64-double records
+    if not os.path.exists(probe):
+        out["probe"] = {"skipped": "tools/hop_bench.bin not built (__graft_entry__.build())"}
+        return out
+    try:
+        r = subprocess.run([probe, "--json", "24:32", "64:32", "96:32", f"{n_vio}:32", f"{n_lio}:32", "192:32", "64:64", f"{n_ik}:64"], capture_output=True,
+                           text=True, timeout=120)
+        pr = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception as e:           # the section must not take the bench line down
+        out["probe"] = {"failed": repr(e)[:200]}
+        return out
+    out["probe"] = pr
+    if lio_us is None or vio_us is None:          # (--only latency_model: the pass times of this process)
+        import torch
+        hl = capi.Handle(cfg); hl.set_stream(torch.cuda.current_stream().cuda_stream)
+        hl.lio_set_points(fr.body_xyz); hl.lio_begin18(x0, x0); hl.lio_set_neighbours(nbr, valid)
+        hl.vio_set_frame(vf.img); hl.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+        ev0, ev1 = _events(torch)
+        res = []
+        for it in (lambda: hl.lio_iterate18(PASSES_PER_LAUNCH, capi.FL_ITER_FORCE, want_info=False),
+                   lambda: hl.vio_iterate(VIO_LEVEL, PASSES_PER_LAUNCH, capi.FL_ITER_FORCE, want_info=False)):
+            if len(res) == 1:
+                hl.vio_begin(x0, x0)
+            for _ in range(10):
+                it()
+            torch.cuda.synchronize(); ev0.record()
+            for _ in range(100):
+                it()
+            ev1.record(); torch.cuda.synchronize()
+            res.append(ev0.elapsed_time(ev1) * 1e3 / (100 * PASSES_PER_LAUNCH))
+        hl.close()
+        lio_us, vio_us = res
+    hop = pr["hop_cross_xcd_ns"] * 1e-3
+    fan = pr["fan_in_ns"]
+    # ---- phase stamps of the two 18-state pass kernels (instrumented build; same sizes, same options)
+    stamps = {}
+    try:
+        F = capi.FL_ITER_FORCE
+        hd = capi.Handle(cfg, debug=True)
+        hd.lio_set_points(fr.body_xyz); hd.lio_begin18(x0, x0); hd.lio_set_neighbours(nbr, valid)
+        hd.vio_set_frame(vf.img); hd.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
+        for name, it in (("lio", lambda fl: hd.lio_iterate18(11, fl, want_info=False)), ("vio", lambda fl: hd.vio_iterate(VIO_LEVEL, 11, fl, want_info=False))):
+            if name == "vio":
+                hd.vio_begin(x0, x0)
+            for _ in range(5):
+                it(F)
+            prod, solve, gath = [], [], []
+            for rep in range(6):
+                it(F | capi.FL_ITER_STAMP); hd.sync()
+                st = np.array(hd.debug_stamps(), dtype=np.int64)
+                # (stamp 36 = the solve's pose / control stores issued, solve18.h; 18 = the solver workgroup past its closing barrier)
+                s_end = st[36] if st[17] < st[36] <= st[18] else st[18]
+                prod.append((st[23] - st[21]) * 0.01); solve.append((s_end - st[17]) * 0.01); gath.append((st[17] - st[23]) * 0.01)
+            stamps[name] = {"producer_pose_seen_to_record_issued_us": float(np.median(prod)), "solver_records_held_to_pose_published_us": float(np.median(solve)),
+                            "record_issued_by_producer_0_to_all_records_held_us": float(np.median(gath))}
+        hd.close()
+    except Exception as e:
+        stamps["failed"] = repr(e)[:200]
+    out["stamps"] = stamps
+    rows = {}
+    for name, P, words, pass_us in (("lio18", n_lio, 32, lio_us), ("vio", n_vio, 32, vio_us),
+                                    ("mode23", n_ik, 64, (mode23 or {}).get("marginal_pass_us") or (mode23 or {}).get("pass_us"))):
+        fi = _interp_fan_in(fan, P, words)
+        if fi is None or not pass_us:
+            continue
+        row = {"records": P, "record_bytes": words * 8, "hop_us": hop, "fan_in_us": fi, "handoff_floor_us": fi, "pass_us": pass_us,
+               "frac_of_latency_floor": fi / pass_us}
+        key = {"lio18": "lio", "vio": "vio"}.get(name)
+        if key in stamps:
+            row["modelled_pass_us"] = fi + stamps[key]["producer_pose_seen_to_record_issued_us"] + stamps[key]["solver_records_held_to_pose_published_us"]
+            row["model_over_measured"] = row["modelled_pass_us"] / pass_us
+        rows[name] = row
+    out["passes"] = rows
+    out["note"] = ("a pass = [solver publishes pose] -> hop -> [producers: residuals, rows, record] -> records -> [solver: gather, gain solve, state, pose]; "
+                   "fan_in_us covers both hand-offs (the collector's go word plays the pose), so it is the floor of the STRUCTURE; the rest of a pass is "
+                   "instruction count on the producers' and the solver's critical paths (stamps). Mode-23 has no stamp set in the default instrumented build.")
+    return out
+
+
+def _at_scale_traffic():
+    """FETCH_SIZE / WRITE_SIZE of the at-scale kernels (tools/pmc_traffic_at_scale.sh, separate rocprofv3 --pmc passes, committed under profiles/)"""
+    import glob
+    try:
+        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_at_scale.json")))[-1]
+        return os.path.basename(latest), json.load(open(latest))["kernels"]
+    except Exception:
+        return None, {}
+
+
 def section_at_scale(capi, synth, scene, cfg, x0):
     out = []
     for n in AT_SCALE_POINTS:
         us, gbs, check = lio_pass_at(capi, synth, scene, cfg, x0, n)
+        src, pm = _at_scale_traffic()
+        tr = next((d for k, d in pm.items() if k.startswith("lio18_pass_kernel") and d.get("units") == n and "read_bytes_x2_corrected" in d), None)
         out.append({"kernel": "lio18_pass_kernel", "points": n, "pass_us": us, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                     "algorithmic_bytes": LIO_BYTES_PER_POINT * n, "check": check,
+                    "traffic": (tr["read_bytes_x2_corrected"] + tr.get("write_bytes_raw", 0.0)) if tr else None, "traffic_source": src if tr else None,
                     "note": "8 M points x 32 B read = 256 MB = the size of the Infinity Cache: part of it stays on chip between the passes of a "
                             "frame" if n <= 8000000 else "streams from HBM (32 B read per point and pass)"})
     return out
@@ -304,6 +422,35 @@ def section_vio_sweep(capi, synth, fr, vf, cfg, x0, distinct_cap=None):
             if kind == "distinct":
                 row["distinct_positions"] = int(base.m)
         row["unit"] = "GB/s"
+        src, pm = _at_scale_traffic()
+        tr = next((d for k, d in pm.items() if k.startswith("void vio_pass_kernel") and d.get("units") == m and "read_bytes_x2_corrected" in d), None)
+        row["traffic"] = (tr["read_bytes_x2_corrected"] + tr.get("write_bytes_raw", 0.0)) if tr else None
+        row["traffic_source"] = src if tr else None
+        # the fence (option B): pass_us above is a FORCED pass (no accept test). A REAL pass of the reference decides accept /
+        # revert on its float running sum over all patches (lidar_selection.cpp:849-861), one workgroup's serial chain of ~1.5-2 us per 1 000
+        # patches: measured here beside it, so that nobody reads the forced figure as the cost of a usable pass at this size.
+        try:
+            reps = (m + vf.m - 1) // vf.m
+            h = capi.Handle(cfg)
+            h.set_stream(torch.cuda.current_stream().cuda_stream)
+            h.set_timing(True)
+            h.vio_set_frame(vf.img)
+            h.vio_set_patches(np.tile(vf.ref_patch, (reps, 1, 1))[:m], np.tile(vf.pos, (reps, 1))[:m], np.tile(vf.search_level, reps)[:m])
+            per = []
+            for rep in range(4):
+                h.vio_begin(x0, x0)
+                err, info = h.vio_update_state(1e10, VIO_LEVEL)
+                if rep >= 1 and info.iterations > 0:
+                    per.append(h.last_kernel_ms() * 1e3 / info.iterations)
+            h.close()
+            row["real_pass_us"] = float(np.median(per)) if per else None
+            row["real_pass_what"] = ("fl_vio_update_state (real passes: the reference's float running sum over all patches decides accept / revert), "
+                                     "event time of its launches / passes run")
+            if row["real_pass_us"]:
+                row["real_pass_frac"] = VIO_BYTES_PER_PATCH * m / (row["real_pass_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        except Exception as e:           # noqa: BLE001
+            row["real_pass_us"] = None
+            row["real_pass_what"] = "failed: " + repr(e)[:160]
         out.append(row)
     return out
 
@@ -793,8 +940,9 @@ def section_pipeline(capi, synth, scene, budget_s, with_cpu=True):
             vox, _ = orc.voxel_grid(p2, leaf); t2 = time.perf_counter()
             orc.lio18_frame(x, np.ascontiguousarray(vox[:, :3]), lio.R_LI, lio.t_LI, lio.laser_point_cov, 10, lambda w: synth.knn5(scene, w), nthreads=4)
             return t1 - t0, t2 - t1, time.perf_counter() - t2
-        parts = [cpu_front() for _ in range(2)]
-        und, vox_t, lio_t = (float(np.median([p_[i] for p_ in parts])) * 1e3 for i in range(3))
+        parts = [cpu_front() for _ in range(3)]
+        und, vox_t, lio_t = (float(np.min([p_[i] for p_ in parts])) * 1e3 for i in range(3))          # best of three (the first call pays page faults / thread start-up)
+        out["cpu_lidar_front_parts_first_call_ms"] = {"undistort": parts[0][0] * 1e3, "voxel_filter": parts[0][1] * 1e3, "lio_frame_4_threads": parts[0][2] * 1e3}
         out["cpu_lidar_front_ms"] = und + vox_t + lio_t
         out["cpu_lidar_front_parts_ms"] = {"undistort": und, "voxel_filter": vox_t, "lio_frame_4_threads": lio_t}
         # camera half on the CPU: the oracle's visual map driven as detect() drives it, on the demo's inputs (one image, two frames; the second tracks)
@@ -823,8 +971,9 @@ def section_pipeline(capi, synth, scene, budget_s, with_cpu=True):
         except Exception as e:
             out["cpu_camera_half_ms_without_ComputeJ"] = None
             out["cpu_camera_half_note"] = "failed: " + repr(e)[:200]
-        if "lidar_front_fused_ms" in out:
-            out["lidar_front_speedup_vs_cpu"] = out["cpu_lidar_front_ms"] / out["lidar_front_fused_ms"]
+        out["cpu_lidar_front_note"] = ("best of three calls per part; no speed-up ratio is quoted from this leg: round 5's driver run and the builder's differed 22x "
+                                       "in the undistortion part (3.65 vs 80 ms) -- its first call on a box pays page faults of the 100 k-point clouds and the "
+                                       "OpenMP team's start-up (first-call figures beside it)")
     return out
 
 
@@ -920,7 +1069,8 @@ def main():
                "config5": lambda: section_config5(capi, synth, scene),
                "cpu_frame": lambda: section_cpu_frame(synth, scene, fr, vf, args.cpu_seconds),
                "pipeline": lambda: section_pipeline(capi, synth, scene, args.cpu_seconds),
-               "map_scale": lambda: section_map_scale(capi, synth, scene)}[args.only]()
+               "map_scale": lambda: section_map_scale(capi, synth, scene),
+               "latency_model": lambda: section_latency_model(capi, synth, fr, vf, nbr, valid, cfg, x0, None, None, None)}[args.only]()
         print(json.dumps({"section": args.only, "result": sec}), file=json_out, flush=True)
         return
 
@@ -1174,6 +1324,7 @@ def main():
         extras["config5"] = section_config5(capi, synth, scene)
         extras["pipeline"] = section_pipeline(capi, synth, scene, args.cpu_seconds, with_cpu=not args.no_cpu_baseline)
         extras["map_scale"] = section_map_scale(capi, synth, scene)
+        roof["latency_model"] = section_latency_model(capi, synth, fr, vf, nbr, valid, cfg, x0, lio_us, vio_us, extras.get("mode23"))
         if args.sweep:
             sweep(capi, synth, scene, cfg, x0, sys.stderr)
 

@@ -242,6 +242,7 @@ SYMBOLS = {
     "fl_map_add_points": (C.c_int32, [_H, _fp, C.c_int32, C.c_float, C.c_void_p]),
     "fl_map_delete_boxes": (C.c_int32, [_H, _fp, C.c_int32, C.c_void_p]),
     "fl_map_get_points": (C.c_int32, [_H, _fp, C.c_int32, C.POINTER(C.c_int32)]),
+    "fl_map_compact": (C.c_int32, [_H]),
     "fl_lio_search18": (C.c_int32, [_H, _fp, _u8p]),
     "fl_ikfom_search": (C.c_int32, [_H, _fp, _u8p]),
     "fl_lio_frame18_dev": (C.c_int32, [_H, C.POINTER(State18), _fp, C.c_int32, C.POINTER(IterInfo)]),
@@ -981,6 +982,9 @@ def _knn_methods():
     def debug_drop_record(self, passes_ahead=0):
         self._chk(self.L.fl_debug_drop_record(self.h, int(passes_ahead)), "fl_debug_drop_record")
 
+    def map_compact(self):
+        self._chk(self.L.fl_map_compact(self.h), "fl_map_compact")
+
     def debug_map_pool_limit(self, spare_entries):
         self._chk(self.L.fl_debug_map_pool_limit(self.h, int(spare_entries)), "fl_debug_map_pool_limit")
 
@@ -1022,7 +1026,7 @@ def _knn_methods():
                                                       _p_hot(limit, C.c_double, own_l), C.byref(info)), "fl_ikfom_update_iterated_dev")
         return info
 
-    for f in (map_set_points, map_clear, map_add_points, map_delete_boxes, map_get_points, lio_search18, ikfom_search, lio_frame18_dev, ikfom_update_iterated_dev,
+    for f in (map_set_points, map_clear, map_add_points, map_delete_boxes, map_get_points, map_compact, lio_search18, ikfom_search, lio_frame18_dev, ikfom_update_iterated_dev,
               debug_hog, debug_chain, debug_drop_record, debug_knn_stamp, debug_map_pool_limit, set_option, diagnostics):
         setattr(Handle, f.__name__, f)
 

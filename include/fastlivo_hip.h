@@ -375,6 +375,12 @@ int32_t fl_map_clear(fl_handle h, float cell_size);
 int32_t fl_map_add_points(fl_handle h, const float *world_xyz, int32_t n, float downsample_size, fl_map_info *info);
 int32_t fl_map_delete_boxes(fl_handle h, const float *boxes, int32_t nb, fl_map_info *info);
 int32_t fl_map_get_points(fl_handle h, float *xyz_out, int32_t cap, int32_t *n_out);
+/* The in-place updates (FL_OPT_MAP_INCREMENTAL 1) leave tombstones in the map array and holes in the index's point pool; when those fill
+ * up, the update that finds them full first compacts the array and re-indexes the map -- an O(map) step inside that frame's
+ * fl_map_add_points. fl_map_compact does that step NOW (no-op if nothing is dead), so that a caller can pay for it where the frame has
+ * slack (e.g. while the camera half runs) instead of in the frame that happens to hit it. Map content and search results are unchanged.
+ * bench.py's map_scale section times it per map size (the worst-case frame of the in-place form). */
+int32_t fl_map_compact(fl_handle h);
 /* One search pass at the current device state (after fl_lio_begin18 / fl_ikfom_begin): neighbours ->
  * planes -> selection flags, nothing leaves the device. nbr_xyz_out (n x 5 x 3) / valid_out (n) are
  * optional read-backs for parity checks. */

@@ -350,3 +350,33 @@ def test_search_after_an_update_that_ran_out_of_pool_sees_every_point(gpu_lib, o
     assert np.array_equal(valid_g, valid_o) and np.array_equal(nbr_g[ok], nbr_o[ok])
     assert np.array_equal(h.map_get_points(), cur)
     h.close()
+
+
+def test_map_compact_on_demand_changes_nothing(gpu_lib, oracle_lib, scene):
+    """fl_map_compact: the O(map) compaction + re-index of the in-place form, run when the caller chooses. Map content, order and search results
+    are those of the oracle before and after; a second call (nothing dead) is a no-op."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    rng = np.random.default_rng(123)
+    fr = synth.make_lio_frame(2000, scene=scene)
+    h = _handle(capi, synth, fr)
+    cur = scene.map_xyz[rng.choice(len(scene.map_xyz), 30000, replace=False)].copy()
+    h.map_set_points(cur, 0.5)
+    for k in range(3):
+        new = _scan_world(scene, rng, 5000, 0.04)
+        h.map_add_points(new, 0.3, want_info=False)
+        cur, _ = orc.map_add_points(cur, new, 0.3)
+    nbr0, valid0, world = _search(h, capi, fr)
+    h.map_compact()
+    nbr1, valid1, _ = _search(h, capi, fr)
+    h.map_compact()
+    nbr_o, _, valid_o, _ = orc.knn5_bruteforce(cur, world)
+    ok = valid_o != 0
+    assert np.array_equal(valid0, valid_o) and np.array_equal(valid1, valid_o)
+    assert np.array_equal(nbr0[ok], nbr_o[ok]) and np.array_equal(nbr1[ok], nbr_o[ok])
+    assert np.array_equal(h.map_get_points(), cur)
+    new = _scan_world(scene, rng, 5000, 0.04)
+    h.map_add_points(new, 0.3, want_info=False)          # in place again on the compacted arrays
+    cur, _ = orc.map_add_points(cur, new, 0.3)
+    assert np.array_equal(h.map_get_points(), cur)
+    h.close()

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <string>
 #include <algorithm>
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
@@ -60,8 +61,9 @@ __global__ void pingpong(unsigned long long *w, int a, int b, int rounds, long l
 // 8-byte words, ST flavour) when the collector's "go" word (sc1) reaches them; the collector (block `cblk`) polls all records with
 // 16-byte LD-flavour loads (one 16-lane row per record) until every tag matches. Time: go -> collector holds all records.
 template <int ST, int LD>
-__global__ void fanin(unsigned long long *rec, unsigned long long *go, int P, int stride, int cblk, int rounds, long long *t, unsigned *xcc)
+__global__ void fanin(unsigned long long *rec, unsigned long long *go, int P, int stride, int cblk, int rounds, long long *t, unsigned *xcc, int words = 32)
 {
+    const int S = P * (words / 32);                      // 256-byte slots the collector polls (<= 256)
     if (threadIdx.x == 0) xcc[blockIdx.x] = xcc_id();
     const int b = blockIdx.x;
     const bool producer = (b % stride == 0) && (b / stride < P) && b != cblk;
@@ -75,21 +77,21 @@ __global__ void fanin(unsigned long long *rec, unsigned long long *go, int P, in
             if (threadIdx.x == 0) st64<3>(go, (unsigned long long)r);
             // 256 threads: row = tid / 16 covers record row + 16 k; all loads of a sweep in flight together (as handoff.h gather_records)
             const int kp = threadIdx.x & 15, row = threadIdx.x >> 4;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)rec, 0, P * 256, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)rec, 0, S * 256, 0x00020000);
             bool all = false;
             int spin = 0;
             while (!all && spin < 4000) {
                 bool ok = true;
-                u4 v[12];
+                u4 v[16];
 #pragma unroll
-                for (int k = 0; k < 12; k++) {
+                for (int k = 0; k < 16; k++) {
                     const int q = row + 16 * k;
-                    if (q < P) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, q * 256 + kp * 16, 0, LD == 0 ? 16 : 17);
+                    if (q < S) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, q * 256 + kp * 16, 0, LD == 0 ? 16 : 17);
                 }
 #pragma unroll
-                for (int k = 0; k < 12; k++) {
+                for (int k = 0; k < 16; k++) {
                     const int q = row + 16 * k;
-                    if (q < P) ok = ok && (v[k].x == (unsigned)r) && (v[k].z == (unsigned)r);
+                    if (q < S) ok = ok && (v[k].x == (unsigned)r) && (v[k].z == (unsigned)r);
                 }
                 all = __syncthreads_and(ok ? 1 : 0) != 0;
                 spin++;
@@ -110,7 +112,7 @@ __global__ void fanin(unsigned long long *rec, unsigned long long *go, int P, in
             while (ld64<0>(go) < (unsigned long long)r && ++spin < 400000) {}
         }
         __syncthreads();
-        if (threadIdx.x < 32) st64<ST>(rec + (size_t)q * 32 + threadIdx.x, ((unsigned long long)(threadIdx.x + 1) << 32) | (unsigned long long)r);
+        if ((int)threadIdx.x < words) st64<ST>(rec + (size_t)q * words + threadIdx.x, ((unsigned long long)(threadIdx.x + 1) << 32) | (unsigned long long)r);
     }
 }
 
@@ -148,8 +150,54 @@ static void run_fi(unsigned long long *rec, unsigned long long *go, long long *t
            hx[cblk], hx[stride], sn[ST], ln[LD], d[0] * 10, d[d.size() / 2] * 10, d[d.size() * 9 / 10] * 10, ht[2]);
 }
 
+// --json P:words [P:words ...]: what bench.py's `roofline.latency_model` is built from, measured in the SAME run as the bench line -- one hop
+// (sc1 store -> sc1 load, today's protocol) inside an XCD and across, and the fan-in of P records of `words` 8-byte words each from
+// producers spread over all XCDs into one collector workgroup (go word -> all records held), median over 480 rounds. One JSON line.
+static double pp_ns(unsigned long long *w, long long *t, unsigned *xcc, int b)
+{
+    const int grid = 64, rounds = 2000;
+    hipMemset(w, 0, 4096);
+    hipLaunchKernelGGL((pingpong<2, 0>), dim3(grid), dim3(64), 0, 0, w, 0, b, rounds, t, xcc);
+    hipDeviceSynchronize();
+    long long ht[3];
+    hipMemcpy(ht, t, 24, hipMemcpyDeviceToHost);
+    return ht[2] ? -1.0 : (ht[1] - ht[0]) * 10.0 / rounds / 2;
+}
+static double fi_ns(unsigned long long *rec, unsigned long long *go, long long *t, unsigned *xcc, int P, int words)
+{
+    const int rounds = 500, grid = 256;
+    hipMemset(rec, 0, 1 << 20); hipMemset(go, 0, 4096);
+    hipLaunchKernelGGL((fanin<2, 0>), dim3(grid), dim3(256), 0, 0, rec, go, P, 1, 255, rounds, t, xcc, words);
+    hipDeviceSynchronize();
+    std::vector<long long> ht(8 + rounds + 1);
+    hipMemcpy(ht.data(), t, 8 * ht.size(), hipMemcpyDeviceToHost);
+    if (ht[2]) return -1.0;
+    std::vector<long long> d(ht.begin() + 9 + 20, ht.end());
+    std::sort(d.begin(), d.end());
+    return d[d.size() / 2] * 10.0;
+}
+static int json_mode(int argc, char **argv)
+{
+    unsigned long long *w, *rec, *go; long long *t; unsigned *xcc;
+    if (hipMalloc(&t, 65536) != hipSuccess) { printf("{\"error\": \"no device\"}\n"); return 1; }
+    hipMalloc(&xcc, 4096); hipMalloc(&w, 4096); hipMalloc(&rec, 1 << 20); hipMalloc(&go, 4096);
+    pp_ns(w, t, xcc, 8); fi_ns(rec, go, t, xcc, 64, 32);            // warm up
+    printf("{\"hop_same_xcd_ns\": %.0f, \"hop_cross_xcd_ns\": %.0f, \"fan_in_ns\": {", pp_ns(w, t, xcc, 8), pp_ns(w, t, xcc, 1));
+    bool first = true;
+    for (int a = 2; a < argc; a++) {
+        int P = 0, words = 32;
+        if (sscanf(argv[a], "%d:%d", &P, &words) < 1 || P < 1 || (words != 32 && words != 64) || P * (words / 32) > 255) continue;
+        const double a1 = fi_ns(rec, go, t, xcc, P, words), a2 = fi_ns(rec, go, t, xcc, P, words);
+        printf("%s\"%d:%d\": %.0f", first ? "" : ", ", P, words, a1 < a2 ? a1 : a2);
+        first = false;
+    }
+    printf("}, \"protocol\": \"8-byte tagged words, sc1 stores, sc1 16-byte loads (csrc/handoff.h); fan-in = collector's go word -> every record held, producers on all XCDs\"}\n");
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 1 && std::string(argv[1]) == "--json") return json_mode(argc, argv);
     unsigned long long *w, *rec, *go; long long *t; unsigned *xcc;
     hipMalloc(&t, 65536); hipMalloc(&xcc, 4096);
     const int memkind = argc > 1 ? atoi(argv[1]) : 0;      // 0 hipMalloc, 1 fine-grained, 2 uncached

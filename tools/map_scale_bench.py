@@ -46,9 +46,20 @@ def run(sizes, n_new=20000, ds=0.3, reps=12, scene=None):
             for r in range(8):
                 xx = x.copy(); h.sync()
                 t0 = time.perf_counter(); h.lio_frame18_dev(xx, fr.body_xyz); ft.append(time.perf_counter() - t0)
+            comp = None
+            if incr:          # the worst-case frame of the in-place form: the O(map) compaction + re-index its arrays ask for every capacity / points-per-frame
+                ct = []       # frames (fl_map_compact = that step on demand), timed behind an update that left tombstones
+                for r in range(3):
+                    new = (scene.map_xyz[rng.integers(0, len(scene.map_xyz), n_new)] + rng.normal(0, 0.03, (n_new, 3))).astype(np.float32)
+                    h.map_add_points(new, ds, want_info=False); h.sync()
+                    t0 = time.perf_counter(); h.map_compact(); h.sync(); ct.append(time.perf_counter() - t0)
+                comp = round(float(np.median(ct)) * 1e3, 4)
             key = "in_place" if incr else "rebuild"
             row[key] = {"map_add_wall_ms": round(float(np.median(wall[2:])) * 1e3, 4), "map_add_device_ms": round(float(np.median(dev[2:])), 4),
                         "lio_frame_ms": round(float(np.median(ft[2:])) * 1e3, 4)}
+            if comp is not None:
+                row[key]["compaction_ms"] = comp
+                row[key]["worst_case_map_add_wall_ms"] = round(comp + row[key]["map_add_wall_ms"], 4)
             h.close()
         out.append(row)
     return out
