@@ -357,7 +357,7 @@ def section_at_scale(capi, synth, scene, cfg, x0):
     for n in AT_SCALE_POINTS:
         us, gbs, check = lio_pass_at(capi, synth, scene, cfg, x0, n)
         src, pm = _at_scale_traffic()
-        tr = next((d for k, d in pm.items() if k.startswith("lio18_pass_kernel") and d.get("units") == n and "read_bytes_x2_corrected" in d), None)
+        tr = next((d for k, d in pm.items() if "lio18_pass_kernel" in k and d.get("units") == n and "read_bytes_x2_corrected" in d), None)
         out.append({"kernel": "lio18_pass_kernel", "points": n, "pass_us": us, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                     "algorithmic_bytes": LIO_BYTES_PER_POINT * n, "check": check,
                     "traffic": (tr["read_bytes_x2_corrected"] + tr.get("write_bytes_raw", 0.0)) if tr else None, "traffic_source": src if tr else None,
@@ -423,7 +423,8 @@ def section_vio_sweep(capi, synth, fr, vf, cfg, x0, distinct_cap=None):
                 row["distinct_positions"] = int(base.m)
         row["unit"] = "GB/s"
         src, pm = _at_scale_traffic()
-        tr = next((d for k, d in pm.items() if k.startswith("void vio_pass_kernel") and d.get("units") == m and "read_bytes_x2_corrected" in d), None)
+        tr = next((d for k, d in pm.items() if ("vio_pass_kernel<0, 1>" if wide else "vio_pass_kernel<0, 0>") in k and d.get("units") == m
+                   and "read_bytes_x2_corrected" in d), None)
         row["traffic"] = (tr["read_bytes_x2_corrected"] + tr.get("write_bytes_raw", 0.0)) if tr else None
         row["traffic_source"] = src if tr else None
         # the fence (option B): pass_us above is a FORCED pass (no accept test). A REAL pass of the reference decides accept /
