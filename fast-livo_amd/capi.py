@@ -478,9 +478,14 @@ class Handle:
     def vio_detect(self, img, pg, pg_down, Rci, Pci, state, frame_id, ncc_en=False, ncc_thre=0.0, outlier_threshold=300.0):
         """fl_vio_detect: LidarSelector::detect in one call. Mutates state; returns (selected, founded, observed)."""
         img = np.ascontiguousarray(img, np.uint8)
-        pg = np.ascontiguousarray(pg, np.float32).reshape(-1, 3); pd = np.ascontiguousarray(pg_down, np.float32).reshape(-1, 3)
         Rci = np.ascontiguousarray(Rci, np.float64).reshape(9); Pci = np.ascontiguousarray(Pci, np.float64)
         a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        if pg is None:              # FL_DETECT_SCAN_ON_DEVICE: the handle's staged scan under `state`, down-sampled on the device
+            self._chk(self.L.fl_vio_detect(self.h, img.ctypes.data_as(_u8p), img.shape[1], img.shape[0], img.shape[1], None, -1, None, 0,
+                                           Rci.ctypes.data_as(_dp), Pci.ctypes.data_as(_dp), C.byref(state), frame_id,
+                                           1 if ncc_en else 0, ncc_thre, outlier_threshold, C.byref(a), C.byref(b), C.byref(c)), "fl_vio_detect")
+            return a.value, b.value, c.value
+        pg = np.ascontiguousarray(pg, np.float32).reshape(-1, 3); pd = np.ascontiguousarray(pg_down, np.float32).reshape(-1, 3)
         self._chk(self.L.fl_vio_detect(self.h, img.ctypes.data_as(_u8p), img.shape[1], img.shape[0], img.shape[1], pg.ctypes.data_as(_fp), len(pg),
                                        pd.ctypes.data_as(_fp), len(pd), Rci.ctypes.data_as(_dp), Pci.ctypes.data_as(_dp), C.byref(state), frame_id,
                                        1 if ncc_en else 0, ncc_thre, outlier_threshold, C.byref(a), C.byref(b), C.byref(c)), "fl_vio_detect")

@@ -87,7 +87,7 @@ struct FlDev18 {
 
 // What fl_lidar_front's kernels leave for the host in the tail behind FlDev18 (FL_DEV18_TAIL bytes, travels with the result mailbox)
 // ... and what fl_vio_detect's fused form leaves there BEHIND the three FlVioLevelInfo of ComputeJ (offset FL_DETECT_TAIL_OFF)
-struct FlDetectTail { int32_t n_cand, n_selected, n_added, n_observed; };
+struct FlDetectTail { int32_t n_cand, n_selected, n_added, n_observed, n_down, vox_cells_short, pad0, pad1; long long vox_cells; };
 #define FL_DETECT_TAIL_OFF 512
 struct FlFrontTail {
     double acc_s_last[3], angvel_last[3];      // ImuProcess members the next frame starts from (IMU_Processing.cpp:731-732)

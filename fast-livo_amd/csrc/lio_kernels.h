@@ -483,22 +483,29 @@ __device__ __forceinline__ void eskf18_cov_update_body(FlDev18 *__restrict__ D)
 __global__ __launch_bounds__(384) void eskf18_cov_update_kernel(FlDev18 *__restrict__ D) { eskf18_cov_update_body(D); }
 __device__ __attribute__((noinline)) void eskf18_cov_outofline(FlDev18 *D) { eskf18_cov_update_body(D); }
 
+// pointBodyToWorld (laserMapping.cpp:695-698) of one body point under the device state: double arithmetic, stored as float
+__device__ __forceinline__ void fl_world_point(const FlDev18 *__restrict__ D, float bx, float by, float bz, float &wx, float &wy, float &wz)
+{
+    double R[9], p[3], RLI[9], tLI[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { R[k] = D->x[k]; RLI[k] = D->R_LI[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { p[k] = D->x[9 + k]; tLI[k] = D->t_LI[k]; }
+    const double b0 = (double)bx, b1 = (double)by, b2 = (double)bz;
+    const double q0 = (RLI[0] * b0 + RLI[1] * b1 + RLI[2] * b2) + tLI[0];
+    const double q1 = (RLI[3] * b0 + RLI[4] * b1 + RLI[5] * b2) + tLI[1];
+    const double q2 = (RLI[6] * b0 + RLI[7] * b1 + RLI[8] * b2) + tLI[2];
+    wx = (float)((R[0] * q0 + R[1] * q1 + R[2] * q2) + p[0]);
+    wy = (float)((R[3] * q0 + R[4] * q1 + R[5] * q2) + p[1]);
+    wz = (float)((R[6] * q0 + R[7] * q1 + R[8] * q2) + p[2]);
+}
 // world points at the current device state (pointBodyToWorld) for the host kNN on rematch passes
 __global__ __launch_bounds__(FL_BLOCK) void lio_world_points_kernel(const float *__restrict__ body, float *__restrict__ world, int n,
                                                                    const FlDev18 *__restrict__ D)
 {
     const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
     if (i >= n) return;
-    double R[9], p[3], RLI[9], tLI[3];
-#pragma unroll
-    for (int k = 0; k < 9; k++) { R[k] = D->x[k]; RLI[k] = D->R_LI[k]; }
-#pragma unroll
-    for (int k = 0; k < 3; k++) { p[k] = D->x[9 + k]; tLI[k] = D->t_LI[k]; }
-    const double b0 = (double)body[i * 3], b1 = (double)body[i * 3 + 1], b2 = (double)body[i * 3 + 2];
-    const double q0 = (RLI[0] * b0 + RLI[1] * b1 + RLI[2] * b2) + tLI[0];
-    const double q1 = (RLI[3] * b0 + RLI[4] * b1 + RLI[5] * b2) + tLI[1];
-    const double q2 = (RLI[6] * b0 + RLI[7] * b1 + RLI[8] * b2) + tLI[2];
-    world[i * 3 + 0] = (float)((R[0] * q0 + R[1] * q1 + R[2] * q2) + p[0]);
-    world[i * 3 + 1] = (float)((R[3] * q0 + R[4] * q1 + R[5] * q2) + p[1]);
-    world[i * 3 + 2] = (float)((R[6] * q0 + R[7] * q1 + R[8] * q2) + p[2]);
+    float wx, wy, wz;
+    fl_world_point(D, body[i * 3], body[i * 3 + 1], body[i * 3 + 2], wx, wy, wz);
+    world[i * 3 + 0] = wx; world[i * 3 + 1] = wy; world[i * 3 + 2] = wz;
 }

@@ -29,10 +29,11 @@ struct FlSelectParams {
 };
 
 // one scan point of the depth image (:393-409)
+template <int STRIDE = 3>      // floats per scan point: 3 (x, y, z) or 4 (the voxel filter's x, y, z, intensity)
 __device__ __forceinline__ void fl_depth_point(const float *__restrict__ scan, int i, const FlSelectParams *__restrict__ S,
                                                const FlVioConst *__restrict__ VC, unsigned long long *__restrict__ depth64)
 {
-    const double pw[3] = {(double)scan[3 * i], (double)scan[3 * i + 1], (double)scan[3 * i + 2]};
+    const double pw[3] = {(double)scan[STRIDE * i], (double)scan[STRIDE * i + 1], (double)scan[STRIDE * i + 2]};
     double pc[3];
     pc[0] = (S->Rcw[0] * pw[0] + S->Rcw[1] * pw[1] + S->Rcw[2] * pw[2]) + S->Pcw[0];
     pc[1] = (S->Rcw[3] * pw[0] + S->Rcw[4] * pw[1] + S->Rcw[5] * pw[2]) + S->Pcw[1];

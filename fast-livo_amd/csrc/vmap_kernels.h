@@ -18,6 +18,8 @@
 
 #include "select_kernels.h"
 #include "knn_kernels.h"
+#include "voxel_kernels.h"
+#include "lio_kernels.h"
 
 #define FL_VMAP_MAX_OBS 20
 struct FlVObs {                 // == fl_vmap_obs (C ABI)
@@ -68,10 +70,11 @@ __device__ __forceinline__ void fl_frame_pos(const double *R, const double *t, d
 
 // ---- fl_vmap_select ----------------------------------------------------------------------------------------------------------
 // one scan point's voxel key into the set of voxels the scan touches (sub_feat_map, :383-391)
+template <int STRIDE = 3>
 __device__ __forceinline__ void fl_subkey_point(const float *__restrict__ scan, int i, unsigned long long *__restrict__ set, unsigned mask)
 {
-    const int kx = (int)floor((double)scan[3 * i] / (double)0.5f), ky = (int)floor((double)scan[3 * i + 1] / (double)0.5f),
-              kz = (int)floor((double)scan[3 * i + 2] / (double)0.5f);                       // :387-389
+    const int kx = (int)floor((double)scan[STRIDE * i] / (double)0.5f), ky = (int)floor((double)scan[STRIDE * i + 1] / (double)0.5f),
+              kz = (int)floor((double)scan[STRIDE * i + 2] / (double)0.5f);                       // :387-389
     const unsigned long long key = fl_cell_key(kx, ky, kz);
     unsigned h = fl_hash64(key) & mask;
     while (true) {
@@ -221,11 +224,14 @@ __global__ __launch_bounds__(FL_BLOCK) void vmap_score_kernel(const float *__res
 __global__ __launch_bounds__(FL_VMAP_WG) void vmap_commit_kernel(const float *__restrict__ scan, const FlVmapParams *__restrict__ G,
                                                                 const FlVioConst *__restrict__ VC, const unsigned long long *__restrict__ best,
                                                                 int *__restrict__ val /* map_value bits, carried from the select step */,
-                                                                int32_t *__restrict__ gnum, FlVPoint *__restrict__ pts, FlVmapCount *__restrict__ cnt)
+                                                                int32_t *__restrict__ gnum, FlVPoint *__restrict__ pts, FlVmapCount *__restrict__ cnt,
+                                                                const struct FlVxCtl *__restrict__ vx /* nullable; fused detect with the scan on the device */)
 {
     __shared__ int s_scan[FL_VMAP_WG];
     __shared__ int s_base;
     const int t = (int)threadIdx.x;
+    // (the down-sampling did not fit its occupancy bitmap: the host grows it and runs the frame again -- nothing may have changed the map)
+    if (vx && vx->cells_short) { if (t == 0) cnt->added = 0; return; }
     if (t == 0) s_base = 0;
     __syncthreads();
     for (int g0 = 0; g0 < G->length; g0 += FL_VMAP_WG) {
@@ -399,6 +405,43 @@ __global__ __launch_bounds__(FL_BLOCK) void vmap_scan_kernel(const float *__rest
     fl_subkey_point(scan, i, set, mask);
 }
 
+// The scan stays on the device (fl_vio_detect with n_pg = FL_DETECT_SCAN_ON_DEVICE): pg = the handle's staged scan registered under
+// the state block (pointBodyToWorld, laserMapping.cpp:695-698 -- what fl_lio_get_world_points hands to the host), written twice: as
+// x, y, z (what addSparseMap's kernels read) and as x, y, z, 0 for the voxel filter (downSizeFilter, lidar_selection.cpp:352-353), whose
+// per-workgroup bounding boxes come out of the same launch (as undistort_apply_kernel does for the LiDAR front).
+__global__ __launch_bounds__(FL_BLOCK) void detect_world_kernel(const float *__restrict__ body, int n, const FlDev18 *__restrict__ D,
+                                                               float *__restrict__ world3, float4 *__restrict__ world4, FlVxPartial *__restrict__ box)
+{
+    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+        fl_world_point(D, body[i * 3], body[i * 3 + 1], body[i * 3 + 2], p.x, p.y, p.z);
+        world3[i * 3] = p.x; world3[i * 3 + 1] = p.y; world3[i * 3 + 2] = p.z;
+        world4[i] = p;
+    }
+    static_assert(FL_BLOCK == 256, "fl_vx_block_box");
+    __shared__ unsigned s_red[4][7];
+    unsigned mn[3] = {0u, 0u, 0u}, mx[3] = {0u, 0u, 0u};
+    int cnt = 0;
+    if (i < n && isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+        mn[0] = ~fl_vx_enc(p.x); mn[1] = ~fl_vx_enc(p.y); mn[2] = ~fl_vx_enc(p.z);
+        mx[0] = fl_vx_enc(p.x); mx[1] = fl_vx_enc(p.y); mx[2] = fl_vx_enc(p.z);
+        cnt = 1;
+    }
+    const FlVxPartial r = fl_vx_block_box(mn, mx, cnt, s_red);
+    if (threadIdx.x == 0) box[blockIdx.x] = r;
+}
+// vmap_scan_kernel over the voxel filter's output (x, y, z, intensity; its count on the device), launched for the scan's full size
+__global__ __launch_bounds__(FL_BLOCK) void vmap_scan4_kernel(const float4 *__restrict__ scan4, const FlVxCtl *__restrict__ vx, const FlSelectParams *__restrict__ S,
+                                                             const FlVioConst *__restrict__ VC, unsigned long long *__restrict__ depth64,
+                                                             unsigned long long *__restrict__ set, unsigned mask)
+{
+    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
+    if (vx->cells_short || i >= vx->count) return;
+    fl_depth_point<4>(reinterpret_cast<const float *>(scan4), i, S, VC, depth64);
+    fl_subkey_point<4>(reinterpret_cast<const float *>(scan4), i, set, mask);
+}
+
 // addObservation under the pose of the state ComputeJ left (derived here as the host's vmap_frame_pose derives it: Rcw = Rci R^T,
 // Pcw = -Rcw p + Pci, the same operations in the same order), sized for the upper bound of the selection; the workgroup that finishes
 // last writes the frame's counts behind the state block and serves the result mailbox.
@@ -407,7 +450,8 @@ __global__ __launch_bounds__(FL_BLOCK) void vmap_addobs_dev_kernel(FlVPoint *__r
                                                                   const int32_t *__restrict__ sel_point, const int32_t *__restrict__ levels,
                                                                   const int32_t *__restrict__ n_sel_ptr, FlVmapCount *__restrict__ cnt,
                                                                   FlDev18 *__restrict__ D, unsigned *__restrict__ ticket,
-                                                                  unsigned long long *pub_flag, void *pub_dst, unsigned long long pub_seq)
+                                                                  unsigned long long *pub_flag, void *pub_dst, unsigned long long pub_seq,
+                                                                  const FlVxCtl *__restrict__ vx /* nullable: the down-sampling's control block */)
 {
     __shared__ double s_pose[15];            // Rcw, Pcw, fpos
     __shared__ int s_last;
@@ -449,6 +493,7 @@ __global__ __launch_bounds__(FL_BLOCK) void vmap_addobs_dev_kernel(FlVPoint *__r
         T->n_selected = n_sel;
         T->n_added = __hip_atomic_load(&cnt->added, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         T->n_observed = __hip_atomic_load(&cnt->obs_added, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        T->n_down = vx ? vx->count : 0; T->vox_cells_short = vx ? vx->cells_short : 0; T->vox_cells = vx ? vx->cells : 0ll; T->pad0 = T->pad1 = 0;
         D->pub_flag = pub_flag; D->pub_dst = pub_dst; D->pub_seq = pub_seq;
         *ticket = 0u;
         __threadfence();

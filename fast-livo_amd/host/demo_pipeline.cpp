@@ -195,6 +195,26 @@ int main(int argc, char **argv)
                 fprintf(stderr, "camera_half_ms median %.4f min %.4f p90 %.4f (detect: %d patches tracked, %d scan points, %d down-sampled; C++ over the C ABI)\n",
                         ms[ms.size() / 2], ms[0], ms[(ms.size() * 9) / 10], sel.n_selected, feats_down_size, n_down);
             }
+            // the same with the scan left on the device (FL_DETECT_SCAN_ON_DEVICE): pointBodyToWorld + the 0.2 m down-sampling (lidar_selection.cpp:352-353)
+            // are part of the timed call now, nothing but the image goes up
+            std::vector<double> md;
+            int32_t ns = 0, nf = 0, no = 0;
+            for (int r = 0; r < reps + 3; r++) {
+                StatesGroup xc = xc0;
+                fl_state18 st18;
+                to_abi(xc, st18);
+                const auto t0 = std::chrono::steady_clock::now();
+                const int32_t rc = fl_vio_detect(h, image.data(), cfg.img_width, cfg.img_height, cfg.img_width, nullptr, FL_DETECT_SCAN_ON_DEVICE, nullptr, 0, Rci, Pci,
+                                                 &st18, 100 + r, 0, 0.0, 1e12, &ns, &nf, &no);
+                const auto t1 = std::chrono::steady_clock::now();
+                if (rc < 0) { fprintf(stderr, "detect (device scan): %s\n", fl_last_error_string(h)); return 1; }
+                if (r >= 3) md.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+            }
+            if (!md.empty()) {
+                std::sort(md.begin(), md.end());
+                fprintf(stderr, "camera_half_device_scan_ms median %.4f min %.4f p90 %.4f (detect with the scan on the device: world points + 0.2 m voxel filter inside the call; %d patches tracked)\n",
+                        md[md.size() / 2], md[0], md[(md.size() * 9) / 10], ns);
+            }
         }
     }
     fl_destroy(h);

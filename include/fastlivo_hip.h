@@ -532,6 +532,12 @@ int32_t fl_vmap_add_observation(fl_handle h, const double *Rcw, const double *Pc
  * fl_vio_compute_j + fl_vmap_add_observation, the frame pose taken from state_io before and after ComputeJ as updateFrameState does
  * (:904-911; Rci, Pci: camera extrinsics of the state frame, lidar_selection.cpp:35-52). pg_world_xyz: the registered scan (n_pg x 3),
  * pg_down_world_xyz: its 0.2 m down-sampled form (:352-353). state_io: in = state_propagat = the LIO result, out = after ComputeJ. */
+/* n_pg = FL_DETECT_SCAN_ON_DEVICE (pg_world_xyz, pg_down_world_xyz ignored): the registered scan never leaves the device -- pg = the scan this
+ * handle holds (fl_lio_set_points / fl_lio_frame18_dev / fl_lidar_front: feats_down_body) under state_io (pointBodyToWorld, laserMapping.cpp:695-698,
+ * exactly what fl_lio_get_world_points returns), its 0.2 m down-sampling (downSizeFilter, lidar_selection.cpp:7,352-353) by the device voxel filter
+ * with the count kept on the device. Same results as handing both clouds in. */
+#define FL_DETECT_SCAN_ON_DEVICE (-1)
+#define FL_DETECT_DOWN_LEAF 0.2f
 int32_t fl_vio_detect(fl_handle h, const uint8_t *gray, int32_t width, int32_t height, int32_t stride, const float *pg_world_xyz, int32_t n_pg,
                       const float *pg_down_world_xyz, int32_t n_down, const double *Rci, const double *Pci, fl_state18 *state_io,
                       int32_t frame_id, int32_t ncc_en, double ncc_thre, double outlier_threshold, int32_t *n_selected, int32_t *n_founded,

@@ -133,3 +133,55 @@ def test_fused_detect_matches_the_oracle(gpu_lib, oracle_lib, scene):
     from fast_livo_amd import synth
     log, _ = _walk(capi, orc, synth, scene, 6, 3000, 4, 40, True, True, blind_frame=3)
     assert sum(r["counts"][0] for r in log) > 60 and sum(r["counts"][2] for r in log) > 0, [r["counts"] for r in log]
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_detect_with_the_scan_on_the_device(gpu_lib, oracle_lib, scene, fused):
+    """n_pg = FL_DETECT_SCAN_ON_DEVICE: pg = the handle's staged scan under state_io (pointBodyToWorld), its 0.2 m down-sampling by the device
+    voxel filter, the count never leaving the device (lidar_selection.cpp:352-353). Against a second handle that is handed both clouds (computed
+    by fl_lio_get_world_points / fl_scan_voxel_filter, i.e. the same kernels): counts, states, per-patch errors and the visual map bit for bit.
+    fused = False: FL_OPT_DETECT_FUSED 0 on the device-scan handle -- the fallback that materialises the clouds and runs the staged calls."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    n_scan, max_iter, grid, frames = 4000, 4, 40, 6
+    fr0 = synth.make_lio_frame(n_scan, scene=scene)
+    vf0 = synth.make_vio_frame(8, fr0, max_iterations=max_iter)
+    hs = [capi.Handle(capi.config_from_frames(fr0, vf0, max_iterations=max_iter)) for _ in range(2)]
+    hs[1].set_option(capi.FL_OPT_DETECT_FUSED, 1 if fused else 0)
+    for h in hs:
+        h.vmap_clear(grid)
+    Rci = vf0.Rcl @ fr0.R_LI.T
+    Pci = vf0.Rcl @ (-fr0.R_LI.T @ fr0.t_LI) + vf0.Pcl
+    R_t, p_t = fr0.R_true.copy(), fr0.p_true.copy()
+    Q = np.diag([1e-5] * 3 + [1e-4] * 3 + [1e-3] * 3 + [1e-8] * 9)
+    cov = fr0.cov18.copy()
+    tracked = 0
+    for k in range(frames):
+        R_t = R_t @ synth.exp_so3(np.array([0.0, 0.0, 0.01]))
+        p_t = p_t + np.array([0.05, 0.03, 0.0])
+        body = synth.scan_from_pose(scene, R_t, p_t, n_scan, seed=700 + k)
+        Rc_t, Pc_t = synth.cam_pose(vf0.Rcl, vf0.Pcl, fr0.R_LI, fr0.t_LI, R_t, p_t)
+        img = synth.render_image(scene, vf0.cam, Rc_t, Pc_t, seed=k)
+        dR = synth.exp_so3(np.array([0.002, -0.001, 0.0015])); dp = np.array([0.01, -0.008, 0.005])
+        xs = [capi.State18.make(R_t @ dR, p_t + dp, fr0.vel, fr0.bg, fr0.ba, fr0.grav, cov + Q) for _ in range(2)]
+        # handle 0: both clouds through the host
+        hs[0].lio_set_points(body); hs[0].lio_begin18(xs[0], xs[0])
+        world = hs[0].lio_get_world_points(n_scan)
+        down, nd, _ = hs[0].scan_voxel_filter(np.ascontiguousarray(np.concatenate([world, np.zeros((n_scan, 1), np.float32)], axis=1)), 0.2)
+        down = np.ascontiguousarray(down[:nd, :3])
+        c0 = hs[0].vio_detect(img, world, down, Rci, Pci, xs[0], k, outlier_threshold=3000.0)
+        # handle 1: nothing but the image goes up
+        hs[1].lio_set_points(body)
+        c1 = hs[1].vio_detect(img, None, None, Rci, Pci, xs[1], k, outlier_threshold=3000.0)
+        assert c0 == c1, f"frame {k}: {c0} vs {c1}"
+        assert np.array_equal(xs[0].vec(), xs[1].vec()) and np.array_equal(xs[0].cov_np(), xs[1].cov_np()), f"frame {k}: state"
+        if c0[0] > 0:
+            assert np.array_equal(hs[0].vio_get_errors(c0[0]), hs[1].vio_get_errors(c1[0])), f"frame {k}: per-patch errors"
+        tracked += c0[0]
+        cov = xs[0].cov_np()
+    assert tracked > 60 and hs[0].vmap_size() == hs[1].vmap_size()
+    for i in range(hs[0].vmap_size()):
+        p, q = hs[0].vmap_get_point(i), hs[1].vmap_get_point(i)
+        assert np.array_equal(p[0], q[0]) and p[1] == q[1] and len(p[2]) == len(q[2]) and _same_obs(p[2], q[2]), f"visual map point {i}"
+    for h in hs:
+        h.close()
