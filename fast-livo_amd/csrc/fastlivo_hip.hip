@@ -162,6 +162,7 @@ struct fl_context {
     int opt_vio_spec = 1;                  // FL_OPT_VIO_SPECULATE
     int opt_vio_wide = 1;                  // FL_OPT_VIO_WIDE
     int opt_detect_fused = 1;              // FL_OPT_DETECT_FUSED
+    int front_unsorted_left = 0;           // fl_lidar_front: frames left on the general undistortion kernels (api_front.inc)
     struct FlDetectParams *d_det_prm = nullptr;    // fl_vio_detect, fused form (api_vmap.inc)
     unsigned *d_det_ticket = nullptr;
     size_t map_pool_cap = 0;               // float4 entries of d_map_pts

@@ -92,7 +92,8 @@ struct FlDetectTail { int32_t n_cand, n_selected, n_added, n_observed, n_down, v
 struct FlFrontTail {
     double acc_s_last[3], angvel_last[3];      // ImuProcess members the next frame starts from (IMU_Processing.cpp:731-732)
     int32_t n_poses;
-    int32_t vox_count, vox_leaf_too_small, vox_cells_short, vox_nfinite, pad;
+    int32_t vox_count, vox_leaf_too_small, vox_cells_short, vox_nfinite;
+    int32_t unsorted;                          // undistort_sorted_kernel met a point earlier than its predecessor (or a NaN time): the frame is run again with the general kernels
     long long vox_cells;
 };
 

@@ -130,6 +130,10 @@ __device__ __forceinline__ double fl_imu_cov_w(const FlImuStep &S, const double 
 // state chain, (C) one lane per interval forms the pieces of F_x / cov_w that need that interval's R, (D) the workgroup walks the
 // covariance chain, one element per lane. Every quantity is computed by the same expression as before, so the results are
 // bit-identical; only the schedule changed.
+// (Round 6, measured and rejected: (B) and (C) on a seventh wavefront one interval AHEAD of (D), joined at (D)'s two barriers per interval. The
+// chain's step on one lane -- ~1 us with its 22 pose stores -- is as long as both covariance phases together, so an interval became
+// max(B, phase 1) + phase 2 instead of B + phases: 100 samples 149 -> 183 us, 20 samples 59-63 us either way, and fl_lidar_front did not move
+// at all: there the launch is bound by the fetch of the raw scan over the host link (~33 us for 100 k points) that runs beside the chain.)
 #define FL_IMU_CH 64
 // out18 / tail (fl_lidar_front, nullable): the propagated state goes straight into the LIO state block on the device -- state,
 // state_propagat (:1292 of laserMapping.cpp: state_propagat = state) and cov -- and the members the next frame starts from into the
@@ -326,6 +330,7 @@ __global__ __launch_bounds__(FL_IMU_NT) void imu_forward_kernel(FlImuDev *__rest
         if (tail) {
             for (int k = 0; k < 3; k++) { tail->acc_s_last[k] = s_acc[k]; tail->angvel_last[k] = s_w[k]; }
             tail->n_poses = s_K;
+            tail->unsorted = 0;
         }
     }
 }
@@ -438,6 +443,52 @@ __global__ __launch_bounds__(FL_BLOCK) void undistort_apply_kernel(float4 *__res
         }
     }
     if (!box) return;
+    static_assert(FL_BLOCK == 256, "fl_vx_block_box");
+    __shared__ unsigned s_red[4][7];
+    unsigned mn[3] = {0u, 0u, 0u}, mx[3] = {0u, 0u, 0u};
+    int cnt = 0;
+    if (i < n && isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+        mn[0] = ~fl_vx_enc(p.x); mn[1] = ~fl_vx_enc(p.y); mn[2] = ~fl_vx_enc(p.z);
+        mx[0] = fl_vx_enc(p.x); mx[1] = fl_vx_enc(p.y); mx[2] = fl_vx_enc(p.z);
+        cnt = 1;
+    }
+    const FlVxPartial r = fl_vx_block_box(mn, mx, cnt, s_red);
+    if (threadIdx.x == 0) box[blockIdx.x] = r;
+}
+
+// The three kernels above in ONE launch for clouds whose times do not decrease (what a LiDAR driver delivers; the reference's own
+// UndistortPcl has its sort commented out, :647, and therefore handles any order -- the general kernels replicate that): then the latest
+// interval that starts before a point is never later than its successor's, the suffix minimum of undistort_scan_kernel is the point's own
+// head, and "the loops ended before they reached this point" (term) is the point's own test (head 0 and not later than IMUpose[0]). Every
+// point checks its predecessor's time; a decrease (or a NaN time) anywhere raises tail->unsorted and the host runs the frame again with the
+// general kernels (and keeps to them for a while). Same arithmetic per point: same bits. box as in undistort_apply_kernel.
+__global__ __launch_bounds__(FL_BLOCK) void undistort_sorted_kernel(float4 *__restrict__ pts, int n, const FlImuDev *__restrict__ D,
+                                                                   const FlPose6 *__restrict__ poses, FlVxPartial *__restrict__ box,
+                                                                   FlFrontTail *__restrict__ tail)
+{
+    const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
+    const int K = D->n_poses;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool disorder = false;
+    if (i < n) {
+        p = pts[i];
+        const float w_prev = (i > 0) ? pts[i - 1].w : p.w;       // (the predecessor's time is never rewritten: only x, y, z are)
+        disorder = !(w_prev <= p.w);
+        const double t = (double)p.w / 1000.0;
+        const int hd = fl_imu_head(poses, K, t);
+        const bool stays = (hd == 0) && !(t > poses[0].offset_time);
+        if (!(K < 2 || stays)) {
+            fl_undistort_point(D, poses[hd], t, p.x, p.y, p.z);
+            if (i == 0) {
+                for (int k = hd - 1; k >= 0; k--)                                  // :803: no step back after the first point
+                    if (t > poses[k].offset_time) fl_undistort_point(D, poses[k], t, p.x, p.y, p.z);
+            }
+        }
+    }
+    if (__ballot(disorder) != 0ull && (threadIdx.x & 63u) == 0u) tail->unsorted = 1;      // (same value from everybody)
+    // every lane has read its predecessor's time before anybody's store lands on it? Stores touch x, y, z AND w of the own point only (a
+    // float4 store): w is rewritten with the value it had, so a neighbour that reads it late sees the same bits.
+    if (i < n) pts[i] = p;
     static_assert(FL_BLOCK == 256, "fl_vx_block_box");
     __shared__ unsigned s_red[4][7];
     unsigned mn[3] = {0u, 0u, 0u}, mx[3] = {0u, 0u, 0u};

@@ -84,3 +84,37 @@ def test_fused_front_against_the_cpu_oracle(gpu_lib):
     sg = np.frombuffer(bytes(x), np.float64); sc = np.frombuffer(bytes(xo), np.float64)
     assert np.abs(sg - sc).max() <= 1e-9
     h.close()
+
+
+@pytest.mark.parametrize("kind", ["shuffled", "one_swap", "nan_time", "first_point_late"])
+def test_fused_front_with_a_cloud_out_of_time_order(gpu_lib, kind):
+    """The fused frame undistorts with ONE kernel that assumes the cloud's times never decrease and checks it (imu_kernels.h
+    undistort_sorted_kernel); a cloud that fails the check is run again with the general kernels (the reference's loops handle any order,
+    IMU_Processing.cpp:778-808, its sort is commented out, :647). Either way every bit equals the staged calls' -- also for the frames that
+    follow (the handle keeps to the general kernels for a while, then tries the fast one again)."""
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    lio = synth.make_lio_frame(30000)
+    if kind == "first_point_late":
+        f = synth.make_imu_frame(30000, n_imu=20, lio=lio, quiet=True, first_point_late=True)
+    else:
+        f = synth.make_imu_frame(30000, n_imu=20, lio=lio, quiet=True)
+    f.pts_xyzt[:, :3] = lio.body_xyz
+    rng = np.random.default_rng(3)
+    if kind == "shuffled":
+        f.pts_xyzt = np.ascontiguousarray(f.pts_xyzt[rng.permutation(len(f.pts_xyzt))])
+    elif kind == "one_swap":
+        f.pts_xyzt[[20000, 20001]] = f.pts_xyzt[[20001, 20000]]
+        assert f.pts_xyzt[20000, 3] > f.pts_xyzt[20001, 3]
+    elif kind == "nan_time":
+        f.pts_xyzt[12345, 3] = np.nan
+    res = []
+    for staged in (True, False):
+        h = capi.Handle(capi.config_from_frames(lio, max_iterations=6))
+        h.map_set_points(lio.scene.map_xyz, 0.5)
+        res.append(_run(capi, h, lio, f, 0.2, staged, frames=3))
+        h.close()
+    for a, b in zip(*res):
+        assert a[2] == b[2] and a[3:7] == b[3:7], (a[2:7], b[2:7])
+        assert a[0] == b[0] and a[1] == b[1]
+        assert np.array_equal(a[7], b[7]) and np.array_equal(a[8].view(np.uint32), b[8].view(np.uint32))
