@@ -134,7 +134,17 @@ __global__ __launch_bounds__(FL_BLOCK) void mapinc_resolve_kernel(FlBoxSlot *__r
                                                                  unsigned *__restrict__ pend_next, FlMapIncCtl *__restrict__ ctl)
 {
     const unsigned s = blockIdx.x * FL_BLOCK + threadIdx.x;
-    int removed = 0, added = 0;
+    int removed = 0, added = 0, amb_old = 0;
+    // is box `k` claimed by a new point of this update? (open addressing, as mapupd_new_kernel filled it; tab_cap is a power of two)
+    auto touched = [&](unsigned long long k) -> bool {
+        unsigned hh = fl_hash64(k) & (tab_cap - 1u);
+        while (true) {
+            const unsigned long long kk = tab[hh].key;
+            if (kk == k) return true;
+            if (kk == FL_KNN_EMPTY) return false;
+            hh = (hh + 1u) & (tab_cap - 1u);
+        }
+    };
     if (s < tab_cap) {
         const unsigned long long bkey = tab[s].key;
         if (bkey != FL_KNN_EMPTY) {
@@ -149,7 +159,27 @@ __global__ __launch_bounds__(FL_BLOCK) void mapinc_resolve_kernel(FlBoxSlot *__r
                         const unsigned st = V.htab[hs].start, cn = V.htab[hs].count;
                         for (unsigned j = st; j < st + cn; j++) {
                             const float4 p = V.pts[j];
+                            if (__float_as_int(p.w) == FL_MI_DEAD) continue;
                             const FlBoxGeom g = fl_box_of(p.x, p.y, p.z, ds);
+                            // n_ambiguous of the update (include/fastlivo_hip.h): the OLD points whose box depends on a rounding and that could
+                            // matter to it -- those of a touched box (counted by their own box) and those next to a touched box whose own box
+                            // no new point claimed (the reference's coordinate test could have put them into the neighbour)
+                            if (g.ambiguous && !g.range_error) {      // (rare: ~1e-7 per coordinate on real data)
+                                const unsigned long long own = fl_cell_key(g.ix, g.iy, g.iz);
+                                if (own == bkey) amb_old++;
+                                else if (!touched(own)) {
+                                    // counted ONCE: by the touched box with the smallest key among the 26 neighbours of its own box
+                                    unsigned long long first = FL_KNN_EMPTY;
+                                    for (int dz = -1; dz <= 1; dz++)
+                                        for (int dy = -1; dy <= 1; dy++)
+                                            for (int dx = -1; dx <= 1; dx++) {
+                                                if (!(dx | dy | dz)) continue;
+                                                const unsigned long long nk = fl_cell_key(g.ix + dx, g.iy + dy, g.iz + dz);
+                                                if (nk < first && touched(nk)) first = nk;
+                                            }
+                                    if (first == bkey) amb_old++;
+                                }
+                            }
                             if (g.range_error || fl_cell_key(g.ix, g.iy, g.iz) != bkey) continue;
                             const float d = fl_calc_dist(p.x, p.y, p.z, g.cx, g.cy, g.cz);
                             const unsigned long long cand = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned)__float_as_int(p.w);
@@ -183,19 +213,34 @@ __global__ __launch_bounds__(FL_BLOCK) void mapinc_resolve_kernel(FlBoxSlot *__r
             if (!old_wins) {         // the closest new point (the latest among equals) enters: queued at its cell
                 const unsigned jn = 0xFFFFFFFFu - (unsigned)best_new;
                 const float x = new_pts[jn * 3], y = new_pts[jn * 3 + 1], z = new_pts[jn * 3 + 2];
-                const int hs = fl_mi_find_or_insert(V, fl_mi_cell_key_of(x, y, z, V.inv_cell), ctl);
-                if (hs < 0) ctl->needs_rebuild = 1;
-                else {
-                    pend_next[jn] = atomicExch(&V.pend_head[hs], jn);
-                    V.dirty[hs] = 1u;
-                    dead[n_raw + (int)jn] = 0;
-                    added = 1;
+                //  a point that is not finite or whose box index does not fit the key (|p / ds| >= 2^20) is never admitted: it stays
+                // dead in the array, the update's status says FL_NUM_NONFINITE (mapupd_new_kernel counted it) -- (int)floorf(NaN) below is undefined
+                const bool ok = isfinite(x) && isfinite(y) && isfinite(z) && !fl_box_of(x, y, z, ds).range_error;
+                if (ok) {
+                    // the cell the point is queued at must be one of those mapinc_apply_kernel visits for this box (B.c0 .. B.c1, derived by probing
+                    // the box's faces within one ulp): if the rounding of p * inv_cell ever puts it outside, the cell would stay dirty with a queue
+                    // into pend_next, which the next update overwrites. Checked here instead of argued: the point then enters the array only and
+                    // the index is re-built before anybody searches it (needs_rebuild -> map_index_ready, api_knn.inc).
+                    const int qx = (int)floorf(x * V.inv_cell), qy = (int)floorf(y * V.inv_cell), qz = (int)floorf(z * V.inv_cell);
+                    const bool covered = qx >= B.c0[0] && qx <= B.c1[0] && qy >= B.c0[1] && qy <= B.c1[1] && qz >= B.c0[2] && qz <= B.c1[2];
+                    const int hs = covered ? fl_mi_find_or_insert(V, fl_cell_key(qx, qy, qz), ctl) : -1;
+                    if (hs < 0) {                       // (not covered, or the table is full: the point lives in the array, the index follows at the rebuild)
+                        ctl->needs_rebuild = 1;
+                        dead[n_raw + (int)jn] = 0;
+                        added = 1;
+                    } else {
+                        pend_next[jn] = atomicExch(&V.pend_head[hs], jn);
+                        V.dirty[hs] = 1u;
+                        dead[n_raw + (int)jn] = 0;
+                        added = 1;
+                    }
                 }
             }
         }
     }
     fl_mi_count_wave(removed, &ctl->removed);
     fl_mi_count_wave(added, &ctl->added);
+    fl_mi_count_wave(amb_old, &ctl->ambiguous);
 }
 
 // the owner of a dirty cell: tombstones out, queued points in, moved if it no longer fits
@@ -360,7 +405,7 @@ __global__ void mapinc_status_kernel(FlMapIncCtl *__restrict__ ctl, const FlMapU
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     ctl->live += ctl->added - ctl->removed;
-    if (upd) { ctl->ambiguous = upd->ambiguous; ctl->range_error = upd->range_error; }
+    if (upd) { ctl->ambiguous += upd->ambiguous; ctl->range_error = upd->range_error; }      // (new points: mapupd_new_kernel; old ones: mapinc_resolve_kernel)
     FlMapIncCtl c = *ctl;
     c.seq = 0ull;
     *status = c;

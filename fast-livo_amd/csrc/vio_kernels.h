@@ -1344,6 +1344,14 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
             if (p + 1 < count) eskf18_restage(s_solve);
         }
         if constexpr (SPEC != 0) {
+            // A launch left on the ABANDON path (gather time-out of pass p, or the solve raised ctrl & 4) with the verdict on pass p - 1 still
+            // out: the deferred old_state / sums_acc / solution / error bookkeeping of that pass live in LDS only and would be
+            // lost with the kernel -- the device block would then hold x_{p} beside last_error and old_state of pass p - 2, and the host's
+            // resume would revert to the wrong state. Pass p - 1's records and per-patch words are complete (it was gathered and solved):
+            // take the chain's verdict now (replay fallback inside), commit or roll back, then leave.
+            if (s_solve.spec_pending && !rollback && (s_solve.ctrl & 4)) {      // (uniform: LDS, behind the loop's last barrier)
+                if (vio_spec_confirm(D, &s_solve, err_base, err_cap, m, s_ex, errors, VC, nullptr, 0u)) rollback = 2;
+            }
             // the revert of a fragile accept the float chain did not confirm (rare; out of the loop and out of line). rollback == 1: the
             // producers of pass done - 1 wait for a control word -- they get "stop"; their records are dropped
             if (rollback) vio_spec_rollback(D, &s_solve, err_base, err_cap, m, errors, VC, rollback == 1 ? bcast : (unsigned long long *)nullptr, epoch0 + (unsigned)done);

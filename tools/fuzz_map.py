@@ -44,13 +44,16 @@ for tr in range(trials):
             gi = h.map_add_points(new, ds)
             want, oi = orc.map_add_points(cur, new, ds)
             amb = oi.n_ambiguous
-            ok = gi.n_ambiguous == oi.n_ambiguous
-            if amb == 0:
-                ok = ok and np.array_equal(h.map_get_points(), want)
-                cur = want
-            else:                       # the two sides may legitimately differ: continue from the device's map
+            # n_ambiguous: the oracle counts EVERY point (old and new) whose box depends on a rounding; the in-place form (FL_OPT_MAP_INCREMENTAL,
+            # round 5) only looks at the boxes an update touches, so it counts the new points and the old ones that could matter to this update.
+            # The contract (include/fastlivo_hip.h): results may differ from the sequential reference ONLY where the device's count is not 0.
+            ok = gi.n_ambiguous <= oi.n_ambiguous
+            got = h.map_get_points().copy()
+            if gi.n_ambiguous == 0:
+                ok = ok and np.array_equal(got, want)
+            if amb:
                 amb_cases += 1
-                cur = h.map_get_points().copy()
+            cur = got if not np.array_equal(got, want) else want
         updates += 1
         if not ok:
             mism += 1
