@@ -1,6 +1,6 @@
 """Randomised cross-check of the VIO side (run on the GPU box): random patch counts / iteration caps, ComputeJ vs the oracle
 (state 1e-9, per-patch errors bit for bit), selection vs the oracle (bit-identical). FL_FUZZ_WIDE=2: ComputeJ on the one-patch-per-lane
-producers (FL_OPT_VIO_WIDE)."""
+producers (FL_OPT_VIO_WIDE). FL_FUZZ_SCALE=1: patch counts drawn from 16 384 ... 100 000 (the automatic switch to those producers)."""
 import os, sys, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +13,10 @@ T = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 for trial in range(T):
     m = int(rng.choice([1, 2, 7, 8, 9, 63, 64, 65, 300, 1000, 2040, 2041, 2600]))
     max_iter = int(rng.integers(1, 11))
+    if os.environ.get("FL_FUZZ_SCALE"):          # round 6: sizes at which the one-patch-per-lane producers switch on BY THEMSELVES (default option),
+        m = int(rng.integers(16384, 100001))     # distinct patches; the oracle's patch loop over the host's cores (bit-identical for any thread count)
+        max_iter = int(rng.integers(1, 5))
+        orc.lib().orc_vio_set_threads(min(os.cpu_count() or 1, 64))
     seed = int(rng.integers(1 << 20))
     lio = synth.make_lio_frame(500, seed=synth.SEED + seed % 7)
     vf = synth.make_vio_frame(m, lio, max_iterations=max_iter, patch_seed=seed)
