@@ -85,6 +85,7 @@ struct fl_context {
     std::mutex pinned_mu;
     int opt_mailbox = 3;            // bit 0: fl_vio_compute_j, bit 1: fl_lio_frame18_dev
 #define FL_UP_SLOTS 12
+    void *d_small = nullptr;        // device address of h_small
     void *h_small = nullptr;        // page-locked scratch: 4 KB for the small per-call read-backs (counts, control blocks) + FL_UP_SLOTS x 1 KB for parameter uploads
     unsigned up_slot = 0;
     unsigned up_pending = 0;        // uploads through the slot ring since the last stream synchronisation this code knows of (upload_small)
@@ -383,6 +384,7 @@ int32_t fl_create(const fl_config *cfg, fl_handle *out)
     HIPCHK(h, hipHostMalloc(&h->h_dev23, sizeof(FlDev23)));
     HIPCHK(h, hipHostGetDevicePointer(&h->d_hdev23, h->h_dev23, 0));
     HIPCHK(h, hipHostMalloc(&h->h_small, 4096 + FL_UP_SLOTS * 1024));
+    HIPCHK(h, hipHostGetDevicePointer(&h->d_small, h->h_small, 0));      // (kernels that fetch a parameter block themselves: fl_vio_detect)
     HIPCHK(h, hipMalloc(&h->d_records, (size_t)16 * FL_MAX_BLOCKS * FL_SUMS23));
     HIPCHK(h, hipMalloc(&h->d_epoch, 64));
     {

@@ -364,13 +364,34 @@ struct FlDetectParams {             // one small upload per frame
     double Rci[9], Pci[3];          // camera <- IMU: the pose after ComputeJ is derived on the device (updateFrameState, :904-911)
 };
 
+// fl_vio_begin's launch (vio_prepare_kernel) with the state block and the frame's parameter block FETCHED from page-locked memory by the
+// kernel itself (as imu_forward_kernel does for fl_lidar_front): two copy commands (~4-5 us of stream time each) less in front of the frame
+__global__ __launch_bounds__(128) void detect_begin_kernel(FlDev18 *__restrict__ D, const FlVioConst *__restrict__ VC, const FlDev18 *__restrict__ x18_host,
+                                                          FlDetectParams *__restrict__ prm, const FlDetectParams *__restrict__ prm_host)
+{
+    {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(x18_host);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(D);
+        for (int w = (int)threadIdx.x; w < (int)(sizeof(FlDev18) / 8); w += 128) dst[w] = __builtin_nontemporal_load(src + w);
+        const unsigned long long *ps = reinterpret_cast<const unsigned long long *>(prm_host);
+        unsigned long long *pd = reinterpret_cast<unsigned long long *>(prm);
+        static_assert(sizeof(FlDetectParams) % 8 == 0, "word copy");
+        for (int w = (int)threadIdx.x; w < (int)(sizeof(FlDetectParams) / 8); w += 128) pd[w] = __builtin_nontemporal_load(ps + w);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x >= 116) vio_derive_pose(D->x, VC, D, (int)threadIdx.x - 116);
+    eskf18_prepare_body(D);
+}
+
 // every clear of the frame in one launch (they were 4 fills + vio_grid_init_kernel) + the keyframe copy of the staged image + the keyframe
 // table entry + the record slots of ComputeJ's launches (sized for the upper bound; what a launch does not rewrite must carry no tag)
 __global__ __launch_bounds__(FL_BLOCK) void vmap_frame_init_kernel(unsigned long long *__restrict__ depth64, int n_depth, unsigned long long *__restrict__ set,
                                                                   int n_set, int *__restrict__ owner, int n_owner, unsigned long long *__restrict__ best,
                                                                   unsigned long long *__restrict__ key, int *__restrict__ val, int32_t *__restrict__ gnum,
                                                                   int length, unsigned long long *__restrict__ records, int n_rec_words,
-                                                                  const uint4 *__restrict__ img, uint4 *__restrict__ kf_img, int n_img16,
+                                                                  const uint4 *__restrict__ img /* the staged image, or the caller's page-locked one */,
+                                                                  uint4 *__restrict__ img_cur /* nullable: then `img` IS the staged copy */, uint4 *__restrict__ kf_img, int n_img16,
                                                                   const uint8_t **__restrict__ kf_table, int kf_id, FlVmapCount *__restrict__ cnt,
                                                                   int32_t *__restrict__ sel_count, unsigned *__restrict__ ticket)
 {
@@ -385,7 +406,12 @@ __global__ __launch_bounds__(FL_BLOCK) void vmap_frame_init_kernel(unsigned long
         gnum[i] = 3;
     }
     for (int i = t; i < n_rec_words; i += nt) records[i] = 0ull;
-    for (int i = t; i < n_img16; i += nt) kf_img[i] = img[i];
+    if (img_cur) {                                                                              // (one trip over the host link)
+        const fl_u4 *src = reinterpret_cast<const fl_u4 *>(img);
+        fl_u4 *d0 = reinterpret_cast<fl_u4 *>(kf_img), *d1 = reinterpret_cast<fl_u4 *>(img_cur);
+        for (int i = t; i < n_img16; i += nt) { const fl_u4 v = __builtin_nontemporal_load(src + i); d0[i] = v; d1[i] = v; }
+    }
+    else for (int i = t; i < n_img16; i += nt) kf_img[i] = img[i];
     if (t == 0) {
         kf_table[kf_id] = reinterpret_cast<const uint8_t *>(kf_img);
         cnt->cand = 0; cnt->added = 0; cnt->obs_added = 0;

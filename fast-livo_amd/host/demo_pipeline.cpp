@@ -199,12 +199,16 @@ int main(int argc, char **argv)
             // are part of the timed call now, nothing but the image goes up
             std::vector<double> md;
             int32_t ns = 0, nf = 0, no = 0;
+            // (the image in page-locked memory of the library: the frame's first kernel fetches it, no copy command at all)
+            uint8_t *img_pinned = nullptr;
+            if (fl_host_alloc(h, image.size(), (void **)&img_pinned) || !img_pinned) { fprintf(stderr, "fl_host_alloc: %s\n", fl_last_error_string(h)); return 1; }
+            memcpy(img_pinned, image.data(), image.size());
             for (int r = 0; r < reps + 3; r++) {
                 StatesGroup xc = xc0;
                 fl_state18 st18;
                 to_abi(xc, st18);
                 const auto t0 = std::chrono::steady_clock::now();
-                const int32_t rc = fl_vio_detect(h, image.data(), cfg.img_width, cfg.img_height, cfg.img_width, nullptr, FL_DETECT_SCAN_ON_DEVICE, nullptr, 0, Rci, Pci,
+                const int32_t rc = fl_vio_detect(h, img_pinned, cfg.img_width, cfg.img_height, cfg.img_width, nullptr, FL_DETECT_SCAN_ON_DEVICE, nullptr, 0, Rci, Pci,
                                                  &st18, 100 + r, 0, 0.0, 1e12, &ns, &nf, &no);
                 const auto t1 = std::chrono::steady_clock::now();
                 if (rc < 0) { fprintf(stderr, "detect (device scan): %s\n", fl_last_error_string(h)); return 1; }
@@ -212,9 +216,10 @@ int main(int argc, char **argv)
             }
             if (!md.empty()) {
                 std::sort(md.begin(), md.end());
-                fprintf(stderr, "camera_half_device_scan_ms median %.4f min %.4f p90 %.4f (detect with the scan on the device: world points + 0.2 m voxel filter inside the call; %d patches tracked)\n",
+                fprintf(stderr, "camera_half_device_scan_ms median %.4f min %.4f p90 %.4f (detect with the scan on the device: world points + 0.2 m voxel filter inside the call, image in fl_host_alloc memory; %d patches tracked)\n",
                         md[md.size() / 2], md[0], md[(md.size() * 9) / 10], ns);
             }
+            fl_host_free(h, img_pinned);
         }
     }
     fl_destroy(h);
