@@ -182,6 +182,13 @@ __global__ __launch_bounds__(FL_BLOCK) void vox_centroid_kernel(const float4 *__
 // Everything the sequence sets it clears, so the (large) bitmap is zeroed once, at allocation. Cells beyond the bitmap's capacity:
 // cells_short is raised, nothing is filtered, the host grows the bitmap and runs the frame again (first frames of a run only).
 // Bit-identical to the sorted path and to oracle/orc_voxel.c: same keys, same output order, same summation order.
+// (Round 6, built, measured and removed: FIVE launches instead of seven -- a member counter per grid CELL (512 MB for 2^27 cells) raised where
+// the voxel is claimed, plus one per 32-cell bitmap word, so that the counts are final before the prefix pass, the pass scans members along
+// with voxels, and rank + segment start + scatter are one kernel. Bit-identical, and no faster: 35.7 vs 38 us at 24 k points stand-alone, but
+// fl_lidar_front 0.196 -> 0.217 ms and the camera half 0.167 -> 0.171 ms -- 100 k atomics WITH a return value scattered over a half-gigabyte
+// array (DRAM and TLB misses in a frame whose caches other kernels have just used) cost more than the two kernel boundaries they save; the
+// per-voxel counters of the seven-launch form live in a compact, cache-resident array. A first version that walked the set bits of a
+// group and loaded their counters one after the other took 60 us for the prefix pass alone.)
 #define FL_VX_NT 256
 #define FL_VX_L1_SHIFT 8            /* 256 cells (8 bitmap words = one 32-byte line) per group */
 #define FL_VX_L2_SHIFT 18           /* 1024 groups per block */
