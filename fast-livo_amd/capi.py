@@ -258,6 +258,7 @@ DEBUG_SYMBOLS = {
     "fl_debug_chain": (C.c_int32, [_H, C.POINTER(C.c_float), C.c_int32, C.c_float, C.POINTER(C.c_float)]),
     "fl_debug_drop_record": (C.c_int32, [_H, C.c_int32]),
     "fl_debug_map_pool_limit": (C.c_int32, [_H, C.c_int32]),
+    "fl_debug_mp_refuse": (C.c_int32, [_H, C.c_int32, C.c_int32]),
 }
 FL_OPT_MULTIPASS, FL_OPT_MAX_PRODUCERS, FL_OPT_IK_PRODUCERS, FL_OPT_MP_CAPACITY, FL_OPT_VIO_WHOLE_CU, FL_OPT_MAILBOX, FL_OPT_SCAN_PULL, FL_OPT_INCR_SEARCH = 1, 2, 3, 4, 5, 6, 7, 8
 FL_OPT_DEMOTE_AFTER, FL_OPT_DEMOTE_CALLS, FL_OPT_VOXEL_SORT, FL_OPT_MAP_INCREMENTAL, FL_OPT_VIO_SPECULATE, FL_OPT_VIO_WIDE = 9, 10, 11, 12, 13, 14
@@ -990,6 +991,9 @@ def _knn_methods():
     def map_compact(self):
         self._chk(self.L.fl_map_compact(self.h), "fl_map_compact")
 
+    def debug_mp_refuse(self, nth, count=1):
+        self._chk(self.L.fl_debug_mp_refuse(self.h, int(nth), int(count)), "fl_debug_mp_refuse")
+
     def debug_map_pool_limit(self, spare_entries):
         self._chk(self.L.fl_debug_map_pool_limit(self.h, int(spare_entries)), "fl_debug_map_pool_limit")
 
@@ -1032,7 +1036,7 @@ def _knn_methods():
         return info
 
     for f in (map_set_points, map_clear, map_add_points, map_delete_boxes, map_get_points, map_compact, lio_search18, ikfom_search, lio_frame18_dev, ikfom_update_iterated_dev,
-              debug_hog, debug_chain, debug_drop_record, debug_knn_stamp, debug_map_pool_limit, set_option, diagnostics):
+              debug_hog, debug_chain, debug_drop_record, debug_knn_stamp, debug_map_pool_limit, debug_mp_refuse, set_option, diagnostics):
         setattr(Handle, f.__name__, f)
 
 

@@ -230,6 +230,7 @@ struct fl_context {
     int ev_frame_kind[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // what ended at event i: 1 search + plane fit, 2 passes, 3 covariance update
     bool timing = false;
     bool dbg_knn_stamp = false;   // FL_INSTRUMENT build only
+    int dbg_mp_refuse_in = 0, dbg_mp_refuse_n = 0;     // FL_INSTRUMENT build only: reservations nth .. nth + count - 1 from now are refused (fl_debug_mp_refuse)
     float last_ms = 0.f;
     int last_launches = 0;
     std::string err;
@@ -328,6 +329,8 @@ static unsigned mp_reserve(fl_handle h, int slots, int capacity, bool need_idle 
 {
     std::lock_guard<std::mutex> lk(g_mp_mu);
     const int busy = mp_busy_locked(h);
+    FL_INSTR(if (h->dbg_mp_refuse_in > 1) h->dbg_mp_refuse_in--;                                              // test aid: as if another handle's launch were in flight
+             else if (h->dbg_mp_refuse_in == 1) { if (--h->dbg_mp_refuse_n <= 0) h->dbg_mp_refuse_in = 0; h->mp_fallbacks++; return 0u; })
     if (need_idle ? (busy != 0 || slots > capacity) : (busy + slots > capacity)) {
         if (!need_idle) h->mp_fallbacks++;
         return 0u;
@@ -1162,6 +1165,14 @@ int32_t fl_debug_drop_record(fl_handle h, int32_t passes_ahead)
     HIPCHK(h, hipMemcpy(&e, h->d_epoch, sizeof e, hipMemcpyDeviceToHost));
     e += (unsigned)passes_ahead;
     HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(g_fl_fault_epoch), &e, sizeof e));
+    return FL_OK;
+}
+int32_t fl_debug_mp_refuse(fl_handle h, int32_t nth, int32_t count)
+{
+    if (!h || nth < 0 || count < 0) return fail_arg(h, "fl_debug_mp_refuse: bad argument");
+    std::lock_guard<std::mutex> lk(g_mp_mu);
+    h->dbg_mp_refuse_in = count > 0 ? nth : 0;
+    h->dbg_mp_refuse_n = count;
     return FL_OK;
 }
 int32_t fl_debug_map_pool_limit(fl_handle h, int32_t spare_entries)

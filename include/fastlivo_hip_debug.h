@@ -38,6 +38,12 @@ int32_t fl_debug_drop_record(fl_handle h, int32_t passes_ahead);
  * update keeps seeing the old size), so that update runs out of pool, drops its queued points from the index and raises
  * needs_rebuild -- the path every search must notice before it reads the index (tests/test_map_gpu.py). */
 int32_t fl_debug_map_pool_limit(fl_handle h, int32_t spare_entries);
+/* `count` consecutive multi-pass reservations of this handle, starting with the nth from now (1 = the next one; nth or count 0 disarms), are refused as if
+ * another handle's launch were in flight:
+ * the caller's per-pass path -- or, for the frame drivers that keep a size on the device (fl_lidar_front, fl_vio_detect), the path that reads
+ * the size back and finishes with launches that know it. Every variant the admission code tries counts as one reservation (the VIO launches try
+ * the whole-CU variant first, then the shared one: count = 2 refuses a level outright). */
+int32_t fl_debug_mp_refuse(fl_handle h, int32_t nth, int32_t count);
 
 #ifdef __cplusplus
 }

@@ -33,10 +33,13 @@ def _frame_pose(Rci, Pci, rot9, pos3):
     return Rcw, Pcw
 
 
-def _walk(capi, orc, synth, scene, frames, n_scan, max_iter, grid, fused, with_oracle, blind_frame=-1, outlier=3000.0):
+def _walk(capi, orc, synth, scene, frames, n_scan, max_iter, grid, fused, with_oracle, blind_frame=-1, outlier=3000.0, drop=None, refuse=None):
+    """drop = (frame, passes_ahead): the instrumented build's fault injector makes a producer of that ComputeJ pass withhold its record"""
     fr0 = synth.make_lio_frame(n_scan, scene=scene)
     vf0 = synth.make_vio_frame(8, fr0, max_iterations=max_iter)
-    h = capi.Handle(capi.config_from_frames(fr0, vf0, max_iterations=max_iter))
+    h = capi.Handle(capi.config_from_frames(fr0, vf0, max_iterations=max_iter), debug=drop is not None or refuse is not None)
+    if drop is not None:
+        h.debug_drop_record(1 << 30)            # (park the process-wide injector: an earlier test may have left it armed)
     h.set_option(capi.FL_OPT_DETECT_FUSED, 1 if fused else 0)
     h.vmap_clear(grid)
     Rli = fr0.R_LI.T
@@ -63,7 +66,19 @@ def _walk(capi, orc, synth, scene, frames, n_scan, max_iter, grid, fused, with_o
         down, _ = orc.voxel_grid(np.concatenate([world, np.zeros((n_scan, 1), np.float32)], axis=1), 0.2)
         down = np.ascontiguousarray(down[:, :3])
         x_in = xg.copy()
+        if drop is not None and k == drop[0]:
+            r0 = h.diagnostics()["resumes"]
+            h.debug_drop_record(drop[1])
+        if refuse is not None and k == refuse[0]:
+            f0 = h.diagnostics()["fallbacks"]
+            h.debug_mp_refuse(refuse[1], refuse[2])
         ns, na, no = h.vio_detect(img, world, down, Rci, Pci, xg, k, outlier_threshold=outlier)
+        if refuse is not None and k == refuse[0]:
+            assert h.diagnostics()["fallbacks"] - f0 >= 1, "no reservation was refused"
+            h.debug_mp_refuse(0, 0)
+        if drop is not None and k == drop[0]:
+            assert h.diagnostics()["resumes"] - r0 >= 1, "the pass was not abandoned: the injector missed ComputeJ's launches"
+            h.debug_drop_record(1 << 30)
         rec = dict(counts=(ns, na, no), x=xg.vec().copy(), P=xg.cov_np().copy(), errors=h.vio_get_errors(ns).copy() if ns > 0 else np.zeros(0, np.float32))
         if ns == 0:
             assert np.array_equal(xg.vec(), x_in.vec()) and np.array_equal(xg.cov_np(), x_in.cov_np()), f"frame {k}: no selection, state must be untouched"
@@ -185,3 +200,43 @@ def test_detect_with_the_scan_on_the_device(gpu_lib, oracle_lib, scene, fused):
         assert np.array_equal(p[0], q[0]) and p[1] == q[1] and len(p[2]) == len(q[2]) and _same_obs(p[2], q[2]), f"visual map point {i}"
     for h in hs:
         h.close()
+
+
+@pytest.mark.parametrize("passes_ahead", [0, 1, 3])
+def test_fused_detect_with_an_abandoned_computej_pass(gpu_lib, oracle_lib, scene, passes_ahead):
+    """A hand-off time-out inside ComputeJ's launches of the fused frame (fault injector of the instrumented build): the pass is abandoned, every
+    launch behind it is a no-op, vmap_addobs_dev_kernel leaves the map alone and publishes; the host resumes ComputeJ per pass and adds the
+    observations through the staged call. Counts, state, per-patch errors and the visual map must equal the undisturbed walk's, bit for bit --
+    in the faulted frame and in the frames after it."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    good, map_good = _walk(capi, orc, synth, scene, 5, 3000, 4, 40, True, False)
+    bad, map_bad = _walk(capi, orc, synth, scene, 5, 3000, 4, 40, True, False, drop=(2, passes_ahead))
+    assert good[2]["counts"][0] > 10
+    for k, (a, b) in enumerate(zip(good, bad)):
+        assert a["counts"] == b["counts"], f"frame {k}: {a['counts']} vs {b['counts']}"
+        assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["P"], b["P"]), f"frame {k}: state"
+        assert np.array_equal(a["errors"], b["errors"]), f"frame {k}: per-patch errors"
+    assert len(map_good) == len(map_bad)
+    for i, (p, q) in enumerate(zip(map_good, map_bad)):
+        assert np.array_equal(p[0], q[0]) and p[1] == q[1] and len(p[2]) == len(q[2]) and _same_obs(p[2], q[2]), f"visual map point {i}"
+
+
+@pytest.mark.parametrize("nth,count", [(1, 1), (1, 2), (2, 1), (2, 2), (3, 2), (1, 6)])
+def test_fused_detect_losing_the_multipass_admission_half_way(gpu_lib, oracle_lib, scene, nth, count):
+    """The fused frame's ComputeJ launches take their patch count from the device, which only the multi-pass kernels can do. If the admission
+    is lost at some level (another handle of the process launched in between; here: the debug library refuses `count` reservations from the nth
+    on -- each level tries the whole-CU variant first, then the shared one: (1, 1) moves level 2 to the shared variant, (1, 2) refuses level 2
+    outright, (2, 2) level 1, (3, 2) level 0, (1, 6) every level), nothing more is enqueued, the counts are read back and the remaining levels
+    run per pass with launches that know the count; addObservation goes through the staged call. Same bits as the undisturbed walk."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    good, map_good = _walk(capi, orc, synth, scene, 4, 3000, 4, 40, True, False)
+    bad, map_bad = _walk(capi, orc, synth, scene, 4, 3000, 4, 40, True, False, refuse=(2, nth, count))
+    for k, (a, b) in enumerate(zip(good, bad)):
+        assert a["counts"] == b["counts"], f"frame {k}: {a['counts']} vs {b['counts']}"
+        assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["P"], b["P"]), f"frame {k}: state"
+        assert np.array_equal(a["errors"], b["errors"]), f"frame {k}: per-patch errors"
+    assert len(map_good) == len(map_bad)
+    for i, (p, q) in enumerate(zip(map_good, map_bad)):
+        assert np.array_equal(p[0], q[0]) and p[1] == q[1] and len(p[2]) == len(q[2]) and _same_obs(p[2], q[2]), f"visual map point {i}"
