@@ -118,3 +118,36 @@ def test_fused_front_with_a_cloud_out_of_time_order(gpu_lib, kind):
         assert a[2] == b[2] and a[3:7] == b[3:7], (a[2:7], b[2:7])
         assert a[0] == b[0] and a[1] == b[1]
         assert np.array_equal(a[7], b[7]) and np.array_equal(a[8].view(np.uint32), b[8].view(np.uint32))
+
+
+@pytest.mark.parametrize("nth", [1, 2])
+def test_fused_front_losing_the_multipass_admission(gpu_lib, nth):
+    """fl_lidar_front keeps the scan's size on the device, which only the multi-pass LIO kernel can read. If its reservation is refused (another
+    handle of the process launched in between; here: fl_debug_mp_refuse of the instrumented build, first or second pass launch of the frame),
+    nothing more is enqueued, the voxel count is read back and the frame is finished with launches that know it. Same bits as the staged calls."""
+    capi = gpu_lib
+    from fast_livo_amd import synth
+    lio, f = _frame(synth, 30000)
+    hs = capi.Handle(capi.config_from_frames(lio, max_iterations=6))
+    hs.map_set_points(lio.scene.map_xyz, 0.5)
+    want = _run(capi, hs, lio, f, 0.2, True, frames=2)
+    hs.close()
+    h = capi.Handle(capi.config_from_frames(lio, max_iterations=6), debug=True)
+    h.map_set_points(lio.scene.map_xyz, 0.5)
+    x = capi.state18_from_frame(lio); pr = capi.imu_proc_from_frame(f)
+    got = []
+    for k in range(2):
+        f0 = h.diagnostics()["fallbacks"]
+        if k == 1:
+            h.debug_mp_refuse(nth, 1)
+        info, m = h.lidar_front(pr, x, f.imu, f.pcl_beg_time, f.pcl_end_time, f.pts_xyzt, 0.2)
+        if k == 1:
+            assert h.diagnostics()["fallbacks"] - f0 >= 1
+            h.debug_mp_refuse(0, 0)
+        mask, normvec = h.lio_get_selection(m)
+        got.append((bytes(x), bytes(pr), m, info.iterations, info.effct_feat_num, info.status, info.stop, mask.copy(), normvec.copy()))
+    h.close()
+    for a, b in zip(want, got):
+        assert a[2] == b[2] and a[3:7] == b[3:7], (a[2:7], b[2:7])
+        assert a[0] == b[0] and a[1] == b[1]
+        assert np.array_equal(a[7], b[7]) and np.array_equal(a[8].view(np.uint32), b[8].view(np.uint32))
