@@ -54,12 +54,30 @@ struct FlMapIncView {                  // what the update kernels need of the in
     float inv_cell;
 };
 
-__device__ __forceinline__ void fl_mi_count_wave(int n, int *counter)      // n per lane, one atomic per wavefront
+// The update's counters (added / removed / ambiguous): n per lane, ONE atomic per WORKGROUP, striped over FL_MI_STRIPES addresses in
+// separate 128-byte lines behind the control block. (Round 6: they were one atomic per wavefront on one address each -- 2 048 wavefronts of
+// mapinc_resolve_kernel x up to three counters at ~12 ns per same-address atomic were more than half of that kernel's 47-60 us.)
+// mapinc_begin_kernel zeroes the stripes, mapinc_status_kernel folds them into the control block. All threads of the workgroup call it.
+#define FL_MI_STRIPES 16
+#define FL_MI_CNT_ADDED 0
+#define FL_MI_CNT_REMOVED 1
+#define FL_MI_CNT_AMBIGUOUS 2
+struct FlMapIncStripes { int v[3][FL_MI_STRIPES][32]; };
+__device__ __forceinline__ FlMapIncStripes *fl_mi_stripes(FlMapIncCtl *ctl) { return reinterpret_cast<FlMapIncStripes *>(ctl + 1); }
+__device__ __forceinline__ void fl_mi_count_block(int n, int which, FlMapIncCtl *ctl)
 {
+    __shared__ int s_cnt[3][FL_BLOCK / 64];
     int s = n;
 #pragma unroll
     for (int k = 32; k >= 1; k >>= 1) s += __shfl_xor(s, k);
-    if ((threadIdx.x & 63u) == 0 && s) atomicAdd(counter, s);
+    if ((threadIdx.x & 63u) == 0) s_cnt[which][threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+#pragma unroll
+        for (int w = 0; w < FL_BLOCK / 64; w++) t += s_cnt[which][w];
+        if (t) atomicAdd(&fl_mi_stripes(ctl)->v[which][blockIdx.x % FL_MI_STRIPES][0], t);
+    }
 }
 
 // read-only probe: table slot of a cell, -1 if the cell does not exist
@@ -128,12 +146,18 @@ __device__ __forceinline__ FlBoxCells fl_mi_box_cells(unsigned long long box_key
     return b;
 }
 
-// one thread per slot of the box table
+// FL_MI_RESOLVE_LANES lanes per slot of the box table, one per overlapped cell (a box of the down-sampling grid overlaps up to 2 x 2 x 2 cells of
+// the k-NN grid when ds <= cell; more cells: the lanes stride). Round 6: it was ONE lane per box walking all its cells' points twice, one
+// dependent load after the other -- up to 160 sequential visits on the slowest lane of a wavefront, 45-60 us for 20 k new points. Now a
+// lane walks ONE cell's points (pass 1: its candidate for the box's closest old point), the eight lanes of a box take the minimum between
+// them (three shuffles), and pass 2 marks each lane's own cell. Same candidates, same minimum, same marks: same map.
+#define FL_MI_RESOLVE_LANES 8
 __global__ __launch_bounds__(FL_BLOCK) void mapinc_resolve_kernel(FlBoxSlot *__restrict__ tab, unsigned tab_cap, const float *__restrict__ new_pts,
                                                                  float ds, FlMapIncView V, unsigned char *__restrict__ dead, int n_raw,
                                                                  unsigned *__restrict__ pend_next, FlMapIncCtl *__restrict__ ctl)
 {
-    const unsigned s = blockIdx.x * FL_BLOCK + threadIdx.x;
+    const unsigned t = blockIdx.x * FL_BLOCK + threadIdx.x;
+    const unsigned s = t / FL_MI_RESOLVE_LANES, sub = t % FL_MI_RESOLVE_LANES;
     int removed = 0, added = 0, amb_old = 0;
     // is box `k` claimed by a new point of this update? (open addressing, as mapupd_new_kernel filled it; tab_cap is a power of two)
     auto touched = [&](unsigned long long k) -> bool {
@@ -145,102 +169,111 @@ __global__ __launch_bounds__(FL_BLOCK) void mapinc_resolve_kernel(FlBoxSlot *__r
             hh = (hh + 1u) & (tab_cap - 1u);
         }
     };
-    if (s < tab_cap) {
-        const unsigned long long bkey = tab[s].key;
-        if (bkey != FL_KNN_EMPTY) {
-            const FlBoxCells B = fl_mi_box_cells(bkey, ds, V.inv_cell);
-            // pass 1: the box's closest old point (lowest index among equals)
-            unsigned long long best_old = FL_KNN_EMPTY;
-            for (int iz = B.c0[2]; iz <= B.c1[2]; iz++)
-                for (int iy = B.c0[1]; iy <= B.c1[1]; iy++)
-                    for (int ix = B.c0[0]; ix <= B.c1[0]; ix++) {
-                        const int hs = fl_mi_find(V, fl_cell_key(ix, iy, iz));
-                        if (hs < 0) continue;
-                        const unsigned st = V.htab[hs].start, cn = V.htab[hs].count;
-                        for (unsigned j = st; j < st + cn; j++) {
-                            const float4 p = V.pts[j];
-                            if (__float_as_int(p.w) == FL_MI_DEAD) continue;
-                            const FlBoxGeom g = fl_box_of(p.x, p.y, p.z, ds);
-                            // n_ambiguous of the update (include/fastlivo_hip.h): the OLD points whose box depends on a rounding and that could
-                            // matter to it -- those of a touched box (counted by their own box) and those next to a touched box whose own box
-                            // no new point claimed (the reference's coordinate test could have put them into the neighbour)
-                            if (g.ambiguous && !g.range_error) {      // (rare: ~1e-7 per coordinate on real data)
-                                const unsigned long long own = fl_cell_key(g.ix, g.iy, g.iz);
-                                if (own == bkey) amb_old++;
-                                else if (!touched(own)) {
-                                    // counted ONCE: by the touched box with the smallest key among the 26 neighbours of its own box
-                                    unsigned long long first = FL_KNN_EMPTY;
-                                    for (int dz = -1; dz <= 1; dz++)
-                                        for (int dy = -1; dy <= 1; dy++)
-                                            for (int dx = -1; dx <= 1; dx++) {
-                                                if (!(dx | dy | dz)) continue;
-                                                const unsigned long long nk = fl_cell_key(g.ix + dx, g.iy + dy, g.iz + dz);
-                                                if (nk < first && touched(nk)) first = nk;
-                                            }
-                                    if (first == bkey) amb_old++;
-                                }
+    const unsigned long long bkey = (s < tab_cap) ? tab[s].key : FL_KNN_EMPTY;
+    const bool live = bkey != FL_KNN_EMPTY;                     // (uniform over the box's lanes)
+    FlBoxCells B;
+    int nx = 0, ny = 0, ncell = 0;
+    if (live) {
+        B = fl_mi_box_cells(bkey, ds, V.inv_cell);
+        nx = B.c1[0] - B.c0[0] + 1; ny = B.c1[1] - B.c0[1] + 1;
+        ncell = nx * ny * (B.c1[2] - B.c0[2] + 1);
+    }
+    // pass 1: this lane's cells' candidate for the box's closest old point (lowest index among equals)
+    unsigned long long best_old = FL_KNN_EMPTY;
+    for (int c = (int)sub; c < ncell; c += FL_MI_RESOLVE_LANES) {
+        const int ix = B.c0[0] + c % nx, iy = B.c0[1] + (c / nx) % ny, iz = B.c0[2] + c / (nx * ny);
+        const int hs = fl_mi_find(V, fl_cell_key(ix, iy, iz));
+        if (hs < 0) continue;
+        const unsigned st = V.htab[hs].start, cn = V.htab[hs].count;
+        for (unsigned j = st; j < st + cn; j++) {
+            const float4 p = V.pts[j];
+            if (__float_as_int(p.w) == FL_MI_DEAD) continue;
+            const FlBoxGeom g = fl_box_of(p.x, p.y, p.z, ds);
+            // n_ambiguous of the update (include/fastlivo_hip.h): the OLD points whose box depends on a rounding and that could
+            // matter to it -- those of a touched box (counted by their own box) and those next to a touched box whose own box
+            // no new point claimed (the reference's coordinate test could have put them into the neighbour)
+            if (g.ambiguous && !g.range_error) {      // (rare: ~1e-7 per coordinate on real data)
+                const unsigned long long own = fl_cell_key(g.ix, g.iy, g.iz);
+                if (own == bkey) amb_old++;
+                else if (!touched(own)) {
+                    // counted ONCE: by the touched box with the smallest key among the 26 neighbours of its own box
+                    unsigned long long first = FL_KNN_EMPTY;
+                    for (int dz = -1; dz <= 1; dz++)
+                        for (int dy = -1; dy <= 1; dy++)
+                            for (int dx = -1; dx <= 1; dx++) {
+                                if (!(dx | dy | dz)) continue;
+                                const unsigned long long nk = fl_cell_key(g.ix + dx, g.iy + dy, g.iz + dz);
+                                if (nk < first && touched(nk)) first = nk;
                             }
-                            if (g.range_error || fl_cell_key(g.ix, g.iy, g.iz) != bkey) continue;
-                            const float d = fl_calc_dist(p.x, p.y, p.z, g.cx, g.cy, g.cz);
-                            const unsigned long long cand = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned)__float_as_int(p.w);
-                            best_old = cand < best_old ? cand : best_old;
-                        }
-                    }
-            const unsigned long long best_new = tab[s].best_new;
-            const bool old_wins = best_old != FL_KNN_EMPTY && (unsigned)(best_old >> 32) < (unsigned)(best_new >> 32);      // strictly closer than every new point
-            tab[s].best_old = best_old;
-            // pass 2: every other old point of the box goes
-            for (int iz = B.c0[2]; iz <= B.c1[2]; iz++)
-                for (int iy = B.c0[1]; iy <= B.c1[1]; iy++)
-                    for (int ix = B.c0[0]; ix <= B.c1[0]; ix++) {
-                        const int hs = fl_mi_find(V, fl_cell_key(ix, iy, iz));
-                        if (hs < 0) continue;
-                        const unsigned st = V.htab[hs].start, cn = V.htab[hs].count;
-                        bool touched = false;
-                        for (unsigned j = st; j < st + cn; j++) {
-                            const float4 p = V.pts[j];
-                            const FlBoxGeom g = fl_box_of(p.x, p.y, p.z, ds);
-                            if (g.range_error || fl_cell_key(g.ix, g.iy, g.iz) != bkey) continue;
-                            const int id = __float_as_int(p.w);
-                            if (old_wins && (unsigned)id == (unsigned)best_old) continue;
-                            V.pts[j].w = __int_as_float(FL_MI_DEAD);      // (a point belongs to exactly one box: nobody else writes it)
-                            dead[id] = 1;
-                            removed++;
-                            touched = true;
-                        }
-                        if (touched) V.dirty[hs] = 1u;
-                    }
-            if (!old_wins) {         // the closest new point (the latest among equals) enters: queued at its cell
-                const unsigned jn = 0xFFFFFFFFu - (unsigned)best_new;
-                const float x = new_pts[jn * 3], y = new_pts[jn * 3 + 1], z = new_pts[jn * 3 + 2];
-                //  a point that is not finite or whose box index does not fit the key (|p / ds| >= 2^20) is never admitted: it stays
-                // dead in the array, the update's status says FL_NUM_NONFINITE (mapupd_new_kernel counted it) -- (int)floorf(NaN) below is undefined
-                const bool ok = isfinite(x) && isfinite(y) && isfinite(z) && !fl_box_of(x, y, z, ds).range_error;
-                if (ok) {
-                    // the cell the point is queued at must be one of those mapinc_apply_kernel visits for this box (B.c0 .. B.c1, derived by probing
-                    // the box's faces within one ulp): if the rounding of p * inv_cell ever puts it outside, the cell would stay dirty with a queue
-                    // into pend_next, which the next update overwrites. Checked here instead of argued: the point then enters the array only and
-                    // the index is re-built before anybody searches it (needs_rebuild -> map_index_ready, api_knn.inc).
-                    const int qx = (int)floorf(x * V.inv_cell), qy = (int)floorf(y * V.inv_cell), qz = (int)floorf(z * V.inv_cell);
-                    const bool covered = qx >= B.c0[0] && qx <= B.c1[0] && qy >= B.c0[1] && qy <= B.c1[1] && qz >= B.c0[2] && qz <= B.c1[2];
-                    const int hs = covered ? fl_mi_find_or_insert(V, fl_cell_key(qx, qy, qz), ctl) : -1;
-                    if (hs < 0) {                       // (not covered, or the table is full: the point lives in the array, the index follows at the rebuild)
-                        ctl->needs_rebuild = 1;
-                        dead[n_raw + (int)jn] = 0;
-                        added = 1;
-                    } else {
-                        pend_next[jn] = atomicExch(&V.pend_head[hs], jn);
-                        V.dirty[hs] = 1u;
-                        dead[n_raw + (int)jn] = 0;
-                        added = 1;
-                    }
+                    if (first == bkey) amb_old++;
                 }
+            }
+            if (g.range_error || fl_cell_key(g.ix, g.iy, g.iz) != bkey) continue;
+            const float d = fl_calc_dist(p.x, p.y, p.z, g.cx, g.cy, g.cz);
+            const unsigned long long cand = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned)__float_as_int(p.w);
+            best_old = cand < best_old ? cand : best_old;
+        }
+    }
+    // the box's minimum over its lanes (aligned groups of FL_MI_RESOLVE_LANES inside a wavefront: the xor pattern stays inside the group)
+#pragma unroll
+    for (int m = 1; m < FL_MI_RESOLVE_LANES; m <<= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)best_old, m), hi = (unsigned)__shfl_xor((int)(unsigned)(best_old >> 32), m);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        best_old = o < best_old ? o : best_old;
+    }
+    const unsigned long long best_new = live ? tab[s].best_new : 0ull;
+    const bool old_wins = live && best_old != FL_KNN_EMPTY && (unsigned)(best_old >> 32) < (unsigned)(best_new >> 32);      // strictly closer than every new point
+    if (live && sub == 0) tab[s].best_old = best_old;
+    // pass 2: every other old point of the box goes
+    for (int c = (int)sub; c < ncell; c += FL_MI_RESOLVE_LANES) {
+        const int ix = B.c0[0] + c % nx, iy = B.c0[1] + (c / nx) % ny, iz = B.c0[2] + c / (nx * ny);
+        const int hs = fl_mi_find(V, fl_cell_key(ix, iy, iz));
+        if (hs < 0) continue;
+        const unsigned st = V.htab[hs].start, cn = V.htab[hs].count;
+        bool dirtied = false;
+        for (unsigned j = st; j < st + cn; j++) {
+            const float4 p = V.pts[j];
+            if (__float_as_int(p.w) == FL_MI_DEAD) continue;        // (a tombstone of this or an earlier update: its coordinates are kept)
+            const FlBoxGeom g = fl_box_of(p.x, p.y, p.z, ds);
+            if (g.range_error || fl_cell_key(g.ix, g.iy, g.iz) != bkey) continue;
+            const int id = __float_as_int(p.w);
+            if (old_wins && (unsigned)id == (unsigned)best_old) continue;
+            V.pts[j].w = __int_as_float(FL_MI_DEAD);      // (a point belongs to exactly one box: nobody else writes it)
+            dead[id] = 1;
+            removed++;
+            dirtied = true;
+        }
+        if (dirtied) V.dirty[hs] = 1u;
+    }
+    if (live && sub == 0 && !old_wins) {         // the closest new point (the latest among equals) enters: queued at its cell
+        const unsigned jn = 0xFFFFFFFFu - (unsigned)best_new;
+        const float x = new_pts[jn * 3], y = new_pts[jn * 3 + 1], z = new_pts[jn * 3 + 2];
+        //  a point that is not finite or whose box index does not fit the key (|p / ds| >= 2^20) is never admitted: it stays
+        // dead in the array, the update's status says FL_NUM_NONFINITE (mapupd_new_kernel counted it) -- (int)floorf(NaN) below is undefined
+        const bool ok = isfinite(x) && isfinite(y) && isfinite(z) && !fl_box_of(x, y, z, ds).range_error;
+        if (ok) {
+            // the cell the point is queued at must be one of those mapinc_apply_kernel visits for this box (B.c0 .. B.c1, derived by probing
+            // the box's faces within one ulp): if the rounding of p * inv_cell ever puts it outside, the cell would stay dirty with a queue
+            // into pend_next, which the next update overwrites. Checked here instead of argued: the point then enters the array only and
+            // the index is re-built before anybody searches it (needs_rebuild -> map_index_ready, api_knn.inc).
+            const int qx = (int)floorf(x * V.inv_cell), qy = (int)floorf(y * V.inv_cell), qz = (int)floorf(z * V.inv_cell);
+            const bool covered = qx >= B.c0[0] && qx <= B.c1[0] && qy >= B.c0[1] && qy <= B.c1[1] && qz >= B.c0[2] && qz <= B.c1[2];
+            const int hs = covered ? fl_mi_find_or_insert(V, fl_cell_key(qx, qy, qz), ctl) : -1;
+            if (hs < 0) {                       // (not covered, or the table is full: the point lives in the array, the index follows at the rebuild)
+                ctl->needs_rebuild = 1;
+                dead[n_raw + (int)jn] = 0;
+                added = 1;
+            } else {
+                pend_next[jn] = atomicExch(&V.pend_head[hs], jn);
+                V.dirty[hs] = 1u;
+                dead[n_raw + (int)jn] = 0;
+                added = 1;
             }
         }
     }
-    fl_mi_count_wave(removed, &ctl->removed);
-    fl_mi_count_wave(added, &ctl->added);
-    fl_mi_count_wave(amb_old, &ctl->ambiguous);
+    fl_mi_count_block(removed, FL_MI_CNT_REMOVED, ctl);
+    fl_mi_count_block(added, FL_MI_CNT_ADDED, ctl);
+    fl_mi_count_block(amb_old, FL_MI_CNT_AMBIGUOUS, ctl);
 }
 
 // the owner of a dirty cell: tombstones out, queued points in, moved if it no longer fits
@@ -319,7 +352,7 @@ __global__ __launch_bounds__(FL_BLOCK) void mapinc_append_queue_kernel(const flo
             added = 1;
         }
     }
-    fl_mi_count_wave(added, &ctl->added);
+    fl_mi_count_block(added, FL_MI_CNT_ADDED, ctl);
 }
 // ... and the first of a cell's new points to arrive applies the queue
 __global__ __launch_bounds__(FL_BLOCK) void mapinc_append_apply_kernel(const float *__restrict__ new_pts, int n, FlMapIncView V, int n_raw,
@@ -371,7 +404,7 @@ __global__ __launch_bounds__(FL_BLOCK) void mapinc_delete_kernel(FlMapIncView V,
             }
         }
     }
-    fl_mi_count_wave(removed, &ctl->removed);
+    fl_mi_count_block(removed, FL_MI_CNT_REMOVED, ctl);
 }
 
 // all slots of a fresh table: no capacity, clean, nothing queued
@@ -385,10 +418,20 @@ __global__ __launch_bounds__(FL_BLOCK) void mapinc_clear_kernel(unsigned *__rest
 }
 __global__ __launch_bounds__(FL_BLOCK) void mapinc_count_cells_kernel(const FlCellEntry *__restrict__ htab, unsigned slots, FlMapIncCtl *__restrict__ ctl)
 {
-    const unsigned i = blockIdx.x * FL_BLOCK + threadIdx.x;
-    const bool occ = i < slots && htab[i].key != FL_KNN_EMPTY;
-    const unsigned long long b = __ballot(occ);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&ctl->ncells, (unsigned)__popcll(b));
+    // (grid-stride over at most 256 workgroups, one atomic each: one atomic per wavefront on this one address was 3 ms of a 5 M-point map's
+    // re-index -- 260 k same-address atomics at ~12 ns)
+    __shared__ unsigned s_c[FL_BLOCK / 64];
+    unsigned c = 0;
+    for (unsigned i = blockIdx.x * FL_BLOCK + threadIdx.x; i < slots; i += gridDim.x * FL_BLOCK) c += (htab[i].key != FL_KNN_EMPTY) ? 1u : 0u;
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) c += __shfl_xor(c, k);
+    if ((threadIdx.x & 63u) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (int w = 0; w < FL_BLOCK / 64; w++) t += s_c[w];
+        if (t) atomicAdd(&ctl->ncells, t);
+    }
 }
 // flags of the compaction that precedes a full rebuild: 1 = live
 __global__ __launch_bounds__(FL_BLOCK) void mapinc_live_flags_kernel(const unsigned char *__restrict__ dead, int n, int *__restrict__ flags)
@@ -396,14 +439,26 @@ __global__ __launch_bounds__(FL_BLOCK) void mapinc_live_flags_kernel(const unsig
     const int i = blockIdx.x * FL_BLOCK + threadIdx.x;
     if (i < n) flags[i] = dead[i] ? 0 : 1;
 }
-__global__ void mapinc_begin_kernel(FlMapIncCtl *__restrict__ ctl)
+// (upd, nullable: the down-sampling update's info block is reset here too -- mapupd_init_kernel was a launch of its own)
+__global__ void mapinc_begin_kernel(FlMapIncCtl *__restrict__ ctl, FlMapUpdInfo *__restrict__ upd = nullptr)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { ctl->added = 0; ctl->removed = 0; ctl->ambiguous = 0; ctl->range_error = 0; }
+    if (blockIdx.x != 0) return;
+    if (upd && threadIdx.x == 1) { upd->total = 0; upd->kept_old = 0; upd->kept_new = 0; upd->ambiguous = 0; upd->range_error = 0; }
+    if (threadIdx.x == 0) { ctl->added = 0; ctl->removed = 0; ctl->ambiguous = 0; ctl->range_error = 0; }
+    FlMapIncStripes *S = fl_mi_stripes(ctl);
+    for (int e = (int)threadIdx.x; e < 3 * FL_MI_STRIPES; e += (int)blockDim.x) S->v[e / FL_MI_STRIPES][e % FL_MI_STRIPES][0] = 0;
 }
 // the update's last kernel: live count + the status block in page-locked memory (system-scope stores; the host polls seq)
 __global__ void mapinc_status_kernel(FlMapIncCtl *__restrict__ ctl, const FlMapUpdInfo *__restrict__ upd, FlMapIncCtl *__restrict__ status, unsigned long long seq)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    {
+        FlMapIncStripes *S = fl_mi_stripes(ctl);
+        int a = 0, r = 0, m = 0;
+        for (int k = 0; k < FL_MI_STRIPES; k++) { a += S->v[FL_MI_CNT_ADDED][k][0]; r += S->v[FL_MI_CNT_REMOVED][k][0]; m += S->v[FL_MI_CNT_AMBIGUOUS][k][0]; }
+        for (int k = 0; k < FL_MI_STRIPES; k++) { S->v[FL_MI_CNT_ADDED][k][0] = 0; S->v[FL_MI_CNT_REMOVED][k][0] = 0; S->v[FL_MI_CNT_AMBIGUOUS][k][0] = 0; }
+        ctl->added += a; ctl->removed += r; ctl->ambiguous += m;
+    }
     ctl->live += ctl->added - ctl->removed;
     if (upd) { ctl->ambiguous += upd->ambiguous; ctl->range_error = upd->range_error; }      // (new points: mapupd_new_kernel; old ones: mapinc_resolve_kernel)
     FlMapIncCtl c = *ctl;

@@ -89,13 +89,17 @@ __global__ __launch_bounds__(FL_BLOCK) void mapupd_init_kernel(FlMapUpdInfo *__r
 }
 
 // new points: claim the box, compete for "best new point of the box"
+// raw_out / dead_out (in-place map update, nullable): the point also goes to the end of the map array, flagged dead until its box admits it
+// (they were a device-to-device copy command and a fill in front of this launch: two DMA-to-kernel transitions per update)
 __global__ __launch_bounds__(FL_BLOCK) void mapupd_new_kernel(const float *__restrict__ pts, int n, float ds, FlBoxSlot *__restrict__ tab,
-                                                             unsigned mask, int *__restrict__ slot_of, FlMapUpdInfo *__restrict__ info)
+                                                             unsigned mask, int *__restrict__ slot_of, FlMapUpdInfo *__restrict__ info,
+                                                             float *__restrict__ raw_out = nullptr, unsigned char *__restrict__ dead_out = nullptr)
 {
     const int j = blockIdx.x * FL_BLOCK + threadIdx.x;
     int amb = 0, rerr = 0;
     if (j < n) {
         const float x = pts[j * 3], y = pts[j * 3 + 1], z = pts[j * 3 + 2];
+        if (raw_out) { raw_out[j * 3] = x; raw_out[j * 3 + 1] = y; raw_out[j * 3 + 2] = z; dead_out[j] = 1; }
         const FlBoxGeom g = fl_box_of(x, y, z, ds);
         amb = g.ambiguous; rerr = g.range_error;
         const unsigned long long key = fl_cell_key(g.ix, g.iy, g.iz);
