@@ -240,3 +240,45 @@ def test_fused_detect_losing_the_multipass_admission_half_way(gpu_lib, oracle_li
     assert len(map_good) == len(map_bad)
     for i, (p, q) in enumerate(zip(map_good, map_bad)):
         assert np.array_equal(p[0], q[0]) and p[1] == q[1] and len(p[2]) == len(q[2]) and _same_obs(p[2], q[2]), f"visual map point {i}"
+
+
+def test_device_scan_detect_when_the_downsampling_grid_outgrows_its_bitmap(gpu_lib, oracle_lib, scene):
+    """A scan with a few far-away returns: the 0.2 m down-sampling grid of its bounding box has more cells than the occupancy bitmap is allocated
+    for (2^27). The fused frame with the scan on the device notices that on the device (nothing has touched the visual map: vmap_commit_kernel
+    leaves, nothing is selected), the host grows the bitmap, gives the keyframe slot back and runs the frame again. Against a handle that is
+    handed both clouds (fl_scan_voxel_filter grows its bitmap the same way): every count, state and map point equal."""
+    capi, orc = gpu_lib, oracle_lib
+    from fast_livo_amd import synth
+    n_scan, max_iter, grid = 4000, 4, 40
+    fr0 = synth.make_lio_frame(n_scan, scene=scene)
+    vf0 = synth.make_vio_frame(8, fr0, max_iterations=max_iter)
+    hs = [capi.Handle(capi.config_from_frames(fr0, vf0, max_iterations=max_iter)) for _ in range(2)]
+    for h in hs:
+        h.vmap_clear(grid)
+    Rci = vf0.Rcl @ fr0.R_LI.T
+    Pci = vf0.Rcl @ (-fr0.R_LI.T @ fr0.t_LI) + vf0.Pcl
+    R_t, p_t = fr0.R_true.copy(), fr0.p_true.copy()
+    cov = fr0.cov18.copy()
+    for k in range(4):
+        R_t = R_t @ synth.exp_so3(np.array([0.0, 0.0, 0.01]))
+        p_t = p_t + np.array([0.05, 0.03, 0.0])
+        body = synth.scan_from_pose(scene, R_t, p_t, n_scan, seed=900 + k).copy()
+        if k == 2:                          # three returns a few hundred metres out: 700 x 500 x 120 m / 0.2^3 = 5.3e9 ... too many; 350 x 300 x 60 m = 7.9e8 cells > 2^27
+            body[-3:] = np.float32([[330.0, 5.0, 2.0], [10.0, 280.0, 1.0], [4.0, -3.0, 55.0]])
+        img = synth.render_image(scene, vf0.cam, *synth.cam_pose(vf0.Rcl, vf0.Pcl, fr0.R_LI, fr0.t_LI, R_t, p_t), seed=k)
+        xs = [capi.State18.make(R_t, p_t, fr0.vel, fr0.bg, fr0.ba, fr0.grav, cov) for _ in range(2)]
+        hs[0].lio_set_points(body); hs[0].lio_begin18(xs[0], xs[0])
+        world = hs[0].lio_get_world_points(n_scan)
+        down, nd, _ = hs[0].scan_voxel_filter(np.ascontiguousarray(np.concatenate([world, np.zeros((n_scan, 1), np.float32)], axis=1)), 0.2)
+        c0 = hs[0].vio_detect(img, world, np.ascontiguousarray(down[:nd, :3]), Rci, Pci, xs[0], k, outlier_threshold=3000.0)
+        hs[1].lio_set_points(body)
+        c1 = hs[1].vio_detect(img, None, None, Rci, Pci, xs[1], k, outlier_threshold=3000.0)
+        assert c0 == c1, f"frame {k}: {c0} vs {c1}"
+        assert np.array_equal(xs[0].vec(), xs[1].vec()) and np.array_equal(xs[0].cov_np(), xs[1].cov_np()), f"frame {k}"
+        cov = xs[0].cov_np()
+    assert hs[0].vmap_size() == hs[1].vmap_size() > 50
+    for i in range(hs[0].vmap_size()):
+        p, q = hs[0].vmap_get_point(i), hs[1].vmap_get_point(i)
+        assert np.array_equal(p[0], q[0]) and p[1] == q[1] and len(p[2]) == len(q[2]) and _same_obs(p[2], q[2]), f"visual map point {i}"
+    for h in hs:
+        h.close()
