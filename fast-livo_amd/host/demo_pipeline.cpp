@@ -173,6 +173,8 @@ int main(int argc, char **argv)
             if (sel.last_status < 0) { fprintf(stderr, "detect: %s\n", fl_last_error_string(h)); return 1; }
             printf("cam %d selected %d founded %d observed %d\n", f2, sel.n_selected, sel.n_founded, sel.n_observed);
         }
+        lm.compact();                                    // (exercises fl_map_compact from the host mirror; the map's content does not change)
+        if (lm.last_status < 0) { fprintf(stderr, "compact: %s\n", fl_last_error_string(h)); return 1; }
         for (int i = 0; i < 9; i++) printf("%.17g ", state.rot_end.m[i]);
         for (int i = 0; i < 3; i++) printf("%.17g ", state.pos_end.v[i]);
         printf("\n");

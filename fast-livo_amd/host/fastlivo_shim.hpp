@@ -310,6 +310,8 @@ struct LocalMapDev {
     {
         last_status = fl_map_add_points(handle, nullptr, 0, first_frame_build ? 0.0f : downsample_size, &last);
     }
+    // the in-place map's O(map) compaction + re-index, where the frame has slack (it happens by itself when the arrays fill up otherwise)
+    void compact() { last_status = fl_map_compact(handle); }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -444,6 +446,13 @@ struct LidarSelectorDev {
         from_abi(st, state);
         n_selected = ns; n_founded = na; n_observed = no;
         frame_id++;
+    }
+    // The same with pg left where the LiDAR frame put it (round 6): the scan this handle holds (fl_lidar_front / fl_lio_frame18_dev:
+    // feats_down_body) is registered under `state` on the device (laserMapping.cpp:695-698) and down-sampled there (lidar_selection.cpp:352-353);
+    // nothing but the image goes up -- and an image in fl_host_alloc memory is fetched by the frame's first kernel.
+    void detect(const uint8_t *img, int width, int height, int stride, const double *Rci, const double *Pci, StatesGroup &state)
+    {
+        detect(img, width, height, stride, nullptr, FL_DETECT_SCAN_ON_DEVICE, nullptr, 0, Rci, Pci, state);
     }
 };
 
