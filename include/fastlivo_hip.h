@@ -531,7 +531,9 @@ int32_t fl_vmap_add_observation(fl_handle h, const double *Rcw, const double *Pc
  * on the device's visual map, i.e. fl_vio_set_frame + fl_vio_add_keyframe (the staged image) + fl_vmap_select + fl_vmap_add_sparse +
  * fl_vio_compute_j + fl_vmap_add_observation, the frame pose taken from state_io before and after ComputeJ as updateFrameState does
  * (:904-911; Rci, Pci: camera extrinsics of the state frame, lidar_selection.cpp:35-52). pg_world_xyz: the registered scan (n_pg x 3),
- * pg_down_world_xyz: its 0.2 m down-sampled form (:352-353). state_io: in = state_propagat = the LIO result, out = after ComputeJ. */
+ * pg_down_world_xyz: its 0.2 m down-sampled form (:352-353). state_io: in = state_propagat = the LIO result, out = after ComputeJ.
+ * ONE enqueue and one wait (FL_OPT_DETECT_FUSED, csrc/api_vmap.inc): the counts that size the steps stay on the device and come back with
+ * the state; an image in fl_host_alloc memory (rows contiguous, 16-byte aligned) is fetched by the frame's first kernel instead of copied. */
 /* n_pg = FL_DETECT_SCAN_ON_DEVICE (pg_world_xyz, pg_down_world_xyz ignored): the registered scan never leaves the device -- pg = the scan this
  * handle holds (fl_lio_set_points / fl_lio_frame18_dev / fl_lidar_front: feats_down_body) under state_io (pointBodyToWorld, laserMapping.cpp:695-698,
  * exactly what fl_lio_get_world_points returns), its 0.2 m down-sampling (downSizeFilter, lidar_selection.cpp:7,352-353) by the device voxel filter
