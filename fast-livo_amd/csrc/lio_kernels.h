@@ -125,7 +125,9 @@ __device__ __forceinline__ bool fl_pass_skipped(FlDev18 *__restrict__ D, int fla
 // -------------------------------------------------------------------------------------------- K1
 // grid = producers + 1 ; MODE 0: fused pass ; MODE 1: accumulate only (sums -> sums_out)
 // FL_LIO_PASS_WAVES (tuning aid): 4 = a 128-VGPR budget, 4 instead of 3 wavefronts per SIMD. Measured: 32 M points 217 -> 207 us per
-// pass, 8 M points 45 -> 48 us, 50 k points 8.2 -> 8.5 us (12 bytes of scratch): not adopted.
+// pass, 8 M points 45 -> 48 us, 50 k points 8.2 -> 8.5 us (12 bytes of scratch): not adopted. (Round 6, checked before choosing it by size as
+// the round-5 review suggested: the kernel has since come down to 116 VGPRs, i.e. it runs four wavefronts per SIMD under EITHER launch bound --
+// the two instantiations compile to the same resources; there is no 5 % left to take.)
 #ifndef FL_LIO_PASS_WAVES
 #define FL_LIO_PASS_WAVES 1
 #endif
