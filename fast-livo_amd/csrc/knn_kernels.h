@@ -322,6 +322,14 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
         return;
     }
     if ((int)blockIdx.x * FL_KNN_QPB >= n) return;         // capacity-sized grid (n_dev), or an empty scan
+    int vb = (int)blockIdx.x;
+    {
+        const int nqb = (n + FL_KNN_QPB - 1) / FL_KNN_QPB, per = nqb >> 3;
+        // XCD-aware mapping (round 6): workgroup b runs on XCD b % 8, each XCD has an L2 of its own -- XCD x serves a CONTIGUOUS eighth of the
+        // queries (which arrive in voxel order: neighbours probe the same map cells) instead of every eighth workgroup, so a map cell is
+        // fetched into one L2, not eight. Worth 2 us of the frame's two searches (0.116 -> 0.114 ms, interleaved A/B); results are per query.
+        if (vb < per * 8) vb = (vb & 7) * per + (vb >> 3);
+    }
     // (the first search of a frame always runs: begin raises need_search; with host_state the block is not on the device yet)
     if (!host_state && (cond & 1) && (!D->need_search || D->stop || (D->status & 8 /* FL_NUM_TIMEOUT: abandoned chain */))) return;
     const bool stamp = (cond & 2) && threadIdx.x == 0 && blockIdx.x < 512;
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
     __shared__ unsigned s_cstart[FL_KNN_QPB][28];
     __shared__ unsigned s_ccnt[FL_KNN_QPB][28];
     const int ql = (int)(threadIdx.x >> 2), j = (int)(threadIdx.x & 3u);
-    const int q0 = blockIdx.x * FL_KNN_QPB;
+    const int q0 = vb * FL_KNN_QPB;
     const int i = min(q0 + ql, n - 1);                // tail quads repeat the last query (results unused)
     // previous winners of this query (incremental): position + map index, 5 x float4 per point
     float4 rec_mine = make_float4(0.f, 0.f, 0.f, 0.f), rec_4th = rec_mine;
