@@ -152,6 +152,7 @@ __device__ __forceinline__ FlBoxCells fl_mi_box_cells(unsigned long long box_key
 // lane walks ONE cell's points (pass 1: its candidate for the box's closest old point), the eight lanes of a box take the minimum between
 // them (three shuffles), and pass 2 marks each lane's own cell. Same candidates, same minimum, same marks: same map.
 #define FL_MI_RESOLVE_LANES 8
+#define FL_MI_RESOLVE_KEEP 6
 __global__ __launch_bounds__(FL_BLOCK) void mapinc_resolve_kernel(FlBoxSlot *__restrict__ tab, unsigned tab_cap, const float *__restrict__ new_pts,
                                                                  float ds, FlMapIncView V, unsigned char *__restrict__ dead, int n_raw,
                                                                  unsigned *__restrict__ pend_next, FlMapIncCtl *__restrict__ ctl)
@@ -178,8 +179,13 @@ __global__ __launch_bounds__(FL_BLOCK) void mapinc_resolve_kernel(FlBoxSlot *__r
         nx = B.c1[0] - B.c0[0] + 1; ny = B.c1[1] - B.c0[1] + 1;
         ncell = nx * ny * (B.c1[2] - B.c0[2] + 1);
     }
-    // pass 1: this lane's cells' candidate for the box's closest old point (lowest index among equals)
+    // pass 1: this lane's cells' candidate for the box's closest old point (lowest index among equals). The box's points it meets on the way
+    // are remembered (pool slot + map index, up to FL_MI_RESOLVE_KEEP of them -- a 0.3 m box holds a handful), so that pass 2 does not walk
+    // the cells again; a lane that meets more falls back to the walk.
     unsigned long long best_old = FL_KNN_EMPTY;
+    unsigned keep_j[FL_MI_RESOLVE_KEEP];
+    int keep_id[FL_MI_RESOLVE_KEEP], keep_hs[FL_MI_RESOLVE_KEEP], nkeep = 0;
+    bool overflow = false;
     for (int c = (int)sub; c < ncell; c += FL_MI_RESOLVE_LANES) {
         const int ix = B.c0[0] + c % nx, iy = B.c0[1] + (c / nx) % ny, iz = B.c0[2] + c / (nx * ny);
         const int hs = fl_mi_find(V, fl_cell_key(ix, iy, iz));
@@ -212,6 +218,12 @@ __global__ __launch_bounds__(FL_BLOCK) void mapinc_resolve_kernel(FlBoxSlot *__r
             const float d = fl_calc_dist(p.x, p.y, p.z, g.cx, g.cy, g.cz);
             const unsigned long long cand = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned)__float_as_int(p.w);
             best_old = cand < best_old ? cand : best_old;
+            if (nkeep < FL_MI_RESOLVE_KEEP) {
+#pragma unroll
+                for (int q = 0; q < FL_MI_RESOLVE_KEEP; q++)          // (constant indices: a run-time index would put the arrays into scratch)
+                    if (q == nkeep) { keep_j[q] = j; keep_id[q] = __float_as_int(p.w); keep_hs[q] = hs; }
+                nkeep++;
+            } else overflow = true;
         }
     }
     // the box's minimum over its lanes (aligned groups of FL_MI_RESOLVE_LANES inside a wavefront: the xor pattern stays inside the group)
@@ -225,7 +237,18 @@ __global__ __launch_bounds__(FL_BLOCK) void mapinc_resolve_kernel(FlBoxSlot *__r
     const bool old_wins = live && best_old != FL_KNN_EMPTY && (unsigned)(best_old >> 32) < (unsigned)(best_new >> 32);      // strictly closer than every new point
     if (live && sub == 0) tab[s].best_old = best_old;
     // pass 2: every other old point of the box goes
-    for (int c = (int)sub; c < ncell; c += FL_MI_RESOLVE_LANES) {
+    if (!overflow) {
+#pragma unroll
+        for (int q = 0; q < FL_MI_RESOLVE_KEEP; q++) {
+            if (q >= nkeep) continue;
+            if (old_wins && (unsigned)keep_id[q] == (unsigned)best_old) continue;
+            V.pts[keep_j[q]].w = __int_as_float(FL_MI_DEAD);      // (a point belongs to exactly one box: nobody else writes it)
+            dead[keep_id[q]] = 1;
+            V.dirty[keep_hs[q]] = 1u;
+            removed++;
+        }
+    }
+    for (int c = (int)sub; overflow && c < ncell; c += FL_MI_RESOLVE_LANES) {
         const int ix = B.c0[0] + c % nx, iy = B.c0[1] + (c / nx) % ny, iz = B.c0[2] + c / (nx * ny);
         const int hs = fl_mi_find(V, fl_cell_key(ix, iy, iz));
         if (hs < 0) continue;
