@@ -344,22 +344,43 @@ __global__ __launch_bounds__(FL_VX_NT) void vx_claim_kernel(const float4 *__rest
     const FlVxGrid g = fl_vx_grid(mn_enc, mx_enc, ilx, ily, ilz, n);
     const bool is_short = g.cells > cells_cap;
     if (i == 0) { C->leaf_too_small = g.too_small; C->cells = g.cells; C->cells_short = is_short ? 1 : 0; }
-    if (i >= n) return;
     unsigned key = 0xFFFFFFFFu;
-    const float4 p = in[i];
-    if (!is_short && isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
-        if (g.too_small) {
-            key = (unsigned)i;
-        } else {
-            const int i0 = (int)(floorf(p.x * g.inv[0]) - (float)g.min_b[0]);
-            const int i1 = (int)(floorf(p.y * g.inv[1]) - (float)g.min_b[1]);
-            const int i2 = (int)(floorf(p.z * g.inv[2]) - (float)g.min_b[2]);
-            key = (unsigned)(i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2]);
+    if (i < n) {
+        const float4 p = in[i];
+        if (!is_short && isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            if (g.too_small) {
+                key = (unsigned)i;
+            } else {
+                const int i0 = (int)(floorf(p.x * g.inv[0]) - (float)g.min_b[0]);
+                const int i1 = (int)(floorf(p.y * g.inv[1]) - (float)g.min_b[1]);
+                const int i2 = (int)(floorf(p.z * g.inv[2]) - (float)g.min_b[2]);
+                key = (unsigned)(i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2]);
+            }
         }
-        atomicOr(&bits[key >> 5], 1u << (key & 31u));        // (result unused: a fire-and-forget atomic -- the counts come from popcounts, vx_scan_l2)
-        l2flag[key >> FL_VX_L2_SHIFT] = 1u;                  // (same value from everybody)
     }
-    keys[i] = key;
+    // The occupancy bits. The 100 k fire-and-forget atomics of a scan were 7 of this kernel's 12 us (a launch ends when its atomics have
+    // retired). Clouds that arrive in scan-line or voxel order -- a LiDAR driver's, and the camera half's input, which IS the first filter's
+    // output -- put runs of consecutive points into one 32-cell word: the lanes of a run OR their bits together (six shuffle steps; the
+    // doubling stays inside a run because a lane only takes from a lane with ITS word) and the run's first lane issues one atomic.
+    // The same bits either way; a cloud in random order pays thirty instructions per lane for nothing.
+    {
+        const int lane = (int)(threadIdx.x & 63u);
+        const bool live = key != 0xFFFFFFFFu;
+        const unsigned w = live ? (key >> 5) : (0xFFFFFFC0u + (unsigned)lane);        // (dead lanes: words of their own, no atomic)
+        unsigned bv = live ? (1u << (key & 31u)) : 0u;
+        const unsigned wprev = (unsigned)__shfl_up((int)w, 1);
+        const bool head = (lane == 0) || (wprev != w);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned wo = (unsigned)__shfl_down((int)w, d), bo = (unsigned)__shfl_down((int)bv, d);
+            if (lane + d < 64 && wo == w) bv |= bo;
+        }
+        if (live && head) {
+            atomicOr(&bits[key >> 5], bv);                   // (result unused: the counts come from popcounts, vx_scan_l2)
+            l2flag[key >> FL_VX_L2_SHIFT] = 1u;              // (same value from everybody; a 32-cell word lies inside one 2^18-cell block)
+        }
+    }
+    if (i < n) keys[i] = key;
 }
 
 // grid = blocks the bitmap can hold; block b serves cells [b << 18, (b + 1) << 18)
