@@ -416,6 +416,8 @@ class Handle:
             self.set_option(FL_OPT_VIO_WHOLE_CU, 0)
         if os.environ.get("FL_NO_VIO_SPEC"):
             self.set_option(FL_OPT_VIO_SPECULATE, 0)
+        elif os.environ.get("FL_VIO_SPEC"):           # (A/B tools: 1 = speculating accept with one launch per pyramid level, 2 = one launch)
+            self.set_option(FL_OPT_VIO_SPECULATE, int(os.environ["FL_VIO_SPEC"]))
 
     def close(self):
         if self.h:

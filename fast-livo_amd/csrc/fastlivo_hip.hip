@@ -160,7 +160,7 @@ struct fl_context {
     bool map_has_dead = false;             // the raw array holds dead entries (compacted by the next full rebuild)
     bool map_index_stale = false;          // the last status said needs_rebuild
     int opt_map_incr = 1;                  // FL_OPT_MAP_INCREMENTAL
-    int opt_vio_spec = 1;                  // FL_OPT_VIO_SPECULATE
+    int opt_vio_spec = 2;                  // FL_OPT_VIO_SPECULATE (2: + all pyramid levels of ComputeJ in one launch)
     int opt_vio_wide = 1;                  // FL_OPT_VIO_WIDE
     int opt_detect_fused = 1;              // FL_OPT_DETECT_FUSED
     int front_unsorted_left = 0;           // fl_lidar_front: frames left on the general undistortion kernels (api_front.inc)
@@ -550,7 +550,7 @@ int32_t fl_set_option(fl_handle h, int32_t option, int32_t value)
     case FL_OPT_INCR_SEARCH: h->opt_incr_search = value != 0; break;
     case FL_OPT_VOXEL_SORT: h->opt_voxel_sort = value != 0; break;
     case FL_OPT_MAP_INCREMENTAL: h->opt_map_incr = value != 0; break;
-    case FL_OPT_VIO_SPECULATE: h->opt_vio_spec = value != 0; break;
+    case FL_OPT_VIO_SPECULATE: h->opt_vio_spec = value < 0 ? 0 : (value > 2 ? 2 : (int)value); break;
     case FL_OPT_DETECT_FUSED: h->opt_detect_fused = value != 0; break;
     case FL_OPT_VIO_WIDE:
         if (value < 0 || value > 2) return fail_arg(h, "fl_set_option: FL_OPT_VIO_WIDE out of range");

@@ -130,6 +130,18 @@ __device__ __forceinline__ int gather_records(const void *records, int nprod, un
                 need |= ((base + 4 * wave_u + j * ROWS) < nprod) ? (1u << (g * BATCH + j)) : 0u;
                 t[g][j].x = 0u; t[g][j].y = 0u; t[g][j].z = 0u; t[g][j].w = 0u;
             }
+        // The byte offsets of the sweep's loads, one register each and opaque to the compiler: left to itself under register pressure
+        // (vio_multipass_kernel<1, 1>, round 6) it re-derived each offset from the first one INTO the destination registers of that
+        // load, which costs an s_waitcnt vmcnt(0) in front of every load -- the sixteen polls of a sweep went out one round trip after
+        // the other (1.5 us of every pass).
+        int off[G][BATCH];
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int j = 0; j < BATCH; j++) {
+                off[g][j] = ((b0 + j * ROWS) * NV + g * 32 + kp * 2) * 8;
+                asm volatile("" : "+v"(off[g][j]));
+            }
         for (int spin = 0; need != 0u; spin++) {
 #ifdef FL_GATHER_STAMPS
             if (tid == 0 && spin < 8) { g_fl_stamps[56 + spin] = (long long)wall_clock64(); g_fl_wall[2040 + spin] = (long long)__builtin_popcount(need); }
@@ -139,8 +151,7 @@ __device__ __forceinline__ int gather_records(const void *records, int nprod, un
 #pragma unroll
                 for (int j = 0; j < BATCH; j++) {
                     if (need & (1u << (g * BATCH + j))) {
-                        const int b = b0 + j * ROWS;
-                        t[g][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (b * NV + g * 32 + kp * 2) * 8, 0, 16 /* sc1 */);
+                        t[g][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[g][j], 0, 16 /* sc1 */);
                     }
                 }
 #pragma unroll

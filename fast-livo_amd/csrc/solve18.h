@@ -57,6 +57,10 @@ struct FlSolveLds {
     unsigned spec_epoch, spec_acc_epoch;
     float spec_nall, spec_last_error, spec_last_exact;
     double def_xold[24], def_sums[FL_SUMS18], def_sol[18];      // old_state / sums_acc / solution of that pass, written to the device block once it is confirmed
+    // VIO, round 6 -- all pyramid levels of ComputeJ in one launch (vio_multipass_kernel under FL_VIO_LEVELS): `levels` says so; `hold`
+    // = the pass that just ended a level went ahead on the fp64 decision, its broadcast carried ctrl bit 3 ("the verdict is out: wait
+    // for the level's go word"), the solver sends that word once the float chain has spoken
+    int levels, hold;
 };
 
 enum { FL_EPI_LIO = 0, FL_EPI_VIO = 1 };
@@ -296,7 +300,7 @@ __device__ __forceinline__ void eskf18_prefetch_commit(double v, FlSolveLds &L)
     else if (tid == 200) L.acc_epoch = (unsigned)v;
     else if (tid == 201) L.last_exact_valid = (int)v;
     else if (tid == 202) L.last_exact = (float)v;
-    else if (tid == 203) { L.jpass = 0; L.jflag = 0; L.spec_pending = 0; }
+    else if (tid == 203) { L.jpass = 0; L.jflag = 0; L.spec_pending = 0; L.levels = 0; L.hold = 0; }
     __syncthreads();
     eskf18_form_vec(L);
     __syncthreads();
@@ -452,7 +456,7 @@ __device__ __forceinline__ void vio_exact_decide(const FlVioExact ex, FlSolveLds
 
 // The judgement of a pass (wavefront 1 of the solver workgroup, see eskf18_solve_block): delta and the solve's status bits come out
 // of LDS. Uniform arithmetic; lane 0 publishes the control word and writes the bookkeeping.
-template <int KIND>
+template <int KIND, int SPEC = 0>
 __device__ __forceinline__ void eskf18_judge(FlDev18 *__restrict__ D, const double *s_sums, FlSolveLds &L, unsigned long long *bcast, unsigned bepoch)
 {
     const int lane = threadIdx.x & 63;
@@ -491,8 +495,11 @@ __device__ __forceinline__ void eskf18_judge(FlDev18 *__restrict__ D, const doub
         const int it = L.iters_run + 1;
         if (it >= L.max_iter) stop = 1;
         const int accepted = L.accepted + 1;
+        int hold = 0;
+        if constexpr (SPEC != 0) hold = (stop && L.levels && L.spec_pending) ? 8 : 0;      // (spec_pending: written by wavefront 0 before it raised jflag)
         if (lane == 0) {
-            if (bcast) fl_bcast_ctrl(bcast, stop ? 1 : 0, bepoch);
+            if (bcast) fl_bcast_ctrl(bcast, (stop ? 1 : 0) | hold, bepoch);
+            if constexpr (SPEC != 0) L.hold = hold;
             L.accepted = accepted; L.iters_run = it;
             L.ctrl = stop ? 1 : 0;
             D->converged = converged;
@@ -625,7 +632,7 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
             __builtin_amdgcn_s_sleep(1);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (f == jtag) eskf18_judge<KIND>(D, s_sums, L, bcast, bepoch);
+        if (f == jtag) eskf18_judge<KIND, SPEC>(D, s_sums, L, bcast, bepoch);
         if (lane == 0) L.jpass = jtag;
         return;
     }

@@ -1212,6 +1212,10 @@ __device__ __attribute__((noinline)) void vio_cov_outofline(FlDev18 *D) { vio_co
                                           for the real count (same partition, same record order, same bits), the others leave at once; no
                                           patches: no passes (ComputeJ returns at once then, lidar_selection.cpp:969) */
 
+#define FL_VIO_LEVELS 0x800            /* launch flag (internal, vio_multipass_kernel<1, 1> only): the launch runs pyramid level `level` and then the
+                                          finer ones down to 0 -- ComputeJ's whole coarse-to-fine schedule (lidar_selection.cpp:971-977) in one kernel:
+                                          every level begins with `begin_residual`, `count` = max_iterations, level_info = the array of the three
+                                          results (indexed by level). A level's last broadcast (stop) is the next level's first pose. */
 // Up to `count` passes of one pyramid level in ONE launch (see lio18_multipass_kernel): the solver broadcasts the derived camera
 // pose (Rcw, Pcw: what the producers consume) and the stop bit; a rejected solve (error went up, lidar_selection.cpp:888-892)
 // reverts and stops like the reference. Bit-identical to `count` launches of vio_pass_kernel<0>.
@@ -1258,6 +1262,11 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
     unsigned long long *err_base = D->err_words;
     const int err_cap = D->err_cap;
     const int pass0 = begin ? 0 : D->iters_run;          // index of this launch's first pass within its pyramid level
+    // SPEC: all levels in this launch (FL_VIO_LEVELS). Everybody follows the broadcasts by the same rule: a level ends with a broadcast
+    // that carries "stop" (tag t); it holds the pose the next level starts from (the accepted state's, or the reverted one's) and the
+    // next level's first pass has epoch t -- unless bit 3 says that the float chain's verdict on that pass is still out (a fragile
+    // accept that went ahead): then the solver sends the pose again, as tag t + 1, once it has the verdict, and the level starts there.
+    const bool levels = SPEC != 0 && (flags & FL_VIO_LEVELS) != 0;
 
     if (blockIdx.x == auditor_block) {
         // auditor workgroup (see vio_audit_pass): follows the passes through the broadcast like a producer
@@ -1265,18 +1274,40 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
 #ifndef FL_AB_NO_AUDITOR
         __shared__ double s_apose[12];
         __shared__ int s_actrl;
-        for (int ps = 0; ps < count; ps++) {
-            const unsigned epoch = epoch0 + (unsigned)ps;
-            FL_AUDIT_STAMP(16 * (epoch & 15) + 0, wall_clock64());
-            if (ps > 0) {
-                bcast_wait(bcast, epoch, s_apose, &s_actrl, FL_GATHER_SPIN_LIMIT);
-                __syncthreads();
-                if (s_actrl & 7) break;
+        unsigned ebase = epoch0;
+        int pb = pass0, lv = level;
+        for (;;) {
+            int ps;
+            for (ps = 0; ps < count; ps++) {
+                const unsigned epoch = ebase + (unsigned)ps;
+                FL_AUDIT_STAMP(16 * (epoch & 15) + 0, wall_clock64());
+                if (ps > 0) {
+                    bcast_wait(bcast, epoch, s_apose, &s_actrl, FL_GATHER_SPIN_LIMIT);
+                    __syncthreads();
+                    if (s_actrl & 7) break;
+                }
+                FL_AUDIT_STAMP(16 * (epoch & 15) + 1, wall_clock64());
+                const int to = vio_audit_pass(err_base, err_cap, (pb + ps) & 1, m, epoch);
+                FL_AUDIT_STAMP(16 * (epoch & 15) + 2, wall_clock64());
+                FL_AUDIT_STAMP(16 * (epoch & 15) + 3, to);
             }
-            FL_AUDIT_STAMP(16 * (epoch & 15) + 1, wall_clock64());
-            const int to = vio_audit_pass(err_base, err_cap, (pass0 + ps) & 1, m, epoch);
-            FL_AUDIT_STAMP(16 * (epoch & 15) + 2, wall_clock64());
-            FL_AUDIT_STAMP(16 * (epoch & 15) + 3, to);
+            if constexpr (SPEC == 0) break;
+            if (!levels || lv == 0 || count <= 0) break;
+            if (ps == count) {                            // (a level that used all its passes: its last broadcast has not been read)
+                __syncthreads();
+                bcast_wait(bcast, ebase + (unsigned)ps, s_apose, &s_actrl, FL_GATHER_SPIN_LIMIT);
+                __syncthreads();
+            }
+            if (s_actrl & 4) break;
+            ebase += (unsigned)ps;
+            if (s_actrl & 8) {                            // the go word of the next level
+                __syncthreads();
+                ebase += 1u;
+                bcast_wait(bcast, ebase, s_apose, &s_actrl, FL_GATHER_SPIN_LIMIT);
+                __syncthreads();
+                if (s_actrl & 4) break;
+            }
+            lv--; pb = 0;
         }
 #endif
         return;
@@ -1287,6 +1318,8 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
         __shared__ FlSolveLds s_solve;
         __shared__ __attribute__((aligned(16))) float s_ex[FL_EXACT_LDS];
         eskf18_prefetch(D, s_solve);
+        int lv = level;            // SPEC under FL_VIO_LEVELS: the level this workgroup is on
+        unsigned ebase = epoch0;   // ... and the epoch of that level's first pass (otherwise: epoch0)
         if (begin) {
             __syncthreads();
             if (threadIdx.x < 24) D->xold[threadIdx.x] = s_solve.x[threadIdx.x];      // old_state = *state
@@ -1296,6 +1329,7 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
                 D->last_exact = begin_residual; D->last_exact_valid = 1; D->err_acc_buf = 0; D->err_acc_epoch = 0u;
                 D->last_error = begin_residual; D->level = level; D->stop = 0; D->converged = 0; D->iters_run = 0; D->accepted = 0;
                 D->status = 0;
+                if constexpr (SPEC != 0) { s_solve.levels = levels ? 1 : 0; s_solve.ctrl = 0; }
             }
             __syncthreads();
         }
@@ -1305,10 +1339,13 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
         const unsigned xe0 = PV.world > 1 ? *D->xchg_epoch : 0u;
         int done = 0;
         int rollback = 0;          // SPEC: 1 = a verdict taken at the top of pass `done - 1` rejected the pass before it, 2 = taken behind the launch's last pass
+      for (;;) {                   // (one round per pyramid level; one round unless FL_VIO_LEVELS)
         for (int p = 0; p < count; p++) {
-            const unsigned epoch = epoch0 + (unsigned)p;
+            const unsigned epoch = ebase + (unsigned)p;
             FlSolveRegs G;
+            FL_AUDIT_STAMP(16 * (epoch & 15) + 13, wall_clock64());
             eskf18_load_regs(s_solve, G, VC);                    // solve operands into wave 0's registers while the producers work
+            FL_AUDIT_STAMP(16 * (epoch & 15) + 14, wall_clock64());
             FL_INSTR(if (p == 5) fl_stamp(flags, 16);)
             int gst = gather_records<NT, FL_SUMS18>(records, nprod, epoch, s_fin, s_sums);
             if (PV.world > 1) gst |= peer_allreduce32(PV, xe0 + (unsigned)p, s_sums, s_xchg);      // sharded form: totals over the ranks
@@ -1354,19 +1391,44 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
             }
             // the revert of a fragile accept the float chain did not confirm (rare; out of the loop and out of line). rollback == 1: the
             // producers of pass done - 1 wait for a control word -- they get "stop"; their records are dropped
-            if (rollback) vio_spec_rollback(D, &s_solve, err_base, err_cap, m, errors, VC, rollback == 1 ? bcast : (unsigned long long *)nullptr, epoch0 + (unsigned)done);
+            if (rollback) vio_spec_rollback(D, &s_solve, err_base, err_cap, m, errors, VC, rollback == 1 ? bcast : (unsigned long long *)nullptr, ebase + (unsigned)done);
         }
-        if (threadIdx.x == 0) {
-            *epoch_ptr = epoch0 + (unsigned)done;
-            if (PV.world > 1) *D->xchg_epoch = xe0 + (unsigned)done;
-        }
+        ebase += (unsigned)done;
         if (level_info) {
+            FlVioLevelInfo *li = level_info + (levels ? lv : 0);
             __syncthreads();
-            if (threadIdx.x < 18) level_info->solution[threadIdx.x] = D->solution[threadIdx.x];
+            if (threadIdx.x < 18) li->solution[threadIdx.x] = D->solution[threadIdx.x];
             if (threadIdx.x == 32) {
-                level_info->error = D->last_error; level_info->iterations = D->iters_run; level_info->n_meas = D->neff;
-                level_info->accepted = D->accepted; level_info->status = D->status; level_info->converged = D->converged;
+                li->error = D->last_error; li->iterations = D->iters_run; li->n_meas = D->neff;
+                li->accepted = D->accepted; li->status = D->status; li->converged = D->converged;
             }
+        }
+        if constexpr (SPEC == 0) break;
+        if (!levels || lv == 0 || (s_solve.ctrl & 4)) break;
+        // ---- the next pyramid level (UpdateState's prologue, lidar_selection.cpp:747,756, as `begin` above): the state the level
+        // ended with -- accepted, reverted or rolled back -- is in xn / xadd, the producers have it as the pose of the level's last broadcast
+        __syncthreads();
+        if (s_solve.hold) {                                   // ... which said "wait": the verdict is in, the pose goes out again
+            ebase += 1u;
+            if (threadIdx.x < 12) fl_bcast_store(bcast, threadIdx.x, s_solve.cam[threadIdx.x], ebase);
+            if (threadIdx.x == 0) fl_bcast_ctrl(bcast, 0, ebase);
+        }
+        lv--; done = 0; rollback = 0;
+        if (count > 0) eskf18_restage(s_solve);                // (no patches: no passes ran, x is what it was)
+        if (threadIdx.x < 24) D->xold[threadIdx.x] = s_solve.x[threadIdx.x];
+        if (threadIdx.x == 32) {
+            s_solve.last_error = begin_residual; s_solve.iters_run = 0; s_solve.accepted = 0; s_solve.fragile = 0; s_solve.sticky = 0;
+            s_solve.last_exact = begin_residual; s_solve.last_exact_valid = 1; s_solve.acc_buf = 0; s_solve.acc_epoch = 0u;
+            s_solve.hold = 0;
+            D->last_exact = begin_residual; D->last_exact_valid = 1; D->err_acc_buf = 0; D->err_acc_epoch = 0u;
+            D->last_error = begin_residual; D->level = lv; D->stop = 0; D->converged = 0; D->iters_run = 0; D->accepted = 0;
+            D->status = 0;
+        }
+        __syncthreads();
+      }
+        if (threadIdx.x == 0) {
+            *epoch_ptr = ebase;
+            if (PV.world > 1) *D->xchg_epoch = xe0 + (unsigned)done;
         }
         if (flags & FL_VIO_DO_COV) {                              // the frame's last launch: covariance update + result mailbox
             __threadfence();
@@ -1391,9 +1453,14 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
     for (int i = 0; i < 3; i++) Pcw[i] = D->Pcw[i];
     FlVioLaneRole role = fl_vio_lane_role((int)(threadIdx.x & 15), VC);
     fl_vio_lane_role_pose(role, (int)(threadIdx.x & 15), D->Rcw);
-    for (int ps = 0; ps < count; ps++) {
-        const unsigned epoch = epoch0 + (unsigned)ps;
-        const FlVioFirst pf = vio_prefetch_first(ref, pos, slevel, m, level, nprod);
+    unsigned ebase = epoch0;
+    int pb = pass0, lv = level;
+  for (;;) {                       // (one round per pyramid level; one round unless FL_VIO_LEVELS)
+    int ps;
+    for (ps = 0; ps < count; ps++) {
+        const unsigned epoch = ebase + (unsigned)ps;
+        const FlVioFirst pf = vio_prefetch_first(ref, pos, slevel, m, lv, nprod);
+        if (blockIdx.x == 0) FL_AUDIT_STAMP(16 * (epoch & 15) + 4, wall_clock64());
         if (ps > 0) {
             FL_INSTR(if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 20 + 4 * (ps - 5));)
             bcast_wait(bcast, epoch, s_pose, &s_ctrl, spin_limit);
@@ -1407,11 +1474,38 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
             for (int i = 0; i < 3; i++) Pcw[i] = s_pose[9 + i];
             fl_vio_lane_role_pose(role, (int)(threadIdx.x & 15), s_pose);
         }
-        vio_produce<1>(img, ref, pos, slevel, errors, m, level, level, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records,
-                    (ps == 5) ? flags : (flags & ~FL_ITER_STAMP), err_base ? err_base + (size_t)((pass0 + ps) & 1) * err_cap : nullptr, s_res, s_pidx, role);
+        if (blockIdx.x == 0) FL_AUDIT_STAMP(16 * (epoch & 15) + 5, wall_clock64());
+        if (blockIdx.x < 127) FL_AUDIT_STAMP(256 + 2 * blockIdx.x, wall_clock64());
+        vio_produce<1>(img, ref, pos, slevel, errors, m, lv, lv, vc, Rcw, Pcw, pf, nprod, s_red, epoch, records,
+                    (ps == 5) ? flags : (flags & ~FL_ITER_STAMP), err_base ? err_base + (size_t)((pb + ps) & 1) * err_cap : nullptr, s_res, s_pidx, role);
         FL_INSTR(if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 23 + 4 * (ps - 5));)
+        if (blockIdx.x == 0) FL_AUDIT_STAMP(16 * (epoch & 15) + 6, wall_clock64());
+        if (blockIdx.x < 127) FL_AUDIT_STAMP(256 + 2 * blockIdx.x + 1, wall_clock64());
         __syncthreads();
     }
+    if constexpr (SPEC == 0) break;
+    if (!levels || lv == 0 || count <= 0) break;      // (no patches: no passes, nothing to wait for)
+    if (ps == count) {                                // (a level that used all its passes: its last broadcast has not been read)
+        bcast_wait(bcast, ebase + (unsigned)ps, s_pose, &s_ctrl, spin_limit);
+        __syncthreads();
+    }
+    if (s_ctrl & 4) break;
+    ebase += (unsigned)ps;
+    if (s_ctrl & 8) {                                 // the verdict on the level's last pass was out: the pose comes again
+        __syncthreads();
+        ebase += 1u;
+        bcast_wait(bcast, ebase, s_pose, &s_ctrl, spin_limit);
+        __syncthreads();
+        if (s_ctrl & 4) break;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) Rcw[i] = s_pose[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) Pcw[i] = s_pose[9 + i];
+    fl_vio_lane_role_pose(role, (int)(threadIdx.x & 15), s_pose);
+    __syncthreads();
+    lv--; pb = 0;
+  }
 }
 
 // UpdateState prologue: old_state = *state, last_error = total_residual (:747,756); per-level counters.

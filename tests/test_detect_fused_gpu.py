@@ -33,7 +33,7 @@ def _frame_pose(Rci, Pci, rot9, pos3):
     return Rcw, Pcw
 
 
-def _walk(capi, orc, synth, scene, frames, n_scan, max_iter, grid, fused, with_oracle, blind_frame=-1, outlier=3000.0, drop=None, refuse=None):
+def _walk(capi, orc, synth, scene, frames, n_scan, max_iter, grid, fused, with_oracle, blind_frame=-1, outlier=3000.0, drop=None, refuse=None, spec=None):
     """drop = (frame, passes_ahead): the instrumented build's fault injector makes a producer of that ComputeJ pass withhold its record"""
     fr0 = synth.make_lio_frame(n_scan, scene=scene)
     vf0 = synth.make_vio_frame(8, fr0, max_iterations=max_iter)
@@ -41,6 +41,8 @@ def _walk(capi, orc, synth, scene, frames, n_scan, max_iter, grid, fused, with_o
     if drop is not None:
         h.debug_drop_record(1 << 30)            # (park the process-wide injector: an earlier test may have left it armed)
     h.set_option(capi.FL_OPT_DETECT_FUSED, 1 if fused else 0)
+    if spec is not None:
+        h.set_option(capi.FL_OPT_VIO_SPECULATE, spec)       # 2 (default): ComputeJ's three pyramid levels in one launch, 1: a launch per level
     h.vmap_clear(grid)
     Rli = fr0.R_LI.T
     Rci = vf0.Rcl @ Rli
@@ -222,17 +224,19 @@ def test_fused_detect_with_an_abandoned_computej_pass(gpu_lib, oracle_lib, scene
         assert np.array_equal(p[0], q[0]) and p[1] == q[1] and len(p[2]) == len(q[2]) and _same_obs(p[2], q[2]), f"visual map point {i}"
 
 
-@pytest.mark.parametrize("nth,count", [(1, 1), (1, 2), (2, 1), (2, 2), (3, 2), (1, 6)])
-def test_fused_detect_losing_the_multipass_admission_half_way(gpu_lib, oracle_lib, scene, nth, count):
+@pytest.mark.parametrize("spec,nth,count", [(1, 1, 1), (1, 1, 2), (1, 2, 1), (1, 2, 2), (1, 3, 2), (1, 1, 6), (2, 1, 1), (2, 1, 2), (2, 1, 6)])
+def test_fused_detect_losing_the_multipass_admission_half_way(gpu_lib, oracle_lib, scene, spec, nth, count):
     """The fused frame's ComputeJ launches take their patch count from the device, which only the multi-pass kernels can do. If the admission
     is lost at some level (another handle of the process launched in between; here: the debug library refuses `count` reservations from the nth
-    on -- each level tries the whole-CU variant first, then the shared one: (1, 1) moves level 2 to the shared variant, (1, 2) refuses level 2
-    outright, (2, 2) level 1, (3, 2) level 0, (1, 6) every level), nothing more is enqueued, the counts are read back and the remaining levels
-    run per pass with launches that know the count; addObservation goes through the staged call. Same bits as the undisturbed walk."""
+    on -- with a launch per pyramid level (FL_OPT_VIO_SPECULATE 1) each level tries the whole-CU variant first, then the shared one: (1, 1)
+    moves level 2 to the shared variant, (1, 2) refuses level 2 outright, (2, 2) level 1, (3, 2) level 0, (1, 6) every level), nothing more is
+    enqueued, the counts are read back and the remaining levels run per pass with launches that know the count; addObservation goes through the
+    staged call. With all levels in ONE launch (2, the default) there is one reservation: (1, 1) sends level 2 to the shared variant and
+    levels 1-0 into one launch, (1, 2) and (1, 6) refuse. Same bits as the undisturbed walk of the default form."""
     capi, orc = gpu_lib, oracle_lib
     from fast_livo_amd import synth
     good, map_good = _walk(capi, orc, synth, scene, 4, 3000, 4, 40, True, False)
-    bad, map_bad = _walk(capi, orc, synth, scene, 4, 3000, 4, 40, True, False, refuse=(2, nth, count))
+    bad, map_bad = _walk(capi, orc, synth, scene, 4, 3000, 4, 40, True, False, refuse=(2, nth, count), spec=spec)
     for k, (a, b) in enumerate(zip(good, bad)):
         assert a["counts"] == b["counts"], f"frame {k}: {a['counts']} vs {b['counts']}"
         assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["P"], b["P"]), f"frame {k}: state"

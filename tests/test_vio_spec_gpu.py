@@ -10,7 +10,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROLLBACK_CASES = [dict(m=2000, max_iter=7, seed=1028591, lio_seed=3, noise=6.0), dict(m=2000, max_iter=6, seed=25685, lio_seed=0, noise=6.0),
-                  dict(m=700, max_iter=5, seed=607895, lio_seed=2, noise=2.0)]
+                  dict(m=700, max_iter=5, seed=607895, lio_seed=2, noise=2.0),
+                  # (round 6, found with all pyramid levels in one launch)
+                  dict(m=1000, max_iter=3, seed=641667, lio_seed=4, noise=6.0), dict(m=2040, max_iter=7, seed=1008255, lio_seed=6, noise=6.0)]
 CONFIRM_CASES = [dict(m=2000, max_iter=10, seed=103, lio_seed=0, noise=2.0), dict(m=1000, max_iter=4, seed=7, lio_seed=5, noise=0.5)]
 
 
@@ -18,7 +20,7 @@ def _run(capi, orc, synth, c):
     lio = synth.make_lio_frame(500, seed=synth.SEED + c["lio_seed"])
     vf = synth.make_vio_frame(c["m"], lio, max_iterations=c["max_iter"], patch_seed=c["seed"], ref_noise=c["noise"])
     res, counts = [], None
-    for spec in (1, 0):
+    for spec in (2, 1, 0):           # 2 (default): all three pyramid levels in ONE launch (round 6), 1: a launch per level, 0: the waiting form
         h = capi.Handle(capi.config_from_frames(lio, vf, max_iterations=c["max_iter"]), debug=True)
         h.set_option(capi.FL_OPT_VIO_SPECULATE, spec)
         w0 = np.array(h.debug_wall(), dtype=np.int64)[2040:2043].copy()
@@ -27,13 +29,16 @@ def _run(capi, orc, synth, c):
         ig = h.vio_compute_j(xg, xp)
         eg = h.vio_get_errors(c["m"])
         if spec:
-            counts = np.array(h.debug_wall(), dtype=np.int64)[2040:2043] - w0
+            c_now = np.array(h.debug_wall(), dtype=np.int64)[2040:2043] - w0
+            assert counts is None or np.array_equal(counts, c_now), (counts, c_now)      # both speculating forms speculate on the same passes
+            counts = c_now
         res.append((bytes(xg), eg.copy(), [(int(i.iterations), int(i.accepted), int(i.status)) for i in ig]))
         h.close()
     xo = orc.state18_from_frame(lio)
     ro = orc.vio_compute_j(vf, xo, orc.state18_from_frame(lio))
-    assert res[0][0] == res[1][0]                                       # state + covariance: bit for bit
-    assert np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32)) and res[0][2] == res[1][2]
+    for r in res[1:]:
+        assert res[0][0] == r[0]                                        # state + covariance: bit for bit
+        assert np.array_equal(res[0][1].view(np.uint32), r[1].view(np.uint32)) and res[0][2] == r[2]
     xs = np.frombuffer(res[0][0], np.float64)
     assert np.abs(xs[:24] - xo.vec()[:24]).max() <= 1e-9
     assert np.array_equal(res[0][1].view(np.uint32), ro["errors"].view(np.uint32))

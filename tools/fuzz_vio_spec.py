@@ -20,7 +20,7 @@ for trial in range(T):
     noise = float(rng.choice([0.5, 2.0, 6.0]))
     vf = synth.make_vio_frame(m, lio, max_iterations=max_iter, patch_seed=seed, ref_noise=noise)
     res = []
-    for spec in (1, 0):
+    for spec in (2, 1, 0):           # all levels in one launch (default) / a launch per level / the waiting form
         h = capi.Handle(capi.config_from_frames(lio, vf, max_iterations=max_iter), debug=True)
         h.set_option(capi.FL_OPT_VIO_SPECULATE, spec)
         w0 = np.array(h.debug_wall(), dtype=np.int64)[2040:2043].copy()
@@ -29,7 +29,7 @@ for trial in range(T):
         ig = h.vio_compute_j(xg, xp)
         eg = h.vio_get_errors(m)
         w1 = np.array(h.debug_wall(), dtype=np.int64)[2040:2043]
-        if spec:
+        if spec == 2:
             tot += w1 - w0
             if (w1 - w0)[2]:
                 print("ROLLED BACK", dict(m=m, max_iter=max_iter, seed=seed, lio_seed=seed % 11, noise=noise, counts=(w1 - w0).tolist()))
@@ -37,11 +37,11 @@ for trial in range(T):
         h.close()
     xo = orc.state18_from_frame(lio); xq = orc.state18_from_frame(lio)
     ro = orc.vio_compute_j(vf, xo, xq)
-    same = res[0][0] == res[1][0] and np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32)) and res[0][2] == res[1][2]
+    same = all(res[0][0] == r[0] and np.array_equal(res[0][1].view(np.uint32), r[1].view(np.uint32)) and res[0][2] == r[2] for r in res[1:])
     xs = np.frombuffer(res[0][0], np.float64)
     vs_orc = np.abs(xs[:24] - xo.vec()[:24]).max() <= 1e-9 and np.array_equal(res[0][1].view(np.uint32), ro["errors"].view(np.uint32)) and \
         [r[0] for r in res[0][2]] == [int(o.iterations) for o in ro["outs"]]
     if not (same and vs_orc):
         bad += 1
-        print("MISMATCH", dict(m=m, max_iter=max_iter, seed=seed, same=bool(same), vs_oracle=bool(vs_orc), spec=res[0][2], wait=res[1][2]))
+        print("MISMATCH", dict(m=m, max_iter=max_iter, seed=seed, same=bool(same), vs_oracle=bool(vs_orc), spec=res[0][2], per_level=res[1][2], wait=res[2][2]))
 print(json.dumps({"trials": T, "mismatches": bad, "speculated": int(tot[0]), "confirmed": int(tot[1]), "rolled_back": int(tot[2])}))
