@@ -858,10 +858,13 @@ static int32_t begin18_common(fl_handle h, const fl_state18 *state, const fl_sta
     }
     // leave_in_mirror (fl_lio_frame18_dev, prepare_in_search): no copy command -- the frame's first search kernel fetches the block
     // from the mirror (knn_kernels.h host_state); it arrives as that search would leave it (searched_at = iters_run = 0)
+    // (vio && leave_in_mirror: fl_vio_compute_j -- vio_prepare_kernel fetches the block)
+    const bool vio_pull = vio && leave_in_mirror && h->d_hdev && h->opt_scan_pull;
     if (leave_in_mirror && prepare_in_search) D->searched_at = 0;
-    else HIPCHK(h, hipMemcpyAsync(h->d_dev, D, sizeof(FlDev18), hipMemcpyHostToDevice, h->stream));
+    else if (!vio_pull) HIPCHK(h, hipMemcpyAsync(h->d_dev, D, sizeof(FlDev18), hipMemcpyHostToDevice, h->stream));
     h->hdev_busy = true;
-    if (vio) hipLaunchKernelGGL(vio_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev, (const FlVioConst *)h->d_vc);   // + the camera pose
+    if (vio) hipLaunchKernelGGL(vio_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev, (const FlVioConst *)h->d_vc,
+                                vio_pull ? (const FlDev18 *)h->d_hdev : (const FlDev18 *)nullptr);      // + the camera pose
     else if (!prepare_in_search) hipLaunchKernelGGL(eskf18_prepare_kernel, dim3(1), dim3(128), 0, h->stream, h->d_dev);
     // (prepare_in_search: fl_lio_frame18_dev -- the first search launch of the frame carries the prepare workgroup, api_knn.inc)
     HIPCHK(h, hipGetLastError());

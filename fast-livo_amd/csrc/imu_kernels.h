@@ -162,20 +162,18 @@ __global__ __launch_bounds__(FL_IMU_NT) void imu_forward_kernel(FlImuDev *__rest
         for (int i = ((int)blockIdx.x - 1) * FL_IMU_NT + (int)threadIdx.x; i < pull.n_scan; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
         return;
     }
-    if (pull.in_host) {
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(pull.in_host);
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(D);
-        for (int w = (int)threadIdx.x; w < (int)(sizeof(FlImuDev) / 8); w += FL_IMU_NT) dst[w] = __builtin_nontemporal_load(src + w);
-    }
-    if (pull.x18_host && out18) {
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(pull.x18_host);
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(out18);
-        for (int w = (int)threadIdx.x; w < (int)(sizeof(FlDev18) / 8); w += FL_IMU_NT) dst[w] = __builtin_nontemporal_load(src + w);
-    }
+    // (every load of both blocks in flight before the first store: fl_device.h FlPull)
+    FlPull<FL_IMU_NT, (int)sizeof(FlImuDev)> blk_in;
+    FlPull<FL_IMU_NT, (int)sizeof(FlDev18)> blk_x;
+    const bool pull_in = pull.in_host != nullptr, pull_x = pull.x18_host != nullptr && out18 != nullptr;      // (uniform)
+    if (pull_in) blk_in.load(pull.in_host);
+    if (pull_x) blk_x.load(pull.x18_host);
     // the first chunk's samples travel with the blocks above (one trip over the host link for all of them when v is host memory too)
     FlImuSample pre_head = {}, pre_tail = {};
     if ((int)threadIdx.x < min(FL_IMU_CH, nv - 1)) { pre_head = v[threadIdx.x]; pre_tail = v[threadIdx.x + 1]; }
-    if (pull.in_host || pull.x18_host) { __threadfence_block(); __syncthreads(); }
+    if (pull_in) blk_in.store(D);
+    if (pull_x) blk_x.store(out18);
+    if (pull_in || pull_x) { __threadfence_block(); __syncthreads(); }
     __shared__ double sP[324], sT[324];        // the covariance; (F cov)^T of the interval in flight
     __shared__ FlImuStep sS[FL_IMU_CH];
     __shared__ double sExpF[FL_IMU_CH][9], sW[FL_IMU_CH][3], sA[FL_IMU_CH][3], sRb[FL_IMU_CH][9];

@@ -212,8 +212,17 @@ __global__ void vio_derive_kernel(FlDev18 *__restrict__ D, const FlVioConst *__r
 }
 // fl_vio_begin in one launch: the gain-solve constants of the state block (eskf18_prepare_kernel) and, by the last 12 threads, the
 // camera pose of the initial state
-__global__ __launch_bounds__(128) void vio_prepare_kernel(FlDev18 *__restrict__ D, const FlVioConst *__restrict__ VC)
+// x18_host != nullptr (fl_vio_compute_j, round 6): the state block waits in the handle's page-locked mirror and this kernel fetches it itself
+// (as detect_begin_kernel does for fl_vio_detect) -- one copy command (4-6 us of stream time) less in front of ComputeJ
+__global__ __launch_bounds__(128) void vio_prepare_kernel(FlDev18 *__restrict__ D, const FlVioConst *__restrict__ VC, const FlDev18 *__restrict__ x18_host)
 {
+    if (x18_host) {      // (uniform)
+        FlPull<128, (int)sizeof(FlDev18)> blk;
+        blk.load(x18_host);
+        blk.store(D);
+        __threadfence_block();
+        __syncthreads();
+    }
     if (threadIdx.x >= 116) vio_derive_pose(D->x, VC, D, (int)threadIdx.x - 116);
     eskf18_prepare_body(D);
 }
@@ -1394,6 +1403,15 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
             if (rollback) vio_spec_rollback(D, &s_solve, err_base, err_cap, m, errors, VC, rollback == 1 ? bcast : (unsigned long long *)nullptr, ebase + (unsigned)done);
         }
         ebase += (unsigned)done;
+        if constexpr (SPEC != 0) {
+            // the level's last broadcast said "wait" (a fragile accept that ended the level went ahead, solve18.h eskf18_judge): the verdict
+            // is in -- the pose of the state the level really ended with goes out again, before anything else: the producers wait for it
+            if (levels && lv > 0 && !(s_solve.ctrl & 4) && s_solve.hold) {      // (uniform: LDS, behind a barrier)
+                ebase += 1u;
+                if (threadIdx.x < 12) fl_bcast_store(bcast, threadIdx.x, s_solve.cam[threadIdx.x], ebase);
+                if (threadIdx.x == 0) fl_bcast_ctrl(bcast, 0, ebase);
+            }
+        }
         if (level_info) {
             FlVioLevelInfo *li = level_info + (levels ? lv : 0);
             __syncthreads();
@@ -1408,11 +1426,6 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
         // ---- the next pyramid level (UpdateState's prologue, lidar_selection.cpp:747,756, as `begin` above): the state the level
         // ended with -- accepted, reverted or rolled back -- is in xn / xadd, the producers have it as the pose of the level's last broadcast
         __syncthreads();
-        if (s_solve.hold) {                                   // ... which said "wait": the verdict is in, the pose goes out again
-            ebase += 1u;
-            if (threadIdx.x < 12) fl_bcast_store(bcast, threadIdx.x, s_solve.cam[threadIdx.x], ebase);
-            if (threadIdx.x == 0) fl_bcast_ctrl(bcast, 0, ebase);
-        }
         lv--; done = 0; rollback = 0;
         if (count > 0) eskf18_restage(s_solve);                // (no patches: no passes ran, x is what it was)
         if (threadIdx.x < 24) D->xold[threadIdx.x] = s_solve.x[threadIdx.x];

@@ -370,13 +370,12 @@ __global__ __launch_bounds__(128) void detect_begin_kernel(FlDev18 *__restrict__
                                                           FlDetectParams *__restrict__ prm, const FlDetectParams *__restrict__ prm_host)
 {
     {
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(x18_host);
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(D);
-        for (int w = (int)threadIdx.x; w < (int)(sizeof(FlDev18) / 8); w += 128) dst[w] = __builtin_nontemporal_load(src + w);
-        const unsigned long long *ps = reinterpret_cast<const unsigned long long *>(prm_host);
-        unsigned long long *pd = reinterpret_cast<unsigned long long *>(prm);
-        static_assert(sizeof(FlDetectParams) % 8 == 0, "word copy");
-        for (int w = (int)threadIdx.x; w < (int)(sizeof(FlDetectParams) / 8); w += 128) pd[w] = __builtin_nontemporal_load(ps + w);
+        FlPull<128, (int)sizeof(FlDev18)> blk;                 // (both blocks in ONE trip over the host link: fl_device.h FlPull)
+        FlPull<128, (int)sizeof(FlDetectParams)> pblk;
+        blk.load(x18_host);
+        pblk.load(prm_host);
+        blk.store(D);
+        pblk.store(prm);
     }
     __threadfence_block();
     __syncthreads();
