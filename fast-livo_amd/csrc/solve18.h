@@ -263,23 +263,35 @@ __device__ __forceinline__ void eskf18_form_vec(FlSolveLds &L)
 // Split in two so that the loads can be issued before the kernel's control-word round trip.
 __device__ __forceinline__ double eskf18_prefetch_issue(const FlDev18 *__restrict__ D)
 {
+    // ONE 8-byte load for the 192 doubles and ONE 4-byte load for the eleven scalars, each lane at its own offset. (As an if / else chain
+    // over the fields -- the form of rounds 1-5 -- the compiler emitted one masked load + s_waitcnt per field: fifteen round trips to the L2
+    // one after the other, ~6 us at the head of every launch, longer than the producers' first pass beside it.)
     const int tid = threadIdx.x;
+    const char *base = reinterpret_cast<const char *>(D);
     double v = 0.0;
-    if (tid < 36) v = D->Q[tid];
-    else if (tid < 144) v = D->T[tid - 36];
-    else if (tid < 168) v = D->x[tid - 144];
-    else if (tid < 192) v = D->xprop[tid - 168];
-    else if (tid == 192) v = (double)D->last_error;
-    else if (tid == 193) v = (double)D->rematch_num;
-    else if (tid == 194) v = (double)D->iterCount;
-    else if (tid == 195) v = (double)D->max_iter;
-    else if (tid == 196) v = (double)D->iters_run;
-    else if (tid == 197) v = (double)D->accepted;
-    else if (tid == 198) v = (double)D->status;
-    else if (tid == 199) v = (double)D->err_acc_buf;
-    else if (tid == 200) v = (double)D->err_acc_epoch;
-    else if (tid == 201) v = (double)D->last_exact_valid;
-    else if (tid == 202) v = (double)D->last_exact;
+    if (tid < 192) {
+        size_t off = offsetof(FlDev18, Q) + 8 * (size_t)tid;
+        off = tid >= 36 ? offsetof(FlDev18, T) + 8 * (size_t)(tid - 36) : off;
+        off = tid >= 144 ? offsetof(FlDev18, x) + 8 * (size_t)(tid - 144) : off;
+        off = tid >= 168 ? offsetof(FlDev18, xprop) + 8 * (size_t)(tid - 168) : off;
+        v = *reinterpret_cast<const double *>(base + off);
+    } else if (tid < 203) {
+        const int k = tid - 192;
+        size_t off = offsetof(FlDev18, last_error);
+        off = k == 1 ? offsetof(FlDev18, rematch_num) : off;
+        off = k == 2 ? offsetof(FlDev18, iterCount) : off;
+        off = k == 3 ? offsetof(FlDev18, max_iter) : off;
+        off = k == 4 ? offsetof(FlDev18, iters_run) : off;
+        off = k == 5 ? offsetof(FlDev18, accepted) : off;
+        off = k == 6 ? offsetof(FlDev18, status) : off;
+        off = k == 7 ? offsetof(FlDev18, err_acc_buf) : off;
+        off = k == 8 ? offsetof(FlDev18, err_acc_epoch) : off;
+        off = k == 9 ? offsetof(FlDev18, last_exact_valid) : off;
+        off = k == 10 ? offsetof(FlDev18, last_exact) : off;
+        const unsigned raw = *reinterpret_cast<const unsigned *>(base + off);
+        const double as_int = (double)(int)raw, as_uint = (double)raw, as_float = (double)__uint_as_float(raw);
+        v = (k == 0 || k == 10) ? as_float : (k == 8 ? as_uint : as_int);      // (float: last_error, last_exact; unsigned: err_acc_epoch)
+    }
     return v;
 }
 __device__ __forceinline__ void eskf18_prefetch_commit(double v, FlSolveLds &L)

@@ -213,7 +213,7 @@ __global__ void vio_derive_kernel(FlDev18 *__restrict__ D, const FlVioConst *__r
 // fl_vio_begin in one launch: the gain-solve constants of the state block (eskf18_prepare_kernel) and, by the last 12 threads, the
 // camera pose of the initial state
 // x18_host != nullptr (fl_vio_compute_j, round 6): the state block waits in the handle's page-locked mirror and this kernel fetches it itself
-// (as detect_begin_kernel does for fl_vio_detect) -- one copy command (4-6 us of stream time) less in front of ComputeJ
+// (as vmap_frame_init_kernel does for fl_vio_detect) -- one copy command (4-6 us of stream time) less in front of ComputeJ
 __global__ __launch_bounds__(128) void vio_prepare_kernel(FlDev18 *__restrict__ D, const FlVioConst *__restrict__ VC, const FlDev18 *__restrict__ x18_host)
 {
     if (x18_host) {      // (uniform)

@@ -364,27 +364,10 @@ struct FlDetectParams {             // one small upload per frame
     double Rci[9], Pci[3];          // camera <- IMU: the pose after ComputeJ is derived on the device (updateFrameState, :904-911)
 };
 
-// fl_vio_begin's launch (vio_prepare_kernel) with the state block and the frame's parameter block FETCHED from page-locked memory by the
-// kernel itself (as imu_forward_kernel does for fl_lidar_front): two copy commands (~4-5 us of stream time each) less in front of the frame
-__global__ __launch_bounds__(128) void detect_begin_kernel(FlDev18 *__restrict__ D, const FlVioConst *__restrict__ VC, const FlDev18 *__restrict__ x18_host,
-                                                          FlDetectParams *__restrict__ prm, const FlDetectParams *__restrict__ prm_host)
-{
-    {
-        FlPull<128, (int)sizeof(FlDev18)> blk;                 // (both blocks in ONE trip over the host link: fl_device.h FlPull)
-        FlPull<128, (int)sizeof(FlDetectParams)> pblk;
-        blk.load(x18_host);
-        pblk.load(prm_host);
-        blk.store(D);
-        pblk.store(prm);
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (threadIdx.x >= 116) vio_derive_pose(D->x, VC, D, (int)threadIdx.x - 116);
-    eskf18_prepare_body(D);
-}
-
 // every clear of the frame in one launch (they were 4 fills + vio_grid_init_kernel) + the keyframe copy of the staged image + the keyframe
 // table entry + the record slots of ComputeJ's launches (sized for the upper bound; what a launch does not rewrite must carry no tag)
+// + fl_vio_begin's launch (vio_prepare_kernel) with the state block and the frame's parameter block FETCHED from page-locked memory by
+// the kernel itself (as imu_forward_kernel does for fl_lidar_front): two copy commands (~4-5 us of stream time each) less in front of the frame
 __global__ __launch_bounds__(FL_BLOCK) void vmap_frame_init_kernel(unsigned long long *__restrict__ depth64, int n_depth, unsigned long long *__restrict__ set,
                                                                   int n_set, int *__restrict__ owner, int n_owner, unsigned long long *__restrict__ best,
                                                                   unsigned long long *__restrict__ key, int *__restrict__ val, int32_t *__restrict__ gnum,
@@ -392,9 +375,27 @@ __global__ __launch_bounds__(FL_BLOCK) void vmap_frame_init_kernel(unsigned long
                                                                   const uint4 *__restrict__ img /* the staged image, or the caller's page-locked one */,
                                                                   uint4 *__restrict__ img_cur /* nullable: then `img` IS the staged copy */, uint4 *__restrict__ kf_img, int n_img16,
                                                                   const uint8_t **__restrict__ kf_table, int kf_id, FlVmapCount *__restrict__ cnt,
-                                                                  int32_t *__restrict__ sel_count, unsigned *__restrict__ ticket)
+                                                                  int32_t *__restrict__ sel_count, unsigned *__restrict__ ticket,
+                                                                  FlDev18 *__restrict__ D, const FlVioConst *__restrict__ VC, const FlDev18 *__restrict__ x18_host,
+                                                                  FlDetectParams *__restrict__ prm, const FlDetectParams *__restrict__ prm_host)
 {
-    const int t = blockIdx.x * FL_BLOCK + threadIdx.x, nt = gridDim.x * FL_BLOCK;
+    // x18_host != nullptr: the launch's LAST workgroup does what fl_vio_begin's launch does (state block + parameter block fetched, gain-solve constants,
+    // camera pose) -- it used to be a launch of its own in front of this one (8 us), now it runs beside the image's trip over the host link
+    const int nblk = (int)gridDim.x - (x18_host ? 1 : 0);
+    if ((int)blockIdx.x == nblk) {
+        FlPull<FL_BLOCK, (int)sizeof(FlDev18)> blk;
+        FlPull<FL_BLOCK, (int)sizeof(FlDetectParams)> pblk;
+        blk.load(x18_host);
+        pblk.load(prm_host);
+        blk.store(D);
+        pblk.store(prm);
+        __threadfence_block();
+        __syncthreads();
+        if (threadIdx.x >= 116 && threadIdx.x < 128) vio_derive_pose(D->x, VC, D, (int)threadIdx.x - 116);
+        eskf18_prepare_body(D);
+        return;
+    }
+    const int t = blockIdx.x * FL_BLOCK + threadIdx.x, nt = nblk * FL_BLOCK;
     for (int i = t; i < n_depth; i += nt) depth64[i] = 0ull;
     for (int i = t; i < n_set; i += nt) set[i] = FL_KNN_EMPTY;
     for (int i = t; i < n_owner; i += nt) owner[i] = 0x7F7F7F7F;                                   // "no owner yet" = a huge index
