@@ -89,11 +89,12 @@ __device__ __forceinline__ void fl_publish_state23(FlDev23 *__restrict__ D)
 // no-op launch? (abandoned chain: count what is skipped; stopped / waiting for a search) -- as fl_pass_skipped of lio_kernels.h
 __device__ __forceinline__ bool ik_pass_skipped(FlDev23 *__restrict__ D, int flags, int passes, bool counter_thread)
 {
-    if (D->status & FL_NUM_TIMEOUT) {
+    const int status = D->status, stop = D->stop, need = D->need_search, searched_at = D->searched_at, iters_run = D->iters_run;      // (in flight together)
+    if (status & FL_NUM_TIMEOUT) {
         if (counter_thread) D->resume_count += passes;
         return true;
     }
-    return !(flags & FL_ITER_FORCE) && (D->stop || (D->need_search && D->searched_at != D->iters_run));
+    return !(flags & FL_ITER_FORCE) && (stop || (need && searched_at != iters_run));
 }
 
 // one producer workgroup's share of a pass at state x: rows [n, A, B, C] reduced to the 96-double record and published.

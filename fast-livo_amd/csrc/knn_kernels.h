@@ -331,7 +331,10 @@ __global__ __launch_bounds__(FL_KNN_NT) void lio_search_fit_kernel(const float *
         if (vb < per * 8) vb = (vb & 7) * per + (vb >> 3);
     }
     // (the first search of a frame always runs: begin raises need_search; with host_state the block is not on the device yet)
-    if (!host_state && (cond & 1) && (!D->need_search || D->stop || (D->status & 8 /* FL_NUM_TIMEOUT: abandoned chain */))) return;
+    if (!host_state && (cond & 1)) {
+        const int need = D->need_search, stop = D->stop, status = D->status;      // (in flight together, not one round trip after the other)
+        if (!need || stop || (status & 8 /* FL_NUM_TIMEOUT: abandoned chain */)) return;
+    }
     const bool stamp = (cond & 2) && threadIdx.x == 0 && blockIdx.x < 512;
     FL_INSTR(if (stamp) g_fl_wall[blockIdx.x] = (long long)wall_clock64();)
     __shared__ int s_at[FL_KNN_QPB][5];

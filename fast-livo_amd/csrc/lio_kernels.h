@@ -115,11 +115,13 @@ __device__ __forceinline__ void fl_mp_done(unsigned *done_word, unsigned seq, bo
 // resident after the same launch's solver has timed out sees the bit too and must not count); (b) the filter stopped or waits for a search (not under FL_ITER_FORCE). Uniform over the grid.
 __device__ __forceinline__ bool fl_pass_skipped(FlDev18 *__restrict__ D, int flags, int passes, bool counter_thread)
 {
-    if (D->status & FL_NUM_TIMEOUT) {
+    // (all five words in flight at once: as a short-circuit chain they were up to four L2 round trips in a row at the head of every launch)
+    const int status = D->status, stop = D->stop, need = D->need_search, searched_at = D->searched_at, iters_run = D->iters_run;
+    if (status & FL_NUM_TIMEOUT) {
         if (counter_thread) D->resume_count += passes;
         return true;
     }
-    return !(flags & FL_ITER_FORCE) && (D->stop || (D->need_search && D->searched_at != D->iters_run));
+    return !(flags & FL_ITER_FORCE) && (stop || (need && searched_at != iters_run));
 }
 
 // -------------------------------------------------------------------------------------------- K1
@@ -271,12 +273,17 @@ __global__ __launch_bounds__(FL_LIO_NT, 2) void lio18_multipass_kernel(const flo
     constexpr int NT = FL_LIO_NT;
     const int solver_block = gridDim.x - 1;
     int nprod = solver_block;
+    // the words of the prologue in flight together (one L2 round trip, not one per branch): the epoch, the device-side scan size, the
+    // five words of fl_pass_skipped
+    const unsigned epoch0 = *epoch_ptr;
+    const int n_dev_now = *(n_dev ? n_dev : reinterpret_cast<const int *>(epoch_ptr));
+    const bool skipped = fl_pass_skipped(D, flags, count, (int)blockIdx.x == solver_block && threadIdx.x == 0);
     // n_dev (fl_lidar_front): the scan's size is known to the device only; the grid was sized for the raw scan. The producers that
     // lio_grid() would give a scan of the real size take the points (same partition, same record order: same bits as the staged
     // calls); the workgroups beyond them mark their record slot "never written" (tag 0 -- a later, larger launch must not meet an old
     // tag there, see records_for) and leave.
     if (n_dev) {
-        n = *n_dev;
+        n = n_dev_now;
         const int want = fl_lio_producers(n, max_prod);
         if ((int)blockIdx.x < solver_block && (int)blockIdx.x >= want) {
             if (threadIdx.x < FL_SUMS18)
@@ -287,12 +294,11 @@ __global__ __launch_bounds__(FL_LIO_NT, 2) void lio18_multipass_kernel(const flo
         nprod = min(nprod, want);
     }
     const bool force = (flags & FL_ITER_FORCE) != 0;
-    if (fl_pass_skipped(D, flags, count, (int)blockIdx.x == solver_block && threadIdx.x == 0)) {
+    if (skipped) {
         if ((extra & FL_LIO_DO_COV) && (int)blockIdx.x == solver_block) eskf18_cov_outofline(D);
         fl_mp_done(done_word, done_seq, (int)blockIdx.x == solver_block);
         return;
     }
-    const unsigned epoch0 = *epoch_ptr;
 
     if ((int)blockIdx.x == solver_block) {
         // ------------------------------------------------------------------ solver workgroup

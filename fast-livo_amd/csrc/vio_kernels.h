@@ -1248,9 +1248,15 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
     // needs one launch per level instead of three.
     constexpr int NT = FL_VIO_NT;
     constexpr int WPB = NT / 64;
+    // every word of the launch's prologue in flight at once (behind one another's branches they were four L2 round trips in a row at the
+    // head of the launch, in every workgroup)
+    const int status0 = D->status, stop0 = D->stop, iters0 = D->iters_run, m_dev0 = D->m_dev;
+    const unsigned epoch0 = *epoch_ptr;
+    unsigned long long *err_base = D->err_words;
+    const int err_cap = D->err_cap;
     int nprod = gridDim.x - 2;                    // then the solver and the auditor (FL_VIO_SOLVER_BLOCK / FL_VIO_AUDITOR_BLOCK)
     if (flags & FL_VIO_M_DEV) {                   // (uniform over the grid)
-        m = D->m_dev;
+        m = m_dev0;
         int want = (m + FL_VIO_GPW * WPB - 1) / (FL_VIO_GPW * WPB);
         want = want < 1 ? 1 : want;
         nprod = want < nprod ? want : nprod;
@@ -1260,17 +1266,14 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
     const int solver_block = FL_VIO_SOLVER_BLOCK(nprod), auditor_block = FL_VIO_AUDITOR_BLOCK(nprod);
     const bool force = (flags & FL_ITER_FORCE) != 0;
     const bool begin = begin_residual >= 0.f;
-    if (D->status & FL_NUM_TIMEOUT) {             // an earlier pass of the chain was abandoned: nothing runs until the host has resumed
+    if (status0 & FL_NUM_TIMEOUT) {               // an earlier pass of the chain was abandoned: nothing runs until the host has resumed
         if (blockIdx.x == solver_block && threadIdx.x == 0) D->resume_count += count;  // (the solver workgroup is the only writer)
         if ((flags & FL_VIO_DO_COV) && blockIdx.x == solver_block) { __syncthreads(); vio_cov_outofline(D); }    // (publishes the abandoned block)
         fl_mp_done(done_word, done_seq, blockIdx.x == solver_block);
         return;
     }
-    if (!force && !begin && D->stop) { fl_mp_done(done_word, done_seq, blockIdx.x == solver_block); return; }
-    const unsigned epoch0 = *epoch_ptr;
-    unsigned long long *err_base = D->err_words;
-    const int err_cap = D->err_cap;
-    const int pass0 = begin ? 0 : D->iters_run;          // index of this launch's first pass within its pyramid level
+    if (!force && !begin && stop0) { fl_mp_done(done_word, done_seq, blockIdx.x == solver_block); return; }
+    const int pass0 = begin ? 0 : iters0;                // index of this launch's first pass within its pyramid level
     // SPEC: all levels in this launch (FL_VIO_LEVELS). Everybody follows the broadcasts by the same rule: a level ends with a broadcast
     // that carries "stop" (tag t); it holds the pose the next level starts from (the accepted state's, or the reverted one's) and the
     // next level's first pass has epoch t -- unless bit 3 says that the float chain's verdict on that pass is still out (a fragile
