@@ -26,6 +26,12 @@
 #include "handoff.h"
 #include "exact_chain.h"
 
+// one pyramid level's result of ComputeJ (UpdateState's outputs), behind the state block (api_vio.inc)
+struct FlVioLevelInfo {
+    double solution[18];
+    float error;
+    int32_t iterations, n_meas, accepted, status, converged;
+};
 struct FlSolveLds {
     double Q[36];
     double T[108];
@@ -57,10 +63,17 @@ struct FlSolveLds {
     unsigned spec_epoch, spec_acc_epoch;
     float spec_nall, spec_last_error, spec_last_exact;
     double def_xold[24], def_sums[FL_SUMS18], def_sol[18];      // old_state / sums_acc / solution of that pass, written to the device block once it is confirmed
-    // VIO, round 6 -- all pyramid levels of ComputeJ in one launch (vio_multipass_kernel under FL_VIO_LEVELS): `levels` says so; `hold`
-    // = the pass that just ended a level went ahead on the fp64 decision, its broadcast carried ctrl bit 3 ("the verdict is out: wait
-    // for the level's go word"), the solver sends that word once the float chain has spoken
-    int levels, hold;
+    // VIO, round 6 -- all pyramid levels of ComputeJ in one launch (vio_multipass_kernel under FL_VIO_LEVELS): `levels` says so; `pb` =
+    // the half of the per-patch word buffer the level's first pass writes (0 in a launch of one level; across levels the halves go on
+    // alternating, so that the first pass of a level never overwrites the words of the last pass of the level before).
+    // xl_*: a fragile accept that ENDED a level and went ahead (the next level has begun on the speculated state): what the finished
+    // level's result block gets when the float chain confirms it, and the old_state a rejection goes back to (vio_spec_confirm /
+    // vio_spec_rollback); xl_restart: the rejection happened -- the level that had begun starts again from the reverted state.
+    int levels, pb;
+    int xl_pending, xl_restart, xl_level, xl_iters, xl_accepted, xl_status, xl_converged, xl_neff;
+    float xl_err;
+    double xl_xold[24];
+    FlVioLevelInfo *li_base;
 };
 
 enum { FL_EPI_LIO = 0, FL_EPI_VIO = 1 };
@@ -312,7 +325,7 @@ __device__ __forceinline__ void eskf18_prefetch_commit(double v, FlSolveLds &L)
     else if (tid == 200) L.acc_epoch = (unsigned)v;
     else if (tid == 201) L.last_exact_valid = (int)v;
     else if (tid == 202) L.last_exact = (float)v;
-    else if (tid == 203) { L.jpass = 0; L.jflag = 0; L.spec_pending = 0; L.levels = 0; L.hold = 0; }
+    else if (tid == 203) { L.jpass = 0; L.jflag = 0; L.spec_pending = 0; L.levels = 0; L.pb = 0; L.xl_pending = 0; L.xl_restart = 0; L.li_base = nullptr; }
     __syncthreads();
     eskf18_form_vec(L);
     __syncthreads();
@@ -431,7 +444,7 @@ __device__ __forceinline__ void vio_exact_decide(const FlVioExact ex, FlSolveLds
     FlSolveLds &L = *Lp;
     const int tid = threadIdx.x;
     __syncthreads();
-    const int cur_buf = L.iters_run & 1;
+    const int cur_buf = (L.iters_run + L.pb) & 1;
     bool audited = false;
     const unsigned long long *audit = ex.words + 2 * (size_t)ex.cap;
     if (ex.world <= 1) {     // single rank: the auditor workgroup has been adding this pass's chain up since its words arrived
@@ -468,7 +481,7 @@ __device__ __forceinline__ void vio_exact_decide(const FlVioExact ex, FlSolveLds
 
 // The judgement of a pass (wavefront 1 of the solver workgroup, see eskf18_solve_block): delta and the solve's status bits come out
 // of LDS. Uniform arithmetic; lane 0 publishes the control word and writes the bookkeeping.
-template <int KIND, int SPEC = 0>
+template <int KIND>
 __device__ __forceinline__ void eskf18_judge(FlDev18 *__restrict__ D, const double *s_sums, FlSolveLds &L, unsigned long long *bcast, unsigned bepoch)
 {
     const int lane = threadIdx.x & 63;
@@ -507,11 +520,8 @@ __device__ __forceinline__ void eskf18_judge(FlDev18 *__restrict__ D, const doub
         const int it = L.iters_run + 1;
         if (it >= L.max_iter) stop = 1;
         const int accepted = L.accepted + 1;
-        int hold = 0;
-        if constexpr (SPEC != 0) hold = (stop && L.levels && L.spec_pending) ? 8 : 0;      // (spec_pending: written by wavefront 0 before it raised jflag)
         if (lane == 0) {
-            if (bcast) fl_bcast_ctrl(bcast, (stop ? 1 : 0) | hold, bepoch);
-            if constexpr (SPEC != 0) L.hold = hold;
+            if (bcast) fl_bcast_ctrl(bcast, stop ? 1 : 0, bepoch);
             L.accepted = accepted; L.iters_run = it;
             L.ctrl = stop ? 1 : 0;
             D->converged = converged;
@@ -608,7 +618,7 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
             slow = false;
             FL_INSTR(if (tid == 0) g_fl_wall[2040]++;)        // (debug build: speculated / confirmed / rolled back, tools/fuzz_vio_spec.py)
             if (tid == 0) {
-                L.spec_pending = 1; L.spec_epoch = ex.epoch; L.spec_buf = L.iters_run & 1; L.spec_nall = n_meas;
+                L.spec_pending = 1; L.spec_epoch = ex.epoch; L.spec_buf = (L.iters_run + L.pb) & 1; L.spec_nall = n_meas;
                 L.spec_last_error = L.last_error; L.spec_last_exact = L.last_exact; L.spec_accepted = L.accepted; L.spec_iters = L.iters_run;
                 L.spec_acc_buf = L.acc_buf; L.spec_acc_epoch = L.acc_epoch;
             }
@@ -644,7 +654,7 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
             __builtin_amdgcn_s_sleep(1);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (f == jtag) eskf18_judge<KIND, SPEC>(D, s_sums, L, bcast, bepoch);
+        if (f == jtag) eskf18_judge<KIND>(D, s_sums, L, bcast, bepoch);
         if (lane == 0) L.jpass = jtag;
         return;
     }
@@ -666,7 +676,7 @@ __device__ __forceinline__ void eskf18_solve_block(FlDev18 *__restrict__ D, cons
             L.accept = accept;
             if (accept) {
                 L.last_error = error;
-                L.acc_buf = L.iters_run & 1; L.acc_epoch = ex.epoch;
+                L.acc_buf = (L.iters_run + L.pb) & 1; L.acc_epoch = ex.epoch;
                 L.last_exact_valid = vio_exact; L.last_exact = error;
             }
         }
@@ -893,6 +903,39 @@ __device__ __attribute__((noinline)) void vio_spec_rollback(FlDev18 *D, FlSolveL
     const float exact = L.exact_cur;
     FlSolveRegs G;
     eskf18_load_regs(L, G, VC);
+    if (L.xl_pending) {      // (uniform) the rejected pass had ENDED its pyramid level and the next level has begun on its state
+        // The finished level ends as lidar_selection.cpp:888-892 ends it at that pass -- its result block says so --, the state goes back
+        // to that level's old_state, and the level that had begun begins again from there: old_state = *state (:747), the counters are
+        // still those of its prologue (its first pass was gathered, never solved). The producers wait for that pass's broadcast: they
+        // get the reverted pose and "start the level again" (ctrl bit 4).
+        FlVioLevelInfo *li = L.li_base + L.xl_level;
+        FL_INSTR(if (tid == 0) g_fl_wall[2043]++;)           // (debug build: cross-level roll-backs, tools/fuzz_vio_spec.py)
+        if (tid < 24) {
+            const double xo = L.xl_xold[tid];
+            D->x[tid] = xo; D->xold[tid] = xo;
+            if (tid < 12) L.xn[tid] = xo;
+            if (tid >= 9) L.xadd[tid - 9] = xo;
+        } else if (tid >= 64 && tid < 82) li->solution[tid - 64] = D->solution[tid - 64];      // (of the level's last CONFIRMED accept)
+        __syncthreads();
+        if (VC && tid < 12) {
+            const double ce = vio_cam_element(lane, L.xn, G.rci, G.pci);
+            if (tid < 9) D->Rcw[tid] = ce; else D->Pcw[tid - 9] = ce;
+            L.cam[tid] = ce;
+            if (bcast) fl_bcast_store(bcast, tid, ce, bepoch);
+        }
+        // (The per-patch error array is NOT put back to the rejecting pass's values here, as the same-level roll-back below does: the level
+        // that starts again rewrites every entry with its first pass -- and plain stores from this workgroup would sit in this XCD's L2
+        // beside the producers' later ones in theirs, two dirty copies of a line whose write-back order nobody defines. Found the hard
+        // way: 7 of 8 workgroups' entries came back with the restored values.)
+        if (tid == 0) {
+            li->error = L.spec_last_error; li->iterations = L.spec_iters + 1; li->n_meas = L.xl_neff;
+            li->accepted = L.spec_accepted; li->status = L.xl_status; li->converged = 1;
+            L.spec_pending = 0; L.xl_pending = 0; L.xl_restart = 1;
+        }
+        __syncthreads();
+        if (bcast && tid == 0) fl_bcast_ctrl(bcast, 16, bepoch);
+        return;
+    }
     if (tid < 24) {
         const double xo = D->xold[tid];              // old_state of the rejected pass: its deferred write never happened
         D->x[tid] = xo;
@@ -906,10 +949,10 @@ __device__ __attribute__((noinline)) void vio_spec_rollback(FlDev18 *D, FlSolveL
         L.cam[tid] = ce;
         if (bcast) fl_bcast_store(bcast, tid, ce, bepoch);
     }
-    if (bcast) {                                     // a later pass has run: the per-patch errors are the rejecting pass's again
-        const unsigned long long *w = words + (size_t)L.spec_buf * cap;
-        for (int i = tid; i < m; i += blockDim.x) errors[i] = __uint_as_float((unsigned)(w[i] >> 32));
-    }
+    // bcast != nullptr: a later pass has run and the per-patch error array holds ITS values; it has to hold the rejecting pass's again. The
+    // PRODUCERS put them back, each workgroup its own patches out of that pass's half of the word buffer, when they read the control word
+    // below (bit 5, bit 6 = the half; vio_multipass_kernel). (Until round 6 this workgroup did it with plain stores: behind the
+    // producers' own late stores of the dropped pass in time, perhaps, and in another XCD's L2 than theirs -- two dirty copies of a line.)
     if (tid == 0) {
         const int it = L.spec_iters + 1;
         D->error = exact;
@@ -923,7 +966,7 @@ __device__ __attribute__((noinline)) void vio_spec_rollback(FlDev18 *D, FlSolveL
         D->status = L.sticky;
         L.ctrl = 1;
         L.spec_pending = 0;
-        if (bcast) fl_bcast_ctrl(bcast, 1, bepoch);
+        if (bcast) fl_bcast_ctrl(bcast, 1 | 32 | (L.spec_buf ? 64 : 0), bepoch);
     }
     __syncthreads();
 }
@@ -952,6 +995,19 @@ __device__ __forceinline__ int vio_spec_confirm(FlDev18 *D, FlSolveLds *Lp, cons
         if (tid == 0) L.exact_cur = exact;      // the caller leaves its pass loop and calls vio_spec_rollback BEHIND it (a call site inside the loop costs every pass)
         __syncthreads();
         return 1;
+    }
+    if (L.xl_pending) {      // (uniform) the confirmed pass had ended its pyramid level: what that level's result block still lacked; old_state,
+        FlVioLevelInfo *li = L.li_base + L.xl_level;      // last_error and the counters are the NEXT level's by now (its prologue ran)
+        if (tid < 18) li->solution[tid] = L.def_sol[tid];
+        else if (tid >= 64 && tid < 64 + FL_SUMS18) D->sums_acc[tid - 64] = L.def_sums[tid - 64];
+        else if (tid >= 128 && tid < 146) D->solution[tid - 128] = L.def_sol[tid - 128];
+        if (tid == 0) {
+            li->error = L.exact_timeout ? L.xl_err : exact; li->iterations = L.xl_iters; li->n_meas = L.xl_neff;
+            li->accepted = L.xl_accepted; li->status = L.xl_status; li->converged = L.xl_converged;
+            L.spec_pending = 0; L.xl_pending = 0;
+        }
+        __syncthreads();
+        return 0;
     }
     if (tid < 24) D->xold[tid] = L.def_xold[tid];
     else if (tid >= 64 && tid < 64 + FL_SUMS18) D->sums_acc[tid - 64] = L.def_sums[tid - 64];

@@ -1184,11 +1184,6 @@ __global__ __launch_bounds__(256) void fl_chain_debug_kernel(const float *__rest
 }
 #endif
 
-struct FlVioLevelInfo {
-    double solution[18];
-    float error;
-    int32_t iterations, n_meas, accepted, status, converged;
-};
 
 // ComputeJ tail: if (now_error < error) state->cov -= G*state->cov  (:978-981); then the frame's result mailbox (fl_publish_state).
 // Any workgroup of >= 128 threads, barriers inside.
@@ -1276,8 +1271,10 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
     const int pass0 = begin ? 0 : iters0;                // index of this launch's first pass within its pyramid level
     // SPEC: all levels in this launch (FL_VIO_LEVELS). Everybody follows the broadcasts by the same rule: a level ends with a broadcast
     // that carries "stop" (tag t); it holds the pose the next level starts from (the accepted state's, or the reverted one's) and the
-    // next level's first pass has epoch t -- unless bit 3 says that the float chain's verdict on that pass is still out (a fragile
-    // accept that went ahead): then the solver sends the pose again, as tag t + 1, once it has the verdict, and the level starts there.
+    // next level's first pass has epoch t. If the level's last pass was a fragile accept that went ahead, the float chain's verdict on it
+    // is taken behind the next level's first gather (cross-level speculation): confirmed, nothing changes for the producers; rejected
+    // (rare), that pass's records are dropped and its broadcast (tag t + 1) carries the reverted pose and bit 4, "the level starts again".
+    // The halves of the per-patch word buffer go on alternating across levels (pb), so that the verdict's words outlive the next pass.
     const bool levels = SPEC != 0 && (flags & FL_VIO_LEVELS) != 0;
 
     if (blockIdx.x == auditor_block) {
@@ -1297,6 +1294,7 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
                     bcast_wait(bcast, epoch, s_apose, &s_actrl, FL_GATHER_SPIN_LIMIT);
                     __syncthreads();
                     if (s_actrl & 7) break;
+                    if constexpr (SPEC != 0) if (s_actrl & 16) { ebase += (unsigned)ps; pb = (pb + ps) & 1; ps = 0; }      // the level starts again
                 }
                 FL_AUDIT_STAMP(16 * (epoch & 15) + 1, wall_clock64());
                 const int to = vio_audit_pass(err_base, err_cap, (pb + ps) & 1, m, epoch);
@@ -1312,14 +1310,7 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
             }
             if (s_actrl & 4) break;
             ebase += (unsigned)ps;
-            if (s_actrl & 8) {                            // the go word of the next level
-                __syncthreads();
-                ebase += 1u;
-                bcast_wait(bcast, ebase, s_apose, &s_actrl, FL_GATHER_SPIN_LIMIT);
-                __syncthreads();
-                if (s_actrl & 4) break;
-            }
-            lv--; pb = 0;
+            lv--; pb = (pb + ps) & 1;
         }
 #endif
         return;
@@ -1341,7 +1332,7 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
                 D->last_exact = begin_residual; D->last_exact_valid = 1; D->err_acc_buf = 0; D->err_acc_epoch = 0u;
                 D->last_error = begin_residual; D->level = level; D->stop = 0; D->converged = 0; D->iters_run = 0; D->accepted = 0;
                 D->status = 0;
-                if constexpr (SPEC != 0) { s_solve.levels = levels ? 1 : 0; s_solve.ctrl = 0; }
+                if constexpr (SPEC != 0) { s_solve.levels = levels ? 1 : 0; s_solve.ctrl = 0; s_solve.li_base = level_info; }
             }
             __syncthreads();
         }
@@ -1354,6 +1345,14 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
       for (;;) {                   // (one round per pyramid level; one round unless FL_VIO_LEVELS)
         for (int p = 0; p < count; p++) {
             const unsigned epoch = ebase + (unsigned)p;
+            // The float chain's verdict on the PREVIOUS pass, if that one went ahead without it (a fragile accept; possibly the last pass of
+            // the pyramid level before this one): taken HERE, while this pass's records are on their way -- the auditor's total arrives
+            // ~6 us after that pass's records, this pass's gather completes ~7.5 us after them. (Until round 6 it was taken behind the
+            // gather: 1.4 us of barriers, a ring read and the deferred writes between every speculated pass's successor and its solve.)
+            // A rejection ends the level here; this pass's records are never read.
+            if constexpr (SPEC != 0) if (s_solve.spec_pending) {      // (uniform: LDS, written before the barriers of the last pass)
+                if (vio_spec_confirm(D, &s_solve, err_base, err_cap, m, s_ex, errors, VC, bcast, epoch + 1u)) { done = p + 1; rollback = 1; break; }
+            }
             FlSolveRegs G;
             FL_AUDIT_STAMP(16 * (epoch & 15) + 13, wall_clock64());
             eskf18_load_regs(s_solve, G, VC);                    // solve operands into wave 0's registers while the producers work
@@ -1366,19 +1365,14 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
             FlVioExact ex;
             ex.words = err_base; ex.m = m; ex.cap = err_cap; ex.epoch = epoch; ex.scratch = s_ex; ex.enabled = !force;
             ex.own = PV.own; ex.peer = PV.peer; ex.rank = PV.rank; ex.world = PV.world; ex.xe = xe0 + (unsigned)p;
-            // the float chain's verdict on the PREVIOUS pass, if that one went ahead without it: it is there by now (the auditor needs
-            // ~6 us from the records, a pass takes 7); a rejection ends the level here, this pass's records are dropped
-            if constexpr (SPEC != 0) if (s_solve.spec_pending) {      // (uniform: LDS, written before the barriers of the last pass)
-                if (!gst && vio_spec_confirm(D, &s_solve, err_base, err_cap, m, s_ex, errors, VC, bcast, epoch + 1u)) { done = p + 1; rollback = 1; break; }
-                eskf18_load_regs(s_solve, G, VC);              // last_error is the chain's value now
-            }
             // wave 0 solves, derives the camera pose of the new state and publishes it (+ the control word) for the producers
             eskf18_solve_block<FL_EPI_VIO, SPEC>(D, s_sums, s_solve, G, gst, bcast, epoch + 1u, ex, VC, (p == 5) ? (flags & FL_ITER_STAMP) : 0);
             FL_INSTR(if (p == 5) fl_stamp(flags, 35);)
             __syncthreads();
             // ... and on THIS pass if the launch ends behind it (stop raised, or the last pass asked for): the wait of the old form, but
             // the solve has been done in the meantime
-            if constexpr (SPEC != 0) if (s_solve.spec_pending && !(s_solve.ctrl & 4) && ((!force && (s_solve.ctrl & 3)) || p + 1 == count))
+            // (not if another pyramid level follows in this launch: that level's first pass takes the verdict)
+            if constexpr (SPEC != 0) if (s_solve.spec_pending && !(s_solve.ctrl & 4) && ((!force && (s_solve.ctrl & 3)) || p + 1 == count) && !(levels && lv > 0))
                 if (vio_spec_confirm(D, &s_solve, err_base, err_cap, m, s_ex, errors, VC, nullptr, 0u)) rollback = 2;
             FL_AUDIT_STAMP(16 * (epoch & 15) + 9, wall_clock64());
             FL_AUDIT_STAMP(16 * (epoch & 15) + 10, s_solve.fragile + 2 * s_solve.audited + 4 * s_solve.exact_timeout + 8 * s_solve.accept);
@@ -1406,16 +1400,21 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
             if (rollback) vio_spec_rollback(D, &s_solve, err_base, err_cap, m, errors, VC, rollback == 1 ? bcast : (unsigned long long *)nullptr, ebase + (unsigned)done);
         }
         ebase += (unsigned)done;
+        bool restart = false, carry = false;
         if constexpr (SPEC != 0) {
-            // the level's last broadcast said "wait" (a fragile accept that ended the level went ahead, solve18.h eskf18_judge): the verdict
-            // is in -- the pose of the state the level really ended with goes out again, before anything else: the producers wait for it
-            if (levels && lv > 0 && !(s_solve.ctrl & 4) && s_solve.hold) {      // (uniform: LDS, behind a barrier)
-                ebase += 1u;
-                if (threadIdx.x < 12) fl_bcast_store(bcast, threadIdx.x, s_solve.cam[threadIdx.x], ebase);
-                if (threadIdx.x == 0) fl_bcast_ctrl(bcast, 0, ebase);
-            }
+            restart = s_solve.xl_restart != 0;                 // (uniform: LDS, behind a barrier) the level that had begun starts again
+            carry = s_solve.spec_pending != 0 && !restart;     // the level's last pass went ahead: its verdict travels into the next level
         }
-        if (level_info) {
+        if (carry) {
+            // what the level's result block gets once the float chain has spoken, and the old_state a rejection goes back to
+            FL_INSTR(if (threadIdx.x == 0) g_fl_wall[2044]++;)        // (debug build: verdicts carried into the next level)
+            if (threadIdx.x < 24) s_solve.xl_xold[threadIdx.x] = D->xold[threadIdx.x];
+            if (threadIdx.x == 32) {
+                s_solve.xl_pending = 1; s_solve.xl_level = lv; s_solve.xl_iters = s_solve.iters_run; s_solve.xl_accepted = s_solve.accepted;
+                s_solve.xl_status = s_solve.sticky | s_solve.fragile; s_solve.xl_converged = D->converged; s_solve.xl_neff = D->neff;
+                s_solve.xl_err = s_solve.last_error;
+            }
+        } else if (level_info && !restart) {
             FlVioLevelInfo *li = level_info + (levels ? lv : 0);
             __syncthreads();
             if (threadIdx.x < 18) li->solution[threadIdx.x] = D->solution[threadIdx.x];
@@ -1425,17 +1424,19 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
             }
         }
         if constexpr (SPEC == 0) break;
-        if (!levels || lv == 0 || (s_solve.ctrl & 4)) break;
+        if (!levels || (lv == 0 && !restart) || (s_solve.ctrl & 4)) break;
         // ---- the next pyramid level (UpdateState's prologue, lidar_selection.cpp:747,756, as `begin` above): the state the level
         // ended with -- accepted, reverted or rolled back -- is in xn / xadd, the producers have it as the pose of the level's last broadcast
         __syncthreads();
-        lv--; done = 0; rollback = 0;
-        if (count > 0) eskf18_restage(s_solve);                // (no patches: no passes ran, x is what it was)
+        if (threadIdx.x == 0) { s_solve.pb = (s_solve.pb + done) & 1; s_solve.xl_restart = 0; }
+        if (!restart) lv--;
+        const int ran = done;
+        done = 0; rollback = 0;
+        if (count > 0 && ran > 0) eskf18_restage(s_solve);     // (no patches: no passes ran, x is what it was)
         if (threadIdx.x < 24) D->xold[threadIdx.x] = s_solve.x[threadIdx.x];
         if (threadIdx.x == 32) {
             s_solve.last_error = begin_residual; s_solve.iters_run = 0; s_solve.accepted = 0; s_solve.fragile = 0; s_solve.sticky = 0;
             s_solve.last_exact = begin_residual; s_solve.last_exact_valid = 1; s_solve.acc_buf = 0; s_solve.acc_epoch = 0u;
-            s_solve.hold = 0;
             D->last_exact = begin_residual; D->last_exact_valid = 1; D->err_acc_buf = 0; D->err_acc_epoch = 0u;
             D->last_error = begin_residual; D->level = lv; D->stop = 0; D->converged = 0; D->iters_run = 0; D->accepted = 0;
             D->status = 0;
@@ -1484,6 +1485,7 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
             FL_INSTR(if (blockIdx.x == 0 && (ps == 5 || ps == 6)) fl_stamp(flags, 21 + 4 * (ps - 5));)
             if (!force && (s_ctrl & 3)) break;
             if (s_ctrl & 4) break;
+            if constexpr (SPEC != 0) if (s_ctrl & 16) { ebase += (unsigned)ps; pb = (pb + ps) & 1; ps = 0; }      // the level starts again (with this pose)
 #pragma unroll
             for (int i = 0; i < 9; i++) Rcw[i] = s_pose[i];
 #pragma unroll
@@ -1499,6 +1501,20 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
         if (blockIdx.x < 127) FL_AUDIT_STAMP(256 + 2 * blockIdx.x + 1, wall_clock64());
         __syncthreads();
     }
+    if constexpr (SPEC != 0) {
+        // the level ended with the ROLL-BACK of the pass before the one just produced (solve18.h vio_spec_rollback): the per-patch error array
+        // holds the dropped pass's values and has to hold the rejecting pass's -- every workgroup puts its own patches back (the entries it
+        // wrote itself: same L2, program order) out of that pass's half of the word buffer
+        if (ps < count && (s_ctrl & 32) && err_base) {      // (uniform; ps < count: the loop was left at a wait, s_ctrl is that wait's)
+            const unsigned long long *w = err_base + (size_t)((s_ctrl >> 6) & 1) * err_cap;
+            const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+            for (int ib = ((int)blockIdx.x * WPB + wave) * FL_VIO_GPW; ib < m; ib += nprod * WPB * FL_VIO_GPW) {
+                const int i = ib + lane / FL_VIO_LPP;
+                if (lane % FL_VIO_LPP == 0 && i < m)
+                    errors[i] = __uint_as_float((unsigned)(__hip_atomic_load(w + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32));
+            }
+        }
+    }
     if constexpr (SPEC == 0) break;
     if (!levels || lv == 0 || count <= 0) break;      // (no patches: no passes, nothing to wait for)
     if (ps == count) {                                // (a level that used all its passes: its last broadcast has not been read)
@@ -1507,20 +1523,13 @@ __global__ __launch_bounds__(FL_VIO_NT, WAVES) void vio_multipass_kernel(const u
     }
     if (s_ctrl & 4) break;
     ebase += (unsigned)ps;
-    if (s_ctrl & 8) {                                 // the verdict on the level's last pass was out: the pose comes again
-        __syncthreads();
-        ebase += 1u;
-        bcast_wait(bcast, ebase, s_pose, &s_ctrl, spin_limit);
-        __syncthreads();
-        if (s_ctrl & 4) break;
-    }
 #pragma unroll
     for (int i = 0; i < 9; i++) Rcw[i] = s_pose[i];
 #pragma unroll
     for (int i = 0; i < 3; i++) Pcw[i] = s_pose[9 + i];
     fl_vio_lane_role_pose(role, (int)(threadIdx.x & 15), s_pose);
     __syncthreads();
-    lv--; pb = 0;
+    lv--; pb = (pb + ps) & 1;
   }
 }
 

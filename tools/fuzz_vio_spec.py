@@ -11,7 +11,7 @@ from fast_livo_amd import capi, synth
 from oracle import oracle as orc
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-bad, tot = 0, np.zeros(3, np.int64)
+bad, tot = 0, np.zeros(5, np.int64)
 for trial in range(T):
     m = int(rng.choice([300, 700, 1000, 2000, 2040]))
     max_iter = int(rng.integers(3, 11))
@@ -23,12 +23,12 @@ for trial in range(T):
     for spec in (2, 1, 0):           # all levels in one launch (default) / a launch per level / the waiting form
         h = capi.Handle(capi.config_from_frames(lio, vf, max_iterations=max_iter), debug=True)
         h.set_option(capi.FL_OPT_VIO_SPECULATE, spec)
-        w0 = np.array(h.debug_wall(), dtype=np.int64)[2040:2043].copy()
+        w0 = np.array(h.debug_wall(), dtype=np.int64)[2040:2045].copy()
         xg = capi.state18_from_frame(lio); xp = capi.state18_from_frame(lio)
         h.vio_set_frame(vf.img); h.vio_set_patches(vf.ref_patch, vf.pos, vf.search_level)
         ig = h.vio_compute_j(xg, xp)
         eg = h.vio_get_errors(m)
-        w1 = np.array(h.debug_wall(), dtype=np.int64)[2040:2043]
+        w1 = np.array(h.debug_wall(), dtype=np.int64)[2040:2045]
         if spec == 2:
             tot += w1 - w0
             if (w1 - w0)[2]:
@@ -44,4 +44,4 @@ for trial in range(T):
     if not (same and vs_orc):
         bad += 1
         print("MISMATCH", dict(m=m, max_iter=max_iter, seed=seed, same=bool(same), vs_oracle=bool(vs_orc), spec=res[0][2], per_level=res[1][2], wait=res[2][2]))
-print(json.dumps({"trials": T, "mismatches": bad, "speculated": int(tot[0]), "confirmed": int(tot[1]), "rolled_back": int(tot[2])}))
+print(json.dumps({"trials": T, "mismatches": bad, "speculated": int(tot[0]), "confirmed": int(tot[1]), "rolled_back": int(tot[2]), "rolled_back_across_levels": int(tot[3]), "verdicts_carried_into_the_next_level": int(tot[4])}))
