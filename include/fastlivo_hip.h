@@ -185,10 +185,14 @@ int32_t fl_get_frame_timing(fl_handle h, fl_frame_timing *out);
                                     * compacted and re-indexed only when its arrays fill up or its cell size goes out of tune. 0: every update
                                     * compacts the map array and rebuilds the index (rounds 1-4). The map's content (fl_map_get_points) and every
                                     * search result are identical either way. */
-#define FL_OPT_VIO_SPECULATE 13    /* 1 (default): in fl_vio_compute_j / fl_vio_update_state a pass whose accept test is decided inside float rounding
+#define FL_OPT_VIO_SPECULATE 13    /* 1: in fl_vio_compute_j / fl_vio_update_state a pass whose accept test is decided inside float rounding
                                     * noise AND accepted by the fp64 test does not wait for the reference's float running sum (~6 us): it goes ahead
-                                    * and the sum's verdict is applied a pass later, with a roll-back on the (rare) disagreement. 0: every such pass
-                                    * waits (round 2-4). Accept / revert sequences, states and per-patch errors are bit-identical either way. */
+                                    * and the sum's verdict is applied a pass later, with a roll-back on the (rare) disagreement. 2 (default, round
+                                    * 6): as 1, and ComputeJ's three pyramid levels are ONE launch (fl_vio_compute_j, fl_vio_detect) -- a fragile
+                                    * accept that ends a level goes ahead too, the next level begins on its state and takes the verdict behind its
+                                    * first pass (a rejection re-opens the finished level and starts the begun one again). 0: every such pass
+                                    * waits, one launch per level (round 2-4). Accept / revert sequences, states, per-level results and per-patch
+                                    * errors are bit-identical in all three forms. */
 #define FL_OPT_VIO_WIDE 14         /* 1 (default): VIO passes over >= 16 384 patches (any pyramid level) run with ONE PATCH PER LANE (csrc/vio_kernels.h
                                     * vio_produce_wide: shared taps and bilinear values, no cross-lane reductions) instead of a patch per 16 lanes -- at
                                     * these sizes a pass is bound by instruction issue and memory requests, not by hand-offs. 2: every pass does, at
