@@ -100,9 +100,22 @@ __device__ __forceinline__ bool ik_pass_skipped(FlDev23 *__restrict__ D, int fla
 // one producer workgroup's share of a pass at state x: rows [n, A, B, C] reduced to the 96-double record and published.
 // The scan arrives as (x, y, z, T) with the selection threshold T of fl_math.h (fl_gate_threshold) and a NaN normal marks a point
 // that is not selected (lio_fit_planes_kernel): 32 bytes and two loads per point, no sqrt / division in the gate.
+// The first point's inputs do not depend on the state: ikfom_prefetch_first requests them BEFORE the wait for the state (multi-pass
+// kernel) or the state's own loads; inside the loop the next point's inputs are requested before the current point's arithmetic (the
+// rolling prefetch of lio18_pass_kernel). Until round 6 the loop read plane[i], waited, tested the NaN mark and only then read body4[i]:
+// two L2 round trips in a row per point at the head of every pass (tools/isa_chains.py).
+struct FlIkFirst { float4 plq, bq; };
+__device__ __forceinline__ FlIkFirst ikfom_prefetch_first(const float4 *__restrict__ body4, const float4 *__restrict__ plane, int n)
+{
+    FlIkFirst f;
+    f.plq = make_float4(0.f, 0.f, 0.f, 0.f); f.bq = f.plq;
+    const int i = blockIdx.x * FL_IK_NT + threadIdx.x;
+    if (i < n) { f.plq = plane[i]; f.bq = body4[i]; }
+    return f;
+}
 __device__ __forceinline__ void ikfom_produce(const float4 *__restrict__ body4, float4 *__restrict__ plane, uint8_t *__restrict__ sel,
                                               float4 *__restrict__ normvec, int n, const double (&x)[FL_X23_LEN], int nprod, int flags,
-                                              double *s_red, unsigned epoch, void *__restrict__ records)
+                                              double *s_red, unsigned epoch, void *__restrict__ records, FlIkFirst pf)
 {
     constexpr int NT = FL_IK_NT;
     double v[FL_SUMS23I];
@@ -112,9 +125,10 @@ __device__ __forceinline__ void ikfom_produce(const float4 *__restrict__ body4, 
     if (threadIdx.x == 0 && blockIdx.x == 0) g_fl_stamps[41] = (long long)wall_clock64();
 #endif
     for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += nprod * NT) {
-        const float4 plq = plane[i];
+        const float4 plq = pf.plq, bq = pf.bq;
+        const int inext = i + nprod * NT;
+        if (inext < n) { pf.plq = plane[inext]; pf.bq = body4[inext]; }
         if (!(plq.x == plq.x)) continue;
-        const float4 bq = body4[i];
         const float pb[3] = {bq.x, bq.y, bq.z};
         const float pl[4] = {plq.x, plq.y, plq.z, plq.w};
         double p_i[3];
@@ -200,10 +214,11 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_pass_kernel(const float4 *__re
     }
 
     __shared__ double s_red[(NT / 64) * FL_SUMS23I];
+    const FlIkFirst pf = ikfom_prefetch_first(body4, plane, n);
     double x[FL_X23_LEN];
 #pragma unroll
     for (int i = 0; i < FL_X23_LEN; i++) x[i] = D->x[i];
-    ikfom_produce(body4, plane, sel, normvec, n, x, nprod, flags, s_red, epoch, records);
+    ikfom_produce(body4, plane, sel, normvec, n, x, nprod, flags, s_red, epoch, records, pf);
 }
 
 // Up to `count` passes of update_iterated_dyn_share_modified in ONE launch (as lio18_multipass_kernel): the solver broadcasts the
@@ -283,6 +298,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_multipass_kernel(const float4 
     for (int i = 0; i < FL_X23_LEN; i++) x[i] = D->x[i];
     for (int ps = 0; ps < count; ps++) {
         const unsigned epoch = epoch0 + (unsigned)ps;
+        const FlIkFirst pf = ikfom_prefetch_first(body4, plane, n);      // (behind this thread's own store of the last pass's NaN mark: program order)
 #ifdef FL_IK_STAMPS
         if (blockIdx.x == 0 && threadIdx.x == 0 && (ps == 2 || ps == 3)) g_fl_stamps[24 + 4 * (ps - 2)] = (long long)wall_clock64();
 #endif
@@ -297,7 +313,7 @@ __global__ __launch_bounds__(FL_IK_NT) void ikfom_multipass_kernel(const float4 
 #pragma unroll
             for (int i = 0; i < FL_X23_LEN; i++) x[i] = s_state[i];
         }
-        ikfom_produce(body4, plane, sel, normvec, n, x, nprod, flags, s_red, epoch, records);
+        ikfom_produce(body4, plane, sel, normvec, n, x, nprod, flags, s_red, epoch, records, pf);
 #ifdef FL_IK_STAMPS
         if (blockIdx.x == 0 && threadIdx.x == 0 && (ps == 2 || ps == 3)) g_fl_stamps[26 + 4 * (ps - 2)] = (long long)wall_clock64();
 #endif
