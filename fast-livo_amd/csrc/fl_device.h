@@ -221,6 +221,26 @@ __device__ __forceinline__ void fl_wait_own_stores()
 // microsecond), every thread makes its words visible to the system, then one thread raises the flag. The host (read_info18) sees the
 // flag ~1 us after the kernel's last store; against a device-to-host copy command plus a stream synchronisation that is 4-5 us less
 // per frame driver call (tools/mailbox_ab.py).
+// WORDS 8-byte words from device memory (agent-scope loads: what the workgroup itself just wrote) into the page-locked mirror, by a
+// workgroup of >= 128 threads: every load in flight before the first store (as the plain word loop it was, each round of blockDim.x
+// words waited for its loads before the next round's were issued -- three L2 round trips in a row behind every frame's last kernel).
+template <int WORDS>
+__device__ __forceinline__ void fl_publish_copy(unsigned long long *__restrict__ dst, const unsigned long long *__restrict__ src)
+{
+    constexpr int PER = (WORDS + 127) / 128;
+    unsigned long long v[PER];
+    const int nt = (int)blockDim.x;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = (int)threadIdx.x + k * nt;
+        v[k] = (i < WORDS) ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = (int)threadIdx.x + k * nt;
+        if (i < WORDS) dst[i] = v[k];
+    }
+}
 __device__ __forceinline__ void fl_publish_state(FlDev18 *__restrict__ D)
 {
     __syncthreads();
@@ -230,7 +250,7 @@ __device__ __forceinline__ void fl_publish_state(FlDev18 *__restrict__ D)
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(D->pub_dst);
     const unsigned long long seq = D->pub_seq;
     constexpr int WORDS = (int)((sizeof(FlDev18) + FL_DEV18_TAIL) / 8);
-    for (int i = threadIdx.x; i < WORDS; i += blockDim.x) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fl_publish_copy<WORDS>(dst, src);
     // Every wavefront waits for ITS OWN mirror stores to be acknowledged (s_waitcnt vmcnt(0): on gfx9 the counter covers stores; a
     // workgroup-scope release fence compiles to lgkmcnt(0) only, which is not that wait), then ONE wavefront pays the system-scope
     // release -- an L2 write-back of a few microseconds whoever issues it: with every wavefront of the workgroup issuing its own the

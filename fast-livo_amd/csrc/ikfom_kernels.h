@@ -65,7 +65,7 @@ __device__ __forceinline__ void fl_publish_state23(FlDev23 *__restrict__ D)
 #else
     constexpr int WORDS = (int)(sizeof(FlDev23) / 8);
 #endif
-    for (int i = threadIdx.x; i < WORDS; i += blockDim.x) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fl_publish_copy<WORDS>(dst, src);
     // every wavefront waits for its own mirror stores (explicit s_waitcnt vmcnt(0), see fl_publish_state), then ONE wavefront pays the
     // system-scope release (an L2 write-back, ~3 us whoever issues it: with all four wavefronts issuing their own it took 12.8 us)
     fl_wait_own_stores();

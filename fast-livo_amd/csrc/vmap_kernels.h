@@ -515,11 +515,15 @@ __global__ __launch_bounds__(FL_BLOCK) void vmap_addobs_dev_kernel(FlVPoint *__r
     if (!s_last) return;
     if (threadIdx.x == 0) {
         FlDetectTail *T = reinterpret_cast<FlDetectTail *>(reinterpret_cast<char *>(D) + sizeof(FlDev18) + FL_DETECT_TAIL_OFF);
-        T->n_cand = __hip_atomic_load(&cnt->cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        T->n_selected = n_sel;
-        T->n_added = __hip_atomic_load(&cnt->added, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        T->n_observed = __hip_atomic_load(&cnt->obs_added, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        T->n_down = vx ? vx->count : 0; T->vox_cells_short = vx ? vx->cells_short : 0; T->vox_cells = vx ? vx->cells : 0ll; T->pad0 = T->pad1 = 0;
+        // (the six words in flight together, then the stores: one L2 round trip on the frame's last stretch, not six)
+        const int c_cand = __hip_atomic_load(&cnt->cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int c_added = __hip_atomic_load(&cnt->added, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int c_obs = __hip_atomic_load(&cnt->obs_added, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const FlVxCtl *vxs = vx ? vx : reinterpret_cast<const FlVxCtl *>(D);        // (a readable address either way: no branch between the loads)
+        const int v_count = vxs->count, v_short = vxs->cells_short;
+        const long long v_cells = vxs->cells;
+        T->n_cand = c_cand; T->n_selected = n_sel; T->n_added = c_added; T->n_observed = c_obs;
+        T->n_down = vx ? v_count : 0; T->vox_cells_short = vx ? v_short : 0; T->vox_cells = vx ? v_cells : 0ll; T->pad0 = T->pad1 = 0;
         D->pub_flag = pub_flag; D->pub_dst = pub_dst; D->pub_seq = pub_seq;
         *ticket = 0u;
         __threadfence();
