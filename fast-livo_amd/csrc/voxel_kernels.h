@@ -485,14 +485,24 @@ __global__ __launch_bounds__(FL_VX_NT) void vx_order_kernel(int n, const unsigne
 
 // out: centroids (x, y, z, intensity); body (nullable): xyz only, the staged-scan layout. The launch covers max(points, voxels)
 // threads: thread t serves voxel t and cleans up behind point t. `next`: the control block of the NEXT frame, zeroed here.
+// Round 6: the members of a voxel arrive in `members` in the order the scatter's atomics gave them; PCL sums them in ascending point index
+// (the stable sort of downSizeFilter). A voxel of <= 8 members -- nearly all of them -- is put in order in its thread's registers (a
+// 19-comparator network over 8 slots padded with 0xFFFFFFFF) and summed; the rest are left to the workgroup behind a barrier: every
+// thread ranks a member among the voxel's others (what vx_order_kernel did for ALL points, a launch of its own), one lane sums in
+// order. Same order, same sums, one launch less (vx_order_kernel is kept for reference and tests of the staged order).
+#define FL_VX_CE(a, b) do { const unsigned lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; } while (0)
 __global__ __launch_bounds__(FL_VX_NT) void vx_centroid_kernel(const float4 *__restrict__ in, int n, const FlVxCtl *__restrict__ C,
                                                               const unsigned *__restrict__ keys, unsigned *__restrict__ cnt,
-                                                              const unsigned *__restrict__ seg, const unsigned *__restrict__ ordered,
+                                                              const unsigned *__restrict__ seg, const unsigned *__restrict__ members,
+                                                              unsigned *__restrict__ ordered /* scratch of the voxels with > 8 members */,
                                                               float4 *__restrict__ out, float *__restrict__ body, unsigned *__restrict__ bits,
                                                               unsigned *__restrict__ l2flag, FlVxCtl *__restrict__ next,
                                                               FlFrontTail *__restrict__ tail = nullptr)
 {
+    __shared__ int s_big[FL_VX_NT];
+    __shared__ int s_nbig;
     const int t = blockIdx.x * FL_VX_NT + threadIdx.x;
+    if (threadIdx.x == 0) s_nbig = 0;
     if (t == 0) {
         FlVxCtl z; memset(&z, 0, sizeof z); *next = z;
         if (tail) {      // fl_lidar_front: what the host wants to know of the filter rides back behind the state block
@@ -500,19 +510,86 @@ __global__ __launch_bounds__(FL_VX_NT) void vx_centroid_kernel(const float4 *__r
             tail->vox_nfinite = C->nfinite; tail->vox_cells = C->cells;
         }
     }
-    if (C->nfinite <= 0 || C->cells_short) return;
-    if (t < C->count) {
+    if (C->nfinite <= 0 || C->cells_short) return;           // (uniform over the grid)
+    const int nvox = C->count;
+    __syncthreads();
+    if (t < nvox) {
         const unsigned s = seg[t], c = cnt[t];
-        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
-        for (unsigned k = 0; k < c; k++) {
-            const float4 p = in[ordered[s + k]];
-            sx = sx + p.x; sy = sy + p.y; sz = sz + p.z; si = si + p.w;
+        if (c <= 8u) {
+            unsigned m0 = 0xFFFFFFFFu, m1 = m0, m2 = m0, m3 = m0, m4 = m0, m5 = m0, m6 = m0, m7 = m0;
+            if (c > 0u) m0 = members[s];
+            if (c > 1u) m1 = members[s + 1];
+            if (c > 2u) m2 = members[s + 2];
+            if (c > 3u) m3 = members[s + 3];
+            if (c > 4u) m4 = members[s + 4];
+            if (c > 5u) m5 = members[s + 5];
+            if (c > 6u) m6 = members[s + 6];
+            if (c > 7u) m7 = members[s + 7];
+            if (c > 1u) {
+                FL_VX_CE(m0, m1); FL_VX_CE(m2, m3); FL_VX_CE(m4, m5); FL_VX_CE(m6, m7);
+                FL_VX_CE(m0, m2); FL_VX_CE(m1, m3); FL_VX_CE(m4, m6); FL_VX_CE(m5, m7);
+                FL_VX_CE(m1, m2); FL_VX_CE(m5, m6); FL_VX_CE(m0, m4); FL_VX_CE(m3, m7);
+                FL_VX_CE(m1, m5); FL_VX_CE(m2, m6);
+                FL_VX_CE(m1, m4); FL_VX_CE(m3, m6);
+                FL_VX_CE(m2, m4); FL_VX_CE(m3, m5);
+                FL_VX_CE(m3, m4);
+            }
+            const unsigned mm[8] = {m0, m1, m2, m3, m4, m5, m6, m7};
+            float4 p[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) p[k] = ((unsigned)k < c) ? in[mm[k]] : make_float4(0.f, 0.f, 0.f, 0.f);      // (in flight together)
+            float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if ((unsigned)k < c) { sx = sx + p[k].x; sy = sy + p[k].y; sz = sz + p[k].z; si = si + p[k].w; }
+            const float fc = (float)c;
+            const float4 ce = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+            out[t] = ce;
+            if (body) { body[3 * t] = ce.x; body[3 * t + 1] = ce.y; body[3 * t + 2] = ce.z; }
+            cnt[t] = 0u;
+        } else {
+            s_big[atomicAdd(&s_nbig, 1)] = t;
         }
-        const float fc = (float)c;
-        const float4 ce = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
-        out[t] = ce;
-        if (body) { body[3 * t] = ce.x; body[3 * t + 1] = ce.y; body[3 * t + 2] = ce.z; }
-        cnt[t] = 0u;
+    }
+    __syncthreads();
+    const int nbig = s_nbig;                                  // (uniform over the workgroup)
+    if (nbig > 0) {
+        // the workgroup's voxels with more than 8 members: the ranking is spread over (voxel, member) pairs -- every thread ranks members
+        // among their voxel's others, c comparisons each, as vx_order_kernel did for every point of the scan --, then thread b sums voxel b
+        // in order (as the centroid kernel always did: the sums of different voxels run side by side)
+        __shared__ unsigned s_off[FL_VX_NT + 1], s_scan[FL_VX_NT / 64 + 1];
+        const bool mine = (int)threadIdx.x < nbig;
+        const int v = mine ? s_big[threadIdx.x] : 0;
+        const unsigned vs = mine ? seg[v] : 0u, vc = mine ? cnt[v] : 0u;
+        unsigned total = 0;
+        const unsigned off = fl_vx_block_scan(vc, s_scan, &total);
+        s_off[threadIdx.x] = off;
+        if (threadIdx.x == 0) s_off[FL_VX_NT] = total;
+        __syncthreads();
+        for (unsigned w = threadIdx.x; w < total; w += FL_VX_NT) {
+            int lo = 0, hi = nbig - 1;                        // the voxel of pair w: the last b with s_off[b] <= w
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[mid] <= w) lo = mid; else hi = mid - 1; }
+            const int bv = s_big[lo];
+            const unsigned s = seg[bv], c = cnt[bv], j = w - s_off[lo];
+            const unsigned mj = members[s + j];
+            unsigned r = 0;
+            for (unsigned k = 0; k < c; k++) r += (members[s + k] < mj) ? 1u : 0u;
+            ordered[s + r] = mj;
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (mine) {
+            float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+            for (unsigned k = 0; k < vc; k++) {
+                const float4 p = in[ordered[vs + k]];
+                sx = sx + p.x; sy = sy + p.y; sz = sz + p.z; si = si + p.w;
+            }
+            const float fc = (float)vc;
+            const float4 ce = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+            out[v] = ce;
+            if (body) { body[3 * v] = ce.x; body[3 * v + 1] = ce.y; body[3 * v + 2] = ce.z; }
+            cnt[v] = 0u;
+        }
     }
     if (t < n) {
         const unsigned key = keys[t];

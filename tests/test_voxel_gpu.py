@@ -56,6 +56,17 @@ def test_all_in_one_voxel_and_duplicates(gpu_lib):
     _check(h, q, 0.25)
 
 
+@pytest.mark.parametrize("n,span,leaf", [(300000, 4.0, 0.25), (60000, 2.0, 0.2), (400000, 20.0, 0.15)])
+def test_dense_clouds_mix_voxels_of_few_and_of_many_members(gpu_lib, n, span, leaf):
+    """vx_centroid_kernel (round 6) puts a voxel's members in order itself: up to 8 in its thread's registers (a sorting network), more
+    than 8 by the workgroup (ranking spread over (voxel, member) pairs, then a thread per voxel sums). ~9 members per voxel on average:
+    both paths in every workgroup, some voxels with dozens of members."""
+    from fast_livo_amd import capi, synth
+    h = capi.Handle(capi.config_from_frames(synth.make_lio_frame(1000)))
+    out = _check(h, _cloud(n, 4242 + n, span=span), leaf)
+    assert out.shape[0] < n
+
+
 def test_non_finite_points_are_skipped(gpu_lib):
     from fast_livo_amd import capi, synth
     h = capi.Handle(capi.config_from_frames(synth.make_lio_frame(1000)))
