@@ -181,7 +181,7 @@ struct fl_context {
     int vox_cap = 0;
     int vox_resident = 0;          // points left in d_vox_in by fl_imu_undistort
     // the sort-free path (voxel_kernels.h, round 5): occupancy bitmap over the grid's cells + counters; zeroed at allocation, left clean by every run
-    unsigned *d_vx_bits = nullptr, *d_vx_l1pre = nullptr, *d_vx_l2flag = nullptr, *d_vx_l2tot = nullptr, *d_vx_cnt = nullptr, *d_vx_ordered = nullptr;
+    unsigned *d_vx_bits = nullptr, *d_vx_l1pre = nullptr, *d_vx_l2flag = nullptr, *d_vx_l2tot = nullptr, *d_vx_cnt = nullptr, *d_vx_ordered = nullptr, *d_vx_slots = nullptr, *d_vx_ohead = nullptr;
     FlVxPartial *d_vx_partial = nullptr;       // workgroup bounding boxes (vx_minmax_kernel / undistort_apply_kernel)
     FlVxCtl *d_vx_ctl = nullptr;   // two blocks: a run uses [vx_parity] and leaves [1 - vx_parity] zeroed for the next one
     int vx_parity = 0;

@@ -190,6 +190,7 @@ __global__ __launch_bounds__(FL_BLOCK) void vox_centroid_kernel(const float4 *__
 // per-voxel counters of the seven-launch form live in a compact, cache-resident array. A first version that walked the set bits of a
 // group and loaded their counters one after the other took 60 us for the prefix pass alone.)
 #define FL_VX_NT 256
+#define FL_VX_SLOTS 8             /* members a voxel holds in its own slots (vx_rank_kernel); more are chained */
 #define FL_VX_L1_SHIFT 8            /* 256 cells (8 bitmap words = one 32-byte line) per group */
 #define FL_VX_L2_SHIFT 18           /* 1024 groups per block */
 #define FL_VX_L2_MAX 8192           /* 2^31 cells */
@@ -409,7 +410,8 @@ __global__ __launch_bounds__(FL_VX_NT) void vx_scan_l2_kernel(const FlVxCtl *__r
 
 __global__ __launch_bounds__(FL_VX_NT) void vx_rank_kernel(int n, FlVxCtl *__restrict__ C, const unsigned *__restrict__ keys, const unsigned *__restrict__ bits,
                                                           const unsigned *__restrict__ l1pre, const unsigned *__restrict__ l2tot,
-                                                          unsigned *__restrict__ ovox, unsigned *__restrict__ pos, unsigned *__restrict__ cnt)
+                                                          unsigned *__restrict__ slots, unsigned *__restrict__ ohead, unsigned *__restrict__ onext,
+                                                          unsigned *__restrict__ cnt)
 {
     __shared__ unsigned s_l2pre[FL_VX_L2_MAX];
     __shared__ unsigned s_w[FL_VX_NT / 64 + 1];
@@ -442,63 +444,34 @@ __global__ __launch_bounds__(FL_VX_NT) void vx_rank_kernel(int n, FlVxCtl *__res
         below += (unsigned)__popc(wv[k] & m);
     }
     const unsigned o = s_l2pre[key >> FL_VX_L2_SHIFT] + l1pre[grp] + below;
-    ovox[i] = o;
-    pos[i] = atomicAdd(&cnt[o], 1u);
-}
-
-__global__ __launch_bounds__(FL_VX_NT) void vx_segments_kernel(FlVxCtl *__restrict__ C, const unsigned *__restrict__ cnt, unsigned *__restrict__ seg)
-{
-    __shared__ unsigned s_w[FL_VX_NT / 64 + 1];
-    __shared__ unsigned s_base;
-    const int U = C->count;
-    const int o0 = blockIdx.x * FL_VX_NT;
-    if (o0 >= U) return;                                        // (uniform)
-    const int o = o0 + (int)threadIdx.x;
-    const unsigned c = o < U ? cnt[o] : 0u;
-    unsigned total;
-    const unsigned ex = fl_vx_block_scan(c, s_w, &total);
-    if (threadIdx.x == 0) s_base = atomicAdd(&C->cursor, total);
-    __syncthreads();
-    if (o < U) seg[o] = s_base + ex;
-}
-
-__global__ __launch_bounds__(FL_VX_NT) void vx_scatter_kernel(int n, const unsigned *__restrict__ keys, const unsigned *__restrict__ ovox,
-                                                             const unsigned *__restrict__ pos, const unsigned *__restrict__ seg,
-                                                             unsigned *__restrict__ members)
-{
-    const int i = blockIdx.x * FL_VX_NT + threadIdx.x;
-    if (i >= n || keys[i] == 0xFFFFFFFFu) return;
-    members[seg[ovox[i]] + pos[i]] = (unsigned)i;
-}
-
-__global__ __launch_bounds__(FL_VX_NT) void vx_order_kernel(int n, const unsigned *__restrict__ keys, const unsigned *__restrict__ ovox,
-                                                           const unsigned *__restrict__ cnt, const unsigned *__restrict__ seg,
-                                                           const unsigned *__restrict__ members, unsigned *__restrict__ ordered)
-{
-    const int i = blockIdx.x * FL_VX_NT + threadIdx.x;
-    if (i >= n || keys[i] == 0xFFFFFFFFu) return;
-    const unsigned o = ovox[i], s = seg[o], c = cnt[o];
-    unsigned r = 0;
-    for (unsigned k = 0; k < c; k++) r += (members[s + k] < (unsigned)i) ? 1u : 0u;
-    ordered[s + r] = (unsigned)i;
+    // Round 6 (second half): a voxel's first FL_VX_SLOTS members go straight into the voxel's own slots, in the order the atomic hands the
+    // positions out; what comes later -- rare in a scan -- is chained behind the voxel (ohead / onext). vx_centroid_kernel puts either in
+    // ascending point index. (Until then: position + voxel per point, a prefix over the voxels' counts for segment starts, a scatter of
+    // the point indices into the segments -- vx_segments_kernel and vx_scatter_kernel, two launches of their own.)
+    const unsigned p = atomicAdd(&cnt[o], 1u);
+    if (p < (unsigned)FL_VX_SLOTS) slots[(size_t)o * FL_VX_SLOTS + p] = (unsigned)i;
+    else onext[i] = atomicExch(&ohead[o], (unsigned)i);
 }
 
 // out: centroids (x, y, z, intensity); body (nullable): xyz only, the staged-scan layout. The launch covers max(points, voxels)
 // threads: thread t serves voxel t and cleans up behind point t. `next`: the control block of the NEXT frame, zeroed here.
-// Round 6: the members of a voxel arrive in `members` in the order the scatter's atomics gave them; PCL sums them in ascending point index
-// (the stable sort of downSizeFilter). A voxel of <= 8 members -- nearly all of them -- is put in order in its thread's registers (a
-// 19-comparator network over 8 slots padded with 0xFFFFFFFF) and summed; the rest are left to the workgroup behind a barrier: every
-// thread ranks a member among the voxel's others (what vx_order_kernel did for ALL points, a launch of its own), one lane sums in
-// order. Same order, same sums, one launch less (vx_order_kernel is kept for reference and tests of the staged order).
+// Round 6: the members of a voxel arrive in its slots (and, beyond eight, in its chain) in the order vx_rank_kernel's atomics gave them;
+// PCL sums them in ascending point index (the stable sort of downSizeFilter). A voxel of <= 8 members -- nearly all of them -- is put in
+// order in its thread's registers (a 19-comparator network over 8 slots padded with 0xFFFFFFFF) and summed; the rest are left to the
+// workgroup behind a barrier: every thread ranks a member among the voxel's others, a thread per voxel sums in order. Same order, same
+// sums as the three kernels this replaces (per-voxel segments by a prefix over the counts, a scatter of the point indices, a launch
+// that ranked every point within its voxel): the sort-free filter is 4 launches (claim, prefix, rank, centroid), it was 7.
 #define FL_VX_CE(a, b) do { const unsigned lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; } while (0)
-__global__ __launch_bounds__(FL_VX_NT) void vx_centroid_kernel(const float4 *__restrict__ in, int n, const FlVxCtl *__restrict__ C,
+__global__ __launch_bounds__(FL_VX_NT) void vx_centroid_kernel(const float4 *__restrict__ in, int n, FlVxCtl *__restrict__ C,
                                                               const unsigned *__restrict__ keys, unsigned *__restrict__ cnt,
-                                                              const unsigned *__restrict__ seg, const unsigned *__restrict__ members,
-                                                              unsigned *__restrict__ ordered /* scratch of the voxels with > 8 members */,
+                                                              const unsigned *__restrict__ slots, unsigned *__restrict__ ohead,
+                                                              const unsigned *__restrict__ onext, unsigned *__restrict__ scratch,
+                                                              unsigned *__restrict__ ordered /* both: the voxels with > 8 members */,
                                                               float4 *__restrict__ out, float *__restrict__ body, unsigned *__restrict__ bits,
                                                               unsigned *__restrict__ l2flag, FlVxCtl *__restrict__ next,
                                                               FlFrontTail *__restrict__ tail = nullptr)
 {
+    static_assert(FL_VX_SLOTS == 8, "the sorting network below has eight inputs");
     __shared__ int s_big[FL_VX_NT];
     __shared__ int s_nbig;
     const int t = blockIdx.x * FL_VX_NT + threadIdx.x;
@@ -514,17 +487,11 @@ __global__ __launch_bounds__(FL_VX_NT) void vx_centroid_kernel(const float4 *__r
     const int nvox = C->count;
     __syncthreads();
     if (t < nvox) {
-        const unsigned s = seg[t], c = cnt[t];
+        const unsigned c = cnt[t];
         if (c <= 8u) {
-            unsigned m0 = 0xFFFFFFFFu, m1 = m0, m2 = m0, m3 = m0, m4 = m0, m5 = m0, m6 = m0, m7 = m0;
-            if (c > 0u) m0 = members[s];
-            if (c > 1u) m1 = members[s + 1];
-            if (c > 2u) m2 = members[s + 2];
-            if (c > 3u) m3 = members[s + 3];
-            if (c > 4u) m4 = members[s + 4];
-            if (c > 5u) m5 = members[s + 5];
-            if (c > 6u) m6 = members[s + 6];
-            if (c > 7u) m7 = members[s + 7];
+            const uint4 sa = reinterpret_cast<const uint4 *>(slots + (size_t)t * FL_VX_SLOTS)[0], sb = reinterpret_cast<const uint4 *>(slots + (size_t)t * FL_VX_SLOTS)[1];
+            unsigned m0 = c > 0u ? sa.x : 0xFFFFFFFFu, m1 = c > 1u ? sa.y : 0xFFFFFFFFu, m2 = c > 2u ? sa.z : 0xFFFFFFFFu, m3 = c > 3u ? sa.w : 0xFFFFFFFFu;
+            unsigned m4 = c > 4u ? sb.x : 0xFFFFFFFFu, m5 = c > 5u ? sb.y : 0xFFFFFFFFu, m6 = c > 6u ? sb.z : 0xFFFFFFFFu, m7 = c > 7u ? sb.w : 0xFFFFFFFFu;
             if (c > 1u) {
                 FL_VX_CE(m0, m1); FL_VX_CE(m2, m3); FL_VX_CE(m4, m5); FL_VX_CE(m6, m7);
                 FL_VX_CE(m0, m2); FL_VX_CE(m1, m3); FL_VX_CE(m4, m6); FL_VX_CE(m5, m7);
@@ -554,26 +521,38 @@ __global__ __launch_bounds__(FL_VX_NT) void vx_centroid_kernel(const float4 *__r
     __syncthreads();
     const int nbig = s_nbig;                                  // (uniform over the workgroup)
     if (nbig > 0) {
-        // the workgroup's voxels with more than 8 members: the ranking is spread over (voxel, member) pairs -- every thread ranks members
-        // among their voxel's others, c comparisons each, as vx_order_kernel did for every point of the scan --, then thread b sums voxel b
-        // in order (as the centroid kernel always did: the sums of different voxels run side by side)
-        __shared__ unsigned s_off[FL_VX_NT + 1], s_scan[FL_VX_NT / 64 + 1];
+        // the workgroup's voxels with more than 8 members. Thread b takes voxel b: a segment of the scratch array (one atomic on the
+        // frame's cursor), its eight slots and its chain copied there. Then the ranking, spread over (voxel, member) pairs -- every thread
+        // ranks members among their voxel's others, c comparisons each, as vx_order_kernel did for every point of the scan --, then
+        // thread b sums voxel b in order (the sums of different voxels run side by side).
+        __shared__ unsigned s_off[FL_VX_NT + 1], s_seg[FL_VX_NT], s_scan[FL_VX_NT / 64 + 1];
         const bool mine = (int)threadIdx.x < nbig;
         const int v = mine ? s_big[threadIdx.x] : 0;
-        const unsigned vs = mine ? seg[v] : 0u, vc = mine ? cnt[v] : 0u;
+        const unsigned vc = mine ? cnt[v] : 0u;
+        unsigned vs = 0u;
+        if (mine) {
+            vs = atomicAdd(&C->cursor, vc);
+            const uint4 sa = reinterpret_cast<const uint4 *>(slots + (size_t)v * FL_VX_SLOTS)[0], sb = reinterpret_cast<const uint4 *>(slots + (size_t)v * FL_VX_SLOTS)[1];
+            scratch[vs] = sa.x; scratch[vs + 1] = sa.y; scratch[vs + 2] = sa.z; scratch[vs + 3] = sa.w;
+            scratch[vs + 4] = sb.x; scratch[vs + 5] = sb.y; scratch[vs + 6] = sb.z; scratch[vs + 7] = sb.w;
+            unsigned idx = ohead[v];
+            for (unsigned k = FL_VX_SLOTS; k < vc && idx != 0xFFFFFFFFu; k++) { scratch[vs + k] = idx; idx = onext[idx]; }
+            ohead[v] = 0xFFFFFFFFu;
+            s_seg[threadIdx.x] = vs;
+        }
         unsigned total = 0;
         const unsigned off = fl_vx_block_scan(vc, s_scan, &total);
         s_off[threadIdx.x] = off;
         if (threadIdx.x == 0) s_off[FL_VX_NT] = total;
+        __threadfence_block();
         __syncthreads();
         for (unsigned w = threadIdx.x; w < total; w += FL_VX_NT) {
             int lo = 0, hi = nbig - 1;                        // the voxel of pair w: the last b with s_off[b] <= w
             while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[mid] <= w) lo = mid; else hi = mid - 1; }
-            const int bv = s_big[lo];
-            const unsigned s = seg[bv], c = cnt[bv], j = w - s_off[lo];
-            const unsigned mj = members[s + j];
+            const unsigned s = s_seg[lo], c = s_off[lo + 1] - s_off[lo], j = w - s_off[lo];
+            const unsigned mj = scratch[s + j];
             unsigned r = 0;
-            for (unsigned k = 0; k < c; k++) r += (members[s + k] < mj) ? 1u : 0u;
+            for (unsigned k = 0; k < c; k++) r += (scratch[s + k] < mj) ? 1u : 0u;
             ordered[s + r] = mj;
         }
         __threadfence_block();
